@@ -1,0 +1,161 @@
+/*
+ * svdq_amd.h -- C ABI of the MI355X (gfx950) SVDQuant W4A4 + low-rank hot path.
+ *
+ * This is the drop-in boundary for the two operators the reference exports from its pybind11
+ * module `nunchaku._C.ops` (reference: nunchaku/csrc/pybind.cpp:108-116, nunchaku/csrc/ops.h):
+ *
+ *   ops.quantize_w4a4_act_fuse_lora  (csrc/ops.h:83-112 -> src/kernels/zgemm/zgemm.h:39-46)
+ *   ops.gemm_w4a4                    (csrc/ops.h:10-81  -> src/kernels/zgemm/zgemm.h:8-36)
+ *
+ * plus the load-time re-layout of the reference's checkpoint tensors (which are stored in NVIDIA
+ * mma fragment order, nunchaku/lora/flux/packer.py:187-301,362-437) into the CDNA4 tile order the
+ * kernels consume.
+ *
+ * Rules of the boundary (mirrors the reference's behaviour):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *     NULL means "tensor absent" (the reference's `std::optional<Tensor>` / `Tensor::valid()`).
+ *   - the caller owns and allocates every buffer; the library allocates nothing and keeps no
+ *     pointer after a call returns (reference: ops/gemm.py:107-110, interop/torch.h:8-23).
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (reference launches on the
+ *     current torch stream, interop/torch.cpp:84-91; no device sync, csrc/ops.h:80).
+ *   - errors are returned, never abort()ed (the reference asserts: launch_impl.cuh:44-59).
+ *     0 = success; non-zero = SVDQ_E_*; svdq_last_error() gives a thread-local message.
+ *   - re-entrant; no global mutable state besides the thread-local error string.
+ *
+ * "16-bit" below means the model dtype: SVDQ_BF16 or SVDQ_FP16 (the reference picks the kernel
+ * dtype from ascales.dtype(), gemm_w4a4.cu:63-65).
+ */
+#ifndef SVDQ_AMD_H
+#define SVDQ_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVDQ_ABI_VERSION 1
+
+/* model dtype of the 16-bit tensors */
+enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
+
+/* error codes */
+enum {
+    SVDQ_OK = 0,
+    SVDQ_E_INVALID = 1,     /* bad shape / alignment / missing tensor            */
+    SVDQ_E_UNSUPPORTED = 2, /* valid in the reference, not implemented here (fp4, LiteLA, ...) */
+    SVDQ_E_HIP = 3          /* a HIP runtime call failed                                    */
+};
+
+/* epilogue selector of svdq_gemm_w4a4 (the reference infers it from which tensors are valid,
+ * gemm_w4a4_launch_impl.cuh:282-423; the host shim does the same inference and fills `fuse`). */
+enum {
+    SVDQ_FUSE_NONE = 0,        /* EpilogueDefault: store out[M,N]                (launch_impl.cuh:407-420) */
+    SVDQ_FUSE_SILU = 1,        /* EpilogueSilu then store                        (gemm_base.cuh:783-792)   */
+    SVDQ_FUSE_GELU_QUANT = 2,  /* GELU -> [LoraDown] -> shift+smooth+u4 requant  (launch_impl.cuh:282-309) */
+    SVDQ_FUSE_RMSNORM_ROPE = 3 /* QKV: RMSNorm(q,k)+RoPE then store              (launch_impl.cuh:347-405) */
+};
+
+/* ------------------------------------------------------------------------------------------
+ * svdq_quantize_w4a4_act_fuse_lora
+ * replaces kernels::quantize_w4a4_act_fuse_lora (zgemm.h:39-46, gemm_w4a4.cuh:1097-1184).
+ *
+ *   lora_act[M_pad, R] = x @ lora_down            (on the un-smoothed input, fp32)
+ *   x_hat = round16(x / smooth);  per (row, 64-channel group): scale = amax/7,
+ *   q = sat_s4(rne(x_hat / scale));  rows >= M are treated as zero.
+ *
+ * Output buffers are OPAQUE (tile order private to this library); their sizes
+ * are the reference's: act M_pad*K/2 bytes, ascales (K/64)*M_pad 16-bit, lora_act M_pad*R fp32.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct svdq_quantize_args {
+    const void *x;         /* [M, K] 16-bit, row stride ldx elements                          */
+    const void *smooth;    /* [K] 16-bit, natural order (see svdq_repack_vec); NULL = ones    */
+    const void *lora_down; /* [K*R] 16-bit in svdq_repack_lowrank(down=1) order; NULL if R==0 */
+    void *act;             /* out: packed int4 codes, M_pad*K/2 bytes                         */
+    void *ascales;         /* out: (K/64)*M_pad 16-bit                                        */
+    float *lora_act;       /* out: M_pad*R fp32 (fully overwritten, no pre-zeroing needed)    */
+    int32_t M;             /* actual rows                                                     */
+    int32_t M_pad;         /* multiple of 256, >= M                                           */
+    int32_t K;             /* multiple of 128                                                 */
+    int32_t R;             /* multiple of 16 (0 = no low-rank branch)                         */
+    int32_t ldx;           /* row stride of x in elements (>= K)                              */
+    int32_t dtype;         /* SVDQ_BF16 | SVDQ_FP16                                           */
+    int32_t fuse_glu;      /* must be 0 (SVDQ_E_UNSUPPORTED otherwise; not on the FLUX path)  */
+    int32_t fp4;           /* must be 0 (NVFP4 is Blackwell-only)                             */
+} svdq_quantize_args;
+
+int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * svdq_gemm_w4a4
+ * replaces kernels::gemm_w4a4 (zgemm.h:8-36, gemm_w4a4_launch_impl.cuh:7-424).
+ *
+ *   y[m,n] = sum_g ascales[g,m]*wscales[g,n] * (sum_{k in g} act[m,k]*wgt[n,k])      (int4 x int4)
+ *            + bias[n] + sum_r round16(lora_act_in[m,r]*lora_scales[r/16]) * lora_up[n,r]
+ *   then the epilogue selected by `fuse`.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct svdq_gemm_args {
+    const void *act;          /* packed int4 activations (from quantize or a GELU_QUANT gemm)  */
+    const void *wgt;          /* packed int4 weights, svdq_repack_qweight order, N*K/2 bytes   */
+    const void *ascales;      /* (K/64)*M_pad 16-bit                                           */
+    const void *wscales;      /* (K/64)*N 16-bit, natural [g][n] (svdq_repack_wscales)         */
+    const void *bias;         /* [N] 16-bit natural order or NULL                              */
+    const float *lora_act_in; /* M_pad*R fp32 or NULL                                          */
+    const void *lora_up;      /* [N, R] 16-bit natural row-major (svdq_repack_lowrank(down=0)) */
+    const float *lora_scales; /* HOST pointer, R/16 floats, or NULL (= all 1.0)                */
+    void *out;                /* [M, N] 16-bit, row stride ldo; required unless GELU_QUANT     */
+    /* SVDQ_FUSE_GELU_QUANT: this layer emits the NEXT layer's quantized activation */
+    void *qout;               /* packed uint4 codes, M_pad*N/2 bytes                           */
+    void *oscales;            /* (N/64)*M_pad 16-bit                                           */
+    const void *next_smooth;  /* [N] 16-bit natural order                                      */
+    const void *next_lora_down; /* [N*R2] 16-bit, svdq_repack_lowrank(down=1) order, or NULL   */
+    float *lora_act_out;      /* M_pad*R2 fp32; MUST be zeroed by the caller on the same stream
+                                 (reference: lora_act_out.zero_(), launch_impl.cuh:252)        */
+    /* SVDQ_FUSE_RMSNORM_ROPE */
+    const void *norm_q;       /* [128] 16-bit                                                   */
+    const void *norm_k;       /* [128] 16-bit                                                   */
+    const float *rotary_emb;  /* [M_pad, 128] fp32 in the reference's pack_rotemb order
+                                 (models/embeddings.py:100-138)                                 */
+    int32_t M;                /* actual rows (rows >= M are not stored to `out`)                */
+    int32_t M_pad;            /* multiple of 256                                                */
+    int32_t N;                /* multiple of 128                                                */
+    int32_t K;                /* multiple of 128                                                */
+    int32_t R;                /* rank of lora_up (multiple of 16; 0 = none)                     */
+    int32_t R2;               /* rank of next_lora_down (multiple of 16; 0 = none)              */
+    int32_t ldo;              /* row stride of out in elements (>= N)                           */
+    int32_t dtype;            /* SVDQ_BF16 | SVDQ_FP16                                          */
+    int32_t act_unsigned;     /* act codes are uint4 (producer was a GELU_QUANT gemm)           */
+    int32_t fuse;             /* SVDQ_FUSE_*                                                    */
+    int32_t variant;          /* 0 = default kernel; >0 = tuning variants       */
+    int32_t reserved;
+} svdq_gemm_args;
+
+int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Load-time re-layout of reference checkpoint tensors (NVIDIA fragment order -> CDNA4 order).
+ * src and dst must not alias.  All are pure permutations, same byte size in and out.
+ * ------------------------------------------------------------------------------------------ */
+/* qweight [N, K/2] int8 (packer.py:187-239) -> tile order consumed by svdq_gemm_w4a4 */
+int svdq_repack_qweight(const void *src, void *dst, int32_t N, int32_t K, void *stream);
+/* wscales [K/64, N] 16-bit (packer.py:241-301) -> natural [g][n] */
+int svdq_repack_wscales(const void *src, void *dst, int32_t G, int32_t N, void *stream);
+/* bias / smooth_factor [N] 16-bit (same intra-128 permutation, gemm_base.cuh:713) -> natural */
+int svdq_repack_vec(const void *src, void *dst, int32_t N, void *stream);
+/* proj_up [N, R] (down=0) -> natural [n][r];  proj_down [K, R] (down=1) -> [r][k] (rank-major)
+ * (packer.py:362-398, lora.cuh:43-59).  C = N or K. */
+int svdq_repack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_t down, void *stream);
+
+/* Inverse helpers used by the tests to read the opaque activation format back:
+ * act (this library's tile order) -> one int8 code per element, natural [M_pad, K]. */
+int svdq_unpack_act(const void *act, int8_t *codes, int32_t M_pad, int32_t K, int32_t is_unsigned, void *stream);
+
+/* thread-local message of the last failing call on this thread ("" if none) */
+const char *svdq_last_error(void);
+/* SVDQ_ABI_VERSION the library was built with */
+int svdq_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVDQ_AMD_H */

@@ -1,0 +1,165 @@
+"""Drop-in for the reference's pybind11 module ``nunchaku._C`` (hot-path subset).
+
+``ops.quantize_w4a4_act_fuse_lora`` and ``ops.gemm_w4a4`` keep the reference's positional
+signatures (nunchaku/csrc/ops.h:10-38, 83-90): every tensor is optional, outputs are allocated by
+the caller and written in place, the call is asynchronous on the current torch stream and
+returns ``None``.  Underneath they marshal raw device pointers into the C ABI
+(include/svdq_amd.h) -- torch is only used for ``data_ptr()`` and the stream handle.
+
+Shape errors raise ``ValueError`` (the reference aborts the process on a failed ``assert``,
+SURVEY.md section 5), unsupported reference features raise ``NotImplementedError``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_DT = {torch.bfloat16: _lib.SVDQ_BF16, torch.float16: _lib.SVDQ_FP16}
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("nunchaku_amd ops need GPU tensors (there is no CPU path)")
+    if not t.is_contiguous():
+        raise ValueError("nunchaku_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Ops:
+    @staticmethod
+    def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False):
+        """reference: csrc/ops.h:83-112 -> kernels::quantize_w4a4_act_fuse_lora (zgemm.h:39-46)."""
+        lib = _lib.load()
+        if input is None or output is None or oscales is None:
+            raise ValueError("quantize_w4a4_act_fuse_lora: input, output and oscales are required")
+        if input.dtype not in _DT:
+            raise ValueError(f"quantize_w4a4_act_fuse_lora: unsupported dtype {input.dtype}")
+        if input.dim() != 2:
+            input = input.reshape(-1, input.shape[-1])
+        if input.stride(-1) != 1:
+            input = input.contiguous()
+        M, K = input.shape
+        M_pad = output.numel() // output.shape[-1]
+        R = 0 if lora_down is None else lora_down.shape[-1]
+        a = _lib.QuantizeArgs()
+        a.x = input.data_ptr()
+        a.smooth = _ptr(smooth)
+        a.lora_down = _ptr(lora_down)
+        a.act = _ptr(output)
+        a.ascales = _ptr(oscales)
+        a.lora_act = _ptr(lora_act_out)
+        a.M, a.M_pad, a.K, a.R = M, M_pad, K, R
+        a.ldx = input.stride(0)
+        a.dtype = _DT[input.dtype]
+        a.fuse_glu, a.fp4 = int(bool(fuse_glu)), int(bool(fp4))
+        if output.shape[-1] * 2 != K or oscales.numel() != (K // 64) * M_pad:
+            raise ValueError("quantize_w4a4_act_fuse_lora: output/oscales shapes do not match the input")
+        if R and lora_act_out.numel() != M_pad * R:
+            raise ValueError("quantize_w4a4_act_fuse_lora: lora_act_out must hold M_pad*R floats")
+        _lib.check(lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), _stream()), "quantize_w4a4_act_fuse_lora")
+
+    @staticmethod
+    def gemm_w4a4(
+        act, wgt, out, qout, ascales, wscales, oscales, poolout, lora_act_in, lora_up, lora_down, lora_act_out,
+        norm_q, norm_k, rotary_emb, bias, smooth_factor, out_vk, out_linearattn, act_unsigned, lora_scales,
+        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens,
+    ):
+        """reference: csrc/ops.h:10-81 -> kernels::gemm_w4a4 (zgemm.h:8-36).  The epilogue is inferred
+        from which optional tensors are present, exactly as gemm_w4a4_launch_impl.cuh:282-423 does."""
+        lib = _lib.load()
+        if fp4:
+            raise NotImplementedError("gemm_w4a4: fp4 (NVFP4) is Blackwell-only; use int4 checkpoints")
+        if alpha is not None and float(alpha) != 1.0:
+            raise ValueError("gemm_w4a4: alpha must be 1.0 for int4 (launch_impl.cuh:107)")
+        if out_linearattn is not None or out_vk is not None:
+            raise NotImplementedError("gemm_w4a4: the SANA LiteLA epilogue is out of scope")
+        if out_q is not None or out_k is not None or out_v is not None:
+            raise NotImplementedError("gemm_w4a4: packed Q/K/V for nunchaku-fp16 attention is not implemented yet")
+        if act is None or wgt is None or ascales is None or wscales is None:
+            raise ValueError("gemm_w4a4: act, wgt, ascales and wscales are required")
+        if ascales.dtype not in _DT:
+            raise ValueError(f"gemm_w4a4: unsupported dtype {ascales.dtype}")
+
+        a = _lib.GemmArgs()
+        M_pad = act.numel() // act.shape[-1]
+        K = act.shape[-1] * 2
+        N = wgt.shape[0]
+        if wgt.shape[-1] * 2 != K:
+            raise ValueError("gemm_w4a4: act and wgt disagree on K")
+        a.act, a.wgt, a.ascales, a.wscales = _ptr(act), _ptr(wgt), _ptr(ascales), _ptr(wscales)
+        a.bias = _ptr(bias)
+        R = 0
+        if lora_up is not None and lora_up.numel() > 0:
+            R = lora_up.shape[-1]
+            a.lora_up, a.lora_act_in = _ptr(lora_up), _ptr(lora_act_in)
+        keep = None
+        if lora_scales is not None and R:
+            keep = (C.c_float * (R // 16))(*[float(s) for s in list(lora_scales)[: R // 16]])
+            a.lora_scales = C.cast(keep, C.POINTER(C.c_float))
+        a.M_pad, a.N, a.K, a.R = M_pad, N, K, R
+        a.M = M_pad
+        a.dtype = _DT[ascales.dtype]
+        a.act_unsigned = int(bool(act_unsigned))
+
+        if qout is not None and oscales is not None:
+            a.fuse = _lib.FUSE_GELU_QUANT
+            a.qout, a.oscales, a.next_smooth = _ptr(qout), _ptr(oscales), _ptr(smooth_factor)
+            if lora_down is not None and lora_down.numel() > 0:
+                a.R2 = lora_down.shape[-1]
+                a.next_lora_down, a.lora_act_out = _ptr(lora_down), _ptr(lora_act_out)
+                lora_act_out.zero_()  # launch_impl.cuh:252
+        elif rotary_emb is not None:
+            if out is None or norm_q is None or norm_k is None:
+                raise ValueError("gemm_w4a4: the RMSNorm+RoPE epilogue needs out, norm_q and norm_k")
+            if rotary_emb.dtype != torch.float32 or rotary_emb.shape[-1] != 128 or rotary_emb.numel() != M_pad * 128:
+                raise ValueError("gemm_w4a4: rotary_emb must be float32 [M_pad, 128] (pack_rotemb order)")
+            a.fuse = _lib.FUSE_RMSNORM_ROPE
+            a.norm_q, a.norm_k, a.rotary_emb = _ptr(norm_q), _ptr(norm_k), _ptr(rotary_emb)
+        elif out is not None:
+            a.fuse = _lib.FUSE_SILU if fuse_silu else _lib.FUSE_NONE
+        else:
+            raise ValueError("gemm_w4a4: no output tensor given")
+        if out is not None:
+            a.out = _ptr(out)
+            a.M = out.numel() // out.shape[-1]
+            a.ldo = out.shape[-1]
+            if out.shape[-1] != N:
+                raise ValueError("gemm_w4a4: out.shape[-1] must equal N")
+            if a.M > M_pad or M_pad - a.M >= 256:
+                raise ValueError("gemm_w4a4: out rows must satisfy M <= M_pad < M + 256 (launch_impl.cuh:55)")
+        _lib.check(lib.svdq_gemm_w4a4(C.byref(a), _stream()), "gemm_w4a4")
+        del keep
+
+
+class _Utils:
+    """reference: csrc/pybind.cpp:118-123 -- logging / sm_75 toggles; no-ops here."""
+
+    @staticmethod
+    def set_log_level(level: str):
+        return None
+
+    @staticmethod
+    def set_faster_i2f_mode(mode: str):
+        return None
+
+    @staticmethod
+    def disable_memory_auto_release():
+        return None
+
+    @staticmethod
+    def trim_memory():
+        return None
+
+
+ops = _Ops()
+utils = _Utils()

@@ -1,0 +1,82 @@
+"""ctypes view of the C ABI declared in include/svdq_amd.h (struct layouts must match it)."""
+
+import ctypes as C
+import os
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsvdq_amd.so")
+
+SVDQ_BF16, SVDQ_FP16 = 0, 1
+FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
+ABI_VERSION = 1
+
+
+class QuantizeArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("smooth", C.c_void_p), ("lora_down", C.c_void_p),
+        ("act", C.c_void_p), ("ascales", C.c_void_p), ("lora_act", C.c_void_p),
+        ("M", C.c_int32), ("M_pad", C.c_int32), ("K", C.c_int32), ("R", C.c_int32),
+        ("ldx", C.c_int32), ("dtype", C.c_int32), ("fuse_glu", C.c_int32), ("fp4", C.c_int32),
+    ]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("act", C.c_void_p), ("wgt", C.c_void_p), ("ascales", C.c_void_p), ("wscales", C.c_void_p),
+        ("bias", C.c_void_p), ("lora_act_in", C.c_void_p), ("lora_up", C.c_void_p),
+        ("lora_scales", C.POINTER(C.c_float)), ("out", C.c_void_p),
+        ("qout", C.c_void_p), ("oscales", C.c_void_p), ("next_smooth", C.c_void_p),
+        ("next_lora_down", C.c_void_p), ("lora_act_out", C.c_void_p),
+        ("norm_q", C.c_void_p), ("norm_k", C.c_void_p), ("rotary_emb", C.c_void_p),
+        ("M", C.c_int32), ("M_pad", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("R", C.c_int32), ("R2", C.c_int32), ("ldo", C.c_int32), ("dtype", C.c_int32),
+        ("act_unsigned", C.c_int32), ("fuse", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+EXPORTS = {
+    "svdq_quantize_w4a4_act_fuse_lora": (C.c_int, [C.POINTER(QuantizeArgs), C.c_void_p]),
+    "svdq_gemm_w4a4": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "svdq_repack_qweight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "svdq_repack_wscales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "svdq_repack_vec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "svdq_repack_lowrank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "svdq_unpack_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "svdq_last_error": (C.c_char_p, []),
+    "svdq_abi_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load libsvdq_amd.so.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: build it with `python -m nunchaku_amd.build` "
+            "(or __graft_entry__.build()).  nunchaku_amd has no CPU/PyTorch fallback for its kernels."
+        )
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, argt) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, argt
+    if lib.svdq_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libsvdq_amd.so ABI {lib.svdq_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().svdq_last_error().decode("utf-8", "replace")
+        if rc == 1:
+            raise ValueError(f"{what}: {msg}")
+        if rc == 2:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise RuntimeError(f"{what}: {msg}")

@@ -1,0 +1,57 @@
+"""Load-time re-layout: reference checkpoint tensors (NVIDIA mma fragment order,
+nunchaku/lora/flux/packer.py:187-301,362-437) -> the CDNA4 orders the HIP kernels consume.
+
+Each function returns a NEW tensor of the same shape/dtype holding the permuted data; the GPU does
+the work (csrc/repack.hip through the C ABI).  ``SVDQW4A4Linear.repack_()`` applies them in place.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _run(fn_name, src: torch.Tensor, *dims) -> torch.Tensor:
+    lib = _lib.load()
+    if not src.is_cuda:
+        raise RuntimeError("nunchaku_amd.layout: tensors must be on the GPU (no CPU path)")
+    src = src.contiguous()
+    dst = torch.empty_like(src)
+    rc = getattr(lib, fn_name)(src.data_ptr(), dst.data_ptr(), *dims, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, fn_name)
+    return dst
+
+
+def repack_qweight(qweight: torch.Tensor) -> torch.Tensor:
+    """[N, K/2] int8 reference order -> T16 tile order."""
+    N, Kh = qweight.shape
+    return _run("svdq_repack_qweight", qweight, N, Kh * 2)
+
+
+def repack_wscales(wscales: torch.Tensor) -> torch.Tensor:
+    """[K/64, N] 16-bit reference order -> natural [g][n]."""
+    G, N = wscales.shape
+    return _run("svdq_repack_wscales", wscales, G, N)
+
+
+def repack_vec(v: torch.Tensor) -> torch.Tensor:
+    """bias / smooth_factor [N] reference order -> natural."""
+    return _run("svdq_repack_vec", v, v.numel())
+
+
+def repack_lowrank(w: torch.Tensor, down: bool) -> torch.Tensor:
+    """proj_up [N, R] -> natural [n][r];  proj_down [K, R] -> rank-major [r][k] (same storage shape)."""
+    C_, R = w.shape
+    return _run("svdq_repack_lowrank", w, C_, R, 1 if down else 0)
+
+
+def unpack_act(act: torch.Tensor, K: int, unsigned: bool = False) -> torch.Tensor:
+    """Opaque packed activations -> int8 codes [M_pad, K] (test/debug helper)."""
+    lib = _lib.load()
+    M_pad = act.numel() * 2 // K
+    codes = torch.empty(M_pad, K, dtype=torch.int8, device=act.device)
+    rc = lib.svdq_unpack_act(act.data_ptr(), codes.data_ptr(), M_pad, K, int(unsigned),
+                             torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "svdq_unpack_act")
+    return codes

@@ -1,0 +1,147 @@
+"""SVDQuant W4A4 linear layer for MI355X (reference: nunchaku/models/linear.py:13-274).
+
+Same constructor, parameter names/shapes/dtypes and methods as the reference's ``SVDQW4A4Linear``
+so reference checkpoints ``load_state_dict`` unchanged.  Checkpoint tensors arrive in NVIDIA mma
+fragment order; ``repack_()`` permutes them ONCE, in place (same ``nn.Parameter`` objects, same
+shapes), into the CDNA4 tile order the HIP kernels read.  It runs lazily before the first kernel
+call and again after every ``load_state_dict``.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import layout
+from ..ops.gemm import svdq_gemm_w4a4_cuda
+from ..ops.quantize import svdq_quantize_w4a4_act_fuse_lora_cuda
+
+
+class SVDQW4A4Linear(nn.Module):
+    """y = W4A4(x) + (x @ proj_down) @ proj_up^T + bias, SVDQuant INT4 (group size 64).
+
+    Parameters: ``qweight`` int8 [out, in/2]; ``wscales`` [in/64, out]; ``bias`` [out] or None;
+    ``smooth_factor`` / ``smooth_factor_orig`` [in]; ``proj_down`` [in, rank]; ``proj_up`` [out, rank].
+    ``precision`` must be "int4" on MI355X ("nvfp4" needs Blackwell's block-scaled mma).
+    """
+
+    def __init__(
+        self,
+        in_features: int,
+        out_features: int,
+        rank: int = 32,
+        bias: bool = True,
+        precision: str = "int4",
+        act_unsigned: bool = False,
+        torch_dtype: torch.dtype = torch.bfloat16,
+        device: str | torch.device | None = None,
+    ):
+        super().__init__()
+        if precision == "nvfp4":
+            raise NotImplementedError("nvfp4 checkpoints are Blackwell-only; use the int4 checkpoint on MI355X")
+        if precision != "int4":
+            raise ValueError(f"Invalid precision: {precision}")
+        if device is None:
+            device = torch.device("cpu")
+        self.in_features = in_features
+        self.out_features = out_features
+        self.rank = rank
+        self.precision = precision
+        self.torch_dtype = torch_dtype
+        self.group_size = 64
+
+        def p(*shape, dtype=torch_dtype, grad=False):
+            return nn.Parameter(torch.empty(*shape, dtype=dtype, device=device), requires_grad=grad)
+
+        self.qweight = p(out_features, in_features // 2, dtype=torch.int8)
+        self.bias = p(out_features, grad=True) if bias else None
+        self.wscales = p(in_features // self.group_size, out_features)
+        self.smooth_factor = p(in_features)
+        self.smooth_factor_orig = p(in_features)
+        self.proj_down = p(in_features, rank, grad=True)
+        self.proj_up = p(out_features, rank, grad=True)
+        self.wtscale = None  # nvfp4 only
+        self.wcscales = None  # nvfp4 only
+        self.act_unsigned = act_unsigned
+
+        # False while the parameters hold the reference (checkpoint) layout
+        self._amd_layout = False
+        self.register_load_state_dict_post_hook(self._mark_reference_layout)
+
+    # ------------------------------------------------------------------ layout
+    @staticmethod
+    def _mark_reference_layout(module, incompatible_keys):
+        module._amd_layout = False
+
+    @torch.no_grad()
+    def repack_(self) -> "SVDQW4A4Linear":
+        """Permute the checkpoint-layout parameters into the kernel layout, in place (idempotent)."""
+        if self._amd_layout:
+            return self
+        if not self.qweight.is_cuda:
+            raise RuntimeError("SVDQW4A4Linear.repack_(): move the layer to the GPU first (no CPU path)")
+        self.qweight.data.copy_(layout.repack_qweight(self.qweight.data))
+        self.wscales.data.copy_(layout.repack_wscales(self.wscales.data))
+        self.smooth_factor.data.copy_(layout.repack_vec(self.smooth_factor.data))
+        if self.bias is not None:
+            self.bias.data.copy_(layout.repack_vec(self.bias.data))
+        if self.rank > 0:
+            self.proj_down.data.copy_(layout.repack_lowrank(self.proj_down.data, down=True))
+            self.proj_up.data.copy_(layout.repack_lowrank(self.proj_up.data, down=False))
+        self._amd_layout = True
+        return self
+
+    def _ensure_layout(self):
+        if not self._amd_layout:
+            self.repack_()
+
+    # ------------------------------------------------------------------ API of the reference
+    @classmethod
+    def from_linear(cls, linear: nn.Linear, **kwargs):
+        """Uninitialised quantised twin of ``linear`` (same shapes, dtype, device)."""
+        in_features = kwargs.pop("in_features", linear.in_features)
+        return cls(
+            in_features=in_features,
+            out_features=linear.out_features,
+            bias=linear.bias is not None,
+            torch_dtype=linear.weight.dtype,
+            device=linear.weight.device,
+            **kwargs,
+        )
+
+    def forward(self, x: torch.Tensor, output: torch.Tensor | None = None) -> torch.Tensor:
+        """x [B, S, in] 16-bit -> [B, S, out]: quantise (+ low-rank down) then the fused GEMM."""
+        B, S, C_in = x.shape
+        x2 = x.reshape(B * S, C_in)
+        if output is None:
+            output = torch.empty(B * S, self.out_features, dtype=x.dtype, device=x.device)
+        qx, ascales, lora_act = self.quantize(x2)
+        output = self.forward_quant(qx, ascales, lora_act, output)
+        return output.reshape(B, S, -1)
+
+    def quantize(self, x: torch.Tensor, pad_size: int = 256):
+        """x [N, in] -> (codes [N_pad, in/2] uint8, ascales [in/64, N_pad], lora_act [N_pad, rank] f32)."""
+        self._ensure_layout()
+        return svdq_quantize_w4a4_act_fuse_lora_cuda(
+            x, lora_down=self.proj_down, smooth=self.smooth_factor, fp4=False, pad_size=pad_size
+        )
+
+    def forward_quant(self, quantized_x, ascales, lora_act, output: torch.Tensor | None = None) -> torch.Tensor:
+        """GEMM on pre-quantised input (codes from :meth:`quantize` or from a fused GELU epilogue)."""
+        self._ensure_layout()
+        if output is None:
+            output = torch.empty(
+                quantized_x.shape[0], self.out_features, dtype=self.proj_up.dtype, device=quantized_x.device
+            )
+        svdq_gemm_w4a4_cuda(
+            act=quantized_x, wgt=self.qweight, out=output, ascales=ascales, wscales=self.wscales,
+            lora_act_in=lora_act, lora_up=self.proj_up, bias=self.bias, fp4=False, alpha=self.wtscale,
+            wcscales=self.wcscales, act_unsigned=self.act_unsigned,
+        )
+        return output
+
+    def __repr__(self):
+        return (
+            f"SVDQW4A4Linear(in_features={self.in_features}, out_features={self.out_features}, "
+            f"rank={self.rank}, precision={self.precision}, act_unsigned={self.act_unsigned})"
+        )

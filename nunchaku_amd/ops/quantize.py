@@ -1,0 +1,43 @@
+"""Activation quantiser wrapper (reference: nunchaku/ops/quantize.py:11-81)."""
+
+from __future__ import annotations
+
+import torch
+
+from .._C import ops
+from ..utils import ceil_divide
+
+
+def svdq_quantize_w4a4_act_fuse_lora_cuda(
+    input: torch.Tensor,
+    output: torch.Tensor | None = None,
+    oscales: torch.Tensor | None = None,
+    lora_down: torch.Tensor | None = None,
+    lora_act_out: torch.Tensor | None = None,
+    smooth: torch.Tensor | None = None,
+    fuse_glu: bool = False,
+    fp4: bool = False,
+    pad_size: int = 256,
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """4-bit quantisation of ``input`` [M, K] plus the low-rank down projection.
+
+    Returns ``(output [M_pad, K/2] uint8, oscales [K/64, M_pad], lora_act_out [M_pad, R] float32)``
+    with ``M_pad = ceil(M / pad_size) * pad_size``.  The three buffers are opaque (tile order of
+    this library); only their shapes follow the reference.
+    """
+    if fp4:
+        raise NotImplementedError("NVFP4 is not available on MI355X")
+    M, K = input.shape
+    R = lora_down.shape[1]
+    M_pad = ceil_divide(M, pad_size) * pad_size
+    dev = input.device
+    if output is None:
+        output = torch.empty(M_pad, K // 2, dtype=torch.uint8, device=dev)
+    if oscales is None:
+        if K % 64:
+            raise ValueError("K must be a multiple of 64")
+        oscales = torch.empty(K // 64, M_pad, dtype=input.dtype, device=dev)
+    if lora_act_out is None:
+        lora_act_out = torch.empty(M_pad, R, dtype=torch.float32, device=dev)
+    ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4)
+    return output, oscales, lora_act_out

@@ -1,0 +1,602 @@
+"""CPU oracle for the SVDQuant W4A4 + low-rank hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``nunchaku_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and only as the checker.
+
+It restates, in numpy, the arithmetic of the reference's CUDA kernels
+(/root/reference, nunchaku v1.2.0dev).  Each function cites the reference
+file:line it follows.
+
+Parity pin
+----------
+The reference has NO kernel-level golden vectors or known-answer tests for
+this path and its extension cannot be built here
+(CUDA/PTX only).  What IS pinned against the reference's own code:
+
+* every tensor *layout* codec below is checked against the reference's
+  ``nunchaku/lora/flux/packer.py`` (imported by path in this container, see
+  ``tools/make_golden.py``); the resulting fixtures live in ``tests/golden``.
+
+The *arithmetic* (quantiser, per-group dequant, epilogues) is restated from
+the CUDA source by reading it: **arithmetic parity is unpinned** by any
+reference-run output (no NVIDIA GPU, no checkpoints).  The PTX approximations
+``rcp.approx``, ``rsqrt.approx``, ``tanh.approx``, ``ex2.approx`` and
+``__fdividef`` have no CPU twin; the oracle uses exact IEEE math in their
+place (documented per function).
+
+Conventions
+-----------
+16-bit tensors ("half_t" in the reference: bf16 or fp16) are carried as
+float32 numpy arrays whose values are exactly representable in that 16-bit
+type; ``round16(x, dtype)`` performs the round-to-nearest-even conversion.
+Packed on-device tensors are numpy ``int8``/``uint8``/``uint16`` arrays.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+GROUP = 64  # INT4 group size (gemm_base.cuh:89-95: WARP_K = 64 = one k-iteration)
+PAD_M = 256  # BLOCK_M (gemm_base.cuh:34-41); Linear.cpp:445-446
+PAD_N = 128  # BLOCK_N; Linear.cpp:92-93
+GELU_SHIFT = 0.171875  # gemm_w4a4_launch_impl.cuh:286
+RMS_EPS = 1e-6  # gemm_w4a4_launch_impl.cuh:374
+
+
+# --------------------------------------------------------------------------
+# 16-bit helpers
+# --------------------------------------------------------------------------
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """float32 -> nearest-even bfloat16, returned as float32."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    u = x.view(np.uint32).astype(np.uint64)
+    bias = ((u >> 16) & 1) + 0x7FFF
+    r = ((u + bias) & 0xFFFF0000).astype(np.uint32)
+    out = r.view(F32).copy()
+    nan = np.isnan(x)
+    if nan.any():
+        out[nan] = np.nan
+    return out.reshape(x.shape)
+
+
+def fp16_round(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        return np.asarray(x, dtype=F32).astype(np.float16).astype(F32)
+
+
+def round16(x: np.ndarray, dtype: str) -> np.ndarray:
+    if dtype == "bf16":
+        return bf16_round(x)
+    if dtype == "fp16":
+        return fp16_round(x)
+    raise ValueError(dtype)
+
+
+def to_bits16(x: np.ndarray, dtype: str) -> np.ndarray:
+    """Exactly-representable float32 -> raw 16-bit storage (uint16)."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    if dtype == "bf16":
+        return (x.view(np.uint32) >> 16).astype(np.uint16)
+    return x.astype(np.float16).view(np.uint16)
+
+
+def from_bits16(b: np.ndarray, dtype: str) -> np.ndarray:
+    b = np.ascontiguousarray(b, dtype=np.uint16)
+    if dtype == "bf16":
+        return (b.astype(np.uint32) << 16).view(F32)
+    return b.view(np.float16).astype(F32)
+
+
+def ceil_div(a: int, b: int) -> int:
+    return (a + b - 1) // b
+
+
+# --------------------------------------------------------------------------
+# Reference ("on-disk") tensor layouts.  packer.py:187-301,362-437 and the
+# device-side consumers gemm_base.cuh:265-355, lora.cuh:43-59.
+# --------------------------------------------------------------------------
+def _qweight_index(N: int, K: int):
+    """For every (n, k) return (word index, nibble index) in the reference qweight.
+
+    packer.py:187-239 (pack_weight): view (n_tiles, 8, 2, 8, 1, k_tiles, 1, 2, 4, 8),
+    permute(0, 5, 6, 1, 3, 8, 2, 7, 4, 9); consumed by load_wgt, gemm_base.cuh:278-294.
+    """
+    n = np.arange(N)[:, None]
+    k = np.arange(K)[None, :]
+    nt, n_in = n // 128, n % 128
+    npk, n16 = n_in // 16, n_in % 16
+    n_pack, n_lane = n16 // 8, n16 % 8  # n = np*16 + n_pack*8 + n_lane
+    kt, k_in = k // 64, k % 64
+    k_pack, k32 = k_in // 32, k_in % 32
+    k_lane, r = k32 // 8, k32 % 8  # k = kt*64 + k_pack*32 + k_lane*8 + r
+    KT = K // 64
+    lane = n_lane * 4 + k_lane
+    j = n_pack * 2 + k_pack
+    word = (((nt * KT + kt) * 8 + npk) * 32 + lane) * 4 + j
+    word = np.broadcast_to(word, (N, K))
+    nib = np.broadcast_to(r, (N, K))
+    return word, nib
+
+
+def pack_qweight_ref(q: np.ndarray) -> np.ndarray:
+    """int values in [-8, 7], shape [N, K] -> reference packed int8 [N, K/2]."""
+    N, K = q.shape
+    assert N % 128 == 0 and K % 128 == 0, "packer.py:207-212"
+    word, nib = _qweight_index(N, K)
+    words = np.zeros(N * K // 8, dtype=np.uint32)
+    np.bitwise_or.at(words, word.ravel(), ((q.astype(np.int64) & 0xF) << (4 * nib)).astype(np.uint32).ravel())
+    return words.view(np.int8).reshape(N, K // 2)
+
+
+def unpack_qweight_ref(packed: np.ndarray) -> np.ndarray:
+    """reference packed int8 [N, K/2] -> int8 values [N, K] (two's-complement s4)."""
+    N, Kh = packed.shape
+    K = Kh * 2
+    words = np.ascontiguousarray(packed).view(np.uint32).ravel()
+    word, nib = _qweight_index(N, K)
+    v = (words[word] >> (4 * nib).astype(np.uint32)) & 0xF
+    v = v.astype(np.int8)
+    v[v >= 8] -= 16
+    return v
+
+
+def _scale_perm128():
+    """Position inside one 128-channel block for the packed 16-bit scale vectors.
+
+    packer.py:241-301 (pack_scale): reshape(n/128, 1, 8, 2, 4, 2, G), permute(0,6,1,2,4,3,5);
+    consumed by load_wscale/broadcast_wscale, gemm_base.cuh:97-132,315-340.
+    Returns src[n_pos] = logical channel stored at packed position n_pos.
+    """
+    pos = np.arange(128)
+    lane, e = pos // 4, pos % 4
+    return (lane // 4) * 16 + (e // 2) * 8 + (lane % 4) * 2 + e % 2
+
+
+def pack_wscales_ref(ws: np.ndarray) -> np.ndarray:
+    """logical [G, N] -> packed storage [G, N] (flat order ((nt*G+g)*128 + pos))."""
+    G, N = ws.shape
+    src = _scale_perm128()
+    blk = ws.reshape(G, N // 128, 128)[:, :, src]  # [G, nt, pos]
+    return np.ascontiguousarray(blk.transpose(1, 0, 2)).reshape(G, N)
+
+
+def unpack_wscales_ref(packed: np.ndarray) -> np.ndarray:
+    G, N = packed.shape
+    src = _scale_perm128()
+    blk = packed.reshape(N // 128, G, 128)  # [nt, g, pos]
+    out = np.empty((G, N // 128, 128), dtype=packed.dtype)
+    out[:, :, src] = blk.transpose(1, 0, 2)
+    return out.reshape(G, N)
+
+
+def pack_vec_ref(v: np.ndarray) -> np.ndarray:
+    """bias / smooth_factor [N]: same intra-128 permutation with G = 1 (gemm_base.cuh:713)."""
+    return pack_wscales_ref(v.reshape(1, -1)).reshape(-1)
+
+
+def unpack_vec_ref(v: np.ndarray) -> np.ndarray:
+    return unpack_wscales_ref(v.reshape(1, -1)).reshape(-1)
+
+
+def _lowrank_index(C: int, R: int):
+    """(c, r) -> flat position of the packed low-rank weights.
+
+    packer.py:362-398 (pack_lowrank_weight), lora.cuh:43-59 (load_lora_wgt): 16x16 tiles in
+    mma m16n8k16 fragment order:  flat = ((cp*RP + rp)*32 + lane)*8 + h,
+    lane = nl*4 + kl, h = (nps*2 + kps)*2 + rk.
+    ``c`` is the 16-tiled "n" axis, ``r`` the 16-tiled "k" axis of the fragment.
+    """
+    c = np.arange(C)[:, None]
+    r = np.arange(R)[None, :]
+    cp, c16 = c // 16, c % 16
+    nps, nl = c16 // 8, c16 % 8
+    rp, r16 = r // 16, r % 16
+    kps, r8 = r16 // 8, r16 % 8
+    kl, rk = r8 // 2, r8 % 2
+    RP = R // 16
+    lane = nl * 4 + kl
+    h = (nps * 2 + kps) * 2 + rk
+    return np.broadcast_to(((cp * RP + rp) * 32 + lane) * 8 + h, (C, R))
+
+
+def pack_lowrank_ref(w: np.ndarray, down: bool) -> np.ndarray:
+    """Logical low-rank weight -> packed storage.
+
+    up   (down=False): logical [N, R] (out-channel, rank) -> stored shape [N, R].
+    down (down=True):  logical [R, K] (rank, in-channel)  -> stored shape [K, R]
+    (packer.py:378-386: for ``down`` the fragment "n" axis is the rank and the tile
+    order is k-major).
+    """
+    if not down:
+        N, R = w.shape
+        idx = _lowrank_index(N, R)
+        out = np.empty(N * R, dtype=w.dtype)
+        out[idx.ravel()] = w.ravel()
+        return out.reshape(N, R)
+    R, K = w.shape
+    # fragment n-axis = r, k-axis = k; tiles ordered (k_pack, r_pack)
+    r = np.arange(R)[:, None]
+    k = np.arange(K)[None, :]
+    rp, r16 = r // 16, r % 16
+    nps, nl = r16 // 8, r16 % 8
+    kp, k16 = k // 16, k % 16
+    kps, k8 = k16 // 8, k16 % 8
+    kl, rk = k8 // 2, k8 % 2
+    RP = R // 16
+    lane = nl * 4 + kl
+    h = (nps * 2 + kps) * 2 + rk
+    idx = np.broadcast_to(((kp * RP + rp) * 32 + lane) * 8 + h, (R, K))
+    out = np.empty(R * K, dtype=w.dtype)
+    out[idx.ravel()] = w.ravel()
+    return out.reshape(K, R)
+
+
+def unpack_lowrank_ref(p: np.ndarray, down: bool) -> np.ndarray:
+    """Inverse of :func:`pack_lowrank_ref` (packer.py:400-437)."""
+    if not down:
+        N, R = p.shape
+        idx = _lowrank_index(N, R)
+        return p.ravel()[idx]
+    K, R = p.shape
+    r = np.arange(R)[:, None]
+    k = np.arange(K)[None, :]
+    rp, r16 = r // 16, r % 16
+    nps, nl = r16 // 8, r16 % 8
+    kp, k16 = k // 16, k % 16
+    kps, k8 = k16 // 8, k16 % 8
+    kl, rk = k8 // 2, k8 % 2
+    RP = R // 16
+    lane = nl * 4 + kl
+    h = (nps * 2 + kps) * 2 + rk
+    idx = np.broadcast_to(((kp * RP + rp) * 32 + lane) * 8 + h, (R, K))
+    return p.ravel()[idx]
+
+
+def pack_rotemb_ref(rot: np.ndarray) -> np.ndarray:
+    """[M, 64, 2] (sin, cos) float32 -> packed [M, 128] (models/embeddings.py:100-138;
+    consumed by load_rotemb, epilogues.cuh:281-305)."""
+    M = rot.shape[0]
+    D = rot.shape[1] * 2
+    x = rot.reshape(M // 16, 16, D // 8, 8).transpose(0, 2, 1, 3)
+    x = x.reshape(M // 16, D // 8, 2, 8, 4, 2).transpose(0, 1, 3, 4, 2, 5)
+    return np.ascontiguousarray(x).reshape(M, D)
+
+
+def unpack_rotemb_ref(packed: np.ndarray) -> np.ndarray:
+    M, D = packed.shape
+    x = packed.reshape(M // 16, D // 8, 8, 4, 2, 2).transpose(0, 1, 4, 2, 3, 5)
+    x = x.reshape(M // 16, D // 8, 16, 8).transpose(0, 2, 1, 3)
+    return np.ascontiguousarray(x).reshape(M, D // 2, 2)
+
+
+# --------------------------------------------------------------------------
+# Activation quantiser (+ fused low-rank down projection)
+# --------------------------------------------------------------------------
+def quantize_rows(xh: np.ndarray, dtype: str, unsigned: bool):
+    """Per (row, 64-channel group) 4-bit quantisation of an already smoothed 16-bit matrix.
+
+    gemm_w4a4.cuh:429-523 (quantize_w4a4_from_fpsum_warp):
+      amax  = max |x| over the group, in the 16-bit type            (:453-467)
+      scale = float(amax) * (1/7)   [or 1/15 unsigned], fp32        (:469-473)
+      stored ascale = half_t(scale)                                 (:474-477)
+      q = sat_s4|u4( rni( float(x) * rcp(scale) ) ), the UNROUNDED fp32 scale (:479-495;
+          cvt.rni + cvt.pack.sat, gemm_utils.cuh:209-229)
+    rcp.approx.ftz is replaced by the IEEE reciprocal 1.0f/scale.  A zero group gives
+    scale 0 -> rcp = inf -> 0*inf = NaN -> cvt.rni(NaN) = 0, i.e. code 0.
+
+    Returns (codes int8 [M, K], ascales float32-valued-16-bit [K/64, M]).
+    """
+    M, K = xh.shape
+    G = K // GROUP
+    xg = xh.reshape(M, G, GROUP).astype(F32)
+    amax = np.abs(xg).max(axis=2)  # exact in the 16-bit type
+    recip_q = F32(1.0) / F32(15.0 if unsigned else 7.0)
+    scale = (amax.astype(F32) * recip_q).astype(F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rscale = (F32(1.0) / scale).astype(F32)
+        v = (xg * rscale[:, :, None]).astype(F32)
+        q = np.rint(v)
+    q = np.where(np.isnan(q), 0.0, q)
+    lo, hi = (0, 15) if unsigned else (-8, 7)
+    q = np.clip(q, lo, hi).astype(np.int8).reshape(M, K)
+    ascales = round16(scale, dtype).T.copy()  # [G, M]
+    return q, ascales
+
+
+def lora_down_project(x16: np.ndarray, lora_down: np.ndarray) -> np.ndarray:
+    """lora_act[M, R] = x @ lora_down, 16-bit operands, fp32 accumulate
+    (lora.cuh:253-339 EpilogueLoraDown; fp32 atomics across CTAs :82-94).  The oracle sums in
+    float64 and rounds once to fp32 (the reference's summation order is not defined)."""
+    return (x16.astype(np.float64) @ lora_down.astype(np.float64)).astype(F32)
+
+
+def quantize_w4a4_act_fuse_lora(
+    x: np.ndarray,
+    smooth: np.ndarray | None,
+    lora_down: np.ndarray | None,
+    dtype: str = "bf16",
+    pad_size: int = PAD_M,
+    fuse_glu: bool = False,
+):
+    """kernels::quantize_w4a4_act_fuse_lora  (gemm_w4a4.cuh:1097-1184; launch
+    gemm_w4a4_launch_impl.cuh:451-521; caller Linear.cpp:444-502, ops/quantize.py:11-81).
+
+    x         : [M, K] 16-bit input (float32 carrier)
+    smooth    : [K] 16-bit smoothing factor (logical order) or None
+    lora_down : [K, R] 16-bit LOGICAL down projection (x @ lora_down) or None
+
+    Steps: rows padded with zeros to M_pad (load_act_to_fpsum zero-fill, gemm_base.cuh:591-646);
+    lora_act = x @ lora_down on the UN-smoothed input (gemm_w4a4.cuh:1159-1171);
+    x_hat = round16(x / smooth) with an fp32 divide (h2div, gemm_utils.cuh:329-344; the
+    reference uses __fdividef, the oracle IEEE division), shift = 0 (:1181);
+    then :func:`quantize_rows` (signed).
+    Returns (codes int8 [M_pad, K], ascales [K/64, M_pad], lora_act f32 [M_pad, R]).
+    """
+    M, K = x.shape
+    if fuse_glu:
+        raise NotImplementedError("fuse_glu is not on the FLUX path (SURVEY.md §8a)")
+    M_pad = ceil_div(M, pad_size) * pad_size
+    xp = np.zeros((M_pad, K), dtype=F32)
+    xp[:M] = x
+    lora_act = None
+    if lora_down is not None:
+        lora_act = lora_down_project(xp, lora_down)
+    if smooth is not None:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            xh = round16((xp / smooth.astype(F32)[None, :]).astype(F32), dtype)
+    else:
+        xh = xp
+    q, ascales = quantize_rows(xh, dtype, unsigned=False)
+    return q, ascales, lora_act
+
+
+# --------------------------------------------------------------------------
+# GEMM + epilogues
+# --------------------------------------------------------------------------
+def int_group_dot(qa: np.ndarray, qw: np.ndarray) -> np.ndarray:
+    """psum[g, m, n] = sum_{k in group g} qa[m, k] * qw[n, k]  (int32)
+    gemm_w4a4.cuh:408-426 (mma m16n8k64 s4|u4 x s4 -> s32), :721-735."""
+    M, K = qa.shape
+    N = qw.shape[0]
+    G = K // GROUP
+    a = qa.reshape(M, G, GROUP).astype(np.float64)
+    w = qw.reshape(N, G, GROUP).astype(np.float64)
+    # products are tiny integers: float64 matmul is exact and uses BLAS
+    return np.einsum("mgk,ngk->gmn", a, w, optimize=True).astype(np.int32)
+
+
+def gelu_tanh(x: np.ndarray) -> np.ndarray:
+    """gemm_utils.cuh:305-312 (gelu_half2): x*(0.5 + 0.5*tanh(0.79788456*(x + 0.044715*x^3)))
+    in fp32; tanh.approx replaced by exact tanh."""
+    x = x.astype(F32)
+    x3 = (x * x * x).astype(F32)
+    inner = (F32(0.79788456) * (x + F32(0.044715) * x3)).astype(F32)
+    t = (F32(0.5) + F32(0.5) * np.tanh(inner).astype(F32)).astype(F32)
+    return (x * t).astype(F32)
+
+
+def silu(x: np.ndarray) -> np.ndarray:
+    """gemm_base.cuh:783-792, gemm_utils.cuh:280-293,314-319: x*sigmoid(x) in fp32
+    (ex2.approx/rcp.approx replaced by exact math)."""
+    x = x.astype(np.float64)
+    return (x / (1.0 + np.exp(-x))).astype(F32)
+
+
+def rmsnorm_rope(y16: np.ndarray, norm_q, norm_k, rot: np.ndarray, dtype: str) -> np.ndarray:
+    """Epilogues::EpilogueRMSNormRope (epilogues.cuh:269-425).
+
+    y16    : [M, N] 16-bit QKV projection, N = 3 * heads * 128; the first third is Q, the
+             second K, the last V (untouched) (:414-423).
+    norm_* : [128] 16-bit RMSNorm weights.   rot : [M, 64, 2] fp32 (sin, cos).
+    Per row and head: coef = rsqrt(mean(y^2) + 1e-6) (rsqrt.approx -> exact), y *= coef*w[c]
+    (fp32), adjacent pairs rotated (x, y) -> (x cos - y sin, x sin + y cos) (:343-405), then
+    back to 16-bit.
+    """
+    M, N = y16.shape
+    H3 = N // 128
+    assert H3 % 3 == 0
+    y = y16.astype(F32).reshape(M, H3, 128).copy()
+    sin = rot[:, :, 0].astype(F32)[:, None, :]
+    cos = rot[:, :, 1].astype(F32)[:, None, :]
+    for part, w in ((0, norm_q), (1, norm_k)):
+        sl = slice(part * H3 // 3, (part + 1) * H3 // 3)
+        blk = y[:, sl, :]
+        sq = (blk.astype(np.float64) ** 2).sum(axis=2).astype(F32)
+        coef = (F32(1.0) / np.sqrt((sq / F32(128.0) + F32(RMS_EPS)).astype(F32))).astype(F32)
+        blk = (blk * (coef[:, :, None] * w.astype(F32)[None, None, :]).astype(F32)).astype(F32)
+        xe, xo = blk[:, :, 0::2], blk[:, :, 1::2]
+        re = (xe * cos - xo * sin).astype(F32)
+        ro = (xe * sin + xo * cos).astype(F32)
+        out = np.empty_like(blk)
+        out[:, :, 0::2], out[:, :, 1::2] = re, ro
+        y[:, sl, :] = out
+    return round16(y.reshape(M, N), dtype)
+
+
+def gemm_w4a4(
+    qa: np.ndarray,
+    ascales: np.ndarray,
+    qw: np.ndarray,
+    wscales: np.ndarray,
+    *,
+    dtype: str = "bf16",
+    bias: np.ndarray | None = None,
+    lora_act_in: np.ndarray | None = None,
+    lora_up: np.ndarray | None = None,
+    lora_scales=None,
+    fuse: str = "none",  # none | silu | gelu_quant | rmsnorm_rope
+    next_smooth: np.ndarray | None = None,
+    next_lora_down: np.ndarray | None = None,
+    norm_q=None,
+    norm_k=None,
+    rot=None,
+    accum: str = "fp32",  # "fp32": exact accumulation ; "ref16": the reference's 16-bit chain
+):
+    """kernels::gemm_w4a4 (gemm_w4a4_launch_impl.cuh:7-424) with the epilogue chain
+    Bias -> LoraUp -> Mid(Gelu|Silu|Nop) -> [LoraDown] -> Next(Default|Quantize|RMSNormRope)
+    (:172-280, 282-423).
+
+    qa [M, K] int8 codes (signed, or unsigned when the producer was the GELU epilogue),
+    ascales [K/64, M], qw [N, K] int8, wscales [K/64, N], bias [N], lora_act_in f32 [M, R],
+    lora_up [N, R] logical.  Everything 16-bit is a float32 carrier.
+
+    accum="fp32": lin = sum_g as*ws*psum + bias + lora, exact (float64) then ONE rounding to
+                  16-bit -- what the MI355X kernel implements (fp32 accumulators).
+    accum="ref16": emulates gemm_base.cuh:367-409 -- fsum = fma16(cvt16(psum), mul16(as, ws),
+                  fsum) sequentially over groups in the 16-bit type (USE_FP32_ACCUM=false,
+                  gemm_w4a4.cuh:1080), bias add in 16-bit (gemm_base.cuh:717-767), low-rank
+                  in fp32 then back to 16-bit (lora.cuh:145-158,221).
+
+    Returns a dict with "out" (16-bit, [M, N]) or, for fuse="gelu_quant",
+    "qout" (uint4 codes int8 [M, N]), "oscales" [N/64, M], "lora_act_out" f32 [M, R'].
+    """
+    M, K = qa.shape
+    N = qw.shape[0]
+    G = K // GROUP
+    psum = int_group_dot(qa, qw)  # [G, M, N]
+    as_ = ascales.astype(F32)  # [G, M]
+    ws_ = wscales.astype(F32)  # [G, N]
+
+    if accum == "fp32":
+        lin = np.einsum("gmn,gm,gn->mn", psum.astype(np.float64), as_.astype(np.float64), ws_.astype(np.float64))
+        if bias is not None:
+            lin = lin + bias.astype(np.float64)[None, :]
+        if lora_up is not None:
+            R = lora_up.shape[1]
+            sc = np.ones(ceil_div(R, 16), dtype=F32) if lora_scales is None else np.asarray(lora_scales, dtype=F32)
+            la = (lora_act_in.astype(F32) * np.repeat(sc, 16)[None, :R]).astype(F32)
+            la16 = round16(la, dtype)  # lora.cuh:145-158: fp32 act * scale -> 16-bit
+            lin = lin + la16.astype(np.float64) @ lora_up.astype(np.float64).T
+        y16 = round16(lin.astype(F32), dtype)
+    elif accum == "ref16":
+        fsum = np.zeros((M, N), dtype=F32)
+        for g in range(G):
+            p16 = round16(psum[g].astype(F32), dtype)  # int2half2
+            s16 = round16((as_[g][:, None] * ws_[g][None, :]).astype(F32), dtype)  # __hmul2
+            fsum = round16((p16.astype(np.float64) * s16.astype(np.float64) + fsum.astype(np.float64)).astype(F32), dtype)
+        if bias is not None:
+            fsum = round16((fsum + bias.astype(F32)[None, :]).astype(F32), dtype)
+        if lora_up is not None:
+            R = lora_up.shape[1]
+            sc = np.ones(ceil_div(R, 16), dtype=F32) if lora_scales is None else np.asarray(lora_scales, dtype=F32)
+            la16 = round16((lora_act_in.astype(F32) * np.repeat(sc, 16)[None, :R]).astype(F32), dtype)
+            f32 = fsum.astype(np.float64) + la16.astype(np.float64) @ lora_up.astype(np.float64).T
+            fsum = round16(f32.astype(F32), dtype)
+        y16 = fsum
+    else:
+        raise ValueError(accum)
+
+    if fuse == "none":
+        out = y16
+        if dtype == "fp16":  # EpilogueDefault clamp, gemm_base.cuh:689-695
+            out = np.clip(out, -65504.0, 65504.0)
+        return {"out": out}
+    if fuse == "silu":
+        return {"out": round16(silu(y16), dtype)}
+    if fuse == "rmsnorm_rope":
+        return {"out": rmsnorm_rope(y16, norm_q, norm_k, rot, dtype)}
+    if fuse == "gelu_quant":
+        # EpilogueGelu (epilogues.cuh:22-44) -> 16-bit
+        g16 = round16(gelu_tanh(y16), dtype)
+        res = {}
+        if next_lora_down is not None:
+            # EpilogueLoraDown on the GELU output, before shift/smooth (launch_impl.cuh:226-262)
+            res["lora_act_out"] = lora_down_project(g16, next_lora_down)
+        # EpilogueQuantize<false, unsigned=true> (gemm_w4a4.cuh:945-1021): 16-bit add of the
+        # shift (:986), fp32 divide by smooth -> 16-bit (:990-993), then the group quantiser.
+        sh = round16((g16 + F32(GELU_SHIFT)).astype(F32), dtype)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            xh = round16((sh / next_smooth.astype(F32)[None, :]).astype(F32), dtype)
+        q, osc = quantize_rows(xh, dtype, unsigned=True)
+        res["qout"], res["oscales"] = q, osc
+        return res
+    raise ValueError(fuse)
+
+
+# --------------------------------------------------------------------------
+# Whole layers (callers: nunchaku/models/linear.py:161-268, nunchaku/ops/fused.py:14-79)
+# --------------------------------------------------------------------------
+def svdq_linear(x, layer: dict, dtype="bf16", accum="fp32", fuse="none", **kw):
+    """SVDQW4A4Linear.forward (linear.py:161-188): quantize -> gemm.  ``layer`` holds LOGICAL
+    tensors: qweight int8 [N,K], wscales [G,N], bias [N]|None, smooth [K], proj_down [K,R],
+    proj_up [N,R]."""
+    M = x.shape[0]
+    q, asc, la = quantize_w4a4_act_fuse_lora(x, layer["smooth"], layer["proj_down"], dtype)
+    r = gemm_w4a4(
+        q, asc, layer["qweight"], layer["wscales"], dtype=dtype, bias=layer.get("bias"),
+        lora_act_in=la, lora_up=layer["proj_up"], accum=accum, fuse=fuse, **kw,
+    )
+    if "out" in r:
+        r["out"] = r["out"][:M]
+    return r
+
+
+def fused_gelu_mlp(x, fc1: dict, fc2: dict, dtype="bf16", accum="fp32"):
+    """ops/fused.py:14-79: fc1 GEMM with GELU + unsigned requant + fc2's low-rank down
+    projection fused, then fc2 with act_unsigned=True."""
+    M = x.shape[0]
+    q, asc, la = quantize_w4a4_act_fuse_lora(x, fc1["smooth"], fc1["proj_down"], dtype)
+    r = gemm_w4a4(
+        q, asc, fc1["qweight"], fc1["wscales"], dtype=dtype, bias=fc1.get("bias"), lora_act_in=la,
+        lora_up=fc1["proj_up"], accum=accum, fuse="gelu_quant", next_smooth=fc2["smooth"],
+        next_lora_down=fc2["proj_down"],
+    )
+    o = gemm_w4a4(
+        r["qout"], r["oscales"], fc2["qweight"], fc2["wscales"], dtype=dtype, bias=fc2.get("bias"),
+        lora_act_in=r["lora_act_out"], lora_up=fc2["proj_up"], accum=accum,
+    )
+    return o["out"][:M]
+
+
+# --------------------------------------------------------------------------
+# Synthetic SVDQuant layers (SURVEY.md §8d "synthetic inputs")
+# --------------------------------------------------------------------------
+def make_svdq_layer(K: int, N: int, R: int = 32, seed: int = 0, dtype: str = "bf16", bias: bool = True,
+                    cheap: bool = False) -> dict:
+    """W ~ N(0, 0.02^2) [N, K]; smooth ~ exp(N(0, 0.5^2)); W_hat = W*diag(smooth); rank-R
+    truncated SVD -> L1 [K, R], L2 [R, N]; residual -> symmetric s4, group 64, scale = amax/7.
+    proj_down = L1 / smooth (it is applied to the raw x), proj_up = L2^T.  ``cheap`` replaces
+    the SVD by a random rank-R factor pair (for big shapes in benches)."""
+    rng = np.random.default_rng(seed)
+    W = (rng.standard_normal((N, K)) * 0.02).astype(F32)
+    smooth = round16(np.exp(rng.standard_normal(K) * 0.5).astype(F32), dtype)
+    What = W * smooth[None, :]
+    if cheap:
+        L2t = (rng.standard_normal((N, R)) * 0.02).astype(F32)
+        L1 = (rng.standard_normal((K, R)) * 0.05).astype(F32)
+        low = L2t @ L1.T
+    else:
+        U, S, Vt = np.linalg.svd(What.astype(np.float64), full_matrices=False)
+        L2t = (U[:, :R] * np.sqrt(S[:R])).astype(F32)  # [N, R]
+        L1 = (Vt[:R].T * np.sqrt(S[:R])).astype(F32)  # [K, R]
+        low = L2t @ L1.T
+    res = What - low
+    G = K // GROUP
+    rg = res.reshape(N, G, GROUP)
+    amax = np.abs(rg).max(axis=2)
+    ws = round16((amax / 7.0).astype(F32), dtype)  # [N, G]
+    ws = np.where(ws == 0, F32(1.0), ws)
+    qw = np.clip(np.rint(rg / ws[:, :, None]), -8, 7).astype(np.int8).reshape(N, K)
+    layer = {
+        "qweight": qw,
+        "wscales": ws.T.copy(),  # [G, N]
+        "smooth": smooth,
+        "proj_down": round16((L1 / smooth[:, None]).astype(F32), dtype),  # [K, R]
+        "proj_up": round16(L2t, dtype),  # [N, R]
+        "bias": round16((rng.standard_normal(N) * 0.1).astype(F32), dtype) if bias else None,
+        "dense": W,
+    }
+    return layer
+
+
+def make_activations(M: int, K: int, seed: int = 0, dtype: str = "bf16", positive: bool = False) -> np.ndarray:
+    """x ~ N(0,1) with 1 % outlier channels x20."""
+    rng = np.random.default_rng(1000 + seed)
+    x = rng.standard_normal((M, K)).astype(F32)
+    out = rng.choice(K, size=max(1, K // 100), replace=False)
+    x[:, out] *= 20.0
+    if positive:
+        x = np.abs(x)
+    return round16(x, dtype)

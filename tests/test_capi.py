@@ -1,0 +1,74 @@
+"""The C-ABI library builds, loads and exports every symbol include/svdq_amd.h declares; argument
+validation returns error codes + messages instead of aborting.  No kernel is launched here."""
+
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from nunchaku_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "svdq_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(svdq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(built_lib):
+    lib = C.CDLL(built_lib)
+    names = _declared_symbols()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/svdq_amd.h but not exported"
+    assert set(names) == set(_lib.EXPORTS), "ctypes binding and header disagree"
+
+
+def test_abi_version(built_lib):
+    lib = _lib.load()
+    assert lib.svdq_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_sizes_match_header(built_lib):
+    # 6 pointers + 8 int32 ; 17 pointers + 12 int32
+    assert C.sizeof(_lib.QuantizeArgs) == 6 * 8 + 8 * 4
+    assert C.sizeof(_lib.GemmArgs) == 17 * 8 + 12 * 4
+
+
+def test_validation_errors_are_returned_not_aborted(built_lib):
+    lib = _lib.load()
+    assert lib.svdq_quantize_w4a4_act_fuse_lora(None, None) == 1
+    assert b"NULL" in lib.svdq_last_error()
+    a = _lib.QuantizeArgs()
+    a.x, a.act, a.ascales = 16, 16, 16
+    a.M, a.M_pad, a.K, a.ldx = 10, 100, 128, 128  # M_pad not a multiple of 256
+    assert lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), None) == 1
+    assert b"M_pad" in lib.svdq_last_error()
+    a.M_pad, a.fp4 = 256, 1
+    assert lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), None) == 2  # unsupported
+    g = _lib.GemmArgs()
+    g.act, g.wgt, g.ascales, g.wscales = 16, 16, 16, 16
+    g.M, g.M_pad, g.N, g.K = 256, 256, 100, 128
+    assert lib.svdq_gemm_w4a4(C.byref(g), None) == 1
+    assert b"N=100" in lib.svdq_last_error()
+    g.N, g.fuse = 128, 9
+    assert lib.svdq_gemm_w4a4(C.byref(g), None) == 1
+    assert lib.svdq_repack_qweight(16, 32, 100, 128, None) == 1
+    assert lib.svdq_repack_lowrank(16, 16, 128, 32, 0, None) == 1  # aliasing
+
+
+def test_python_wrappers_raise_without_gpu(built_lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nunchaku_amd.models.linear import SVDQW4A4Linear
+
+    m = SVDQW4A4Linear(128, 128)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, 128, dtype=torch.bfloat16))
+    with pytest.raises(NotImplementedError):
+        SVDQW4A4Linear(128, 128, precision="nvfp4")

@@ -1,0 +1,247 @@
+"""HIP path vs the CPU oracle on identical seeded inputs (run on a real MI355X: pytest -m gpu).
+
+Everything goes through the C ABI (ctypes -> libsvdq_amd.so).  Tolerances:
+  * layout kernels, quantiser codes and scales: BIT-EXACT (integer / specified-op arithmetic);
+  * low-rank projections (fp32 accumulation order differs): rtol 2e-5 of the row's |x|.|w|;
+  * GEMM outputs: 1 ulp of the 16-bit output type against the exact (float64) oracle;
+  * fused GELU -> requantise: codes within +-1 on < 0.5 % of elements (tanhf / rounding-boundary
+    flips), everything downstream checked again with the GPU's own codes fed to the oracle.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svdq_oracle as O
+from tests.helpers import TORCH_DT, assert_close_16, f32, make_module, t16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built_lib):
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from nunchaku_amd import _lib
+
+    _lib.load()
+
+
+# ----------------------------------------------------------------------------- layouts
+def test_repack_kernels_match_reference_packer(golden_dir):
+    from nunchaku_amd import layout
+
+    d = np.load(f"{golden_dir}/qweight_256x384.npz")
+    q = d["logical"]  # [N, K]
+    packed = torch.from_numpy(d["packed"]).cuda()
+    t16w = layout.repack_qweight(packed)
+    # read the T16 order back through the activation unpacker (same tile order, rows = N)
+    codes = layout.unpack_act(t16w.view(torch.uint8), K=q.shape[1], unsigned=False)
+    assert np.array_equal(codes.cpu().numpy(), q)
+
+    d = np.load(f"{golden_dir}/wscales_6x256.npz")
+    got = layout.repack_wscales(torch.from_numpy(d["packed"]).to(torch.bfloat16).cuda())
+    assert np.array_equal(f32(got), d["logical"])
+
+    d = np.load(f"{golden_dir}/vec_256.npz")
+    got = layout.repack_vec(torch.from_numpy(d["packed"]).to(torch.bfloat16).cuda())
+    assert np.array_equal(f32(got), d["logical"])
+
+    d = np.load(f"{golden_dir}/lowrank_128_192_32.npz")
+    up = layout.repack_lowrank(torch.from_numpy(d["up_packed"]).to(torch.bfloat16).cuda(), down=False)
+    assert np.array_equal(f32(up), d["up_logical"])
+    down = layout.repack_lowrank(torch.from_numpy(d["down_packed"]).to(torch.bfloat16).cuda(), down=True)
+    assert np.array_equal(f32(down).reshape(32, 192), d["down_logical"])  # rank-major [r][k]
+
+
+# ----------------------------------------------------------------------------- quantiser
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,K,R", [(256, 256, 32), (300, 384, 32), (1, 128, 16), (513, 3072, 32), (77, 256, 48)])
+def test_quantize_bit_exact(dtype, M, K, R):
+    from nunchaku_amd import layout
+
+    L = O.make_svdq_layer(K, 128, R, seed=M, dtype=dtype, cheap=True)
+    x = O.make_activations(M, K, seed=M, dtype=dtype)
+    mod = make_module(L, dtype)
+    qx, asc, la = mod.quantize(t16(x, dtype))
+    q_ref, asc_ref, la_ref = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"], dtype)
+    M_pad = q_ref.shape[0]
+    assert qx.shape == (M_pad, K // 2) and asc.shape == (K // 64, M_pad) and la.shape == (M_pad, R)
+    codes = layout.unpack_act(qx, K).cpu().numpy()
+    assert np.array_equal(codes, q_ref), f"{(codes != q_ref).sum()} code mismatches"
+    assert np.array_equal(f32(asc), asc_ref)
+    xp = np.zeros((M_pad, K), np.float32)
+    xp[:M] = x
+    bound = 2e-5 * (np.abs(xp) @ np.abs(L["proj_down"])) + 1e-6
+    assert np.all(np.abs(la.cpu().numpy() - la_ref) <= bound)
+    # bit-determinism (the reference's fp32 atomics are not)
+    qx2, asc2, la2 = mod.quantize(t16(x, dtype))
+    assert torch.equal(la, la2) and torch.equal(qx, qx2)
+
+
+def test_quantize_strided_input_and_zero_rows():
+    from nunchaku_amd import layout
+
+    L = O.make_svdq_layer(256, 128, 32, seed=9, cheap=True)
+    x = O.make_activations(64, 256, seed=9)
+    x[10] = 0.0
+    big = torch.zeros(64, 512, dtype=torch.bfloat16, device="cuda")
+    big[:, :256] = t16(x, "bf16")
+    mod = make_module(L, "bf16")
+    qx, asc, la = mod.quantize(big[:, :256])  # row stride 512
+    q_ref, asc_ref, _ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"])
+    assert np.array_equal(layout.unpack_act(qx, 256).cpu().numpy(), q_ref)
+    assert np.array_equal(f32(asc), asc_ref)
+    assert not layout.unpack_act(qx, 256)[10].any()
+
+
+# ----------------------------------------------------------------------------- GEMM
+def _gemm_inputs(M, K, N, R, dtype, seed, unsigned=False, bias=True):
+    L = O.make_svdq_layer(K, N, R, seed=seed, dtype=dtype, bias=bias, cheap=True)
+    x = O.make_activations(M, K, seed=seed, dtype=dtype, positive=unsigned)
+    return L, x
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,K,N,R", [(256, 128, 128, 32), (200, 384, 256, 32), (512, 3072, 384, 32), (33, 256, 128, 16),
+                                     (256, 256, 128, 80)])
+def test_linear_forward_matches_oracle(dtype, M, K, N, R):
+    L, x = _gemm_inputs(M, K, N, R, dtype, seed=K + N)
+    mod = make_module(L, dtype)
+    y = mod(t16(x, dtype).view(1, M, K))
+    assert y.shape == (1, M, N) and y.dtype == TORCH_DT[dtype]
+    ref = O.svdq_linear(x, L, dtype, "fp32")["out"]
+    assert_close_16(f32(y)[0], ref, dtype, "linear", max_bad_frac=0.0, ulps=1.0)
+    # and it sits inside the reference's own 16-bit-accumulation error band
+    ref16 = O.svdq_linear(x, L, dtype, "ref16")["out"]
+    n = np.linalg.norm
+    assert n(f32(y)[0] - ref) <= n(ref16 - ref) + 1e-6
+
+
+def test_linear_no_bias_and_lora_scales():
+    from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
+
+    L, x = _gemm_inputs(256, 256, 128, 32, "bf16", seed=3, bias=False)
+    mod = make_module(L, "bf16")
+    xt = t16(x, "bf16")
+    qx, asc, la = mod.quantize(xt)
+    out = torch.empty(256, 128, dtype=torch.bfloat16, device="cuda")
+    svdq_gemm_w4a4_cuda(act=qx, wgt=mod.qweight, out=out, ascales=asc, wscales=mod.wscales, lora_act_in=la,
+                        lora_up=mod.proj_up, lora_scales=[0.5, 2.0])
+    q, a, l_ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"])
+    ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], lora_act_in=l_, lora_up=L["proj_up"], lora_scales=[0.5, 2.0])["out"]
+    assert_close_16(f32(out), ref, "bf16", "lora_scales")
+
+
+def test_silu_epilogue():
+    from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
+
+    L, x = _gemm_inputs(256, 256, 128, 32, "bf16", seed=4)
+    mod = make_module(L, "bf16")
+    qx, asc, la = mod.quantize(t16(x, "bf16"))
+    out = torch.empty(256, 128, dtype=torch.bfloat16, device="cuda")
+    svdq_gemm_w4a4_cuda(act=qx, wgt=mod.qweight, out=out, ascales=asc, wscales=mod.wscales, lora_act_in=la,
+                        lora_up=mod.proj_up, bias=mod.bias, fuse_silu=True)
+    ref = O.svdq_linear(x, L, "bf16", "fp32", fuse="silu")["out"]
+    assert_close_16(f32(out), ref, "bf16", "silu", max_bad_frac=2e-3, ulps=1.0)
+    assert_close_16(f32(out), ref, "bf16", "silu(2ulp)", ulps=2.0)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,K,H", [(256, 256, 1), (300, 384, 2)])
+def test_qkv_rmsnorm_rope(dtype, M, K, H):
+    from nunchaku_amd.ops.fused import fused_qkv_norm_rottary
+
+    N = 3 * H * 128
+    L, x = _gemm_inputs(M, K, N, 32, dtype, seed=11)
+    rng = np.random.default_rng(12)
+    nq = O.round16((1 + 0.1 * rng.standard_normal(128)).astype(np.float32), dtype)
+    nk = O.round16((1 + 0.1 * rng.standard_normal(128)).astype(np.float32), dtype)
+    M_pad = O.ceil_div(M, 256) * 256
+    ang = rng.uniform(0, 6.28, (M_pad, 64)).astype(np.float32)
+    rot = np.stack([np.sin(ang), np.cos(ang)], axis=-1).astype(np.float32)  # [M_pad, 64, (sin, cos)]
+    mod = make_module(L, dtype)
+
+    class W:  # stands in for torch.nn.RMSNorm: only .weight is read
+        def __init__(self, w):
+            self.weight = t16(w, dtype)
+
+    packed = torch.from_numpy(O.pack_rotemb_ref(rot)).cuda().view(1, M_pad, 128)
+    y = fused_qkv_norm_rottary(t16(x, dtype).view(1, M, K), mod, W(nq), W(nk), packed)
+    q, a, l_ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"], dtype)
+    ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=l_,
+                      lora_up=L["proj_up"], fuse="rmsnorm_rope", norm_q=nq, norm_k=nk, rot=rot)["out"][:M]
+    got = f32(y)[0]
+    # V third: plain linear, 1 ulp; Q/K: fp32 epilogue math after a 16-bit rounding point -> 2 ulp,
+    # with rare 1-ulp flips of the pre-norm value
+    assert_close_16(got[:, 2 * N // 3:], ref[:, 2 * N // 3:], dtype, "V")
+    assert_close_16(got[:, : 2 * N // 3], ref[:, : 2 * N // 3], dtype, "QK", max_bad_frac=2e-3, ulps=2.0)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_fused_gelu_mlp(dtype):
+    from nunchaku_amd import layout
+    from nunchaku_amd.ops.fused import fused_gelu_mlp
+    from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
+
+    M, C, Hd = 300, 256, 512
+    fc1 = O.make_svdq_layer(C, Hd, 32, seed=21, dtype=dtype, cheap=True)
+    fc2 = O.make_svdq_layer(Hd, C, 32, seed=22, dtype=dtype, cheap=True)
+    x = O.make_activations(M, C, seed=23, dtype=dtype)
+    m1, m2 = make_module(fc1, dtype), make_module(fc2, dtype, act_unsigned=True)
+    xt = t16(x, dtype)
+
+    # stage 1: fc1 with the fused GELU -> u4 requantisation -> fc2 low-rank down projection
+    qx, asc, la = m1.quantize(xt)
+    M_pad = qx.shape[0]
+    qh = torch.empty(M_pad, Hd // 2, dtype=torch.uint8, device="cuda")
+    sh = torch.empty(Hd // 64, M_pad, dtype=TORCH_DT[dtype], device="cuda")
+    lh = torch.full((M_pad, 32), 7.0, dtype=torch.float32, device="cuda")  # must be zeroed by the op
+    m2._ensure_layout()
+    svdq_gemm_w4a4_cuda(act=qx, wgt=m1.qweight, qout=qh, ascales=asc, wscales=m1.wscales, oscales=sh, lora_act_in=la,
+                        lora_up=m1.proj_up, lora_down=m2.proj_down, lora_act_out=lh, bias=m1.bias,
+                        smooth_factor=m2.smooth_factor)
+    q, a, l_ = O.quantize_w4a4_act_fuse_lora(x, fc1["smooth"], fc1["proj_down"], dtype)
+    r = O.gemm_w4a4(q, a, fc1["qweight"], fc1["wscales"], dtype=dtype, bias=fc1["bias"], lora_act_in=l_,
+                    lora_up=fc1["proj_up"], fuse="gelu_quant", next_smooth=fc2["smooth"], next_lora_down=fc2["proj_down"])
+    codes = layout.unpack_act(qh, Hd, unsigned=True).cpu().numpy()[:M]
+    diff = np.abs(codes.astype(int) - r["qout"][:M].astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 5e-3, f"code mismatch frac {(diff != 0).mean():.2e} max {diff.max()}"
+    s_got, s_ref = f32(sh)[:, :M], r["oscales"][:, :M]
+    assert (s_got != s_ref).mean() < 5e-3 and np.allclose(s_got, s_ref, rtol=2 ** -6)
+    la_ref = r["lora_act_out"][:M]
+    assert np.allclose(lh.cpu().numpy()[:M], la_ref, rtol=2e-2, atol=2e-2 * np.abs(la_ref).max())
+
+    # stage 2: fc2 on the GPU's own codes must match the oracle GEMM on those codes to 1 ulp
+    out = m2.forward_quant(qh, sh, lh)[:M]
+    ref2 = O.gemm_w4a4(layout.unpack_act(qh, Hd, unsigned=True).cpu().numpy(), f32(sh), fc2["qweight"], fc2["wscales"],
+                       dtype=dtype, bias=fc2["bias"], lora_act_in=lh.cpu().numpy(), lora_up=fc2["proj_up"])["out"][:M]
+    assert_close_16(f32(out), ref2, dtype, "fc2 on GPU codes")
+
+    # end to end through the public wrapper
+    y = f32(fused_gelu_mlp(xt.view(1, M, C), m1, m2))[0]
+    ref = O.fused_gelu_mlp(x, fc1, fc2, dtype)
+    assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 2e-2
+
+
+def test_full_size_properties():
+    """BASELINE shapes (M=4096, FLUX qkv 3072->9216): size-independent properties instead of the
+    slow oracle: linearity in the low-rank branch, determinism, and exact agreement with the oracle
+    on a row sample."""
+    M, K, N, R = 4096, 3072, 9216, 32
+    L = O.make_svdq_layer(K, N, R, seed=0, cheap=True)
+    x = O.make_activations(M, K, seed=0)
+    mod = make_module(L, "bf16")
+    xt = t16(x, "bf16")
+    y1 = mod(xt.view(1, M, K))
+    y2 = mod(xt.view(1, M, K))
+    assert torch.equal(y1, y2)
+    rows = np.array([0, 1, 255, 256, 1000, 2047, 4095])
+    q, a, l_ = O.quantize_w4a4_act_fuse_lora(x[rows], L["smooth"], L["proj_down"])
+    ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], bias=L["bias"], lora_act_in=l_, lora_up=L["proj_up"])["out"][: len(rows)]
+    assert_close_16(f32(y1)[0][rows], ref, "bf16", "full-size row sample")
+
+
+def test_errors_surface_as_exceptions():
+    mod = make_module(O.make_svdq_layer(128, 128, 32, seed=1, cheap=True), "bf16")
+    with pytest.raises(ValueError):
+        mod(torch.zeros(1, 4, 192, dtype=torch.bfloat16, device="cuda"))  # K mismatch / not a multiple of 128

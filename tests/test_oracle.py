@@ -1,0 +1,94 @@
+"""Self-consistency of the CPU oracle (the checker must be trustworthy before it checks anything)."""
+
+import numpy as np
+import pytest
+
+from oracle import svdq_oracle as O
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_quantizer_definition(dtype):
+    x = O.make_activations(40, 256, seed=3, dtype=dtype)
+    smooth = O.round16(np.exp(np.random.default_rng(0).standard_normal(256) * 0.3).astype(np.float32), dtype)
+    q, asc, la = O.quantize_w4a4_act_fuse_lora(x, smooth, None, dtype)
+    assert q.shape == (256, 256) and asc.shape == (4, 256) and la is None
+    assert q.min() >= -7 and q.max() <= 7  # scale = amax/7 never needs -8
+    assert np.all(q[40:] == 0) and np.all(asc[:, 40:] == 0)  # padded rows: zero codes, zero scale
+    # every non-zero group attains |q| == 7 at its absmax element
+    qg = np.abs(q[:40].reshape(40, 4, 64)).max(axis=2)
+    assert np.all(qg[asc[:, :40].T > 0] == 7)
+    # dequantised activations reproduce x/smooth to within half a step (plus the 16-bit scale rounding)
+    xh = O.round16(x / smooth[None, :], dtype)
+    deq = q[:40].reshape(40, 4, 64) * asc[:, :40].T[:, :, None]
+    step = asc[:, :40].T[:, :, None]
+    assert np.all(np.abs(deq - xh.reshape(40, 4, 64)) <= 0.5 * step * 1.02 + 1e-6)
+
+
+def test_zero_input_is_all_zero():
+    x = np.zeros((5, 128), dtype=np.float32)
+    q, asc, _ = O.quantize_w4a4_act_fuse_lora(x, np.ones(128, np.float32), None)
+    assert not q.any() and not asc.any()
+
+
+def test_unsigned_quantizer_range():
+    rng = np.random.default_rng(1)
+    xh = O.bf16_round(np.abs(rng.standard_normal((16, 128))).astype(np.float32))
+    q, asc = O.quantize_rows(xh, "bf16", unsigned=True)
+    assert q.min() >= 0 and q.max() == 15
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_linear_modes_agree_and_track_dense(dtype):
+    L = O.make_svdq_layer(256, 128, 32, seed=0, dtype=dtype)
+    x = O.round16(np.random.default_rng(5).standard_normal((64, 256)).astype(np.float32), dtype)
+    y32 = O.svdq_linear(x, L, dtype, "fp32")["out"]
+    y16 = O.svdq_linear(x, L, dtype, "ref16")["out"]
+    dense = x @ L["dense"].T + L["bias"]
+    n = np.linalg.norm
+    assert n(y32 - y16) / n(y32) < (2e-2 if dtype == "bf16" else 3e-3)  # 16-bit chain vs exact
+    assert n(y32 - dense) / n(dense) < 0.25  # 4-bit x 4-bit noise on random weights
+    # the low-rank branch matters: dropping it must make things worse
+    L0 = dict(L)
+    q, asc, la = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"], dtype)
+    y_nolr = O.gemm_w4a4(q, asc, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"])["out"][:64]
+    assert n(y_nolr - dense) > n(y32 - dense)
+
+
+def test_int_group_dot_exact():
+    rng = np.random.default_rng(2)
+    qa = rng.integers(-8, 8, (8, 128)).astype(np.int8)
+    qw = rng.integers(-8, 8, (16, 128)).astype(np.int8)
+    p = O.int_group_dot(qa, qw)
+    ref = np.einsum("mgk,ngk->gmn", qa.reshape(8, 2, 64).astype(np.int64), qw.reshape(16, 2, 64).astype(np.int64))
+    assert np.array_equal(p, ref)
+
+
+def test_rmsnorm_rope_identity_rotation():
+    rng = np.random.default_rng(3)
+    y = O.bf16_round(rng.standard_normal((16, 384)).astype(np.float32))
+    rot = np.zeros((16, 64, 2), np.float32)
+    rot[:, :, 1] = 1.0  # sin = 0, cos = 1
+    w = np.ones(128, np.float32)
+    out = O.rmsnorm_rope(y, w, w, rot, "bf16")
+    rms = np.sqrt((y[:, :128].astype(np.float64) ** 2).mean(axis=1, keepdims=True) + 1e-6)
+    assert np.allclose(out[:, :128], y[:, :128] / rms, rtol=2 ** -7)
+    assert np.array_equal(out[:, 256:], y[:, 256:])  # V untouched
+
+
+def test_lora_scales_and_rank16():
+    L = O.make_svdq_layer(128, 128, 16, seed=4)
+    x = O.make_activations(8, 128, seed=4)
+    q, asc, la = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"])
+    a = O.gemm_w4a4(q, asc, L["qweight"], L["wscales"], lora_act_in=la, lora_up=L["proj_up"], lora_scales=[0.0])["out"]
+    b = O.gemm_w4a4(q, asc, L["qweight"], L["wscales"])["out"]
+    assert np.array_equal(a, b)
+
+
+def test_fused_mlp_tracks_dense():
+    fc1 = O.make_svdq_layer(128, 256, 32, seed=1)
+    fc2 = O.make_svdq_layer(256, 128, 32, seed=2)
+    x = O.bf16_round(np.random.default_rng(7).standard_normal((32, 128)).astype(np.float32))
+    o = O.fused_gelu_mlp(x, fc1, fc2)
+    h = O.gelu_tanh(x @ fc1["dense"].T + fc1["bias"])
+    ref = h @ fc2["dense"].T + fc2["bias"]
+    assert np.linalg.norm(o - ref) / np.linalg.norm(ref) < 0.5  # two stacked 4-bit layers, random weights
