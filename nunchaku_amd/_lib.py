@@ -3,6 +3,11 @@
 import ctypes as C
 import os
 
+# torch must initialise ITS bundled HIP runtime first: libsvdq_amd.so then binds to the already
+# loaded libamdhip64 (same soname) instead of pulling a second runtime from /opt/rocm, which on a
+# GPU box ends in "no ROCm-capable device is detected" for our launches.
+import torch  # noqa: F401
+
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsvdq_amd.so")
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1

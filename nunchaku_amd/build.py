@@ -9,7 +9,7 @@ SOURCES = ["repack.hip", "quantize.hip", "gemm_w4a4.hip"]
 HEADERS = ["svdq_common.h", os.path.join("..", "..", "include", "svdq_amd.h")]
 # -ffp-contract=off: the quantiser's arithmetic is specified operation by operation;
 # the hot loop uses explicit fma.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 
 def _stale() -> bool:

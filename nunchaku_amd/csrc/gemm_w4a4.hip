@@ -29,8 +29,9 @@
 namespace svdq {
 
 constexpr int BM = 128, BN = 128;
-constexpr int STAGE_BYTES = 4096 + 4096 + 512 + 512;
-constexpr int MAX_LORA_TILES = 16; // R <= 256
+constexpr int KG = 2;                                    // quantisation groups per pipeline stage
+constexpr int STAGE_BYTES = KG * (4096 + 4096 + 512 + 512); // A, W, as, ws per group
+constexpr int MAX_LORA_TILES = 16;                       // R <= 256
 
 struct GemmParams {
     const uint8_t *act;
@@ -81,7 +82,7 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 template <int DT, bool ACT_UNSIGNED, int FUSE>
-__global__ __launch_bounds__(256) void gemm_w4a4_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_w4a4_kernel(const GemmParams p) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE_BYTES];
@@ -95,11 +96,16 @@ __global__ __launch_bounds__(256) void gemm_w4a4_kernel(const GemmParams p) {
     const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
     const int m0 = bm * BM, n0 = bn * BN;
 
+    // ---- operand streams ---------------------------------------------------------------------
+    // one 16-byte load per thread covers a (128 rows x 64 k) block of A and of W; threads 0..127
+    // additionally carry the activation scale of row tid, threads 128..255 the weight scale of
+    // column tid-128 (no branch in the loop: pointer/stride/multiplier are selected once).
     const uint8_t *a_src = p.act + ((size_t)bm * G) * 4096 + tid * 16;
     const uint8_t *w_src = p.wgt + ((size_t)bn * G) * 4096 + tid * 16;
-    const T *as_src = (const T *)p.ascales + m0 + (tid & 127);
-    const T *ws_src = (const T *)p.wscales + n0 + (tid & 127);
-    const float prescale = ACT_UNSIGNED ? (1.0f / 16.0f) : (1.0f / 256.0f);
+    const bool is_as = tid < 128;
+    const T *s_src = is_as ? (const T *)p.ascales + m0 + tid : (const T *)p.wscales + n0 + (tid - 128);
+    const size_t s_stride = is_as ? (size_t)p.M_pad : (size_t)p.N;
+    const float s_mul = is_as ? 1.0f : (ACT_UNSIGNED ? (1.0f / 16.0f) : (1.0f / 256.0f));
 
     v4f acc[4][4];
 #pragma unroll
@@ -107,58 +113,87 @@ __global__ __launch_bounds__(256) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
-    // ---- stage 0 ----
-    uint4 ra = *reinterpret_cast<const uint4 *>(a_src);
-    uint4 rw = *reinterpret_cast<const uint4 *>(w_src);
-    float rs = tid < 128 ? h2f(as_src[0]) : h2f(ws_src[0]) * prescale;
-    {
-        uint8_t *st = lds;
-        *reinterpret_cast<uint4 *>(st + tid * 16) = ra;
-        *reinterpret_cast<uint4 *>(st + 4096 + tid * 16) = rw;
-        reinterpret_cast<float *>(st + 8192)[tid] = rs;
-    }
+    T rs[KG];
+    v4i zero = {0, 0, 0, 0};
+    // A and W tiles go HBM -> LDS by DMA (global_load_lds, 16 B per lane, no VGPR round trip: a
+    // register-staged prefetch is spilled by hipcc and drains vmcnt right behind the loads).  The
+    // LDS image is lane-linear (wave base + lane*16), which is exactly the T16 order.
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto fetch = [&](int g0, uint8_t *st) {
+#pragma unroll
+        for (int u = 0; u < KG; u++) {
+            uint8_t *sg = st + u * (STAGE_BYTES / KG) + wave * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src + (size_t)(g0 + u) * 4096),
+                                             (lds_void *)sg, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_src + (size_t)(g0 + u) * 4096),
+                                             (lds_void *)(sg + 4096), 16, 0, 0);
+            rs[u] = s_src[(size_t)(g0 + u) * s_stride];
+        }
+    };
+    auto commit = [&](uint8_t *st) {
+#pragma unroll
+        for (int u = 0; u < KG; u++)
+            reinterpret_cast<float *>(st + u * (STAGE_BYTES / KG) + 8192)[tid] = h2f(rs[u]) * s_mul;
+    };
+
+    const int NS = G / KG; // K % 128 == 0  ->  G even
+    fetch(0, lds);
+    commit(lds);
     __syncthreads();
 
-    for (int g = 0; g < G; g++) {
-        const uint8_t *st = lds + (g & 1) * STAGE_BYTES;
-        if (g + 1 < G) {
-            ra = *reinterpret_cast<const uint4 *>(a_src + (size_t)(g + 1) * 4096);
-            rw = *reinterpret_cast<const uint4 *>(w_src + (size_t)(g + 1) * 4096);
-            rs = tid < 128 ? h2f(as_src[(size_t)(g + 1) * p.M_pad]) : h2f(ws_src[(size_t)(g + 1) * p.N]) * prescale;
-        }
+    for (int s = 0; s < NS; s++) {
+        const uint8_t *st = lds + (s & 1) * STAGE_BYTES;
+        if (s + 1 < NS) fetch((s + 1) * KG, lds + ((s + 1) & 1) * STAGE_BYTES);
 
-        v4i wf[4], af[4];
-        v4f wsv[4];
-        float asv[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            v2i raw = *reinterpret_cast<const v2i *>(st + 4096 + ((wn * 4 + nt) * 64 + lane) * 8);
-            wf[nt] = unpack_s4x16(raw);
-            wsv[nt] = *reinterpret_cast<const v4f *>(st + 8192 + 512 + (wn * 64 + nt * 16 + lq * 4) * 4);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            v2i raw = *reinterpret_cast<const v2i *>(st + ((wm * 4 + mt) * 64 + lane) * 8);
-            af[mt] = ACT_UNSIGNED ? unpack_u4x16(raw) : unpack_s4x16(raw);
-            asv[mt] = *reinterpret_cast<const float *>(st + 8192 + (wm * 64 + mt * 16 + lr) * 4);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
+        for (int u = 0; u < KG; u++) {
+            const uint8_t *sg = st + u * (STAGE_BYTES / KG);
+            v4i wf[4], af[4];
+            v4f wsv[4];
+            float asv[4];
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) {
-                v4i ps = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[nt], af[mt], v4i{0, 0, 0, 0}, 0, 0, 0);
+                v2i raw = *reinterpret_cast<const v2i *>(sg + 4096 + ((wn * 4 + nt) * 64 + lane) * 8);
+                wf[nt] = unpack_s4x16(raw);
+                wsv[nt] = *reinterpret_cast<const v4f *>(sg + 8192 + 512 + (wn * 64 + nt * 16 + lq * 4) * 4);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                v2i raw = *reinterpret_cast<const v2i *>(sg + ((wm * 4 + mt) * 64 + lane) * 8);
+                af[mt] = ACT_UNSIGNED ? unpack_u4x16(raw) : unpack_s4x16(raw);
+                asv[mt] = *reinterpret_cast<const float *>(sg + 8192 + (wm * 64 + mt * 16 + lr) * 4);
+            }
+            // software pipeline over the 16 MFMA tiles of this group: the matrix pipe works on
+            // tile t+DEPTH while the VALU dequantises tile t (psum ring of DEPTH+1 tiles in VGPRs;
+            // without it hipcc parks all 16 psum tiles in AGPRs and serialises the two phases).
+            constexpr int DEPTH = 3;
+            v4i ps[DEPTH + 1];
+            // The zero C operand is laundered through an empty asm before every MFMA and the freshly
+            // updated accumulators after every dequant step: volatile asms keep their program order,
+            // which pins "MFMA(t+DEPTH); dequant(t)" -- otherwise LLVM hoists all 16 MFMAs to the top
+            // of the group and sinks the 192 dequant ops to the bottom (no overlap, 128 extra VGPRs).
+#pragma unroll
+            for (int t = 0; t < DEPTH; t++) {
+                asm volatile("" : "+v"(zero));
+                ps[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[t & 3], af[t >> 2], zero, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                if (t + DEPTH < 16) {
+                    asm volatile("" : "+v"(zero));
+                    ps[(t + DEPTH) % (DEPTH + 1)] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                        wf[(t + DEPTH) & 3], af[(t + DEPTH) >> 2], zero, 0, 0, 0);
+                }
+                const int mt = t >> 2, nt = t & 3;
+                const v4i q = ps[t % (DEPTH + 1)];
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    acc[mt][nt][r] = __builtin_fmaf((float)ps[r], asv[mt] * wsv[nt][r], acc[mt][nt][r]);
+                    acc[mt][nt][r] = __builtin_fmaf((float)q[r], asv[mt] * wsv[nt][r], acc[mt][nt][r]);
+                asm volatile("" : "+v"(acc[mt][nt]));
             }
         }
 
-        if (g + 1 < G) {
-            uint8_t *sn = lds + ((g + 1) & 1) * STAGE_BYTES;
-            *reinterpret_cast<uint4 *>(sn + tid * 16) = ra;
-            *reinterpret_cast<uint4 *>(sn + 4096 + tid * 16) = rw;
-            reinterpret_cast<float *>(sn + 8192)[tid] = rs;
-        }
+        if (s + 1 < NS) commit(lds + ((s + 1) & 1) * STAGE_BYTES);
         __syncthreads();
     }
 
