@@ -150,6 +150,18 @@ int svdq_repack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_
  * act (this library's tile order) -> one int8 code per element, natural [M_pad, K]. */
 int svdq_unpack_act(const void *act, int8_t *codes, int32_t M_pad, int32_t K, int32_t is_unsigned, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Launch profiler (used by bench.py for the roofline line).  While enabled, every
+ * svdq_gemm_w4a4 / svdq_quantize call brackets its kernel launch with two hipEvents recorded on
+ * the launch stream.  svdq_prof_read synchronises the recorded events and returns, per kernel
+ * class (0 = gemm_w4a4, 1 = quantize), the number of launches, the summed kernel time in
+ * milliseconds and the summed ALGORITHMIC work (gemm: 2*M_pad*N*K + 2*M_pad*N*R operations;
+ * quantize: bytes read + written).  Process-global state, guarded by a mutex; off by default.
+ * ------------------------------------------------------------------------------------------ */
+int svdq_prof_enable(int32_t max_launches); /* 0 disables and frees the event pool */
+int svdq_prof_reset(void);
+int svdq_prof_read(int32_t kernel_class, int64_t *launches, double *total_ms, double *total_work);
+
 /* thread-local message of the last failing call on this thread ("" if none) */
 const char *svdq_last_error(void);
 /* SVDQ_ABI_VERSION the library was built with */

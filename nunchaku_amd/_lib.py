@@ -46,6 +46,9 @@ EXPORTS = {
     "svdq_repack_vec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "svdq_repack_lowrank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_unpack_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "svdq_prof_enable": (C.c_int, [C.c_int32]),
+    "svdq_prof_reset": (C.c_int, []),
+    "svdq_prof_read": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "svdq_last_error": (C.c_char_p, []),
     "svdq_abi_version": (C.c_int, []),
 }

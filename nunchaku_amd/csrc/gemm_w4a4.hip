@@ -524,6 +524,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;
 
     hipStream_t st = (hipStream_t)stream;
+    const int prof = prof_begin(0, 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
     if (a->dtype == SVDQ_BF16) {
         if (a->act_unsigned) launch_fuse<SVDQ_BF16, true>(p, a->fuse, st);
         else launch_fuse<SVDQ_BF16, false>(p, a->fuse, st);
@@ -531,5 +532,6 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         if (a->act_unsigned) launch_fuse<SVDQ_FP16, true>(p, a->fuse, st);
         else launch_fuse<SVDQ_FP16, false>(p, a->fuse, st);
     }
+    prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_gemm_w4a4 launch");
 }

@@ -165,8 +165,16 @@ extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, voi
         set_error("svdq_quantize: x, act, lora_down and smooth must be 16-byte aligned");
         return SVDQ_E_INVALID;
     }
-    if (a->dtype == SVDQ_BF16) return launch_quantize<SVDQ_BF16>(a, (hipStream_t)stream);
-    if (a->dtype == SVDQ_FP16) return launch_quantize<SVDQ_FP16>(a, (hipStream_t)stream);
-    set_error("svdq_quantize: unknown dtype %d", a->dtype);
-    return SVDQ_E_INVALID;
+    if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) {
+        set_error("svdq_quantize: unknown dtype %d", a->dtype);
+        return SVDQ_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // algorithmic bytes: x in, codes + scales + lora_act out, lora_down in (once)
+    const double bytes = (double)a->M * a->K * 2 + (double)a->M_pad * a->K / 2 + (double)a->M_pad * (a->K / 64) * 2 +
+                         (double)a->M_pad * a->R * 4 + (double)a->K * a->R * 2;
+    const int prof = prof_begin(1, bytes, st);
+    int rc = a->dtype == SVDQ_BF16 ? launch_quantize<SVDQ_BF16>(a, st) : launch_quantize<SVDQ_FP16>(a, st);
+    prof_end(prof, st);
+    return rc;
 }

@@ -5,9 +5,33 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <vector>
+
 #include "svdq_common.h"
 
 namespace svdq {
+
+// ---- launch profiler ------------------------------------------------------------------------
+struct ProfRec { hipEvent_t e0, e1; int cls; double work; };
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof_pool;
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+
+int prof_begin(int cls, double work, hipStream_t st) {
+    if (!g_prof_on) return -1;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return -1;
+    int i = (int)g_prof_used++;
+    g_prof_pool[i].cls = cls;
+    g_prof_pool[i].work = work;
+    hipEventRecord(g_prof_pool[i].e0, st);
+    return i;
+}
+void prof_end(int i, hipStream_t st) {
+    if (i >= 0) hipEventRecord(g_prof_pool[i].e1, st);
+}
 
 // ---- thread-local error string -----------------------------------------------------------
 static thread_local char g_err[512] = {0};
@@ -159,6 +183,48 @@ int svdq_unpack_act(const void *act, int8_t *codes, int32_t M_pad, int32_t K, in
     hipLaunchKernelGGL(unpack_act_kernel, dim3(nblk((size_t)M_pad * K, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t *)act, codes, M_pad, K, is_unsigned);
     return hip_check(hipGetLastError(), "svdq_unpack_act launch");
+}
+
+int svdq_prof_enable(int32_t max_launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof_pool) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_prof_pool.clear();
+    g_prof_used = 0;
+    g_prof_on = false;
+    if (max_launches <= 0) return SVDQ_OK;
+    g_prof_pool.resize(max_launches);
+    for (auto &r : g_prof_pool) {
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) {
+            set_error("svdq_prof_enable: hipEventCreate failed");
+            return SVDQ_E_HIP;
+        }
+    }
+    g_prof_on = true;
+    return SVDQ_OK;
+}
+
+int svdq_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_used = 0;
+    return SVDQ_OK;
+}
+
+int svdq_prof_read(int32_t kernel_class, int64_t *launches, double *total_ms, double *total_work) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int64_t n = 0;
+    double ms = 0, work = 0;
+    for (size_t i = 0; i < g_prof_used; i++) {
+        ProfRec &r = g_prof_pool[i];
+        if (r.cls != kernel_class) continue;
+        if (hipEventSynchronize(r.e1) != hipSuccess) { set_error("svdq_prof_read: hipEventSynchronize failed"); return SVDQ_E_HIP; }
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) { set_error("svdq_prof_read: hipEventElapsedTime failed"); return SVDQ_E_HIP; }
+        n++; ms += t; work += r.work;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = work;
+    return SVDQ_OK;
 }
 
 const char *svdq_last_error(void) { return g_err; }

@@ -68,5 +68,8 @@ __host__ __device__ __forceinline__ size_t t16_byte_offset(int row, int k, int G
 // ---- host-side error plumbing --------------------------------------------------------------
 void set_error(const char *fmt, ...);
 int hip_check(hipError_t e, const char *what);
+// launch profiler hooks (repack.hip): returns a record index or -1 when profiling is off
+int prof_begin(int cls, double work, hipStream_t st);
+void prof_end(int rec, hipStream_t st);
 
 } // namespace svdq

@@ -1,0 +1,234 @@
+"""FLUX.1-shaped denoising transformer built on the SVDQuant hot path (stand-alone).
+
+Structure and call pattern follow the reference's V2 model
+(nunchaku/models/transformers/transformer_flux_v2.py:118-342,430-561,
+ nunchaku/models/attention_processors/flux.py:71-108, nunchaku/models/normalization.py:85-165,
+ nunchaku/models/attention.py:76-123): 19 joint + 38 single blocks, hidden 3072 = 24 x 128,
+MLP x4; every 3072-wide projection is an ``SVDQW4A4Linear`` driven through
+``fused_qkv_norm_rottary`` / ``fused_gelu_mlp`` / ``forward``.
+
+``diffusers`` is not a dependency: the few non-quantised pieces it would provide (embedders,
+AdaLayerNorm modulation, SDPA) are restated here with plain torch ops.  The AdaLN modulation
+projections, which the reference runs as AWQ W4A16 GEMVs, are 16-bit ``nn.Linear`` for now
+(SURVEY.md section 8f item 1).  Used by bench.py with synthetic weights and by the GPU tests; a
+reference checkpoint's SVDQ tensors load into the ``SVDQW4A4Linear`` members unchanged.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..ops.fused import fused_gelu_mlp, fused_qkv_norm_rottary
+from ..utils import pad_tensor
+from .embeddings import flux_pos_embed, pack_rotemb
+from .linear import SVDQW4A4Linear
+
+
+def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 10000.0) -> torch.Tensor:
+    """Sinusoidal embedding, (cos, sin) order, as diffusers' ``Timesteps(flip_sin_to_cos=True)``."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    args = t.float()[:, None] * freqs[None]
+    return torch.cat([args.cos(), args.sin()], dim=-1)
+
+
+class _MLPEmbedder(nn.Module):
+    def __init__(self, d_in, d, dtype, device):
+        super().__init__()
+        self.linear_1 = nn.Linear(d_in, d, dtype=dtype, device=device)
+        self.linear_2 = nn.Linear(d, d, dtype=dtype, device=device)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class FluxAttentionAMD(nn.Module):
+    """Joint (img + txt) or single-stream attention with fused QKV/RMSNorm/RoPE projections."""
+
+    def __init__(self, dim, heads, joint: bool, kw):
+        super().__init__()
+        self.heads, self.head_dim = heads, dim // heads
+        self.to_qkv = SVDQW4A4Linear(dim, 3 * dim, **kw)
+        self.norm_q = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=kw["torch_dtype"], device=kw["device"])
+        self.norm_k = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=kw["torch_dtype"], device=kw["device"])
+        self.to_out = SVDQW4A4Linear(dim, dim, **kw)
+        self.joint = joint
+        if joint:
+            self.add_qkv_proj = SVDQW4A4Linear(dim, 3 * dim, **kw)
+            self.norm_added_q = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=kw["torch_dtype"], device=kw["device"])
+            self.norm_added_k = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=kw["torch_dtype"], device=kw["device"])
+            self.to_add_out = SVDQW4A4Linear(dim, dim, **kw)
+
+    def forward(self, hidden, encoder_hidden=None, rotary=None):
+        B = hidden.shape[0]
+        if self.joint:
+            rot_img, rot_txt = rotary
+            qkv = fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rot_img)
+            qkv_c = fused_qkv_norm_rottary(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, rot_txt)
+            qkv = torch.cat([qkv_c, qkv], dim=1)
+        else:
+            qkv = fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary)
+        q, k, v = qkv.chunk(3, dim=-1)
+        shp = (B, -1, self.heads, self.head_dim)
+        o = F.scaled_dot_product_attention(q.view(shp).transpose(1, 2), k.view(shp).transpose(1, 2),
+                                           v.view(shp).transpose(1, 2), dropout_p=0.0, is_causal=False)
+        o = o.transpose(1, 2).reshape(B, -1, self.heads * self.head_dim)
+        if self.joint:
+            t = encoder_hidden.shape[1]
+            return self.to_out(o[:, t:]), self.to_add_out(o[:, :t])
+        return self.to_out(o)
+
+
+class _FeedForward(nn.Module):
+    """fc1 -> GELU(tanh) -> fc2 with the requantisation fused into fc1's epilogue
+    (reference: NunchakuFeedForward, models/attention.py:76-123)."""
+
+    def __init__(self, dim, kw):
+        super().__init__()
+        self.fc1 = SVDQW4A4Linear(dim, 4 * dim, **kw)
+        self.fc2 = SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})
+
+    def forward(self, x):
+        return fused_gelu_mlp(x, self.fc1, self.fc2)
+
+
+class FluxJointBlockAMD(nn.Module):
+    def __init__(self, dim, heads, kw):
+        super().__init__()
+        dt, dev = kw["torch_dtype"], kw["device"]
+        self.mod = nn.Linear(dim, 6 * dim, dtype=dt, device=dev)  # AdaLayerNormZero.linear
+        self.mod_context = nn.Linear(dim, 6 * dim, dtype=dt, device=dev)
+        self.attn = FluxAttentionAMD(dim, heads, True, kw)
+        self.ff = _FeedForward(dim, kw)
+        self.ff_context = _FeedForward(dim, kw)
+        self.dim = dim
+
+    @staticmethod
+    def _ln(x):
+        return F.layer_norm(x, (x.shape[-1],), eps=1e-6)
+
+    def forward(self, hidden, encoder_hidden, temb_act, rotary):
+        # normalization.py:85-98 -- emb.view(B, -1, 6).permute(2, 0, 1): interleaved chunks
+        m = self.mod(temb_act).view(temb_act.shape[0], -1, 6).permute(2, 0, 1)
+        c = self.mod_context(temb_act).view(temb_act.shape[0], -1, 6).permute(2, 0, 1)
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = m
+        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c
+        n_h = self._ln(hidden) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+        n_e = self._ln(encoder_hidden) * (1 + c_scale_msa[:, None]) + c_shift_msa[:, None]
+        a, ca = self.attn(n_h, n_e, rotary)
+        hidden = hidden + gate_msa[:, None] * a
+        n_h = self._ln(hidden) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+        hidden = hidden + gate_mlp[:, None] * self.ff(n_h)
+        encoder_hidden = encoder_hidden + c_gate_msa[:, None] * ca
+        n_e = self._ln(encoder_hidden) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
+        encoder_hidden = encoder_hidden + c_gate_mlp[:, None] * self.ff_context(n_e)
+        return encoder_hidden, hidden
+
+
+class FluxSingleBlockAMD(nn.Module):
+    def __init__(self, dim, heads, kw):
+        super().__init__()
+        dt, dev = kw["torch_dtype"], kw["device"]
+        self.mod = nn.Linear(dim, 3 * dim, dtype=dt, device=dev)  # AdaLayerNormZeroSingle.linear
+        self.mlp_fc1 = SVDQW4A4Linear(dim, 4 * dim, **kw)
+        self.mlp_fc2 = SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})
+        self.attn = FluxAttentionAMD(dim, heads, False, kw)
+
+    def forward(self, hidden, temb_act, rotary):
+        shift, scale, gate = self.mod(temb_act).view(temb_act.shape[0], -1, 3).permute(2, 0, 1)
+        n = F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]
+        mlp = fused_gelu_mlp(n, self.mlp_fc1, self.mlp_fc2)
+        att = self.attn(n, rotary=rotary)
+        return hidden + gate[:, None] * (att + mlp)
+
+
+class FluxTransformerAMD(nn.Module):
+    """One denoising step: ``forward(latents, text states, pooled text, timestep, guidance, ids)``."""
+
+    def __init__(self, num_layers=19, num_single_layers=38, dim=3072, heads=24, in_channels=64,
+                 joint_attention_dim=4096, pooled_projection_dim=768, rank=32, guidance_embeds=True,
+                 axes_dims_rope=(16, 56, 56), torch_dtype=torch.bfloat16, device="cuda"):
+        super().__init__()
+        kw = dict(rank=rank, torch_dtype=torch_dtype, device=device)
+        self.dim, self.axes = dim, tuple(axes_dims_rope)
+        self.x_embedder = nn.Linear(in_channels, dim, dtype=torch_dtype, device=device)
+        self.context_embedder = nn.Linear(joint_attention_dim, dim, dtype=torch_dtype, device=device)
+        self.time_embed = _MLPEmbedder(256, dim, torch_dtype, device)
+        self.guidance_embed = _MLPEmbedder(256, dim, torch_dtype, device) if guidance_embeds else None
+        self.text_embed = _MLPEmbedder(pooled_projection_dim, dim, torch_dtype, device)
+        self.blocks = nn.ModuleList([FluxJointBlockAMD(dim, heads, kw) for _ in range(num_layers)])
+        self.single_blocks = nn.ModuleList([FluxSingleBlockAMD(dim, heads, kw) for _ in range(num_single_layers)])
+        self.norm_out_mod = nn.Linear(dim, 2 * dim, dtype=torch_dtype, device=device)
+        self.proj_out = nn.Linear(dim, in_channels, dtype=torch_dtype, device=device)
+        self.dtype_ = torch_dtype
+
+    def svdq_layers(self):
+        return [m for m in self.modules() if isinstance(m, SVDQW4A4Linear)]
+
+    @torch.no_grad()
+    def init_synthetic_(self, seed: int = 0):
+        """Random-init weights of FLUX shape (no checkpoints in this environment): int4 codes uniform,
+        scales/low-rank factors small so activations stay O(1).  Parameters are written directly in
+        the kernel layout (a permutation of random data is random data)."""
+        dev = self.proj_out.weight.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+
+        def rnd(shape, scale):
+            return torch.randn(shape, generator=g, device=dev) * scale
+
+        def uni(shape):
+            return torch.rand(shape, generator=g, device=dev)
+
+        for m in self.modules():
+            if isinstance(m, SVDQW4A4Linear):
+                K = m.in_features
+                m.qweight.copy_(torch.randint(-128, 128, m.qweight.shape, generator=g, device=dev, dtype=torch.int16))
+                # 4-bit uniform codes have std ~4.6: scale so that |W row| ~ 1/sqrt(K)
+                m.wscales.copy_((uni(m.wscales.shape) * 0.5 + 0.75) * (1.0 / (4.6 * math.sqrt(K))))
+                if m.bias is not None:
+                    m.bias.copy_(rnd(m.bias.shape, 0.02))
+                m.smooth_factor.copy_(uni((K,)) + 0.5)
+                m.smooth_factor_orig.copy_(m.smooth_factor)
+                m.proj_down.copy_(rnd(m.proj_down.shape, 0.5 / math.sqrt(K)))
+                m.proj_up.copy_(rnd(m.proj_up.shape, 0.5 / math.sqrt(m.rank)))
+                m._amd_layout = True
+            elif isinstance(m, nn.Linear):
+                m.weight.copy_(rnd(m.weight.shape, 1.0 / math.sqrt(m.in_features)))
+                m.bias.zero_()
+            elif isinstance(m, nn.RMSNorm):
+                m.weight.fill_(1.0)
+        return self
+
+    def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                guidance=None):
+        """hidden_states [1, T_img, 64]; encoder_hidden_states [1, T_txt, 4096]; pooled [1, 768];
+        timestep/guidance [1]; img_ids [T_img, 3]; txt_ids [T_txt, 3]  ->  [1, T_img, 64]
+        (transformer_flux_v2.py:430-561; batch 1 -- the fused QKV epilogue takes one rotary table)."""
+        dt = self.dtype_
+        hidden = self.x_embedder(hidden_states)
+        temb = self.time_embed(timestep_embedding(timestep * 1000).to(dt))
+        if self.guidance_embed is not None:
+            temb = temb + self.guidance_embed(timestep_embedding(guidance * 1000).to(dt))
+        temb = temb + self.text_embed(pooled_projections)
+        temb_act = F.silu(temb)
+        enc = self.context_embedder(encoder_hidden_states)
+
+        t_txt, t_img = enc.shape[1], hidden.shape[1]
+        rot = flux_pos_embed(torch.cat([txt_ids, img_ids], dim=0), self.axes)  # [1, T, 64, 1, 2]
+        rot_txt = pack_rotemb(pad_tensor(rot[:, :t_txt], 256, 1))
+        rot_img = pack_rotemb(pad_tensor(rot[:, t_txt:], 256, 1))
+        rot_all = pack_rotemb(pad_tensor(rot, 256, 1))
+
+        for blk in self.blocks:
+            enc, hidden = blk(hidden, enc, temb_act, (rot_img, rot_txt))
+        hidden = torch.cat([enc, hidden], dim=1)
+        for blk in self.single_blocks:
+            hidden = blk(hidden, temb_act, rot_all)
+        hidden = hidden[:, t_txt:]
+        scale, shift = self.norm_out_mod(temb_act).chunk(2, dim=-1)  # AdaLayerNormContinuous
+        hidden = F.layer_norm(hidden, (self.dim,), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]
+        return self.proj_out(hidden)
