@@ -48,10 +48,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--shape", type=int, nargs=3, default=None, help="M K N: time a single shape")
     args = ap.parse_args()
     rows = []
     shapes = [(3072, 9216), (3072, 3072), (3072, 12288), (12288, 3072)]
-    for M in (512, 4096, 4608):
+    Ms = (512, 4096, 4608)
+    if args.shape:
+        Ms, shapes = (args.shape[0],), [(args.shape[1], args.shape[2])]
+    for M in Ms:
         for (K, N) in shapes:
             lin = rand_layer(K, N, act_unsigned=False)
             x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
@@ -69,7 +73,7 @@ def main():
             print(json.dumps(row), flush=True)
             del lin
     # fused MLP (fc1 with GELU+requant+lora-down epilogue, fc2 unsigned)
-    for M in (4096, 4608):
+    for M in (() if args.shape else (4096, 4608)):
         fc1, fc2 = rand_layer(3072, 12288), rand_layer(12288, 3072, act_unsigned=True)
         x = torch.randn(1, M, 3072, device="cuda", dtype=torch.bfloat16)
         t = timeit(lambda: fused_gelu_mlp(x, fc1, fc2), args.iters)
