@@ -8,8 +8,15 @@
  *   ops.gemm_w4a4                    (csrc/ops.h:10-81  -> src/kernels/zgemm/zgemm.h:8-36)
  *
  * plus the load-time re-layout of the reference's checkpoint tensors (which are stored in NVIDIA
- * mma fragment order, nunchaku/lora/flux/packer.py:187-301,362-437) into the CDNA4 tile order the
- * kernels consume.
+ * mma fragment order, nunchaku/lora/flux/packer.py:187-301,362-437) into the CDNA4 operand images
+ * the kernels consume.
+ *
+ * Operand images.  4-bit codes (weights and activations) are held as the register image of
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with FP6 (e2m3) operands -- a 4-bit code is exactly an FP6 value --
+ * i.e. 6 bits per code: a [ROWS, K] code matrix occupies ROWS*K*3/4 bytes (ROWS % 32 == 0,
+ * K % 128 == 0).  This is 1.5x the reference's ROWS*K/2 nibble buffers; the host shim
+ * (nunchaku_amd/ops) allocates the opaque activation buffers accordingly.  The bit-level layout is
+ * documented in nunchaku_amd/csrc/svdq_common.h and DESIGN.md.
  *
  * Rules of the boundary (mirrors the reference's behaviour):
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
@@ -34,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 1
+#define SVDQ_ABI_VERSION 2
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -64,21 +71,22 @@ enum {
  *   x_hat = round16(x / smooth);  per (row, 64-channel group): scale = amax/7,
  *   q = sat_s4(rne(x_hat / scale));  rows >= M are treated as zero.
  *
- * Output buffers are OPAQUE (tile order private to this library); their sizes
- * are the reference's: act M_pad*K/2 bytes, ascales (K/64)*M_pad 16-bit, lora_act M_pad*R fp32.
+ * act and ascales are OPAQUE (operand images private to this library):
+ * act M_pad*K*3/4 bytes (FP6 image), ascales (K/64)*M_pad 16-bit (scale image), lora_act M_pad*R
+ * fp32 (natural [m][r], true values).
  * ------------------------------------------------------------------------------------------ */
 typedef struct svdq_quantize_args {
     const void *x;         /* [M, K] 16-bit, row stride ldx elements                          */
     const void *smooth;    /* [K] 16-bit, natural order (see svdq_repack_vec); NULL = ones    */
     const void *lora_down; /* [K*R] 16-bit in svdq_repack_lowrank(down=1) order; NULL if R==0 */
-    void *act;             /* out: packed int4 codes, M_pad*K/2 bytes                         */
+    void *act;             /* out: FP6 image of the int4 codes, M_pad*K*3/4 bytes            */
     void *ascales;         /* out: (K/64)*M_pad 16-bit                                        */
-    float *lora_act;       /* out: M_pad*R fp32 (fully overwritten, no pre-zeroing needed)    */
+    float *lora_act;       /* out: M_pad*R fp32 (zeroed + accumulated inside the call)        */
     int32_t M;             /* actual rows                                                     */
     int32_t M_pad;         /* multiple of 256, >= M                                           */
     int32_t K;             /* multiple of 128                                                 */
     int32_t R;             /* multiple of 16 (0 = no low-rank branch)                         */
-    int32_t ldx;           /* row stride of x in elements (>= K)                              */
+    int32_t ldx;           /* row stride of x in elements (>= K, multiple of 4)               */
     int32_t dtype;         /* SVDQ_BF16 | SVDQ_FP16                                           */
     int32_t fuse_glu;      /* must be 0 (SVDQ_E_UNSUPPORTED otherwise; not on the FLUX path)  */
     int32_t fp4;           /* must be 0 (NVFP4 is Blackwell-only)                             */
@@ -95,18 +103,18 @@ int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *args, void *strea
  *   then the epilogue selected by `fuse`.
  * ------------------------------------------------------------------------------------------ */
 typedef struct svdq_gemm_args {
-    const void *act;          /* packed int4 activations (from quantize or a GELU_QUANT gemm)  */
-    const void *wgt;          /* packed int4 weights, svdq_repack_qweight order, N*K/2 bytes   */
-    const void *ascales;      /* (K/64)*M_pad 16-bit                                           */
-    const void *wscales;      /* (K/64)*N 16-bit, natural [g][n] (svdq_repack_wscales)         */
+    const void *act;          /* FP6 image of the activations (quantize or a GELU_QUANT gemm)  */
+    const void *wgt;          /* FP6 image of the weights (svdq_repack_qweight), N*K*3/4 bytes */
+    const void *ascales;      /* (K/64)*M_pad 16-bit, scale image                              */
+    const void *wscales;      /* (K/64)*N 16-bit, scale image (svdq_repack_wscales)            */
     const void *bias;         /* [N] 16-bit natural order or NULL                              */
     const float *lora_act_in; /* M_pad*R fp32 or NULL                                          */
     const void *lora_up;      /* [N, R] 16-bit natural row-major (svdq_repack_lowrank(down=0)) */
     const float *lora_scales; /* HOST pointer, R/16 floats, or NULL (= all 1.0)                */
     void *out;                /* [M, N] 16-bit, row stride ldo; required unless GELU_QUANT     */
     /* SVDQ_FUSE_GELU_QUANT: this layer emits the NEXT layer's quantized activation */
-    void *qout;               /* packed uint4 codes, M_pad*N/2 bytes                           */
-    void *oscales;            /* (N/64)*M_pad 16-bit                                           */
+    void *qout;               /* FP6 image of the uint4 codes, M_pad*N*3/4 bytes               */
+    void *oscales;            /* (N/64)*M_pad 16-bit, scale image                              */
     const void *next_smooth;  /* [N] 16-bit natural order                                      */
     const void *next_lora_down; /* [N*R2] 16-bit, svdq_repack_lowrank(down=1) order, or NULL   */
     float *lora_act_out;      /* M_pad*R2 fp32; MUST be zeroed by the caller on the same stream
@@ -124,9 +132,9 @@ typedef struct svdq_gemm_args {
     int32_t R2;               /* rank of next_lora_down (multiple of 16; 0 = none)              */
     int32_t ldo;              /* row stride of out in elements (>= N)                           */
     int32_t dtype;            /* SVDQ_BF16 | SVDQ_FP16                                          */
-    int32_t act_unsigned;     /* act codes are uint4 (producer was a GELU_QUANT gemm)           */
+    int32_t act_unsigned;     /* informational: the FP6 image already encodes signedness        */
     int32_t fuse;             /* SVDQ_FUSE_*                                                    */
-    int32_t variant;          /* 0 = default kernel; >0 = tuning variants       */
+    int32_t variant;          /* must be 0                                                      */
     int32_t reserved;
 } svdq_gemm_args;
 
@@ -134,11 +142,11 @@ int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Load-time re-layout of reference checkpoint tensors (NVIDIA fragment order -> CDNA4 order).
- * src and dst must not alias.  All are pure permutations, same byte size in and out.
+ * src and dst must not alias.  All but svdq_repack_qweight are pure permutations of equal size.
  * ------------------------------------------------------------------------------------------ */
-/* qweight [N, K/2] int8 (packer.py:187-239) -> tile order consumed by svdq_gemm_w4a4 */
+/* qweight [N, K/2] int8 (packer.py:187-239) -> FP6 image, N*K*3/4 bytes, consumed by svdq_gemm_w4a4 */
 int svdq_repack_qweight(const void *src, void *dst, int32_t N, int32_t K, void *stream);
-/* wscales [K/64, N] 16-bit (packer.py:241-301) -> natural [g][n] */
+/* wscales [K/64, N] 16-bit (packer.py:241-301) -> scale image [N/32][K/128][2][32]; G must be even */
 int svdq_repack_wscales(const void *src, void *dst, int32_t G, int32_t N, void *stream);
 /* bias / smooth_factor [N] 16-bit (same intra-128 permutation, gemm_base.cuh:713) -> natural */
 int svdq_repack_vec(const void *src, void *dst, int32_t N, void *stream);
@@ -146,9 +154,10 @@ int svdq_repack_vec(const void *src, void *dst, int32_t N, void *stream);
  * (packer.py:362-398, lora.cuh:43-59).  C = N or K. */
 int svdq_repack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_t down, void *stream);
 
-/* Inverse helpers used by the tests to read the opaque activation format back:
- * act (this library's tile order) -> one int8 code per element, natural [M_pad, K]. */
+/* Inverse helpers used by the tests to read the opaque formats back:
+ * FP6 image -> one int8 code per element, natural [ROWS, K];  scale image -> natural [G][ROWS]. */
 int svdq_unpack_act(const void *act, int8_t *codes, int32_t M_pad, int32_t K, int32_t is_unsigned, void *stream);
+int svdq_unpack_scales(const void *simg, void *natural, int32_t ROWS, int32_t G, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Launch profiler (used by bench.py for the roofline line).  While enabled, every

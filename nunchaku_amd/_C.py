@@ -62,8 +62,11 @@ class _Ops:
         a.ldx = input.stride(0)
         a.dtype = _DT[input.dtype]
         a.fuse_glu, a.fp4 = int(bool(fuse_glu)), int(bool(fp4))
-        if output.shape[-1] * 2 != K or oscales.numel() != (K // 64) * M_pad:
-            raise ValueError("quantize_w4a4_act_fuse_lora: output/oscales shapes do not match the input")
+        if output.shape[-1] * 4 != K * 3 or oscales.numel() != (K // 64) * M_pad:
+            raise ValueError(
+                "quantize_w4a4_act_fuse_lora: output must be the [M_pad, 3K/4] byte FP6 operand image of this "
+                "library (nunchaku_amd.layout.act_image_shape) and oscales must hold (K/64)*M_pad scales"
+            )
         if R and lora_act_out.numel() != M_pad * R:
             raise ValueError("quantize_w4a4_act_fuse_lora: lora_act_out must hold M_pad*R floats")
         _lib.check(lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), _stream()), "quantize_w4a4_act_fuse_lora")
@@ -92,10 +95,10 @@ class _Ops:
 
         a = _lib.GemmArgs()
         M_pad = act.numel() // act.shape[-1]
-        K = act.shape[-1] * 2
+        K = act.shape[-1] * 4 // 3  # FP6 operand image: 6 bits per code
         N = wgt.shape[0]
-        if wgt.shape[-1] * 2 != K:
-            raise ValueError("gemm_w4a4: act and wgt disagree on K")
+        if wgt.shape[-1] * 4 != K * 3 or act.shape[-1] * 4 != K * 3:
+            raise ValueError("gemm_w4a4: act and wgt must be [rows, 3K/4]-byte FP6 operand images with the same K")
         a.act, a.wgt, a.ascales, a.wscales = _ptr(act), _ptr(wgt), _ptr(ascales), _ptr(wscales)
         a.bias = _ptr(bias)
         R = 0

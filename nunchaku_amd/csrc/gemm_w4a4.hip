@@ -6,32 +6,40 @@
 //  epilogues.cuh:22-44,269-425; dispatch gemm_w4a4_launch_impl.cuh:7-424).
 //
 // Kernel structure (DESIGN.md "GEMM kernel"):
-//   * workgroup = 256 threads = 4 waves (2 x 2), output tile 128 x 128, wave tile 64 x 64 =
-//     4 x 4 MFMA tiles of v_mfma_i32_16x16x64_i8; one k-iteration = one 64-channel quantisation
-//     group (the int32 partial sums cannot cross groups: scales are per (row, group) x (col, group)).
-//   * operands stay INT4 in HBM and in LDS.  Both are stored in the T16 tile order
-//     (svdq_common.h), so a (128 rows x 64 k) operand block is one contiguous 4 KiB chunk: staged
-//     with one coalesced 16-byte load per thread, read back with conflict-free ds_read_b64 (lane l
-//     gets the 16 codes of row l&15, k-slot l>>4).
-//   * int4 -> int8 in registers without sign extension: (w<<4)&0xF0F0F0F0 and w&0xF0F0F0F0 give
-//     16 x nibble as signed bytes; the 1/256 (1/16 for unsigned activations) is folded into the
-//     weight scale when it is staged.  Both operands use the same nibble->byte map, which is all a
-//     dot product needs.
-//   * the MFMA is issued "transposed" (weights as the A operand, activations as B) so that in the
-//     C layout each lane owns ONE output row m and 4 consecutive columns n: 8-byte output stores,
-//     RoPE pairs and requantisation bytes are lane-local.
-//   * fp32 accumulators: acc += float(psum) * (as[m] * ws[n]).  (The reference accumulates in
-//     16-bit, gemm_w4a4.cuh:1080; fp32 is strictly more accurate.)  Bias and the low-rank up
-//     projection (a bf16/f16 MFMA issued straight onto the fp32 accumulators) are added before the
-//     single rounding to 16-bit that precedes the activation epilogues.
+//   * the 4-bit x 4-bit inner product of one 64-channel quantisation group is ONE
+//     v_mfma_scale_f32_32x32x64_f8f6f4 with FP6 (e2m3) operands: a 4-bit code q is exactly the FP6
+//     value q/8, products and the 64-term sum are exact in the fp32 accumulator (|sum| <= 7680), and
+//     the FP6/FP4 matrix rate is twice the INT8 rate.  Both operands live in HBM and LDS as the
+//     register image of that instruction (svdq_common.h "F6"), so the main loop has no unpack work.
+//   * the per-group scale tile S[n,m] = ws[n,g]*as[m,g] is a rank-1 product: it is produced by a
+//     second MFMA (16-bit operands: the scales themselves in k-slots 0 and 8, zeros elsewhere, so
+//     S = 2*ws*as exactly; the 1/2 is folded into the MX block exponent of the FP6 MFMA).  The VALU
+//     only does acc = fma(P, S, acc): one op per output element and group, the minimum any exact
+//     formulation needs (the int8 formulation needs cvt + mul + fma and is VALU-issue bound at
+//     ~1/3 of the matrix peak, profiles/r1_ubench_*).
+//   * workgroup = 512 threads = 8 waves (4 along M x 2 along N), output tile 256 x 128, wave tile
+//     64 x 64 = 2 x 2 MFMA tiles; two waves per SIMD so that one wave's fma stream overlaps the
+//     other's MFMAs (a single wave issues one VALU op per ~8 cycles on gfx950).
+//   * K-step = 128 channels (two groups).  Operands go HBM -> LDS by DMA (global_load_lds, 16 B per
+//     lane = one 1 KiB plane of an F6 chunk per wave instruction), 3-stage ring.
+//   * the MFMA is issued "transposed" (weights = A operand, activations = B) so that in the C layout
+//     a lane owns ONE output row m and 16 columns n = 32*tile + 8c + 4*(lane>>5) + e: 8-byte output
+//     stores, RoPE pairs and the next layer's FP6 lane record are lane-local.
+//   * fp32 accumulation over groups (the reference accumulates in 16-bit, gemm_w4a4.cuh:1080).  Bias
+//     and the low-rank up projection (a 16-bit MFMA issued straight onto the fp32 accumulators) are
+//     added before the single rounding to 16-bit that precedes the activation epilogues.
 #include "svdq_common.h"
 
 namespace svdq {
 
-constexpr int BM = 128, BN = 128;
-constexpr int KG = 2;                                    // quantisation groups per pipeline stage
-constexpr int STAGE_BYTES = KG * (4096 + 4096 + 512 + 512); // A, W, as, ws per group
-constexpr int MAX_LORA_TILES = 16;                       // R <= 256
+constexpr int BM = 256, BN = 128;
+constexpr int NSTAGE = 3;
+constexpr int A_BYTES = (BM / 32) * F6_CHUNK;  // 24576
+constexpr int W_BYTES = (BN / 32) * F6_CHUNK;  // 12288
+constexpr int AS_BYTES = (BM / 32) * 128;      // 1024
+constexpr int WS_BYTES = (BN / 32) * 128;      // 512
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES + AS_BYTES + WS_BYTES; // 38400
+constexpr int MAX_LORA_TILES = 16;             // R <= 256
 
 struct GemmParams {
     const uint8_t *act;
@@ -54,25 +62,6 @@ struct GemmParams {
     float lora_scales[MAX_LORA_TILES];
 };
 
-__device__ __forceinline__ v4i unpack_s4x16(v2i w) {
-    // 16 signed nibbles -> 16 signed bytes holding 16*value
-    v4i r;
-    r[0] = (w[0] << 4) & 0xF0F0F0F0;
-    r[1] = w[0] & 0xF0F0F0F0;
-    r[2] = (w[1] << 4) & 0xF0F0F0F0;
-    r[3] = w[1] & 0xF0F0F0F0;
-    return r;
-}
-__device__ __forceinline__ v4i unpack_u4x16(v2i w) {
-    // 16 unsigned nibbles -> 16 bytes holding the value (0..15)
-    v4i r;
-    r[0] = w[0] & 0x0F0F0F0F;
-    r[1] = (w[0] >> 4) & 0x0F0F0F0F;
-    r[2] = w[1] & 0x0F0F0F0F;
-    r[3] = (w[1] >> 4) & 0x0F0F0F0F;
-    return r;
-}
-
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     // reference: gemm_utils.cuh:305-312 (tanh.approx there; exact tanhf here)
     float x3 = x * x * x;
@@ -81,194 +70,175 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
-template <int DT, bool ACT_UNSIGNED, int FUSE>
-__global__ __launch_bounds__(256, 2) void gemm_w4a4_kernel(const GemmParams p) {
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gvoid;
+
+#define FMT_FP6 2
+// MX block exponents (E8M0, bias 127): codes are value/8 on both sides (x64) and the scale tile is
+// 2*ws*as (x1/2): 2^3 * 2^2 = 32.
+#define MXS_A 0x82828282
+#define MXS_B 0x81818181
+
+template <int DT, int FUSE>
+__global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 15, lq = lane >> 4;
-    const int G = p.K / GROUP;
+    const int lr = lane & 31, h = lane >> 5;
+    const int KP = p.K / 128;
     const int nbn = p.N / BN;
     const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
     const int m0 = bm * BM, n0 = bn * BN;
 
-    // ---- operand streams ---------------------------------------------------------------------
-    // one 16-byte load per thread covers a (128 rows x 64 k) block of A and of W; threads 0..127
-    // additionally carry the activation scale of row tid, threads 128..255 the weight scale of
-    // column tid-128 (no branch in the loop: pointer/stride/multiplier are selected once).
-    const uint8_t *a_src = p.act + ((size_t)bm * G) * 4096 + tid * 16;
-    const uint8_t *w_src = p.wgt + ((size_t)bn * G) * 4096 + tid * 16;
-    const bool is_as = tid < 128;
-    const T *s_src = is_as ? (const T *)p.ascales + m0 + tid : (const T *)p.wscales + n0 + (tid - 128);
-    const size_t s_stride = is_as ? (size_t)p.M_pad : (size_t)p.N;
-    const float s_mul = is_as ? 1.0f : (ACT_UNSIGNED ? (1.0f / 16.0f) : (1.0f / 256.0f));
+    // ---- operand streams: every wave moves whole 1 KiB planes -------------------------------
+    //   waves 0..7: the three planes of A chunk `wave`;  waves 0..3: the three planes of W chunk
+    //   `wave`;  wave 4: activation scales (8 x 128 B);  wave 5: weight scales (4 x 128 B).
+    const uint8_t *a_src = p.act + ((size_t)(bm * 8 + wave) * KP) * F6_CHUNK + lane * 16;
+    const uint8_t *w_src = p.wgt + ((size_t)(bn * 4 + (wave & 3)) * KP) * F6_CHUNK + lane * 16;
+    const uint8_t *as_src = (const uint8_t *)p.ascales + ((size_t)(bm * 8 + (lane >> 3)) * KP) * 128 + (lane & 7) * 16;
+    const uint8_t *ws_src = (const uint8_t *)p.wscales + ((size_t)(bn * 4 + ((lane >> 3) & 3)) * KP) * 128 + (lane & 7) * 16;
 
-    v4f acc[4][4];
+    auto fetch = [&](int kp, uint8_t *st) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int pl = 0; pl < 3; pl++)
+            __builtin_amdgcn_global_load_lds((gvoid *)(a_src + (size_t)kp * F6_CHUNK + pl * F6_PLANE),
+                                             (lds_void *)(st + wave * F6_CHUNK + pl * F6_PLANE), 16, 0, 0);
+        if (wave < 4) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-
-    T rs[KG];
-    v4i zero = {0, 0, 0, 0};
-    // A and W tiles go HBM -> LDS by DMA (global_load_lds, 16 B per lane, no VGPR round trip: a
-    // register-staged prefetch is spilled by hipcc and drains vmcnt right behind the loads).  The
-    // LDS image is lane-linear (wave base + lane*16), which is exactly the T16 order.
-    typedef __attribute__((address_space(3))) void lds_void;
-    auto fetch = [&](int g0, uint8_t *st) {
-#pragma unroll
-        for (int u = 0; u < KG; u++) {
-            uint8_t *sg = st + u * (STAGE_BYTES / KG) + wave * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src + (size_t)(g0 + u) * 4096),
-                                             (lds_void *)sg, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_src + (size_t)(g0 + u) * 4096),
-                                             (lds_void *)(sg + 4096), 16, 0, 0);
-            rs[u] = s_src[(size_t)(g0 + u) * s_stride];
+            for (int pl = 0; pl < 3; pl++)
+                __builtin_amdgcn_global_load_lds((gvoid *)(w_src + (size_t)kp * F6_CHUNK + pl * F6_PLANE),
+                                                 (lds_void *)(st + A_BYTES + wave * F6_CHUNK + pl * F6_PLANE), 16, 0, 0);
+        } else if (wave == 4) {
+            __builtin_amdgcn_global_load_lds((gvoid *)(as_src + (size_t)kp * 128), (lds_void *)(st + A_BYTES + W_BYTES), 16, 0, 0);
+        } else if (wave == 5) {
+            if (lane < 32)
+                __builtin_amdgcn_global_load_lds((gvoid *)(ws_src + (size_t)kp * 128),
+                                                 (lds_void *)(st + A_BYTES + W_BYTES + AS_BYTES), 16, 0, 0);
         }
     };
-    auto commit = [&](uint8_t *st) {
-#pragma unroll
-        for (int u = 0; u < KG; u++)
-            reinterpret_cast<float *>(st + u * (STAGE_BYTES / KG) + 8192)[tid] = h2f(rs[u]) * s_mul;
-    };
 
-    const int NS = G / KG; // K % 128 == 0  ->  G even
+    v16f acc[2][2]; // [n tile][m tile]
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
     fetch(0, lds);
-    commit(lds);
-    __syncthreads();
+    if (KP > 1) fetch(1, lds + STAGE_BYTES);
 
-    for (int s = 0; s < NS; s++) {
-        const uint8_t *st = lds + (s & 1) * STAGE_BYTES;
-        if (s + 1 < NS) fetch((s + 1) * KG, lds + ((s + 1) & 1) * STAGE_BYTES);
-
-#pragma unroll
-        for (int u = 0; u < KG; u++) {
-            const uint8_t *sg = st + u * (STAGE_BYTES / KG);
-            v4i wf[4], af[4];
-            v4f wsv[4];
-            float asv[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                v2i raw = *reinterpret_cast<const v2i *>(sg + 4096 + ((wn * 4 + nt) * 64 + lane) * 8);
-                wf[nt] = unpack_s4x16(raw);
-                wsv[nt] = *reinterpret_cast<const v4f *>(sg + 8192 + 512 + (wn * 64 + nt * 16 + lq * 4) * 4);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                v2i raw = *reinterpret_cast<const v2i *>(sg + ((wm * 4 + mt) * 64 + lane) * 8);
-                af[mt] = ACT_UNSIGNED ? unpack_u4x16(raw) : unpack_s4x16(raw);
-                asv[mt] = *reinterpret_cast<const float *>(sg + 8192 + (wm * 64 + mt * 16 + lr) * 4);
-            }
-            // software pipeline over the 16 MFMA tiles of this group: the matrix pipe works on
-            // tile t+DEPTH while the VALU dequantises tile t (psum ring of DEPTH+1 tiles in VGPRs;
-            // without it hipcc parks all 16 psum tiles in AGPRs and serialises the two phases).
-            constexpr int DEPTH = 3;
-            v4i ps[DEPTH + 1];
-            // The zero C operand is laundered through an empty asm before every MFMA and the freshly
-            // updated accumulators after every dequant step: volatile asms keep their program order,
-            // which pins "MFMA(t+DEPTH); dequant(t)" -- otherwise LLVM hoists all 16 MFMAs to the top
-            // of the group and sinks the 192 dequant ops to the bottom (no overlap, 128 extra VGPRs).
-#pragma unroll
-            for (int t = 0; t < DEPTH; t++) {
-                asm volatile("" : "+v"(zero));
-                ps[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[t & 3], af[t >> 2], zero, 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
-                if (t + DEPTH < 16) {
-                    asm volatile("" : "+v"(zero));
-                    ps[(t + DEPTH) % (DEPTH + 1)] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
-                        wf[(t + DEPTH) & 3], af[(t + DEPTH) >> 2], zero, 0, 0, 0);
-                }
-                const int mt = t >> 2, nt = t & 3;
-                const v4i q = ps[t % (DEPTH + 1)];
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    acc[mt][nt][r] = __builtin_fmaf((float)q[r], asv[mt] * wsv[nt][r], acc[mt][nt][r]);
-                asm volatile("" : "+v"(acc[mt][nt]));
-            }
-        }
-
-        if (s + 1 < NS) commit(lds + ((s + 1) & 1) * STAGE_BYTES);
+    for (int s = 0; s < KP; s++) {
+        // stage s (and, conservatively, s+1) has landed for this wave; the barrier makes every wave's
+        // planes visible and guarantees everyone is done reading stage s-1 before it is refilled
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
         __syncthreads();
+        if (s + 2 < KP) fetch(s + 2, lds + ((s + 2) % NSTAGE) * STAGE_BYTES);
+        const uint8_t *st = lds + (s % NSTAGE) * STAGE_BYTES;
+
+        // fragments of both groups: 3 x 16 B per (tile, lane)
+        int af[2][12], wf[2][12];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                v4i a = *reinterpret_cast<const v4i *>(st + (wm * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
+                v4i w = *reinterpret_cast<const v4i *>(st + A_BYTES + (wn * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { af[i][pl * 4 + e] = a[e]; wf[i][pl * 4 + e] = w[e]; }
+            }
+        const unsigned short *as_l = reinterpret_cast<const unsigned short *>(st + A_BYTES + W_BYTES);
+        const unsigned short *ws_l = reinterpret_cast<const unsigned short *>(st + A_BYTES + W_BYTES + AS_BYTES);
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+            v4i sa[2], sw[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                sa[i] = v4i{(int)as_l[(wm * 2 + i) * 64 + grp * 32 + lr], 0, 0, 0};
+                sw[i] = v4i{(int)ws_l[(wn * 2 + i) * 64 + grp * 32 + lr], 0, 0, 0};
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++) {
+                    const int o = grp * 6;
+                    v8i A = {wf[ni][o], wf[ni][o + 1], wf[ni][o + 2], wf[ni][o + 3], wf[ni][o + 4], wf[ni][o + 5], 0, 0};
+                    v8i B = {af[mi][o], af[mi][o + 1], af[mi][o + 2], af[mi][o + 3], af[mi][o + 4], af[mi][o + 5], 0, 0};
+                    v16f P = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, FMT_FP6, FMT_FP6, 0, MXS_A, 0, MXS_B);
+                    v16f S = Half<DT>::mfma32(__builtin_bit_cast(V8, sw[ni]), __builtin_bit_cast(V8, sa[mi]), zero16);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = __builtin_fmaf(P[r], S[r], acc[ni][mi][r]);
+                }
+        }
     }
 
     // ------------------------------------------------------------------ epilogue
-    const int nw0 = n0 + wn * 64; // first column of this wave
-    const int mw0 = m0 + wm * 64; // first row of this wave
+    // lane owns rows m = mw0 + 32*mi + lr and columns n = nw0 + 32*ni + 8*c + 4*h + e  (r = 4c + e)
+    const int nw0 = n0 + wn * 64;
+    const int mw0 = m0 + wm * 64;
 
     // bias (reference EpilogueBias, gemm_base.cuh:710-781)
     if (p.bias) {
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            u16x4 b = *reinterpret_cast<const u16x4 *>((const T *)p.bias + nw0 + nt * 16 + lq * 4);
+        for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++)
+            for (int c = 0; c < 4; c++) {
+                u16x4 b = *reinterpret_cast<const u16x4 *>((const T *)p.bias + nw0 + ni * 32 + c * 8 + h * 4);
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[mt][nt][r] += h2f(hfrom<T>(b[r]));
-        }
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[ni][mi][c * 4 + e] += h2f(hfrom<T>(b[e]));
+            }
     }
 
     // low-rank up projection (reference EpilogueLoraUp, lora.cuh:110-241): fp32 activations are
     // scaled per 16 ranks and rounded to 16-bit (:145-158), multiplied on the matrix cores and
     // accumulated in fp32 -- here straight onto the GEMM accumulators.
     if (p.R > 0) {
-        for (int rc = 0; rc < p.R; rc += 32) {
-            const int r0 = rc + lq * 8;
-            const bool live = r0 < p.R;
-            V8 la[4], lu[4];
-            const float sc = live ? p.lora_scales[r0 >> 4] : 0.f;
+        for (int rc = 0; rc < p.R; rc += 16) {
+            const float sc = p.lora_scales[rc >> 4];
+            V8 la[2], lu[2];
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                if (live) {
-                    const float *src = p.lora_act_in + (size_t)(mw0 + mt * 16 + lr) * p.R + r0;
-                    v4f x0 = *reinterpret_cast<const v4f *>(src);
-                    v4f x1 = *reinterpret_cast<const v4f *>(src + 4);
+            for (int mi = 0; mi < 2; mi++) {
+                const float *src = p.lora_act_in + (size_t)(mw0 + mi * 32 + lr) * p.R + rc + h * 8;
+                v4f x0 = *reinterpret_cast<const v4f *>(src);
+                v4f x1 = *reinterpret_cast<const v4f *>(src + 4);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        la[mt][j] = f2h<T>(x0[j] * sc);
-                        la[mt][4 + j] = f2h<T>(x1[j] * sc);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) la[mt][j] = (T)0.f;
+                for (int j = 0; j < 4; j++) {
+                    la[mi][j] = f2h<T>(x0[j] * sc);
+                    la[mi][4 + j] = f2h<T>(x1[j] * sc);
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                if (live) {
-                    lu[nt] = *reinterpret_cast<const V8 *>((const T *)p.lora_up + (size_t)(nw0 + nt * 16 + lr) * p.R + r0);
-                } else {
+            for (int ni = 0; ni < 2; ni++)
+                lu[ni] = *reinterpret_cast<const V8 *>((const T *)p.lora_up + (size_t)(nw0 + ni * 32 + lr) * p.R + rc + h * 8);
 #pragma unroll
-                    for (int j = 0; j < 8; j++) lu[nt][j] = (T)0.f;
-                }
-            }
+            for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-                for (int nt = 0; nt < 4; nt++) acc[mt][nt] = Half<DT>::mfma(lu[nt], la[mt], acc[mt][nt]);
+                for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(lu[ni], la[mi], acc[ni][mi]);
         }
     }
 
     // the single rounding to the 16-bit model dtype (the reference's tile is 16-bit from here on)
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
+        for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[mt][nt][r] = round16<T>(acc[mt][nt][r]);
+            for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(acc[ni][mi][r]);
 
     if constexpr (FUSE == SVDQ_FUSE_SILU) {
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
+        for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++)
+            for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[mt][nt][r] = round16<T>(silu_f(acc[mt][nt][r]));
+                for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(silu_f(acc[ni][mi][r]));
     }
 
     if constexpr (FUSE == SVDQ_FUSE_RMSNORM_ROPE) {
@@ -277,47 +247,47 @@ __global__ __launch_bounds__(256, 2) void gemm_w4a4_kernel(const GemmParams p) {
         const bool is_q = n0 < third;
         const bool is_k = !is_q && n0 < 2 * third;
         if (is_q || is_k) { // block-uniform
-            float *sq = reinterpret_cast<float *>(lds); // [2][128]
-            float part[4];
+            __syncthreads(); // everyone is out of the main loop: the ring can be reused
+            float *sq = reinterpret_cast<float *>(lds); // [2 (wn)][256 rows]
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
+            for (int mi = 0; mi < 2; mi++) {
                 float s = 0.f;
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++)
+                for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) s += acc[mt][nt][r] * acc[mt][nt][r];
-                s += __shfl_xor(s, 16);
+                    for (int r = 0; r < 16; r++) s += acc[ni][mi][r] * acc[ni][mi][r];
                 s += __shfl_xor(s, 32);
-                part[mt] = s;
-                if (lq == 0) sq[wn * 128 + wm * 64 + mt * 16 + lr] = s;
+                if (h == 0) sq[wn * 256 + wm * 64 + mi * 32 + lr] = s;
             }
             __syncthreads();
             const T *nw = (const T *)(is_q ? p.norm_q : p.norm_k);
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                const int row = wm * 64 + mt * 16 + lr;
-                const float tot = sq[row] + sq[128 + row];
+            for (int mi = 0; mi < 2; mi++) {
+                const int row = wm * 64 + mi * 32 + lr;
+                const float tot = sq[row] + sq[256 + row];
                 const float coef = 1.0f / sqrtf(tot / 128.0f + 1e-6f);
                 const int m_abs = m0 + row;
                 // packed rotary order (models/embeddings.py:100-138): [m/16][d/8][r8*4+p][rh][sin,cos]
                 const size_t rbase = ((size_t)(m_abs >> 4) * 16) * 128 + (size_t)((m_abs & 7) * 4) * 4 + ((m_abs >> 3) & 1) * 2;
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++) {
-                    const int c = wn * 64 + nt * 16 + lq * 4; // column inside the head
-                    u16x4 wv = *reinterpret_cast<const u16x4 *>(nw + c);
-                    const int pi = c >> 1; // first pair index
-                    const float *rp = p.rotary_emb + rbase + (size_t)(pi >> 2) * 128 + (size_t)(pi & 3) * 4;
-                    float2 sc0 = *reinterpret_cast<const float2 *>(rp);
-                    float2 sc1 = *reinterpret_cast<const float2 *>(rp + 4);
-                    float v0 = acc[mt][nt][0] * (coef * h2f(hfrom<T>(wv[0])));
-                    float v1 = acc[mt][nt][1] * (coef * h2f(hfrom<T>(wv[1])));
-                    float v2 = acc[mt][nt][2] * (coef * h2f(hfrom<T>(wv[2])));
-                    float v3 = acc[mt][nt][3] * (coef * h2f(hfrom<T>(wv[3])));
-                    acc[mt][nt][0] = round16<T>(v0 * sc0.y - v1 * sc0.x);
-                    acc[mt][nt][1] = round16<T>(v0 * sc0.x + v1 * sc0.y);
-                    acc[mt][nt][2] = round16<T>(v2 * sc1.y - v3 * sc1.x);
-                    acc[mt][nt][3] = round16<T>(v2 * sc1.x + v3 * sc1.y);
-                }
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int col = wn * 64 + ni * 32 + c * 8 + h * 4; // column inside the head
+                        u16x4 wv = *reinterpret_cast<const u16x4 *>(nw + col);
+                        const int pi = col >> 1; // first pair index
+                        const float *rp = p.rotary_emb + rbase + (size_t)(pi >> 2) * 128 + (size_t)(pi & 3) * 4;
+                        float2 sc0 = *reinterpret_cast<const float2 *>(rp);
+                        float2 sc1 = *reinterpret_cast<const float2 *>(rp + 4);
+                        float v0 = acc[ni][mi][c * 4 + 0] * (coef * h2f(hfrom<T>(wv[0])));
+                        float v1 = acc[ni][mi][c * 4 + 1] * (coef * h2f(hfrom<T>(wv[1])));
+                        float v2 = acc[ni][mi][c * 4 + 2] * (coef * h2f(hfrom<T>(wv[2])));
+                        float v3 = acc[ni][mi][c * 4 + 3] * (coef * h2f(hfrom<T>(wv[3])));
+                        acc[ni][mi][c * 4 + 0] = round16<T>(v0 * sc0.y - v1 * sc0.x);
+                        acc[ni][mi][c * 4 + 1] = round16<T>(v0 * sc0.x + v1 * sc0.y);
+                        acc[ni][mi][c * 4 + 2] = round16<T>(v2 * sc1.y - v3 * sc1.x);
+                        acc[ni][mi][c * 4 + 3] = round16<T>(v2 * sc1.x + v3 * sc1.y);
+                    }
             }
         }
     }
@@ -325,129 +295,144 @@ __global__ __launch_bounds__(256, 2) void gemm_w4a4_kernel(const GemmParams p) {
     if constexpr (FUSE == SVDQ_FUSE_GELU_QUANT) {
         // EpilogueGelu (epilogues.cuh:22-44) -> 16-bit
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
+        for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++)
+            for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[mt][nt][r] = round16<T>(gelu_tanh_f(acc[mt][nt][r]));
+                for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(gelu_tanh_f(acc[ni][mi][r]));
 
         // EpilogueLoraDown for the NEXT layer on the GELU output, before shift/smooth
-        // (lora.cuh:243-353, launch_impl.cuh:226-262).  In the C layout a lane already holds, for its
-        // row m, columns {nt*16 + lq*4 + r}: two n-tiles form the 8-element k-slot of a 16x16x32
-        // MFMA operand with no data movement; the weight operand is loaded in the matching order.
+        // (lora.cuh:243-353, launch_impl.cuh:226-262):  D'[r2][m] = sum_n ld[r2][n] * g[n][m].  In the C
+        // layout a lane already holds, for its row m, the 8 columns {16q + 8(j>>2) + 4h + (j&3)} of MFMA
+        // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.
         if (p.R2 > 0) {
             const T *ld = (const T *)p.next_lora_down; // rank-major [R2][N]
-            for (int rt = 0; rt < p.R2 / 16; rt++) {
-                v4f d[4];
+            for (int t2 = 0; t2 < p.R2; t2 += 32) {
+                v16f d[2];
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++) d[mt] = v4f{0.f, 0.f, 0.f, 0.f};
+                for (int mi = 0; mi < 2; mi++) d[mi] = zero16;
+                const bool live = t2 + lr < p.R2;
 #pragma unroll
-                for (int np = 0; np < 2; np++) {
-                    const T *src = ld + (size_t)(rt * 16 + lr) * p.N + nw0 + np * 32 + lq * 4;
-                    u16x4 w0 = *reinterpret_cast<const u16x4 *>(src);
-                    u16x4 w1 = *reinterpret_cast<const u16x4 *>(src + 16);
-                    V8 wv;
+                for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        wv[j] = hfrom<T>(w0[j]);
-                        wv[4 + j] = hfrom<T>(w1[j]);
-                    }
+                    for (int q = 0; q < 2; q++) {
+                        V8 wv;
+                        if (live) {
+                            const T *src = ld + (size_t)(t2 + lr) * p.N + nw0 + ni * 32 + q * 16 + h * 4;
+                            u16x4 w0 = *reinterpret_cast<const u16x4 *>(src);
+                            u16x4 w1 = *reinterpret_cast<const u16x4 *>(src + 8);
 #pragma unroll
-                    for (int mt = 0; mt < 4; mt++) {
-                        V8 gv;
+                            for (int j = 0; j < 4; j++) { wv[j] = hfrom<T>(w0[j]); wv[4 + j] = hfrom<T>(w1[j]); }
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            gv[j] = f2h<T>(acc[mt][np * 2][j]);
-                            gv[4 + j] = f2h<T>(acc[mt][np * 2 + 1][j]);
+                            for (int j = 0; j < 8; j++) wv[j] = (T)0.f;
                         }
-                        d[mt] = Half<DT>::mfma(wv, gv, d[mt]);
+#pragma unroll
+                        for (int mi = 0; mi < 2; mi++) {
+                            V8 gv;
+#pragma unroll
+                            for (int j = 0; j < 8; j++) gv[j] = f2h<T>(acc[ni][mi][q * 8 + j]);
+                            d[mi] = Half<DT>::mfma32(wv, gv, d[mi]);
+                        }
                     }
-                }
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-                    float *dst = p.lora_act_out + (size_t)(mw0 + mt * 16 + lr) * p.R2 + rt * 16 + lq * 4;
+                for (int mi = 0; mi < 2; mi++) {
+                    float *dst = p.lora_act_out + (size_t)(mw0 + mi * 32 + lr) * p.R2 + t2 + h * 4;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) unsafeAtomicAdd(dst + i, d[mt][i]);
+                    for (int i = 0; i < 16; i++) {
+                        const int r2 = (i & 3) + 8 * (i >> 2);
+                        if (t2 + r2 + h * 4 < p.R2) unsafeAtomicAdd(dst + r2, d[mi][i]);
+                    }
                 }
             }
         }
 
         // EpilogueQuantize<false, unsigned> (gemm_w4a4.cuh:930-1043): 16-bit add of the shift,
         // fp32 divide by the next layer's smooth factor -> 16-bit, per (row, 64 columns) absmax,
-        // scale = amax/15, unsigned 4-bit codes in T16 order for the next GEMM.
-        const int G2 = p.N / GROUP;
+        // scale = amax/15, unsigned 4-bit codes.  The wave's 64 columns are exactly one group of the
+        // next GEMM and the lane's 32 values (j = 16*ni + r) are exactly its F6 lane record.
+        const int KP2 = p.N / 128;
         const int g2 = nw0 / GROUP;
-        u16x4 sm[4];
+        u16x4 sm[2][4];
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
-            sm[nt] = *reinterpret_cast<const u16x4 *>((const T *)p.next_smooth + nw0 + nt * 16 + lq * 4);
+        for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            float xh[4][4];
+            for (int c = 0; c < 4; c++)
+                sm[ni][c] = *reinterpret_cast<const u16x4 *>((const T *)p.next_smooth + nw0 + ni * 32 + c * 8 + h * 4);
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+            float xh[32];
             float amax = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++)
+            for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float sh = round16<T>(acc[mt][nt][r] + 0.171875f);
-                    float v = round16<T>(sh / h2f(hfrom<T>(sm[nt][r])));
-                    xh[nt][r] = v;
+                for (int r = 0; r < 16; r++) {
+                    float sh = round16<T>(acc[ni][mi][r] + 0.171875f);
+                    float v = round16<T>(sh / h2f(hfrom<T>(sm[ni][r >> 2][r & 3])));
+                    xh[ni * 16 + r] = v;
                     amax = fmaxf(amax, fabsf(v));
                 }
-            amax = fmaxf(amax, __shfl_xor(amax, 16));
             amax = fmaxf(amax, __shfl_xor(amax, 32));
             const float scale = amax * (1.0f / 15.0f);
             const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
-            const int m_abs = mw0 + mt * 16 + lr;
-            uint8_t *qrow = p.qout + ((((size_t)(m_abs >> 7) * G2 + g2) * 8 + ((m_abs & 127) >> 4)) * 64 + lr) * 8 + lq * 2;
+            uint32_t rec[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                int q0 = (int)fminf(fmaxf(rintf(xh[nt][0] * rscale), 0.f), 15.f);
-                int q1 = (int)fminf(fmaxf(rintf(xh[nt][1] * rscale), 0.f), 15.f);
-                int q2 = (int)fminf(fmaxf(rintf(xh[nt][2] * rscale), 0.f), 15.f);
-                int q3 = (int)fminf(fmaxf(rintf(xh[nt][3] * rscale), 0.f), 15.f);
-                unsigned short v = (unsigned short)(q0 | (q1 << 4) | (q2 << 8) | (q3 << 12));
-                *reinterpret_cast<unsigned short *>(qrow + (size_t)nt * 16 * 8) = v;
+            for (int j = 0; j < 32; j++) {
+                const uint32_t code = (uint32_t)fminf(fmaxf(rintf(xh[j] * rscale), 0.f), 15.f);
+                const int bit = 6 * j;
+                rec[bit >> 5] |= code << (bit & 31);
+                if ((bit & 31) > 26) rec[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
             }
-            if (lq == 0) ((T *)p.oscales)[(size_t)g2 * p.M_pad + m_abs] = f2h<T>(scale);
+            const int m_abs = mw0 + mi * 32 + lr;
+            uint8_t *dst = p.qout + ((size_t)(m_abs >> 5) * KP2 + (g2 >> 1)) * F6_CHUNK + (size_t)lane * 16;
+            if ((g2 & 1) == 0) {
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+                *reinterpret_cast<uint2 *>(dst + F6_PLANE) = make_uint2(rec[4], rec[5]);
+            } else {
+                *reinterpret_cast<uint2 *>(dst + F6_PLANE + 8) = make_uint2(rec[0], rec[1]);
+                *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[2], rec[3], rec[4], rec[5]);
+            }
+            if (h == 0) ((T *)p.oscales)[simg_index(m_abs, g2, KP2)] = f2h<T>(scale);
         }
         return;
     }
 
     // EpilogueDefault (gemm_base.cuh:667-698): store rows < M; fp16 clamps to +-65504
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-        const int m_abs = mw0 + mt * 16 + lr;
+    for (int mi = 0; mi < 2; mi++) {
+        const int m_abs = mw0 + mi * 32 + lr;
         if (m_abs < p.M) {
-            T *orow = (T *)p.out + (size_t)m_abs * p.ldo + nw0 + lq * 4;
+            T *orow = (T *)p.out + (size_t)m_abs * p.ldo + nw0 + h * 4;
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                u16x4 o;
+            for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float v = acc[mt][nt][r];
-                    if constexpr (DT == SVDQ_FP16) v = fminf(fmaxf(v, -65504.f), 65504.f);
-                    o[r] = hbits(f2h<T>(v));
+                for (int c = 0; c < 4; c++) {
+                    u16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float v = acc[ni][mi][c * 4 + e];
+                        if constexpr (DT == SVDQ_FP16) v = fminf(fmaxf(v, -65504.f), 65504.f);
+                        o[e] = hbits(f2h<T>(v));
+                    }
+                    *reinterpret_cast<u16x4 *>(orow + ni * 32 + c * 8) = o;
                 }
-                *reinterpret_cast<u16x4 *>(orow + nt * 16) = o;
-            }
         }
     }
 }
 
-template <int DT, bool UNS, int FUSE>
+template <int DT, int FUSE>
 static void launch_one(const GemmParams &p, hipStream_t st) {
-    dim3 grid((p.M_pad / BM) * (p.N / BN)), block(256);
-    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, UNS, FUSE>), grid, block, 0, st, p);
+    dim3 grid((p.M_pad / BM) * (p.N / BN)), block(512);
+    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE>), grid, block, 0, st, p);
 }
 
-template <int DT, bool UNS>
+template <int DT>
 static void launch_fuse(const GemmParams &p, int fuse, hipStream_t st) {
     switch (fuse) {
-    case SVDQ_FUSE_NONE: launch_one<DT, UNS, SVDQ_FUSE_NONE>(p, st); break;
-    case SVDQ_FUSE_SILU: launch_one<DT, UNS, SVDQ_FUSE_SILU>(p, st); break;
-    case SVDQ_FUSE_GELU_QUANT: launch_one<DT, UNS, SVDQ_FUSE_GELU_QUANT>(p, st); break;
-    case SVDQ_FUSE_RMSNORM_ROPE: launch_one<DT, UNS, SVDQ_FUSE_RMSNORM_ROPE>(p, st); break;
+    case SVDQ_FUSE_NONE: launch_one<DT, SVDQ_FUSE_NONE>(p, st); break;
+    case SVDQ_FUSE_SILU: launch_one<DT, SVDQ_FUSE_SILU>(p, st); break;
+    case SVDQ_FUSE_GELU_QUANT: launch_one<DT, SVDQ_FUSE_GELU_QUANT>(p, st); break;
+    case SVDQ_FUSE_RMSNORM_ROPE: launch_one<DT, SVDQ_FUSE_RMSNORM_ROPE>(p, st); break;
     }
 }
 
@@ -475,6 +460,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     }
     if (a->R > 0 && (!a->lora_act_in || !a->lora_up)) { set_error("svdq_gemm_w4a4: R > 0 needs lora_act_in and lora_up"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemm_w4a4: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
+    if (a->variant != 0) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
     case SVDQ_FUSE_SILU:
@@ -493,13 +479,14 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         return SVDQ_E_INVALID;
     }
     if (a->out && (a->ldo < a->N || a->ldo % 4)) { set_error("svdq_gemm_w4a4: ldo=%d must be >= N and a multiple of 4", a->ldo); return SVDQ_E_INVALID; }
-    if (((uintptr_t)a->act | (uintptr_t)a->wgt | (uintptr_t)a->lora_up | (uintptr_t)a->lora_act_in |
-         (uintptr_t)a->next_lora_down | (uintptr_t)a->rotary_emb) & 15) {
-        set_error("svdq_gemm_w4a4: act, wgt, lora_up, lora_act_in, next_lora_down, rotary_emb must be 16-byte aligned");
+    if (((uintptr_t)a->act | (uintptr_t)a->wgt | (uintptr_t)a->ascales | (uintptr_t)a->wscales | (uintptr_t)a->lora_up |
+         (uintptr_t)a->lora_act_in | (uintptr_t)a->qout | (uintptr_t)a->rotary_emb) & 15) {
+        set_error("svdq_gemm_w4a4: act, wgt, ascales, wscales, lora_up, lora_act_in, qout, rotary_emb must be 16-byte aligned");
         return SVDQ_E_INVALID;
     }
-    if (((uintptr_t)a->out | (uintptr_t)a->bias | (uintptr_t)a->next_smooth | (uintptr_t)a->norm_q | (uintptr_t)a->norm_k) & 7) {
-        set_error("svdq_gemm_w4a4: out, bias, next_smooth, norm_q, norm_k must be 8-byte aligned");
+    if (((uintptr_t)a->out | (uintptr_t)a->bias | (uintptr_t)a->next_smooth | (uintptr_t)a->next_lora_down |
+         (uintptr_t)a->norm_q | (uintptr_t)a->norm_k) & 7) {
+        set_error("svdq_gemm_w4a4: out, bias, next_smooth, next_lora_down, norm_q, norm_k must be 8-byte aligned");
         return SVDQ_E_INVALID;
     }
 
@@ -525,13 +512,8 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
 
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(0, 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
-    if (a->dtype == SVDQ_BF16) {
-        if (a->act_unsigned) launch_fuse<SVDQ_BF16, true>(p, a->fuse, st);
-        else launch_fuse<SVDQ_BF16, false>(p, a->fuse, st);
-    } else {
-        if (a->act_unsigned) launch_fuse<SVDQ_FP16, true>(p, a->fuse, st);
-        else launch_fuse<SVDQ_FP16, false>(p, a->fuse, st);
-    }
+    if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16>(p, a->fuse, st);
+    else launch_fuse<SVDQ_FP16>(p, a->fuse, st);
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_gemm_w4a4 launch");
 }

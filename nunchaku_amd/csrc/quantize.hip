@@ -1,5 +1,5 @@
-// svdq_quantize_w4a4_act_fuse_lora: 16-bit activations -> packed int4 codes + per-(row, group)
-// scales, fused with the rank-R low-rank down projection.
+// svdq_quantize_w4a4_act_fuse_lora: 16-bit activations -> FP6 operand image of the 4-bit codes +
+// per-(row, group) scales, fused with the rank-R low-rank down projection.
 //
 // Replaces the reference's quantize_w4a4_fuse_lora_kernel (gemm_w4a4.cuh:1097-1184; launch
 // gemm_w4a4_launch_impl.cuh:451-521).  Arithmetic (DESIGN.md "Quantiser"):
@@ -8,116 +8,152 @@
 //   amax  = max_{k in group} |x_hat|;  scale = amax * (1/7)  (fp32);  ascales = round16(scale)
 //   q     = clamp(rne(x_hat * (1/scale)), -8, 7)          IEEE reciprocal (reference: rcp.approx)
 //
-// MI355X design: this op is HBM-bound (reads M*K*2 B, writes M*K/2 B).  One workgroup owns a
-// 16-row tile across ALL of K, so the low-rank projection needs no atomics and lora_act is
-// bit-deterministic (the reference reduces K/128 CTAs with fp32 red.add and is not).  The four
-// waves of a workgroup stride over the 64-channel groups; their partial low-rank sums are
-// combined in LDS in a fixed order.  Codes are written in the T16 tile order (svdq_common.h):
-// each wave store instruction writes one contiguous 512-byte MFMA operand tile.
+// MI355X design: the op is HBM-bound (reads M*K*2 B, writes M*K*3/4 B).  The unit of work is one
+// F6 chunk = 32 rows x 128 channels (svdq_common.h), owned by ONE wave: lane (r, h) loads exactly the
+// channels its lane record holds, the group maximum needs a single cross-lane step (lane ^ 32) and
+// the three 16-byte stores of a lane are three fully coalesced 1 KiB wave stores.  A workgroup =
+// 4 waves on one 32-row tile and a slice of K; the low-rank partial sums of the slice are combined
+// in LDS in a fixed order and added to lora_act with fp32 atomics when K is split over several
+// workgroups (the reference reduces K/128 CTAs the same way, lora.cuh:253-339).
 #include "svdq_common.h"
 
 namespace svdq {
 
-template <int DT, int RT /* 16-rank tiles held in registers */>
+template <int DT, int RT32 /* 32-rank tiles held in registers */>
 __global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::T *__restrict__ x,
                                                        const typename Half<DT>::T *__restrict__ smooth,
                                                        const typename Half<DT>::T *__restrict__ lora_down, // [R][K]
                                                        uint8_t *__restrict__ act,
                                                        typename Half<DT>::T *__restrict__ ascales,
-                                                       float *__restrict__ lora_act, int M, int M_pad, int K, int R,
-                                                       int ldx) {
+                                                       float *__restrict__ lora_act, int M, int K, int R, int ldx,
+                                                       int chunks_per_wg, int use_atomics) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int rl = lane & 15, ks = lane >> 4;
-    const int tile = blockIdx.x;
-    const int row = tile * 16 + rl;
+    const int r = lane & 31, h = lane >> 5;
+    const int KP = K / 128;
+    const int slices = (KP + chunks_per_wg - 1) / chunks_per_wg;
+    const int rt = blockIdx.x / slices, slice = blockIdx.x % slices;
+    const int row = rt * 32 + r;
     const bool valid = row < M;
-    const int G = K / GROUP;
-    const int rtiles = R / 16;
+    const int kp_end = min(KP, (slice + 1) * chunks_per_wg);
 
-    v4f accL[RT > 0 ? RT : 1];
+    constexpr int NT = RT32 > 0 ? RT32 : 1;
+    v16f accL[NT];
 #pragma unroll
-    for (int i = 0; i < (RT > 0 ? RT : 1); i++) accL[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) accL[i][j] = 0.f;
 
     const T *xrow = x + (size_t)row * ldx;
-    uint8_t *act_tile = act + (((size_t)(tile >> 3) * G) * 8 + (tile & 7)) * 512 + (size_t)lane * 8;
 
-    for (int g = wave; g < G; g += 4) {
-        const int kbase = g * GROUP + ks * 16;
-        V8 xa, xb;
-        if (valid) {
-            xa = *reinterpret_cast<const V8 *>(xrow + kbase);
-            xb = *reinterpret_cast<const V8 *>(xrow + kbase + 8);
-        } else {
+    for (int kp = slice * chunks_per_wg + wave; kp < kp_end; kp += 4) {
+        uint32_t rec[12];
 #pragma unroll
-            for (int j = 0; j < 8; j++) { xa[j] = (T)0.f; xb[j] = (T)0.f; }
-        }
-
-        if constexpr (RT > 0) {
+        for (int i = 0; i < 12; i++) rec[i] = 0;
+        T sc16[2];
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
-                if (rt < rtiles) { // wave-uniform
-                    const T *ld = lora_down + (size_t)(rt * 16 + rl) * K + kbase;
-                    V8 b0 = *reinterpret_cast<const V8 *>(ld);
-                    V8 b1 = *reinterpret_cast<const V8 *>(ld + 8);
-                    accL[rt] = Half<DT>::mfma(xa, b0, accL[rt]);
-                    accL[rt] = Half<DT>::mfma(xb, b1, accL[rt]);
+        for (int grp = 0; grp < 2; grp++) {
+            const int kbase = kp * 128 + grp * 64 + 4 * h; // + 32t + 8c + e
+            u16x4 xv[8];
+#pragma unroll
+            for (int tc = 0; tc < 8; tc++) {
+                if (valid) xv[tc] = *reinterpret_cast<const u16x4 *>(xrow + kbase + 8 * tc);
+                else xv[tc] = u16x4{0, 0, 0, 0};
+            }
+            if constexpr (RT32 > 0) {
+                // D[m][rank] += x[m][k] * lora_down[k][rank]; MFMA q consumes pieces tc = 2q, 2q+1 of every
+                // lane as k-slots 8h .. 8h+7 (any k order works as long as both operands agree)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    V8 a;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        a[e] = hfrom<T>(xv[2 * q][e]);
+                        a[4 + e] = hfrom<T>(xv[2 * q + 1][e]);
+                    }
+#pragma unroll
+                    for (int t32 = 0; t32 < RT32; t32++) {
+                        if (t32 * 32 < R) { // wave-uniform
+                            const int rank = t32 * 32 + r;
+                            V8 b;
+                            if (rank < R) {
+                                const T *ld = lora_down + (size_t)rank * K + kbase + 16 * q;
+                                u16x4 b0 = *reinterpret_cast<const u16x4 *>(ld);
+                                u16x4 b1 = *reinterpret_cast<const u16x4 *>(ld + 8);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    b[e] = hfrom<T>(b0[e]);
+                                    b[4 + e] = hfrom<T>(b1[e]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; e++) b[e] = (T)0.f;
+                            }
+                            accL[t32] = Half<DT>::mfma32(a, b, accL[t32]);
+                        }
+                    }
                 }
             }
-        }
 
-        float xh[16];
-        if (smooth) {
-            V8 sa = *reinterpret_cast<const V8 *>(smooth + kbase);
-            V8 sb = *reinterpret_cast<const V8 *>(smooth + kbase + 8);
+            float xh[32];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                xh[j] = round16<T>(h2f(xa[j]) / h2f(sa[j]));
-                xh[8 + j] = round16<T>(h2f(xb[j]) / h2f(sb[j]));
+            for (int tc = 0; tc < 8; tc++) {
+                if (smooth) {
+                    u16x4 sv = *reinterpret_cast<const u16x4 *>(smooth + kbase + 8 * tc);
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        xh[4 * tc + e] = round16<T>(h2f(hfrom<T>(xv[tc][e])) / h2f(hfrom<T>(sv[e])));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) xh[4 * tc + e] = h2f(hfrom<T>(xv[tc][e]));
+                }
             }
-        } else {
+            float amax = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                xh[j] = h2f(xa[j]);
-                xh[8 + j] = h2f(xb[j]);
-            }
-        }
-        float amax = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; j++) amax = fmaxf(amax, fabsf(xh[j]));
-        amax = fmaxf(amax, __shfl_xor(amax, 16));
-        amax = fmaxf(amax, __shfl_xor(amax, 32));
+            for (int j = 0; j < 32; j++) amax = fmaxf(amax, fabsf(xh[j]));
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
 
-        const float scale = amax * (1.0f / 7.0f);
-        const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
-        uint32_t w0 = 0, w1 = 0;
+            const float scale = amax * (1.0f / 7.0f);
+            const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
+            sc16[grp] = f2h<T>(scale);
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int q0 = (int)fminf(fmaxf(rintf(xh[j] * rscale), -8.f), 7.f);
-            int q1 = (int)fminf(fmaxf(rintf(xh[8 + j] * rscale), -8.f), 7.f);
-            w0 |= (uint32_t)(q0 & 15) << (4 * j);
-            w1 |= (uint32_t)(q1 & 15) << (4 * j);
+            for (int j = 0; j < 32; j++) {
+                const int q = (int)fminf(fmaxf(rintf(xh[j] * rscale), -8.f), 7.f);
+                const uint32_t code = f6_enc_s4(q);
+                const int bit = 192 * grp + 6 * j;
+                rec[bit >> 5] |= code << (bit & 31);
+                if ((bit & 31) > 26) rec[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+            }
         }
-        *reinterpret_cast<uint2 *>(act_tile + (size_t)g * 8 * 512) = make_uint2(w0, w1);
-        if (ks == 0) ascales[(size_t)g * M_pad + row] = f2h<T>(scale);
+        uint8_t *dst = act + ((size_t)rt * KP + kp) * F6_CHUNK + (size_t)lane * 16;
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        *reinterpret_cast<uint4 *>(dst + F6_PLANE) = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+        *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[8], rec[9], rec[10], rec[11]);
+        // S image: [rt][kp][grp][32]; lane (r, h) writes group h
+        ascales[(((size_t)rt * KP + kp) * 2 + h) * 32 + r] = sc16[h];
     }
 
-    if constexpr (RT > 0) {
-        // combine the four waves' partial sums in a fixed order (deterministic)
-        __shared__ v4f red[4][64];
+    if constexpr (RT32 > 0) {
+        // combine the four waves' partial sums in a fixed order
+        __shared__ v16f red[4][64];
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            if (rt < rtiles) { // block-uniform
-                red[wave][lane] = accL[rt];
+        for (int t32 = 0; t32 < RT32; t32++) {
+            if (t32 * 32 < R) { // block-uniform
+                red[wave][lane] = accL[t32];
                 __syncthreads();
-                if (wave == (rt & 3)) {
-                    v4f s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+                if (wave == (t32 & 3)) {
+                    v16f s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+                    const int rank = t32 * 32 + r; // C layout: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+                    if (rank < R) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        int m = tile * 16 + (lane >> 4) * 4 + i; // MFMA C layout: row=(lane>>4)*4+i, col=lane&15
-                        lora_act[(size_t)m * R + rt * 16 + (lane & 15)] = s[i];
+                        for (int i = 0; i < 16; i++) {
+                            const int m = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            float *dst = lora_act + (size_t)m * R + rank;
+                            if (use_atomics) unsafeAtomicAdd(dst, s[i]);
+                            else *dst = s[i];
+                        }
                     }
                 }
                 __syncthreads();
@@ -129,17 +165,29 @@ __global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::
 template <int DT>
 static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     using T = typename Half<DT>::T;
-    dim3 grid(a->M_pad / 16), block(256);
-    const int rtiles = a->R / 16;
-#define SVDQ_LAUNCH_Q(RT)                                                                                             \
-    hipLaunchKernelGGL((quantize_kernel<DT, RT>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,           \
-                       (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->M_pad, a->K, \
-                       a->R, a->ldx)
-    if (rtiles == 0) SVDQ_LAUNCH_Q(0);
-    else if (rtiles <= 2) SVDQ_LAUNCH_Q(2);
-    else if (rtiles <= 4) SVDQ_LAUNCH_Q(4);
-    else if (rtiles <= 8) SVDQ_LAUNCH_Q(8);
-    else SVDQ_LAUNCH_Q(16);
+    const int KP = a->K / 128, tiles = a->M_pad / 32;
+    // enough workgroups to fill 256 CUs several times over, but at least one chunk per wave
+    int cpw = 4;
+    while ((long)tiles * ((KP + cpw - 1) / cpw) > 4096) cpw *= 2;
+    if (cpw > KP) cpw = ((KP + 3) / 4) * 4;
+    const int slices = (KP + cpw - 1) / cpw;
+    const int atomics = slices > 1;
+    if (a->R > 0 && atomics) {
+        // the reference zeroes the buffer inside the op as well (launch_impl.cuh:487)
+        int rc = hip_check(hipMemsetAsync(a->lora_act, 0, (size_t)a->M_pad * a->R * sizeof(float), st), "svdq_quantize memset");
+        if (rc) return rc;
+    }
+    dim3 grid(tiles * slices), block(256);
+    const int rt32 = (a->R + 31) / 32;
+#define SVDQ_LAUNCH_Q(RT)                                                                                            \
+    hipLaunchKernelGGL((quantize_kernel<DT, RT>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,          \
+                       (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
+                       a->ldx, cpw, atomics)
+    if (rt32 == 0) SVDQ_LAUNCH_Q(0);
+    else if (rt32 <= 1) SVDQ_LAUNCH_Q(1);
+    else if (rt32 <= 2) SVDQ_LAUNCH_Q(2);
+    else if (rt32 <= 4) SVDQ_LAUNCH_Q(4);
+    else SVDQ_LAUNCH_Q(8);
 #undef SVDQ_LAUNCH_Q
     return hip_check(hipGetLastError(), "svdq_quantize_w4a4_act_fuse_lora launch");
 }
@@ -158,11 +206,12 @@ extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, voi
         return SVDQ_E_INVALID;
     }
     if (a->K <= 0 || a->K % 128) { set_error("svdq_quantize: K=%d must be a positive multiple of 128", a->K); return SVDQ_E_INVALID; }
-    if (a->ldx < a->K || a->ldx % 8) { set_error("svdq_quantize: ldx=%d must be >= K and a multiple of 8", a->ldx); return SVDQ_E_INVALID; }
+    if (a->ldx < a->K || a->ldx % 4) { set_error("svdq_quantize: ldx=%d must be >= K and a multiple of 4", a->ldx); return SVDQ_E_INVALID; }
     if (a->R < 0 || a->R % 16 || a->R > 256) { set_error("svdq_quantize: R=%d must be a multiple of 16 in [0, 256]", a->R); return SVDQ_E_INVALID; }
     if (a->R > 0 && (!a->lora_down || !a->lora_act)) { set_error("svdq_quantize: R > 0 needs lora_down and lora_act"); return SVDQ_E_INVALID; }
-    if (((uintptr_t)a->x | (uintptr_t)a->act | (uintptr_t)a->lora_down | (uintptr_t)a->smooth) & 15) {
-        set_error("svdq_quantize: x, act, lora_down and smooth must be 16-byte aligned");
+    if (((uintptr_t)a->act) & 15) { set_error("svdq_quantize: act must be 16-byte aligned"); return SVDQ_E_INVALID; }
+    if (((uintptr_t)a->x | (uintptr_t)a->lora_down | (uintptr_t)a->smooth) & 7) {
+        set_error("svdq_quantize: x, lora_down and smooth must be 8-byte aligned");
         return SVDQ_E_INVALID;
     }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) {
@@ -171,7 +220,7 @@ extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, voi
     }
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes: x in, codes + scales + lora_act out, lora_down in (once)
-    const double bytes = (double)a->M * a->K * 2 + (double)a->M_pad * a->K / 2 + (double)a->M_pad * (a->K / 64) * 2 +
+    const double bytes = (double)a->M * a->K * 2 + (double)a->M_pad * a->K * 3 / 4 + (double)a->M_pad * (a->K / 64) * 2 +
                          (double)a->M_pad * a->R * 4 + (double)a->K * a->R * 2;
     const int prof = prof_begin(1, bytes, st);
     int rc = a->dtype == SVDQ_BF16 ? launch_quantize<SVDQ_BF16>(a, st) : launch_quantize<SVDQ_FP16>(a, st);

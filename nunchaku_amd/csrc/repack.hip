@@ -49,28 +49,49 @@ int hip_check(hipError_t e, const char *what) {
     return SVDQ_E_HIP;
 }
 
-// One thread per OUTPUT dword.  8 consecutive k (aligned to 8) of one output channel are one
-// 32-bit word in the reference order too (packer.py:228-233: reg_k = 8 nibbles, low first), so
-// the re-layout is a dword permutation.
-__global__ void repack_qweight_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int N, int G) {
-    size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t total = (size_t)N * G * 8; // dwords
-    if (d >= total) return;
-    // decode T16 dword index: ((((rb*G + g)*8 + rt)*64 + lane)*2 + h)
-    int h = d & 1;
-    int lane = (d >> 1) & 63;
-    int rt = (d >> 7) & 7;
-    size_t q = d >> 10;
-    int g = q % G;
-    int rb = q / G;
-    int rl = lane & 15, ks = lane >> 4;
-    // reference word: (((nt*KT + kt)*8 + np)*32 + lane_ref)*4 + j
-    int n_pack = rl >> 3, n_lane = rl & 7;
-    int k_pack = ks >> 1, k_lane = (ks & 1) * 2 + h;
-    int lane_ref = n_lane * 4 + k_lane;
-    int j = n_pack * 2 + k_pack;
-    size_t s = ((((size_t)rb * G + g) * 8 + rt) * 32 + lane_ref) * 4 + j;
-    dst[d] = src[s];
+// One thread per OUTPUT (lane record, group) = 32 codes = 24 bytes of the F6 image (svdq_common.h).
+// In the reference order 8 consecutive k (aligned to 8) of one output channel are one 32-bit word
+// (packer.py:228-233: 8 nibbles, low first); the 4 codes e = 0..3 of F6 element j = 16t + 4c + e are
+// the nibbles 4h .. 4h+3 of the word that holds k = 64g + 32t + 8c .. +7.
+__global__ void repack_qweight_kernel(const uint32_t *__restrict__ src, uint8_t *__restrict__ dst, int N, int KP) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)(N / 32) * KP * 2 * 64;
+    if (i >= total) return;
+    const int lane = i & 63;
+    const int grp = (i >> 6) & 1;
+    size_t q = i >> 7;
+    const int kp = q % KP;
+    const int rt = q / KP;
+    const int n = rt * 32 + (lane & 31), h = lane >> 5;
+    const int g = kp * 2 + grp, KT = KP * 2;
+    // reference word: (((nt*KT + kt)*8 + np)*32 + lane_ref)*4 + jj  (oracle: _qweight_index)
+    const int nt = n >> 7, npk = (n & 127) >> 4, n_pack = (n & 15) >> 3, n_lane = n & 7;
+    uint32_t d[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int lane_ref = n_lane * 4 + c, jj = n_pack * 2 + t;
+            const uint32_t w = src[((((size_t)nt * KT + g) * 8 + npk) * 32 + lane_ref) * 4 + jj];
+            const uint32_t four = (w >> (16 * h)) & 0xFFFF;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int v = (four >> (4 * e)) & 15;
+                if (v >= 8) v -= 16;
+                const unsigned code = f6_enc_s4(v);
+                const int bit = 6 * (16 * t + 4 * c + e);
+                d[bit >> 5] |= code << (bit & 31);
+                if ((bit & 31) > 26) d[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+            }
+        }
+    uint8_t *rec = dst + ((size_t)rt * KP + kp) * F6_CHUNK + (size_t)lane * 16;
+    if (grp == 0) {
+        *reinterpret_cast<uint4 *>(rec) = make_uint4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<uint2 *>(rec + F6_PLANE) = make_uint2(d[4], d[5]);
+    } else {
+        *reinterpret_cast<uint2 *>(rec + F6_PLANE + 8) = make_uint2(d[0], d[1]);
+        *reinterpret_cast<uint4 *>(rec + 2 * F6_PLANE) = make_uint4(d[2], d[3], d[4], d[5]);
+    }
 }
 
 // packed position inside a 128-channel block of logical channel c (inverse of packer.py:272-278)
@@ -82,12 +103,17 @@ __host__ __device__ __forceinline__ int scale_pos128(int c) {
     return lane * 4 + e;
 }
 
+// reference [g][n]-packed -> natural [g][n] (SIMG == 0; bias / smooth vectors with G == 1) or the
+// S image [N/32][G/2][2][32] the GEMM stages per K-step (SIMG == 1)
+template <int SIMG>
 __global__ void repack_wscales_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int G, int N) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)G * N) return;
     int g = i / N, n = i % N;
     int nt = n >> 7;
-    dst[i] = src[((size_t)nt * G + g) * 128 + scale_pos128(n & 127)];
+    const uint16_t v = src[((size_t)nt * G + g) * 128 + scale_pos128(n & 127)];
+    if (SIMG) dst[simg_index(n, g, G / 2)] = v;
+    else dst[i] = v;
 }
 
 // 16x16 tiles in mma m16n8k16 fragment order: flat = ((cp*RP + rp)*32 + lane)*8 + h
@@ -116,16 +142,24 @@ __global__ void repack_lowrank_kernel(const uint16_t *__restrict__ src, uint16_t
     }
 }
 
-// T16 packed codes -> one int8 per element, natural [M_pad, K] (test helper)
+// F6 image -> one int8 per element, natural [ROWS, K] (test helper)
 __global__ void unpack_act_kernel(const uint8_t *__restrict__ act, int8_t *__restrict__ codes, int M_pad, int K,
                                   int is_unsigned) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)M_pad * K) return;
     int row = i / K, k = i % K;
-    uint8_t b = act[t16_byte_offset(row, k, K / GROUP)];
-    int v = (k & 1) ? (b >> 4) : (b & 15);
-    if (!is_unsigned && v >= 8) v -= 16;
-    codes[i] = (int8_t)v;
+    const size_t base = f6_record_base(row, k, K / 128);
+    const int bit = f6_record_bit(k);
+    unsigned v = act[f6_byte(base, bit >> 3)] | ((unsigned)act[f6_byte(base, (bit >> 3) + ((bit >> 3) < 47 ? 1 : 0))] << 8);
+    codes[i] = (int8_t)f6_dec((v >> (bit & 7)) & 63, is_unsigned);
+}
+
+// S image -> natural [G][ROWS] (test helper)
+__global__ void unpack_scales_kernel(const uint16_t *__restrict__ simg, uint16_t *__restrict__ nat, int ROWS, int G) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ROWS * G) return;
+    int g = i / ROWS, row = i % ROWS;
+    nat[i] = simg[simg_index(row, g, G / 2)];
 }
 
 } // namespace svdq
@@ -142,25 +176,29 @@ int svdq_repack_qweight(const void *src, void *dst, int32_t N, int32_t K, void *
         set_error("svdq_repack_qweight: N=%d and K=%d must be positive multiples of 128", N, K);
         return SVDQ_E_INVALID;
     }
-    size_t total = (size_t)N * (K / 64) * 8;
+    size_t total = (size_t)(N / 32) * (K / 128) * 2 * 64;
     hipLaunchKernelGGL(repack_qweight_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint32_t *)src, (uint32_t *)dst, N, K / 64);
+                       (const uint32_t *)src, (uint8_t *)dst, N, K / 128);
     return hip_check(hipGetLastError(), "svdq_repack_qweight launch");
 }
 
 int svdq_repack_wscales(const void *src, void *dst, int32_t G, int32_t N, void *stream) {
     if (!src || !dst || src == dst) { set_error("svdq_repack_wscales: null or aliasing pointers"); return SVDQ_E_INVALID; }
-    if (G <= 0 || N <= 0 || N % 128) {
-        set_error("svdq_repack_wscales: G=%d must be > 0 and N=%d a positive multiple of 128", G, N);
+    if (G <= 0 || G % 2 || N <= 0 || N % 128) {
+        set_error("svdq_repack_wscales: G=%d must be a positive even number and N=%d a positive multiple of 128", G, N);
         return SVDQ_E_INVALID;
     }
-    hipLaunchKernelGGL(repack_wscales_kernel, dim3(nblk((size_t)G * N, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(repack_wscales_kernel<1>, dim3(nblk((size_t)G * N, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)src, (uint16_t *)dst, G, N);
     return hip_check(hipGetLastError(), "svdq_repack_wscales launch");
 }
 
 int svdq_repack_vec(const void *src, void *dst, int32_t N, void *stream) {
-    return svdq_repack_wscales(src, dst, 1, N, stream);
+    if (!src || !dst || src == dst) { set_error("svdq_repack_vec: null or aliasing pointers"); return SVDQ_E_INVALID; }
+    if (N <= 0 || N % 128) { set_error("svdq_repack_vec: N=%d must be a positive multiple of 128", N); return SVDQ_E_INVALID; }
+    hipLaunchKernelGGL(repack_wscales_kernel<0>, dim3(nblk((size_t)N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)src, (uint16_t *)dst, 1, N);
+    return hip_check(hipGetLastError(), "svdq_repack_vec launch");
 }
 
 int svdq_repack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_t down, void *stream) {
@@ -176,13 +214,24 @@ int svdq_repack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_
 
 int svdq_unpack_act(const void *act, int8_t *codes, int32_t M_pad, int32_t K, int32_t is_unsigned, void *stream) {
     if (!act || !codes) { set_error("svdq_unpack_act: null pointer"); return SVDQ_E_INVALID; }
-    if (M_pad <= 0 || K <= 0 || M_pad % 128 || K % 64) {
-        set_error("svdq_unpack_act: M_pad=%d must be a multiple of 128 and K=%d of 64", M_pad, K);
+    if (M_pad <= 0 || K <= 0 || M_pad % 32 || K % 128) {
+        set_error("svdq_unpack_act: M_pad=%d must be a multiple of 32 and K=%d of 128", M_pad, K);
         return SVDQ_E_INVALID;
     }
     hipLaunchKernelGGL(unpack_act_kernel, dim3(nblk((size_t)M_pad * K, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t *)act, codes, M_pad, K, is_unsigned);
     return hip_check(hipGetLastError(), "svdq_unpack_act launch");
+}
+
+int svdq_unpack_scales(const void *simg, void *natural, int32_t ROWS, int32_t G, void *stream) {
+    if (!simg || !natural || simg == natural) { set_error("svdq_unpack_scales: null or aliasing pointers"); return SVDQ_E_INVALID; }
+    if (ROWS <= 0 || G <= 0 || ROWS % 32 || G % 2) {
+        set_error("svdq_unpack_scales: ROWS=%d must be a multiple of 32 and G=%d even", ROWS, G);
+        return SVDQ_E_INVALID;
+    }
+    hipLaunchKernelGGL(unpack_scales_kernel, dim3(nblk((size_t)ROWS * G, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)simg, (uint16_t *)natural, ROWS, G);
+    return hip_check(hipGetLastError(), "svdq_unpack_scales launch");
 }
 
 int svdq_prof_enable(int32_t max_launches) {

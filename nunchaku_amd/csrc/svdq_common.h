@@ -1,16 +1,24 @@
 // Shared device/host helpers of the gfx950 SVDQuant kernels.
 //
-// Packed int4 "T16" tile order (both the activations produced by our quantiser and the weights
-// after svdq_repack_qweight use it; DESIGN.md "Data layout in HBM"):
+// Operand images (DESIGN.md "Data layout in HBM").  Both GEMM operands -- the activations produced
+// by our quantiser / by a GELU_QUANT epilogue, and the weights after svdq_repack_qweight -- are
+// stored as the register image of v_mfma_scale_f32_32x32x64_f8f6f4 with FP6 (e2m3) operands: a 4-bit
+// code q is exactly the FP6 value q/8 (sign<<5 | |q| for signed codes, the code itself for unsigned
+// ones), so the matrix core multiplies the integer codes exactly and no unpack work is left in
+// the main loop.
 //
-//   matrix [ROWS, K] of 4-bit codes, ROWS % 128 == 0, K % 64 == 0, G = K / 64
-//   byte(row, k) = ((((row/128)*G + k/64)*8 + (row%128)/16)*64 + lane)*8 + (k%16)/2,
-//   lane = ((k%64)/16)*16 + row%16,   low nibble = even k.
+//   "F6" image of a matrix [ROWS, K] of 4-bit codes, ROWS % 32 == 0, K % 128 == 0, KP = K / 128:
+//     chunk (rt = row/32, kp = k/128) : 3072 bytes at ((rt*KP + kp) * 3072)
+//     a chunk is 3 planes of 1024 bytes; plane p holds bytes [16p, 16p+16) of every lane record,
+//     lane l at plane offset 16*l  (so one 16 B/lane wave load or LDS-DMA moves one plane);
+//     lane l = (row & 31) | (h << 5); its 48-byte record = group 2kp in bytes [0,24), group 2kp+1
+//     in bytes [24,48); inside a group record element j (0..31) sits at bits [6j, 6j+6);
+//     the group-local channel of (h, j) is  k = 32*(j>>4) + 8*((j>>2)&3) + 4*h + (j&3)
+//     (the order in which a 32x32 MFMA accumulator tile holds 64 output columns, so a GELU_QUANT
+//     epilogue packs the next layer's activations without any cross-lane movement).
 //
-// i.e. one (16 rows x 64 k) MFMA operand tile is 512 contiguous bytes in wave-lane order: lane l
-// owns 8 bytes = the 16 codes of row (l&15), k-slot (l>>4).  A (128 rows x 64 k) block is one
-// contiguous 4 KiB chunk, so a workgroup's operand tile for one quantisation group is staged
-// with fully coalesced 16-byte loads and read back from LDS with conflict-free ds_read_b64.
+//   "S" image of the per-(row, 64-channel group) scales: [ROWS/32][KP][2][32] 16-bit, i.e. the 64
+//     scales one K-step (two groups) needs for 32 rows are 128 contiguous bytes.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -23,13 +31,15 @@ namespace svdq {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v6i __attribute__((ext_vector_type(6)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GROUP = 64;   // int4 quantisation group (reference: gemm_base.cuh:89-95)
-constexpr int ROWBLK = 128; // rows per contiguous T16 block
 
 // ---- 16-bit model dtype traits -------------------------------------------------------------
 template <int DT> struct Half;
@@ -39,12 +49,18 @@ template <> struct Half<SVDQ_BF16> {
     static __device__ __forceinline__ v4f mfma(V8 a, V8 b, v4f c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ v16f mfma32(V8 a, V8 b, v16f c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
 };
 template <> struct Half<SVDQ_FP16> {
     using T = _Float16;
     using V8 = f16x8;
     static __device__ __forceinline__ v4f mfma(V8 a, V8 b, v4f c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ v16f mfma32(V8 a, V8 b, v16f c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
 };
 
@@ -60,9 +76,36 @@ template <typename T> __device__ __forceinline__ T hfrom(unsigned short b) { ret
 // epilogue stages; this reproduces those rounding points)
 template <typename T> __device__ __forceinline__ float round16(float v) { return (float)(T)v; }
 
-__host__ __device__ __forceinline__ size_t t16_byte_offset(int row, int k, int G) {
-    int lane = ((k & 63) >> 4) * 16 + (row & 15);
-    return ((((size_t)(row >> 7) * G + (k >> 6)) * 8 + ((row & 127) >> 4)) * 64 + lane) * 8 + ((k & 15) >> 1);
+// ---- F6 / S image addressing ----------------------------------------------------------------
+constexpr int F6_CHUNK = 3072; // bytes of one (32 rows x 128 k) chunk
+constexpr int F6_PLANE = 1024;
+
+// element index j (0..31) and lane half h of group-local channel kg (0..63)
+__host__ __device__ __forceinline__ int f6_half(int kg) { return (kg >> 2) & 1; }
+__host__ __device__ __forceinline__ int f6_elem(int kg) { return ((kg >> 5) << 4) | (((kg >> 3) & 3) << 2) | (kg & 3); }
+// group-local channel of (h, j)
+__host__ __device__ __forceinline__ int f6_channel(int h, int j) { return 32 * (j >> 4) + 8 * ((j >> 2) & 3) + 4 * h + (j & 3); }
+
+// code (row, k) lives in the 48-byte lane record starting (plane 0) at f6_record_base(), at bit
+// f6_record_bit(k) of that record.
+__host__ __device__ __forceinline__ size_t f6_record_base(int row, int k, int KP) {
+    // offset of byte 0 of plane 0 of the lane record (plane p adds p*1024)
+    const int kg = k & 63;
+    const int lane = (row & 31) | (f6_half(kg) << 5);
+    return ((size_t)(row >> 5) * KP + (k >> 7)) * F6_CHUNK + (size_t)lane * 16;
+}
+__host__ __device__ __forceinline__ int f6_record_bit(int k) { return 192 * ((k >> 6) & 1) + 6 * f6_elem(k & 63); }
+// byte b (0..47) of a lane record lives at record_base + (b >> 4) * 1024 + (b & 15)
+__host__ __device__ __forceinline__ size_t f6_byte(size_t record_base, int b) { return record_base + (size_t)(b >> 4) * F6_PLANE + (b & 15); }
+
+__host__ __device__ __forceinline__ size_t simg_index(int row, int g, int KP) {
+    return (((size_t)(row >> 5) * KP + (g >> 1)) * 2 + (g & 1)) * 32 + (row & 31);
+}
+
+// FP6 e2m3 encodings of 4-bit codes
+__host__ __device__ __forceinline__ unsigned f6_enc_s4(int q) { return q < 0 ? (32u | (unsigned)(-q)) : (unsigned)q; }
+__host__ __device__ __forceinline__ int f6_dec(unsigned c, int is_unsigned) {
+    return is_unsigned ? (int)(c & 31) : ((c & 32) ? -(int)(c & 15) : (int)(c & 15));
 }
 
 // ---- host-side error plumbing --------------------------------------------------------------

@@ -23,14 +23,28 @@ def _run(fn_name, src: torch.Tensor, *dims) -> torch.Tensor:
     return dst
 
 
+def act_image_shape(rows: int, K: int) -> tuple[int, int]:
+    """Shape (uint8) of the FP6 operand image of a [rows, K] matrix of 4-bit codes (6 bits per code)."""
+    if K % 128 or rows % 32:
+        raise ValueError("FP6 operand images need K % 128 == 0 and rows % 32 == 0")
+    return rows, K * 3 // 4
+
+
 def repack_qweight(qweight: torch.Tensor) -> torch.Tensor:
-    """[N, K/2] int8 reference order -> T16 tile order."""
+    """[N, K/2] int8 reference order -> [N, 3K/4] FP6 operand image (csrc/svdq_common.h "F6")."""
+    lib = _lib.load()
+    if not qweight.is_cuda:
+        raise RuntimeError("nunchaku_amd.layout: tensors must be on the GPU (no CPU path)")
+    qweight = qweight.contiguous()
     N, Kh = qweight.shape
-    return _run("svdq_repack_qweight", qweight, N, Kh * 2)
+    dst = torch.empty(act_image_shape(N, Kh * 2), dtype=torch.int8, device=qweight.device)
+    rc = lib.svdq_repack_qweight(qweight.data_ptr(), dst.data_ptr(), N, Kh * 2, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "svdq_repack_qweight")
+    return dst
 
 
 def repack_wscales(wscales: torch.Tensor) -> torch.Tensor:
-    """[K/64, N] 16-bit reference order -> natural [g][n]."""
+    """[K/64, N] 16-bit reference order -> scale image [N/32][K/128][2][32] (same storage shape)."""
     G, N = wscales.shape
     return _run("svdq_repack_wscales", wscales, G, N)
 
@@ -49,9 +63,19 @@ def repack_lowrank(w: torch.Tensor, down: bool) -> torch.Tensor:
 def unpack_act(act: torch.Tensor, K: int, unsigned: bool = False) -> torch.Tensor:
     """Opaque packed activations -> int8 codes [M_pad, K] (test/debug helper)."""
     lib = _lib.load()
-    M_pad = act.numel() * 2 // K
+    M_pad = act.numel() * 4 // (3 * K)
     codes = torch.empty(M_pad, K, dtype=torch.int8, device=act.device)
     rc = lib.svdq_unpack_act(act.data_ptr(), codes.data_ptr(), M_pad, K, int(unsigned),
                              torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "svdq_unpack_act")
     return codes
+
+
+def unpack_scales(simg: torch.Tensor, rows: int) -> torch.Tensor:
+    """Opaque scale image -> natural [K/64, rows] (test/debug helper)."""
+    lib = _lib.load()
+    G = simg.numel() // rows
+    nat = torch.empty(G, rows, dtype=simg.dtype, device=simg.device)
+    rc = lib.svdq_unpack_scales(simg.data_ptr(), nat.data_ptr(), rows, G, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "svdq_unpack_scales")
+    return nat

@@ -2,9 +2,11 @@
 
 Same constructor, parameter names/shapes/dtypes and methods as the reference's ``SVDQW4A4Linear``
 so reference checkpoints ``load_state_dict`` unchanged.  Checkpoint tensors arrive in NVIDIA mma
-fragment order; ``repack_()`` permutes them ONCE, in place (same ``nn.Parameter`` objects, same
-shapes), into the CDNA4 tile order the HIP kernels read.  It runs lazily before the first kernel
-call and again after every ``load_state_dict``.
+fragment order; ``repack_()`` converts them ONCE (same ``nn.Parameter`` objects) into the CDNA4
+operand images the HIP kernels read: ``qweight`` becomes the [out, 3*in/4]-byte FP6 (e2m3) register
+image of v_mfma_scale_f32_32x32x64_f8f6f4 (a 4-bit code is exactly an FP6 value), the other tensors
+are permuted in place.  It runs lazily before the first kernel call and again after every
+``load_state_dict`` (a pre-hook restores the checkpoint shape of ``qweight`` first).
 """
 
 from __future__ import annotations
@@ -66,12 +68,20 @@ class SVDQW4A4Linear(nn.Module):
 
         # False while the parameters hold the reference (checkpoint) layout
         self._amd_layout = False
+        self._register_load_state_dict_pre_hook(self._restore_checkpoint_shapes, with_module=True)
         self.register_load_state_dict_post_hook(self._mark_reference_layout)
 
     # ------------------------------------------------------------------ layout
     @staticmethod
     def _mark_reference_layout(module, incompatible_keys):
         module._amd_layout = False
+
+    @staticmethod
+    def _restore_checkpoint_shapes(module, state_dict, prefix, local_metadata, strict, missing, unexpected, errors):
+        # after repack_() qweight holds the FP6 image; a checkpoint brings [out, in/2] int8 again
+        qw = module.qweight
+        if qw.shape[-1] != module.in_features // 2:
+            qw.data = torch.empty(module.out_features, module.in_features // 2, dtype=torch.int8, device=qw.device)
 
     @torch.no_grad()
     def repack_(self) -> "SVDQW4A4Linear":
@@ -80,7 +90,7 @@ class SVDQW4A4Linear(nn.Module):
             return self
         if not self.qweight.is_cuda:
             raise RuntimeError("SVDQW4A4Linear.repack_(): move the layer to the GPU first (no CPU path)")
-        self.qweight.data.copy_(layout.repack_qweight(self.qweight.data))
+        self.qweight.data = layout.repack_qweight(self.qweight.data)
         self.wscales.data.copy_(layout.repack_wscales(self.wscales.data))
         self.smooth_factor.data.copy_(layout.repack_vec(self.smooth_factor.data))
         if self.bias is not None:
@@ -120,7 +130,7 @@ class SVDQW4A4Linear(nn.Module):
         return output.reshape(B, S, -1)
 
     def quantize(self, x: torch.Tensor, pad_size: int = 256):
-        """x [N, in] -> (codes [N_pad, in/2] uint8, ascales [in/64, N_pad], lora_act [N_pad, rank] f32)."""
+        """x [N, in] -> (FP6 code image [N_pad, 3*in/4] uint8, ascales [in/64, N_pad], lora_act [N_pad, rank] f32)."""
         self._ensure_layout()
         return svdq_quantize_w4a4_act_fuse_lora_cuda(
             x, lora_down=self.proj_down, smooth=self.smooth_factor, fp4=False, pad_size=pad_size

@@ -18,7 +18,7 @@ def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256) -> torch.Tens
     qx, ascales, lora_act = fc1.quantize(x2)
     M_pad = ceil_divide(M, pad_size) * pad_size
     dev = x.device
-    q_hidden = torch.empty(M_pad, fc1.out_features // 2, dtype=torch.uint8, device=dev)
+    q_hidden = torch.empty(M_pad, fc1.out_features * 3 // 4, dtype=torch.uint8, device=dev)  # FP6 operand image
     s_hidden = torch.empty(fc1.out_features // 64, M_pad, dtype=x.dtype, device=dev)
     l_hidden = torch.empty(M_pad, fc2.proj_down.shape[1], dtype=torch.float32, device=dev)
     fc1._ensure_layout()

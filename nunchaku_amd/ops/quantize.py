@@ -21,9 +21,10 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """4-bit quantisation of ``input`` [M, K] plus the low-rank down projection.
 
-    Returns ``(output [M_pad, K/2] uint8, oscales [K/64, M_pad], lora_act_out [M_pad, R] float32)``
-    with ``M_pad = ceil(M / pad_size) * pad_size``.  The three buffers are opaque (tile order of
-    this library); only their shapes follow the reference.
+    Returns ``(output [M_pad, 3K/4] uint8, oscales [K/64, M_pad], lora_act_out [M_pad, R] float32)``
+    with ``M_pad = ceil(M / pad_size) * pad_size``.  ``output`` and ``oscales`` are opaque (the FP6
+    operand image / scale image of this library: 6 bits per 4-bit code, so the code buffer is 1.5x the
+    reference's ``[M_pad, K/2]``); ``lora_act_out`` holds the true fp32 projection.
     """
     if fp4:
         raise NotImplementedError("NVFP4 is not available on MI355X")
@@ -32,10 +33,10 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     M_pad = ceil_divide(M, pad_size) * pad_size
     dev = input.device
     if output is None:
-        output = torch.empty(M_pad, K // 2, dtype=torch.uint8, device=dev)
+        output = torch.empty(M_pad, K * 3 // 4, dtype=torch.uint8, device=dev)
     if oscales is None:
-        if K % 64:
-            raise ValueError("K must be a multiple of 64")
+        if K % 128:
+            raise ValueError("K must be a multiple of 128")
         oscales = torch.empty(K // 64, M_pad, dtype=input.dtype, device=dev)
     if lora_act_out is None:
         lora_act_out = torch.empty(M_pad, R, dtype=torch.float32, device=dev)
