@@ -134,7 +134,7 @@ typedef struct svdq_gemm_args {
     int32_t dtype;            /* SVDQ_BF16 | SVDQ_FP16                                          */
     int32_t act_unsigned;     /* informational: the FP6 image already encodes signedness        */
     int32_t fuse;             /* SVDQ_FUSE_*                                                    */
-    int32_t variant;          /* must be 0                                                      */
+    int32_t variant;          /* 0 = hand-scheduled main loop; 1 = compiler-scheduled (debug)   */
     int32_t reserved;
 } svdq_gemm_args;
 

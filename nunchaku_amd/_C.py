@@ -13,6 +13,7 @@ SURVEY.md section 5), unsupported reference features raise ``NotImplementedError
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -113,6 +114,7 @@ class _Ops:
         a.M = M_pad
         a.dtype = _DT[ascales.dtype]
         a.act_unsigned = int(bool(act_unsigned))
+        a.variant = int(os.environ.get("SVDQ_GEMM_VARIANT", "0"))  # 1 = compiler-scheduled loop (debug/A-B only)
 
         if qout is not None and oscales is not None:
             a.fuse = _lib.FUSE_GELU_QUANT

@@ -37,8 +37,8 @@ constexpr int NSTAGE = 3;
 constexpr int A_BYTES = (BM / 32) * F6_CHUNK;  // 24576
 constexpr int W_BYTES = (BN / 32) * F6_CHUNK;  // 12288
 constexpr int AS_BYTES = (BM / 32) * 128;      // 1024
-constexpr int WS_BYTES = (BN / 32) * 128;      // 512
-constexpr int STAGE_BYTES = A_BYTES + W_BYTES + AS_BYTES + WS_BYTES; // 38400
+constexpr int WS_BYTES = 1024;                 // 512 used; the DMA writes whole 1 KiB planes
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES + AS_BYTES + WS_BYTES; // 38912 (tools/gen_gemm_loop.py: STAGE)
 constexpr int MAX_LORA_TILES = 16;             // R <= 256
 
 struct GemmParams {
@@ -79,7 +79,7 @@ typedef const __attribute__((address_space(1))) void gvoid;
 #define MXS_A 0x82828282
 #define MXS_B 0x81818181
 
-template <int DT, int FUSE>
+template <int DT, int FUSE, bool ASM_LOOP>
 __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
@@ -94,6 +94,76 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
     const int m0 = bm * BM, n0 = bn * BN;
 
+    v16f acc[2][2]; // [n tile][m tile]
+    const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    if constexpr (ASM_LOOP) {
+        // ---- hand-scheduled main loop (tools/gen_gemm_loop.py; DESIGN.md "Main loop") -------------
+        // Per K-step every wave issues 3 LDS-DMA plane loads of "its" A chunk plus one or two more
+        // planes (W planes / the scale images), all wave-uniform bases in SGPRs:
+        //   waves 0..3: W planes 2w, 2w+1      waves 4..7: W plane 8 + (w-4)
+        //   wave 4 additionally: activation scales (8 x 128 B)   wave 5: weight scales (4 x 128 B, twice)
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned lds_base = (unsigned)(size_t)(lds_void *)lds;
+        unsigned long long pA = (unsigned long long)(p.act + ((size_t)(bm * 8 + wv) * KP) * F6_CHUNK);
+        const int px1 = wv < 4 ? 2 * wv : 8 + (wv - 4);
+        unsigned long long pX1 = (unsigned long long)(p.wgt + ((size_t)(bn * 4 + px1 / 3) * KP) * F6_CHUNK + (px1 % 3) * F6_PLANE);
+        unsigned dX1 = lds_base + A_BYTES + (px1 / 3) * F6_CHUNK + (px1 % 3) * F6_PLANE;
+        unsigned iX1 = F6_CHUNK, iX2 = F6_CHUNK, nX = 2, dX2 = 0;
+        unsigned long long pX2 = pX1;
+        unsigned offA = lane * 16, offX1 = lane * 16, offX2 = lane * 16;
+        if (wv < 4) {
+            const int px2 = 2 * wv + 1;
+            pX2 = (unsigned long long)(p.wgt + ((size_t)(bn * 4 + px2 / 3) * KP) * F6_CHUNK + (px2 % 3) * F6_PLANE);
+            dX2 = lds_base + A_BYTES + (px2 / 3) * F6_CHUNK + (px2 % 3) * F6_PLANE;
+        } else if (wv == 4) {
+            pX2 = (unsigned long long)((const uint8_t *)p.ascales + ((size_t)(bm * 8) * KP) * 128);
+            offX2 = (lane >> 3) * KP * 128 + (lane & 7) * 16;
+            dX2 = lds_base + A_BYTES + W_BYTES;
+            iX2 = 128;
+        } else if (wv == 5) {
+            pX2 = (unsigned long long)((const uint8_t *)p.wscales + ((size_t)(bn * 4) * KP) * 128);
+            offX2 = ((lane >> 3) & 3) * KP * 128 + (lane & 7) * 16;
+            dX2 = lds_base + A_BYTES + W_BYTES + AS_BYTES;
+            iX2 = 128;
+        } else {
+            nX = 1;
+        }
+        const unsigned dA = lds_base + wv * F6_CHUNK;
+        const unsigned in_la = lds_base + (wm * 2) * F6_CHUNK + lane * 16;
+        const unsigned in_lw = lds_base + A_BYTES + (wn * 2) * F6_CHUNK + lane * 16;
+        const unsigned in_lsa = lds_base + A_BYTES + W_BYTES + (wm * 2) * 128 + lr * 2;
+        const unsigned in_lsw = lds_base + A_BYTES + W_BYTES + AS_BYTES + (wn * 2) * 128 + lr * 2;
+        const unsigned kp_s = KP;
+#define SVDQ_LOOP_OPERANDS                                                                                              \
+        : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
+          "+{s[40:41]}"(pA), "+{s[42:43]}"(pX1), "+{s[44:45]}"(pX2)                                                       \
+        : "{v210}"(in_la), "{v211}"(in_lw), "{v212}"(in_lsa), "{v213}"(in_lsw), "{v214}"(offA), "{v215}"(offX1),         \
+          "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX1), "{s51}"(iX2), "{s52}"(nX) \
+        : "memory", "scc", "m0", "s53", "s54", "s55", "s56", "s57", "v64", "v65", "v66", "v67", "v68", "v69", "v70",     \
+          "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", \
+          "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",       \
+          "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",  \
+          "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129",  \
+          "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143",  \
+          "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157",  \
+          "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171",  \
+          "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185",  \
+          "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199",  \
+          "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220",  \
+          "v221", "v222", "v223", "v224"
+        if constexpr (DT == SVDQ_BF16) {
+            asm volatile(
+#include "gemm_loop_bf16.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else {
+            asm volatile(
+#include "gemm_loop_fp16.inc"
+                SVDQ_LOOP_OPERANDS);
+        }
+#undef SVDQ_LOOP_OPERANDS
+    } else {
+    // ---- reference C++ main loop (variant 1: same arithmetic, compiler-scheduled) ----------------
     // ---- operand streams: every wave moves whole 1 KiB planes -------------------------------
     //   waves 0..7: the three planes of A chunk `wave`;  waves 0..3: the three planes of W chunk
     //   `wave`;  wave 4: activation scales (8 x 128 B);  wave 5: weight scales (4 x 128 B).
@@ -121,14 +191,12 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         }
     };
 
-    v16f acc[2][2]; // [n tile][m tile]
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     fetch(0, lds);
     if (KP > 1) fetch(1, lds + STAGE_BYTES);
@@ -176,6 +244,8 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 }
         }
     }
+
+    } // ASM_LOOP
 
     // ------------------------------------------------------------------ epilogue
     // lane owns rows m = mw0 + 32*mi + lr and columns n = nw0 + 32*ni + 8*c + 4*h + e  (r = 4c + e)
@@ -420,19 +490,19 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     }
 }
 
-template <int DT, int FUSE>
+template <int DT, int FUSE, bool ASM_LOOP>
 static void launch_one(const GemmParams &p, hipStream_t st) {
     dim3 grid((p.M_pad / BM) * (p.N / BN)), block(512);
-    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, ASM_LOOP>), grid, block, 0, st, p);
 }
 
-template <int DT>
+template <int DT, bool ASM_LOOP>
 static void launch_fuse(const GemmParams &p, int fuse, hipStream_t st) {
     switch (fuse) {
-    case SVDQ_FUSE_NONE: launch_one<DT, SVDQ_FUSE_NONE>(p, st); break;
-    case SVDQ_FUSE_SILU: launch_one<DT, SVDQ_FUSE_SILU>(p, st); break;
-    case SVDQ_FUSE_GELU_QUANT: launch_one<DT, SVDQ_FUSE_GELU_QUANT>(p, st); break;
-    case SVDQ_FUSE_RMSNORM_ROPE: launch_one<DT, SVDQ_FUSE_RMSNORM_ROPE>(p, st); break;
+    case SVDQ_FUSE_NONE: launch_one<DT, SVDQ_FUSE_NONE, ASM_LOOP>(p, st); break;
+    case SVDQ_FUSE_SILU: launch_one<DT, SVDQ_FUSE_SILU, ASM_LOOP>(p, st); break;
+    case SVDQ_FUSE_GELU_QUANT: launch_one<DT, SVDQ_FUSE_GELU_QUANT, ASM_LOOP>(p, st); break;
+    case SVDQ_FUSE_RMSNORM_ROPE: launch_one<DT, SVDQ_FUSE_RMSNORM_ROPE, ASM_LOOP>(p, st); break;
     }
 }
 
@@ -460,7 +530,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     }
     if (a->R > 0 && (!a->lora_act_in || !a->lora_up)) { set_error("svdq_gemm_w4a4: R > 0 needs lora_act_in and lora_up"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemm_w4a4: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
-    if (a->variant != 0) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
+    if (a->variant < 0 || a->variant > 1) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
     case SVDQ_FUSE_SILU:
@@ -512,8 +582,14 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
 
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(0, 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
-    if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16>(p, a->fuse, st);
-    else launch_fuse<SVDQ_FP16>(p, a->fuse, st);
+    // variant 0: hand-scheduled main loop; variant 1: the compiler-scheduled C++ loop (same arithmetic)
+    if (a->variant == 0) {
+        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, true>(p, a->fuse, st);
+        else launch_fuse<SVDQ_FP16, true>(p, a->fuse, st);
+    } else {
+        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, false>(p, a->fuse, st);
+        else launch_fuse<SVDQ_FP16, false>(p, a->fuse, st);
+    }
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_gemm_w4a4 launch");
 }

@@ -115,12 +115,15 @@ def test_linear_forward_matches_oracle(dtype, M, K, N, R):
     assert y.shape == (1, M, N) and y.dtype == TORCH_DT[dtype]
     got = f32(y)[0]
     # (1) the GEMM itself: oracle on the very lora_act the kernel consumed (the quantiser's low-rank
-    # sums differ from float64 in the last fp32 bits, which can flip their 16-bit rounding) -> 1 ulp
+    # sums differ from float64 in the last fp32 bits -- and between calls, fp32 atomics over K slices --
+    # which can flip their 16-bit rounding) -> 1 ulp
     q, a, _ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"], dtype)
-    la_gpu = mod.quantize(xt)[2].cpu().numpy()
+    qx, asc, la = mod.quantize(xt)
+    la_gpu = la.cpu().numpy()
+    got_q = f32(mod.forward_quant(qx, asc, la))[:M]
     ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=la_gpu,
                       lora_up=L["proj_up"])["out"][:M]
-    assert_close_16(got, ref, dtype, "gemm on GPU lora_act", max_bad_frac=0.0, ulps=1.0)
+    assert_close_16(got_q, ref, dtype, "gemm on GPU lora_act", max_bad_frac=0.0, ulps=1.0)
     # (2) whole layer vs the pure oracle: additionally one 16-bit ulp of the largest lora_act value
     # times the largest |proj_up| entry (a flipped rounding of one low-rank activation)
     ref_full = O.svdq_linear(x, L, dtype, "fp32")["out"]

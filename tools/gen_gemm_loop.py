@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Generate the hand-scheduled main loop of svdq_gemm_w4a4 (gfx950) as inline-asm text.
+
+    python tools/gen_gemm_loop.py        # writes nunchaku_amd/csrc/gemm_loop_{bf16,fp16}.inc
+
+Why a generator: the loop is software-pipelined by hand (hipcc cannot be steered into this
+interleave, DESIGN.md "Main loop"): for every 32x32 tile and 64-channel group ("tile-group")
+    P = v_mfma_scale_f32_32x32x64_f8f6f4(W codes, A codes)      FP6 operands = exact int4 product
+    S = v_mfma_f32_32x32x16_{bf16,f16}(ws, as)                  rank-1 scale tile (= 2*ws*as)
+    acc += P * S                                                16 v_fmac_f32
+and the MFMAs of tile-group q+1 are issued between the two fma halves of tile-group q, with the
+LDS fragment reads of the next group, the LDS-DMA of K-step s+3 and the one barrier per K-step
+placed in the remaining issue slots.  Register allocation is fixed (the C++ side pins its asm
+operands to the same physical registers):
+
+  v[0:63]    acc, tile t = 2*ni + mi at v[16t:16t+15]      (output operands)
+  v[64:79] P0   v[80:95] S0   v[96:111] P1   v[112:127] S1
+  v[128:151] fragment buffer 0 (group 0 of a K-step): W0 W1 A0 A1, 6 regs each
+  v[152:175] fragment buffer 1 (group 1)
+  v[176:191] scale tuples buffer 0: sw0 sw1 sa0 sa1, 4 regs each = {scale, 0, 0, 0}
+  v[192:207] scale tuples buffer 1
+  v208 v209  MX block exponents of the FP6 MFMA
+  v210..v213 inputs: per-lane LDS offsets (stage-relative) of A frags, W frags, as, ws
+  v214..v216 inputs: per-lane global byte offsets of the DMA streams A, X1, X2
+  v217..v220 LDS addresses of the current stage, v221..v224 of the next stage
+  s[40:41] s[42:43] s[44:45]  inputs: global base of streams A, X1, X2 (advanced here)
+  s46 KP   s47 s48 s49 LDS destinations (stage-relative) of A, X1, X2   s50 s51 step of X1, X2
+  s52 number of X streams (1 or 2)     s53.. scratch
+"""
+import os
+
+STAGE = 24576 + 12288 + 1024 + 1024  # A, W, as, ws(+pad)
+NSTAGE = 3
+CHUNK, PLANE = 3072, 1024
+
+ACC = 0
+PBUF = [64, 96]
+SBUF = [80, 112]
+FRAG = [128, 152]  # + 0: W0, 6: W1, 12: A0, 18: A1
+SCL = [176, 192]   # + 0: sw0, 4: sw1, 8: sa0, 12: sa1
+MXA, MXB = 208, 209
+IN_LA, IN_LW, IN_LSA, IN_LSW = 210, 211, 212, 213
+OFF_A, OFF_X1, OFF_X2 = 214, 215, 216
+CUR = [217, 218, 219, 220]   # A, W, SA, SW address of the current stage
+NXT = [221, 222, 223, 224]
+S_PA, S_PX1, S_PX2 = 40, 42, 44
+S_KP, S_DA, S_DX1, S_DX2, S_IX1, S_IX2, S_NX = 46, 47, 48, 49, 50, 51, 52
+S_STEP, S_CUR, S_NEXT, S_TMP, S_DMASTEP = 53, 54, 55, 56, 57
+
+
+def vr(a, n=1):
+    return f"v{a}" if n == 1 else f"v[{a}:{a + n - 1}]"
+
+
+def sr(a, n=1):
+    return f"s{a}" if n == 1 else f"s[{a}:{a + n - 1}]"
+
+
+class Gen:
+    def __init__(self, smfma):
+        self.smfma = smfma
+        self.lines = []
+        self.label = 0
+
+    def e(self, s):
+        self.lines.append(s)
+
+    def new_label(self):
+        self.label += 1
+        return f".Lsvdq{self.label}_%="
+
+    # ---- building blocks -------------------------------------------------------------
+    def frag_reads(self, buf, grp, addr):
+        """LDS reads of the 4 fragments + 4 scale tuples of one group into buffer `buf`.
+        addr = [A, W, SA, SW] address VGPRs of the stage to read from.  Returns 12 instructions."""
+        out = []
+        for which, base_reg, roff in (("W", addr[1], 0), ("A", addr[0], 12)):
+            for i in range(2):
+                f = FRAG[buf] + roff + 6 * i
+                o = i * CHUNK
+                if grp == 0:
+                    out.append(f"ds_read_b128 {vr(f, 4)}, {vr(base_reg)} offset:{o}")
+                    out.append(f"ds_read_b64 {vr(f + 4, 2)}, {vr(base_reg)} offset:{o + PLANE}")
+                else:
+                    out.append(f"ds_read_b64 {vr(f, 2)}, {vr(base_reg)} offset:{o + PLANE + 8}")
+                    out.append(f"ds_read_b128 {vr(f + 2, 4)}, {vr(base_reg)} offset:{o + 2 * PLANE}")
+        for base_reg, roff in ((addr[3], 0), (addr[2], 8)):
+            for i in range(2):
+                out.append(f"ds_read_u16 {vr(SCL[buf] + roff + 4 * i)}, {vr(base_reg)} offset:{i * 128 + grp * 64}")
+        return out
+
+    def p_mfma(self, dst_buf, buf, t):
+        ni, mi = t >> 1, t & 1
+        w = FRAG[buf] + 6 * ni
+        a = FRAG[buf] + 12 + 6 * mi
+        return (f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(PBUF[dst_buf], 16)}, {vr(w, 6)}, {vr(a, 6)}, 0, "
+                f"{vr(MXA)}, {vr(MXB)} op_sel_hi:[0,0,0] cbsz:2 blgp:2")
+
+    def s_mfma(self, dst_buf, buf, t):
+        ni, mi = t >> 1, t & 1
+        sw = SCL[buf] + 4 * ni
+        sa = SCL[buf] + 8 + 4 * mi
+        return f"{self.smfma} {vr(SBUF[dst_buf], 16)}, {vr(sw, 4)}, {vr(sa, 4)}, 0"
+
+    def fma(self, t, pb, lo, hi):
+        return [f"v_fmac_f32 {vr(ACC + 16 * t + r)}, {vr(PBUF[pb] + r)}, {vr(SBUF[pb] + r)}" for r in range(lo, hi)]
+
+    def dma_issue(self, stage_reg):
+        """5 (or 4) LDS-DMA wave loads of one K-step into the stage whose offset is in stage_reg,
+        then advance the stream pointers."""
+        L = self.new_label()
+        o = [
+            f"s_add_u32 m0, {sr(stage_reg)}, {sr(S_DA)}",
+            "s_nop 0",
+            f"global_load_lds_dwordx4 {vr(OFF_A)}, {sr(S_PA, 2)}",
+            f"global_load_lds_dwordx4 {vr(OFF_A)}, {sr(S_PA, 2)} offset:{PLANE}",
+            f"global_load_lds_dwordx4 {vr(OFF_A)}, {sr(S_PA, 2)} offset:{2 * PLANE}",
+            f"s_add_u32 m0, {sr(stage_reg)}, {sr(S_DX1)}",
+            f"s_add_u32 {sr(S_PA)}, {sr(S_PA)}, {CHUNK}",
+            f"global_load_lds_dwordx4 {vr(OFF_X1)}, {sr(S_PX1, 2)}",
+            f"s_addc_u32 {sr(S_PA + 1)}, {sr(S_PA + 1)}, 0",
+            f"s_add_u32 {sr(S_PX1)}, {sr(S_PX1)}, {sr(S_IX1)}",
+            f"s_addc_u32 {sr(S_PX1 + 1)}, {sr(S_PX1 + 1)}, 0",
+            f"s_cmp_eq_u32 {sr(S_NX)}, 2",
+            f"s_cbranch_scc0 {L}",
+            f"s_add_u32 m0, {sr(stage_reg)}, {sr(S_DX2)}",
+            "s_nop 0",
+            f"global_load_lds_dwordx4 {vr(OFF_X2)}, {sr(S_PX2, 2)}",
+            f"s_add_u32 {sr(S_PX2)}, {sr(S_PX2)}, {sr(S_IX2)}",
+            f"s_addc_u32 {sr(S_PX2 + 1)}, {sr(S_PX2 + 1)}, 0",
+            f"{L}:",
+        ]
+        return o
+
+    def stage_addrs(self, dst, stage_reg):
+        return [f"v_add_u32 {vr(dst[i])}, {sr(stage_reg)}, {vr(src)}"
+                for i, src in enumerate((IN_LA, IN_LW, IN_LSA, IN_LSW))]
+
+    # ---- the kernel body ---------------------------------------------------------------
+    def build(self):
+        e = self.e
+        e("; ---- svdq gemm main loop (generated by tools/gen_gemm_loop.py) ----")
+        for r in range(64):
+            e(f"v_mov_b32 {vr(ACC + r)}, 0")
+        for b in range(2):
+            for tpl in range(4):
+                for k in range(1, 4):
+                    e(f"v_mov_b32 {vr(SCL[b] + 4 * tpl + k)}, 0")
+        e(f"v_mov_b32 {vr(MXA)}, 0x82828282")
+        e(f"v_mov_b32 {vr(MXB)}, 0x81818181")
+        e(f"s_mov_b32 {sr(S_STEP)}, 0")
+        e(f"s_mov_b32 {sr(S_CUR)}, 0")
+        # prologue: DMA of K-steps 0, 1, 2 into stages 0, 1, 2
+        for j in range(NSTAGE):
+            L = self.new_label()
+            if j > 0:
+                e(f"s_cmp_gt_u32 {sr(S_KP)}, {j}")
+                e(f"s_cbranch_scc0 {L}")
+            e(f"s_mov_b32 {sr(S_TMP)}, {j * STAGE}")
+            for ln in self.dma_issue(S_TMP):
+                e(ln)
+            e(f"{L}:")
+        e(f"s_mov_b32 {sr(S_DMASTEP)}, {NSTAGE}")
+        e(f"s_mov_b32 {sr(S_NEXT)}, {STAGE}")
+        for ln in self.stage_addrs(CUR, S_CUR) + self.stage_addrs(NXT, S_NEXT):
+            e(ln)
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
+        for ln in self.frag_reads(0, 0, CUR):
+            e(ln)
+        e("s_waitcnt lgkmcnt(0)")
+        e(self.p_mfma(0, 0, 0))
+        e(self.s_mfma(0, 0, 0))
+        e("s_nop 7")
+
+        loop = self.new_label()
+        e(f"{loop}:")
+        reads_g1 = self.frag_reads(1, 1, CUR)   # (s, group 1) from the current stage
+        reads_n0 = self.frag_reads(0, 0, NXT)   # (s+1, group 0) from the next stage
+        for q in range(8):
+            t = q & 3
+            pb = q & 1                      # P/S buffer holding tile-group q
+            qn = q + 1
+            nbuf, nt = (qn >> 2) & 1, qn & 3  # fragment buffer / tile of tile-group q+1
+            if q in (3, 7):
+                e("s_waitcnt lgkmcnt(0)")
+            e(self.p_mfma(pb ^ 1, nbuf, nt))
+            misc = []
+            if q < 3:
+                misc = reads_g1[4 * q:4 * q + 4]
+            elif q == 3:
+                misc = ["s_nop 2"]
+            elif q == 4:
+                # stage s+1 must have landed (own DMAs), then rendezvous: afterwards every wave's planes
+                # of stage s+1 are visible and nobody reads stage s any more -> refill it with step s+3
+                Lw0, Lw4, Lwd, Lnd = self.new_label(), self.new_label(), self.new_label(), self.new_label()
+                misc = [
+                    f"s_add_u32 {sr(S_TMP)}, {sr(S_STEP)}, 2",
+                    f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_KP)}",
+                    f"s_cbranch_scc0 {Lw0}",
+                    f"s_cmp_eq_u32 {sr(S_NX)}, 2",
+                    f"s_cbranch_scc0 {Lw4}",
+                    "s_waitcnt vmcnt(5)",
+                    f"s_branch {Lwd}",
+                    f"{Lw4}:",
+                    "s_waitcnt vmcnt(4)",
+                    f"s_branch {Lwd}",
+                    f"{Lw0}:",
+                    "s_waitcnt vmcnt(0)",
+                    f"{Lwd}:",
+                    "s_barrier",
+                    f"s_cmp_lt_u32 {sr(S_DMASTEP)}, {sr(S_KP)}",
+                    f"s_cbranch_scc0 {Lnd}",
+                ] + self.dma_issue(S_CUR) + [f"{Lnd}:"] + reads_n0[0:4]
+            elif q in (5, 6):
+                misc = reads_n0[4 * (q - 4):4 * (q - 4) + 4]
+            else:  # q == 7: rotate the ring
+                misc = [
+                    f"s_mov_b32 {sr(S_CUR)}, {sr(S_NEXT)}",
+                    f"s_add_u32 {sr(S_NEXT)}, {sr(S_NEXT)}, {STAGE}",
+                    f"s_cmp_lt_u32 {sr(S_NEXT)}, {NSTAGE * STAGE}",
+                    f"s_cselect_b32 {sr(S_NEXT)}, {sr(S_NEXT)}, 0",
+                    f"s_add_u32 {sr(S_DMASTEP)}, {sr(S_DMASTEP)}, 1",
+                    f"s_add_u32 {sr(S_STEP)}, {sr(S_STEP)}, 1",
+                ] + [f"v_mov_b32 {vr(CUR[i])}, {vr(NXT[i])}" for i in range(4)]
+            for ln in misc:
+                e(ln)
+            for ln in self.fma(t, pb, 0, 8):
+                e(ln)
+            e(self.s_mfma(pb ^ 1, nbuf, nt))
+            if q == 7:
+                for ln in self.stage_addrs(NXT, S_NEXT):
+                    e(ln)
+            for ln in self.fma(t, pb, 8, 16):
+                e(ln)
+        e(f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_KP)}")
+        e(f"s_cbranch_scc1 {loop}")
+        # drain: the speculative MFMAs / fragment reads of the non-existent next step
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_nop 15")
+        e("s_nop 15")
+        e("s_nop 15")
+        return self.lines
+
+
+def emit(path, smfma):
+    g = Gen(smfma)
+    lines = g.build()
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_loop.py -- do not edit.\n")
+        for ln in lines:
+            f.write('"' + ln + '\\n"\n')
+    return len(lines)
+
+
+if __name__ == "__main__":
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nunchaku_amd", "csrc")
+    n = emit(os.path.join(root, "gemm_loop_bf16.inc"), "v_mfma_f32_32x32x16_bf16")
+    emit(os.path.join(root, "gemm_loop_fp16.inc"), "v_mfma_f32_32x32x16_f16")
+    print(f"wrote gemm_loop_{{bf16,fp16}}.inc ({n} lines each)")
