@@ -79,7 +79,7 @@ typedef const __attribute__((address_space(1))) void gvoid;
 #define MXS_A 0x82828282
 #define MXS_B 0x81818181
 
-template <int DT, int FUSE, bool ASM_LOOP>
+template <int DT, int FUSE, int LOOPV /* 0 asm, 1 C++, >= 2 ablations of the asm loop (tools only) */>
 __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     v16f acc[2][2]; // [n tile][m tile]
     const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    if constexpr (ASM_LOOP) {
+    if constexpr (LOOPV != 1) {
         // ---- hand-scheduled main loop (tools/gen_gemm_loop.py; DESIGN.md "Main loop") -------------
         // Per K-step every wave issues 3 LDS-DMA plane loads of "its" A chunk plus one or two more
         // planes (W planes / the scale images), all wave-uniform bases in SGPRs:
@@ -152,7 +152,43 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
           "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199",  \
           "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220",  \
           "v221", "v222", "v223", "v224"
-        if constexpr (DT == SVDQ_BF16) {
+        if constexpr (LOOPV == 2) {
+            asm volatile(
+#include "ablate/gemm_loop_bf16_dma.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else if constexpr (LOOPV == 3) {
+            asm volatile(
+#include "ablate/gemm_loop_bf16_lds.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else if constexpr (LOOPV == 4) {
+            asm volatile(
+#include "ablate/gemm_loop_bf16_fma.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else if constexpr (LOOPV == 5) {
+            asm volatile(
+#include "ablate/gemm_loop_bf16_smfma.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else if constexpr (LOOPV == 6) {
+            asm volatile(
+#include "ablate/gemm_loop_bf16_barrier.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else if constexpr (LOOPV == 7) {
+            asm volatile(
+#include "ablate/gemm_loop_bf16_dma_lds.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else if constexpr (LOOPV == 8) {
+            asm volatile(
+#include "ablate/gemm_loop_bf16_fma_smfma.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else if constexpr (LOOPV == 9) {
+            asm volatile(
+#include "ablate/gemm_loop_bf16_dma_barrier.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else if constexpr (LOOPV == 10) {
+            asm volatile(
+#include "ablate/gemm_loop_bf16_dma_lds_barrier.inc"
+                SVDQ_LOOP_OPERANDS);
+        } else if constexpr (DT == SVDQ_BF16) {
             asm volatile(
 #include "gemm_loop_bf16.inc"
                 SVDQ_LOOP_OPERANDS);
@@ -245,7 +281,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         }
     }
 
-    } // ASM_LOOP
+    } // LOOPV
 
     // ------------------------------------------------------------------ epilogue
     // lane owns rows m = mw0 + 32*mi + lr and columns n = nw0 + 32*ni + 8*c + 4*h + e  (r = 4c + e)
@@ -490,13 +526,13 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     }
 }
 
-template <int DT, int FUSE, bool ASM_LOOP>
+template <int DT, int FUSE, int LOOPV>
 static void launch_one(const GemmParams &p, hipStream_t st) {
     dim3 grid((p.M_pad / BM) * (p.N / BN)), block(512);
-    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, ASM_LOOP>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, LOOPV>), grid, block, 0, st, p);
 }
 
-template <int DT, bool ASM_LOOP>
+template <int DT, int ASM_LOOP>
 static void launch_fuse(const GemmParams &p, int fuse, hipStream_t st) {
     switch (fuse) {
     case SVDQ_FUSE_NONE: launch_one<DT, SVDQ_FUSE_NONE, ASM_LOOP>(p, st); break;
@@ -530,7 +566,11 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     }
     if (a->R > 0 && (!a->lora_act_in || !a->lora_up)) { set_error("svdq_gemm_w4a4: R > 0 needs lora_act_in and lora_up"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemm_w4a4: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
-    if (a->variant < 0 || a->variant > 1) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
+    if (a->variant < 0 || a->variant > 10) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
+    if (a->variant >= 2 && (a->dtype != SVDQ_BF16 || a->fuse != SVDQ_FUSE_NONE)) {
+        set_error("svdq_gemm_w4a4: ablation variants (tools only, WRONG results) exist for bf16 / FUSE_NONE only");
+        return SVDQ_E_INVALID;
+    }
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
     case SVDQ_FUSE_SILU:
@@ -584,11 +624,23 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     const int prof = prof_begin(0, 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
     // variant 0: hand-scheduled main loop; variant 1: the compiler-scheduled C++ loop (same arithmetic)
     if (a->variant == 0) {
-        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, true>(p, a->fuse, st);
-        else launch_fuse<SVDQ_FP16, true>(p, a->fuse, st);
+        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, 0>(p, a->fuse, st);
+        else launch_fuse<SVDQ_FP16, 0>(p, a->fuse, st);
+    } else if (a->variant == 1) {
+        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, 1>(p, a->fuse, st);
+        else launch_fuse<SVDQ_FP16, 1>(p, a->fuse, st);
     } else {
-        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, false>(p, a->fuse, st);
-        else launch_fuse<SVDQ_FP16, false>(p, a->fuse, st);
+        switch (a->variant) { // ablations of the asm loop: timing experiments only, results are garbage
+        case 2: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 2>(p, st); break;
+        case 3: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 3>(p, st); break;
+        case 4: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 4>(p, st); break;
+        case 5: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 5>(p, st); break;
+        case 6: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 6>(p, st); break;
+        case 7: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 7>(p, st); break;
+        case 8: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 8>(p, st); break;
+        case 9: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 9>(p, st); break;
+        default: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 10>(p, st); break;
+        }
     }
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_gemm_w4a4 launch");

@@ -57,12 +57,28 @@ def sr(a, n=1):
 
 
 class Gen:
-    def __init__(self, smfma):
+    def __init__(self, smfma, ablate=""):
         self.smfma = smfma
+        self.ablate = ablate  # debug builds: "dma" | "lds" | "fma" | "smfma" | "barrier" dropped from the loop
         self.lines = []
         self.label = 0
+        self.in_loop = False
 
     def e(self, s):
+        a = self.ablate
+        if self.in_loop:
+            if "dma" in a and s.startswith("global_load_lds"):
+                return
+            if "lds" in a and s.startswith("ds_read"):
+                return
+            if "fma" in a and (s.startswith("v_pk_fma") or s.startswith("v_fmac")):
+                return
+            if "smfma" in a and s.startswith(self.smfma):
+                return
+            if "pmfma" in a and s.startswith("v_mfma_scale"):
+                return
+            if "barrier" in a and s.startswith("s_barrier"):
+                return
         self.lines.append(s)
 
     def new_label(self):
@@ -103,6 +119,12 @@ class Gen:
         return f"{self.smfma} {vr(SBUF[dst_buf], 16)}, {vr(sw, 4)}, {vr(sa, 4)}, 0"
 
     def fma(self, t, pb, lo, hi):
+        # plain v_fmac_f32, NOT v_pk_fma_f32: on gfx950 the packed form does not overlap with a running
+        # MFMA at all (P + 8 pk = 35 ns = sum of parts) while 16 scalar fmas do (P,8fma,S,8fma = 41 ns vs
+        # 57 ns for the parts; profiles/r1_ubench_fp6_issue.jsonl, 2 waves per SIMD)
+        if os.environ.get("SVDQ_GEN_PK"):
+            return [f"v_pk_fma_f32 {vr(ACC + 16 * t + r, 2)}, {vr(PBUF[pb] + r, 2)}, {vr(SBUF[pb] + r, 2)}, {vr(ACC + 16 * t + r, 2)}"
+                    for r in range(lo, hi, 2)]
         return [f"v_fmac_f32 {vr(ACC + 16 * t + r)}, {vr(PBUF[pb] + r)}, {vr(SBUF[pb] + r)}" for r in range(lo, hi)]
 
     def dma_issue(self, stage_reg):
@@ -175,6 +197,7 @@ class Gen:
 
         loop = self.new_label()
         e(f"{loop}:")
+        self.in_loop = True
         reads_g1 = self.frag_reads(1, 1, CUR)   # (s, group 1) from the current stage
         reads_n0 = self.frag_reads(0, 0, NXT)   # (s+1, group 0) from the next stage
         for q in range(8):
@@ -235,6 +258,7 @@ class Gen:
                 e(ln)
         e(f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_KP)}")
         e(f"s_cbranch_scc1 {loop}")
+        self.in_loop = False
         # drain: the speculative MFMAs / fragment reads of the non-existent next step
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         e("s_nop 15")
@@ -243,8 +267,8 @@ class Gen:
         return self.lines
 
 
-def emit(path, smfma):
-    g = Gen(smfma)
+def emit(path, smfma, ablate=""):
+    g = Gen(smfma, ablate)
     lines = g.build()
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_loop.py -- do not edit.\n")
@@ -257,4 +281,6 @@ if __name__ == "__main__":
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nunchaku_amd", "csrc")
     n = emit(os.path.join(root, "gemm_loop_bf16.inc"), "v_mfma_f32_32x32x16_bf16")
     emit(os.path.join(root, "gemm_loop_fp16.inc"), "v_mfma_f32_32x32x16_f16")
+    for ab in ("dma", "lds", "fma", "smfma", "barrier", "dma+lds", "fma+smfma", "dma+barrier", "dma+lds+barrier"):
+        emit(os.path.join(root, "ablate", f"gemm_loop_bf16_{ab.replace('+', '_')}.inc"), "v_mfma_f32_32x32x16_bf16", ab)
     print(f"wrote gemm_loop_{{bf16,fp16}}.inc ({n} lines each)")

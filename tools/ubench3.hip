@@ -37,7 +37,7 @@
 //  0: P only            1: P + S16            2: P + S8(bf16)        3: P + S8(f16)
 //  4: P,4pk,S16,4pk     5: P,4pk,S8,4pk       6: P,8fma,S16,8fma     7: P,8fma,S8,8fma
 //  8: 8pk only          9: 16 fma only       10: P, 8pk (no S)      11: S16 only   12: S8 only
-template <int BODY> __global__ __launch_bounds__(256) void issue_kernel(int iters, float *out, long long *cyc) {
+template <int BODY> __global__ __launch_bounds__(512) void issue_kernel(int iters, float *out, long long *cyc) {
     asm volatile(
         "v_mov_b32 v192, 0x1020304\n v_accvgpr_write_b32 a0, v192\n"
         "v_mov_b32 v192, 0x11121314\n v_accvgpr_write_b32 a1, v192\n"
@@ -101,29 +101,29 @@ template <int BODY> __global__ __launch_bounds__(256) void issue_kernel(int iter
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int BODY> void run(const char *name, float *dout, long long *dcyc) {
+template <int BODY> void run(const char *name, float *dout, long long *dcyc, int block = 256) {
     const int iters = 4000, grid = 256;
-    issue_kernel<BODY><<<grid, 256>>>(10, dout, dcyc);
+    issue_kernel<BODY><<<grid, block>>>(10, dout, dcyc);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0));
-    issue_kernel<BODY><<<grid, 256>>>(iters, dout, dcyc);
+    issue_kernel<BODY><<<grid, block>>>(iters, dout, dcyc);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<long long> h(grid);
     CK(hipMemcpy(h.data(), dcyc, grid * sizeof(long long), hipMemcpyDeviceToHost));
     double avg = 0; for (auto v : h) avg += v; avg /= grid;
-    double ns_tg = ms * 1e6 / iters / 2;
+    double ns_tg = ms * 1e6 / iters / 2 / (block / 256);  // per tile-group per SIMD
     // TOPS if a tile-group (2*32*32*64 ops) took this long on all 1024 SIMDs
-    printf("{\"exp\":\"I\",\"body\":\"%s\",\"ns_per_tilegroup\":%.2f,\"ticks_per_tilegroup\":%.1f,\"equiv_TOPS\":%.0f}\n", name, ns_tg,
+    printf("{\"exp\":\"I\",\"waves_per_simd\":%d,\"body\":\"%s\",\"ns_per_tilegroup\":%.2f,\"ticks_per_tilegroup\":%.1f,\"equiv_TOPS\":%.0f}\n", block / 256, name, ns_tg,
            avg / iters / 2, 1024.0 * 131072 / ns_tg / 1e3);
     fflush(stdout);
 }
 
 int main() {
     float *dout; long long *dcyc;
-    CK(hipMalloc(&dout, 256 * 256 * sizeof(float)));
+    CK(hipMalloc(&dout, 256 * 512 * sizeof(float)));
     CK(hipMalloc(&dcyc, 256 * sizeof(long long)));
     run<0>("P", dout, dcyc);
     run<11>("S16", dout, dcyc);
@@ -145,5 +145,13 @@ int main() {
     run<5>("P,4pk,S8,4pk", dout, dcyc);
     run<6>("P,8fma,S16,8fma", dout, dcyc);
     run<7>("P,8fma,S8,8fma", dout, dcyc);
+    printf("--- 2 waves per SIMD (ns per tile-group per SIMD)\n");
+    run<0>("P", dout, dcyc, 512);
+    run<1>("P+S16", dout, dcyc, 512);
+    run<8>("8pk", dout, dcyc, 512);
+    run<9>("16fma", dout, dcyc, 512);
+    run<10>("P+8pk", dout, dcyc, 512);
+    run<4>("P,4pk,S16,4pk", dout, dcyc, 512);
+    run<6>("P,8fma,S16,8fma", dout, dcyc, 512);
     return 0;
 }
