@@ -114,6 +114,7 @@ class _Ops:
         a.M = M_pad
         a.dtype = _DT[ascales.dtype]
         a.act_unsigned = int(bool(act_unsigned))
+        a.reserved = int(os.environ.get("SVDQ_GEMM_DEBUG", "0"))  # timing experiments only
         a.variant = int(os.environ.get("SVDQ_GEMM_VARIANT", "0"))  # 1 = compiler-scheduled loop (debug/A-B only)
 
         if qout is not None and oscales is not None:

@@ -33,12 +33,13 @@
 namespace svdq {
 
 constexpr int BM = 256, BN = 128;
-constexpr int NSTAGE = 3;
+constexpr int NSTAGE = 4;                      // tools/gen_gemm_loop.py: NSTAGE
 constexpr int A_BYTES = (BM / 32) * F6_CHUNK;  // 24576
 constexpr int W_BYTES = (BN / 32) * F6_CHUNK;  // 12288
 constexpr int AS_BYTES = (BM / 32) * 128;      // 1024
 constexpr int WS_BYTES = 1024;                 // 512 used; the DMA writes whole 1 KiB planes
 constexpr int STAGE_BYTES = A_BYTES + W_BYTES + AS_BYTES + WS_BYTES; // 38912 (tools/gen_gemm_loop.py: STAGE)
+constexpr int EPI_BYTES = 2048;                 // epilogue scratch behind the ring (the ring itself stays live)
 constexpr int MAX_LORA_TILES = 16;             // R <= 256
 
 struct GemmParams {
@@ -59,6 +60,7 @@ struct GemmParams {
     const void *norm_k;
     const float *rotary_emb;
     int M, M_pad, N, K, R, R2, ldo;
+    int debug; // timing experiments (tools/): bit0 skip output stores, bit1 skip bias + low-rank up
     float lora_scales[MAX_LORA_TILES];
 };
 
@@ -83,452 +85,532 @@ template <int DT, int FUSE, int LOOPV /* 0 asm, 1 C++, >= 2 ablations of the asm
 __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES + EPI_BYTES];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, h = lane >> 5;
     const int KP = p.K / 128;
-    const int nbn = p.N / BN;
-    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
-    const int m0 = bm * BM, n0 = bn * BN;
+    const int TM = p.M_pad / BM, TN = p.N / BN, NT = TM * TN;
+
+    // ---- persistent schedule ---------------------------------------------------------------------
+    // One workgroup per CU walks a list of segments.  Tiles are enumerated in strips of 8 column
+    // tiles (tile_coords) and workgroup b sits at position (b % 8) * (G / 8) + b / 8 -- workgroups are
+    // dealt round-robin to the 8 XCDs, so the 32 tiles an XCD works on at a time are a 4 x 8 patch that
+    // shares 4 activation panels and 8 weight panels in that XCD's L2.
+    const int G = gridDim.x;
+    const int pos = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    auto tile_coords = [&](int t, int &bm, int &bn) {
+        const int strip = t / (8 * TM);
+        const int w = min(8, TN - 8 * strip);
+        const int r = t - strip * 8 * TM;
+        bm = r / w;
+        bn = 8 * strip + r % w;
+    };
 
     v16f acc[2][2]; // [n tile][m tile]
     const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint8_t *const lds_epi = lds + NSTAGE * STAGE_BYTES;
 
-    if constexpr (LOOPV != 1) {
-        // ---- hand-scheduled main loop (tools/gen_gemm_loop.py; DESIGN.md "Main loop") -------------
-        // Per K-step every wave issues 3 LDS-DMA plane loads of "its" A chunk plus one or two more
-        // planes (W planes / the scale images), all wave-uniform bases in SGPRs:
-        //   waves 0..3: W planes 2w, 2w+1      waves 4..7: W plane 8 + (w-4)
-        //   wave 4 additionally: activation scales (8 x 128 B)   wave 5: weight scales (4 x 128 B, twice)
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const unsigned lds_base = (unsigned)(size_t)(lds_void *)lds;
-        unsigned long long pA = (unsigned long long)(p.act + ((size_t)(bm * 8 + wv) * KP) * F6_CHUNK);
-        const int px1 = wv < 4 ? 2 * wv : 8 + (wv - 4);
-        unsigned long long pX1 = (unsigned long long)(p.wgt + ((size_t)(bn * 4 + px1 / 3) * KP) * F6_CHUNK + (px1 % 3) * F6_PLANE);
-        unsigned dX1 = lds_base + A_BYTES + (px1 / 3) * F6_CHUNK + (px1 % 3) * F6_PLANE;
-        unsigned iX1 = F6_CHUNK, iX2 = F6_CHUNK, nX = 2, dX2 = 0;
-        unsigned long long pX2 = pX1;
-        unsigned offA = lane * 16, offX1 = lane * 16, offX2 = lane * 16;
-        if (wv < 4) {
-            const int px2 = 2 * wv + 1;
-            pX2 = (unsigned long long)(p.wgt + ((size_t)(bn * 4 + px2 / 3) * KP) * F6_CHUNK + (px2 % 3) * F6_PLANE);
-            dX2 = lds_base + A_BYTES + (px2 / 3) * F6_CHUNK + (px2 % 3) * F6_PLANE;
-        } else if (wv == 4) {
-            pX2 = (unsigned long long)((const uint8_t *)p.ascales + ((size_t)(bm * 8) * KP) * 128);
-            offX2 = (lane >> 3) * KP * 128 + (lane & 7) * 16;
-            dX2 = lds_base + A_BYTES + W_BYTES;
-            iX2 = 128;
-        } else if (wv == 5) {
-            pX2 = (unsigned long long)((const uint8_t *)p.wscales + ((size_t)(bn * 4) * KP) * 128);
-            offX2 = ((lane >> 3) & 3) * KP * 128 + (lane & 7) * 16;
-            dX2 = lds_base + A_BYTES + W_BYTES + AS_BYTES;
-            iX2 = 128;
-        } else {
-            nX = 1;
-        }
-        const unsigned dA = lds_base + wv * F6_CHUNK;
-        const unsigned in_la = lds_base + (wm * 2) * F6_CHUNK + lane * 16;
-        const unsigned in_lw = lds_base + A_BYTES + (wn * 2) * F6_CHUNK + lane * 16;
-        const unsigned in_lsa = lds_base + A_BYTES + W_BYTES + (wm * 2) * 128 + lr * 2;
-        const unsigned in_lsw = lds_base + A_BYTES + W_BYTES + AS_BYTES + (wn * 2) * 128 + lr * 2;
-        const unsigned kp_s = KP;
-#define SVDQ_LOOP_OPERANDS                                                                                              \
-        : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
-          "+{s[40:41]}"(pA), "+{s[42:43]}"(pX1), "+{s[44:45]}"(pX2)                                                       \
-        : "{v210}"(in_la), "{v211}"(in_lw), "{v212}"(in_lsa), "{v213}"(in_lsw), "{v214}"(offA), "{v215}"(offX1),         \
-          "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX1), "{s51}"(iX2), "{s52}"(nX) \
-        : "memory", "scc", "m0", "s53", "s54", "s55", "s56", "s57", "v64", "v65", "v66", "v67", "v68", "v69", "v70",     \
-          "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", \
-          "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",       \
-          "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",  \
-          "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129",  \
-          "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143",  \
-          "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157",  \
-          "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171",  \
-          "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185",  \
-          "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199",  \
-          "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220",  \
-          "v221", "v222", "v223", "v224"
-        if constexpr (LOOPV == 2) {
-            asm volatile(
-#include "ablate/gemm_loop_bf16_dma.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else if constexpr (LOOPV == 3) {
-            asm volatile(
-#include "ablate/gemm_loop_bf16_lds.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else if constexpr (LOOPV == 4) {
-            asm volatile(
-#include "ablate/gemm_loop_bf16_fma.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else if constexpr (LOOPV == 5) {
-            asm volatile(
-#include "ablate/gemm_loop_bf16_smfma.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else if constexpr (LOOPV == 6) {
-            asm volatile(
-#include "ablate/gemm_loop_bf16_barrier.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else if constexpr (LOOPV == 7) {
-            asm volatile(
-#include "ablate/gemm_loop_bf16_dma_lds.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else if constexpr (LOOPV == 8) {
-            asm volatile(
-#include "ablate/gemm_loop_bf16_fma_smfma.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else if constexpr (LOOPV == 9) {
-            asm volatile(
-#include "ablate/gemm_loop_bf16_dma_barrier.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else if constexpr (LOOPV == 10) {
-            asm volatile(
-#include "ablate/gemm_loop_bf16_dma_lds_barrier.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else if constexpr (DT == SVDQ_BF16) {
-            asm volatile(
-#include "gemm_loop_bf16.inc"
-                SVDQ_LOOP_OPERANDS);
-        } else {
-            asm volatile(
-#include "gemm_loop_fp16.inc"
-                SVDQ_LOOP_OPERANDS);
-        }
-#undef SVDQ_LOOP_OPERANDS
+    // ---- per-wave DMA roles (constant over the kernel) ---------------------------------------------
+    //   every wave: the three planes of A chunk `wave` of the tile;  waves 0..3: W planes 2w, 2w+1;
+    //   waves 4..7: W plane 8 + (w-4);  wave 4 additionally the activation scale image (8 x 128 B),
+    //   wave 5 the weight scale image (4 x 128 B, twice).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_base = (unsigned)(size_t)(lds_void *)lds;
+    const int px1 = wv < 4 ? 2 * wv : 8 + (wv - 4);
+    const int px2 = 2 * wv + 1; // waves 0..3 only
+    unsigned dX1 = lds_base + A_BYTES + (px1 / 3) * F6_CHUNK + (px1 % 3) * F6_PLANE;
+    unsigned iX1 = F6_CHUNK, iX2 = F6_CHUNK, nX = 2, dX2 = 0;
+    unsigned offA = lane * 16, offX1 = lane * 16, offX2 = lane * 16;
+    if (wv < 4) {
+        dX2 = lds_base + A_BYTES + (px2 / 3) * F6_CHUNK + (px2 % 3) * F6_PLANE;
+    } else if (wv == 4) {
+        offX2 = (lane >> 3) * KP * 128 + (lane & 7) * 16;
+        dX2 = lds_base + A_BYTES + W_BYTES;
+        iX2 = 128;
+    } else if (wv == 5) {
+        offX2 = ((lane >> 3) & 3) * KP * 128 + (lane & 7) * 16;
+        dX2 = lds_base + A_BYTES + W_BYTES + AS_BYTES;
+        iX2 = 128;
     } else {
-    // ---- reference C++ main loop (variant 1: same arithmetic, compiler-scheduled) ----------------
-    // ---- operand streams: every wave moves whole 1 KiB planes -------------------------------
-    //   waves 0..7: the three planes of A chunk `wave`;  waves 0..3: the three planes of W chunk
-    //   `wave`;  wave 4: activation scales (8 x 128 B);  wave 5: weight scales (4 x 128 B).
-    const uint8_t *a_src = p.act + ((size_t)(bm * 8 + wave) * KP) * F6_CHUNK + lane * 16;
-    const uint8_t *w_src = p.wgt + ((size_t)(bn * 4 + (wave & 3)) * KP) * F6_CHUNK + lane * 16;
-    const uint8_t *as_src = (const uint8_t *)p.ascales + ((size_t)(bm * 8 + (lane >> 3)) * KP) * 128 + (lane & 7) * 16;
-    const uint8_t *ws_src = (const uint8_t *)p.wscales + ((size_t)(bn * 4 + ((lane >> 3) & 3)) * KP) * 128 + (lane & 7) * 16;
-
-    auto fetch = [&](int kp, uint8_t *st) {
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++)
-            __builtin_amdgcn_global_load_lds((gvoid *)(a_src + (size_t)kp * F6_CHUNK + pl * F6_PLANE),
-                                             (lds_void *)(st + wave * F6_CHUNK + pl * F6_PLANE), 16, 0, 0);
-        if (wave < 4) {
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++)
-                __builtin_amdgcn_global_load_lds((gvoid *)(w_src + (size_t)kp * F6_CHUNK + pl * F6_PLANE),
-                                                 (lds_void *)(st + A_BYTES + wave * F6_CHUNK + pl * F6_PLANE), 16, 0, 0);
-        } else if (wave == 4) {
-            __builtin_amdgcn_global_load_lds((gvoid *)(as_src + (size_t)kp * 128), (lds_void *)(st + A_BYTES + W_BYTES), 16, 0, 0);
-        } else if (wave == 5) {
-            if (lane < 32)
-                __builtin_amdgcn_global_load_lds((gvoid *)(ws_src + (size_t)kp * 128),
-                                                 (lds_void *)(st + A_BYTES + W_BYTES + AS_BYTES), 16, 0, 0);
-        }
+        nX = 1;
+    }
+    const unsigned dA = lds_base + wv * F6_CHUNK;
+    const unsigned in_la = lds_base + (wm * 2) * F6_CHUNK + lane * 16;
+    const unsigned in_lw = lds_base + A_BYTES + (wn * 2) * F6_CHUNK + lane * 16;
+    const unsigned in_lsa = lds_base + A_BYTES + W_BYTES + (wm * 2) * 128 + lr * 2;
+    const unsigned in_lsw = lds_base + A_BYTES + W_BYTES + AS_BYTES + (wn * 2) * 128 + lr * 2;
+    // stream bases of (tile, first K-step)
+    auto stream_ptrs = [&](int bm, int bn, int kp0, unsigned long long &a, unsigned long long &x1, unsigned long long &x2) {
+        a = (unsigned long long)(p.act + ((size_t)(bm * 8 + wv) * KP + kp0) * F6_CHUNK);
+        x1 = (unsigned long long)(p.wgt + ((size_t)(bn * 4 + px1 / 3) * KP + kp0) * F6_CHUNK + (px1 % 3) * F6_PLANE);
+        if (wv < 4) x2 = (unsigned long long)(p.wgt + ((size_t)(bn * 4 + px2 / 3) * KP + kp0) * F6_CHUNK + (px2 % 3) * F6_PLANE);
+        else if (wv == 4) x2 = (unsigned long long)((const uint8_t *)p.ascales + ((size_t)(bm * 8) * KP + kp0) * 128);
+        else if (wv == 5) x2 = (unsigned long long)((const uint8_t *)p.wscales + ((size_t)(bn * 4) * KP + kp0) * 128);
+        else x2 = x1;
     };
 
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    fetch(0, lds);
-    if (KP > 1) fetch(1, lds + STAGE_BYTES);
-
-    for (int s = 0; s < KP; s++) {
-        // stage s (and, conservatively, s+1) has landed for this wave; the barrier makes every wave's
-        // planes visible and guarantees everyone is done reading stage s-1 before it is refilled
-        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
-        __syncthreads();
-        if (s + 2 < KP) fetch(s + 2, lds + ((s + 2) % NSTAGE) * STAGE_BYTES);
-        const uint8_t *st = lds + (s % NSTAGE) * STAGE_BYTES;
-
-        // fragments of both groups: 3 x 16 B per (tile, lane)
-        int af[2][12], wf[2][12];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
-                v4i a = *reinterpret_cast<const v4i *>(st + (wm * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
-                v4i w = *reinterpret_cast<const v4i *>(st + A_BYTES + (wn * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
-#pragma unroll
-                for (int e = 0; e < 4; e++) { af[i][pl * 4 + e] = a[e]; wf[i][pl * 4 + e] = w[e]; }
-            }
-        const unsigned short *as_l = reinterpret_cast<const unsigned short *>(st + A_BYTES + W_BYTES);
-        const unsigned short *ws_l = reinterpret_cast<const unsigned short *>(st + A_BYTES + W_BYTES + AS_BYTES);
-#pragma unroll
-        for (int grp = 0; grp < 2; grp++) {
-            v4i sa[2], sw[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                sa[i] = v4i{(int)as_l[(wm * 2 + i) * 64 + grp * 32 + lr], 0, 0, 0};
-                sw[i] = v4i{(int)ws_l[(wn * 2 + i) * 64 + grp * 32 + lr], 0, 0, 0};
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++) {
-                    const int o = grp * 6;
-                    v8i A = {wf[ni][o], wf[ni][o + 1], wf[ni][o + 2], wf[ni][o + 3], wf[ni][o + 4], wf[ni][o + 5], 0, 0};
-                    v8i B = {af[mi][o], af[mi][o + 1], af[mi][o + 2], af[mi][o + 3], af[mi][o + 4], af[mi][o + 5], 0, 0};
-                    v16f P = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, FMT_FP6, FMT_FP6, 0, MXS_A, 0, MXS_B);
-                    v16f S = Half<DT>::mfma32(__builtin_bit_cast(V8, sw[ni]), __builtin_bit_cast(V8, sa[mi]), zero16);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = __builtin_fmaf(P[r], S[r], acc[ni][mi][r]);
-                }
+    int seg_tile = pos; // segment i of this workgroup = tile pos + i*G, all of K
+    unsigned ring = 0, npre = 0, landed = 0;
+    unsigned long long pA = 0, pX1 = 0, pX2 = 0;
+    int bm = 0, bn = 0;
+    if (seg_tile < NT) {
+        tile_coords(seg_tile, bm, bn);
+        stream_ptrs(bm, bn, 0, pA, pX1, pX2);
+    }
+    while (seg_tile < NT) {
+        const int kp0 = 0, kp1 = KP;
+        const int m0 = bm * BM, n0 = bn * BN;
+        // the next segment (its first operands are prefetched by the tail of this one)
+        const int next_tile = seg_tile + G;
+        int nbm = 0, nbn = 0;
+        unsigned ncnt = 0;
+        unsigned long long nA = 0, nX1 = 0, nX2 = 0;
+        if (next_tile < NT) {
+            tile_coords(next_tile, nbm, nbn);
+            stream_ptrs(nbm, nbn, 0, nA, nX1, nX2);
+            ncnt = KP;
         }
-    }
 
-    } // LOOPV
-
-    // ------------------------------------------------------------------ epilogue
-    // lane owns rows m = mw0 + 32*mi + lr and columns n = nw0 + 32*ni + 8*c + 4*h + e  (r = 4c + e)
-    const int nw0 = n0 + wn * 64;
-    const int mw0 = m0 + wm * 64;
-
-    // bias (reference EpilogueBias, gemm_base.cuh:710-781)
-    if (p.bias) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                u16x4 b = *reinterpret_cast<const u16x4 *>((const T *)p.bias + nw0 + ni * 32 + c * 8 + h * 4);
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) acc[ni][mi][c * 4 + e] += h2f(hfrom<T>(b[e]));
-            }
-    }
-
-    // low-rank up projection (reference EpilogueLoraUp, lora.cuh:110-241): fp32 activations are
-    // scaled per 16 ranks and rounded to 16-bit (:145-158), multiplied on the matrix cores and
-    // accumulated in fp32 -- here straight onto the GEMM accumulators.
-    if (p.R > 0) {
-        for (int rc = 0; rc < p.R; rc += 16) {
-            const float sc = p.lora_scales[rc >> 4];
-            V8 la[2], lu[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                const float *src = p.lora_act_in + (size_t)(mw0 + mi * 32 + lr) * p.R + rc + h * 8;
-                v4f x0 = *reinterpret_cast<const v4f *>(src);
-                v4f x1 = *reinterpret_cast<const v4f *>(src + 4);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    la[mi][j] = f2h<T>(x0[j] * sc);
-                    la[mi][4 + j] = f2h<T>(x1[j] * sc);
+        if constexpr (LOOPV != 1) {
+            // ---- hand-scheduled main loop (tools/gen_gemm_loop.py; DESIGN.md "Main loop") ---------
+            const unsigned kp_s = kp1 - kp0;
+#define SVDQ_LOOP_OPERANDS                                                                                              \
+                : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
+                  "+{s[40:41]}"(pA), "+{s[42:43]}"(pX1), "+{s[44:45]}"(pX2), "+{s58}"(ring)                                      \
+                : "{v210}"(in_la), "{v211}"(in_lw), "{v212}"(in_lsa), "{v213}"(in_lsw), "{v214}"(offA), "{v215}"(offX1),         \
+                  "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX1), "{s51}"(iX2), "{s52}"(nX), \
+                  "{s59}"(npre), "{s60}"(ncnt), "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed)            \
+                : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", "v64", "v65", "v66", "v67", "v68", "v69", "v70",     \
+                  "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", \
+                  "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",       \
+                  "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",  \
+                  "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129",  \
+                  "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143",  \
+                  "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157",  \
+                  "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171",  \
+                  "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185",  \
+                  "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199",  \
+                  "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220",  \
+                  "v221", "v222", "v223", "v224"
+                if constexpr (LOOPV == 2) {
+                    asm volatile(
+#include "ablate/gemm_loop_bf16_dma.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else if constexpr (LOOPV == 3) {
+                    asm volatile(
+#include "ablate/gemm_loop_bf16_lds.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else if constexpr (LOOPV == 4) {
+                    asm volatile(
+#include "ablate/gemm_loop_bf16_fma.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else if constexpr (LOOPV == 5) {
+                    asm volatile(
+#include "ablate/gemm_loop_bf16_smfma.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else if constexpr (LOOPV == 6) {
+                    asm volatile(
+#include "ablate/gemm_loop_bf16_barrier.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else if constexpr (LOOPV == 7) {
+                    asm volatile(
+#include "ablate/gemm_loop_bf16_dma_lds.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else if constexpr (LOOPV == 8) {
+                    asm volatile(
+#include "ablate/gemm_loop_bf16_fma_smfma.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else if constexpr (LOOPV == 9) {
+                    asm volatile(
+#include "ablate/gemm_loop_bf16_dma_barrier.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else if constexpr (LOOPV == 10) {
+                    asm volatile(
+#include "ablate/gemm_loop_bf16_dma_lds_barrier.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else if constexpr (DT == SVDQ_BF16) {
+                    asm volatile(
+#include "gemm_loop_bf16.inc"
+                        SVDQ_LOOP_OPERANDS);
+                } else {
+                    asm volatile(
+#include "gemm_loop_fp16.inc"
+                        SVDQ_LOOP_OPERANDS);
                 }
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-                lu[ni] = *reinterpret_cast<const V8 *>((const T *)p.lora_up + (size_t)(nw0 + ni * 32 + lr) * p.R + rc + h * 8);
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(lu[ni], la[mi], acc[ni][mi]);
-        }
-    }
+#undef SVDQ_LOOP_OPERANDS
 
-    // the single rounding to the 16-bit model dtype (the reference's tile is 16-bit from here on)
-#pragma unroll
-    for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-        for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(acc[ni][mi][r]);
-
-    if constexpr (FUSE == SVDQ_FUSE_SILU) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(silu_f(acc[ni][mi][r]));
-    }
-
-    if constexpr (FUSE == SVDQ_FUSE_RMSNORM_ROPE) {
-        // reference EpilogueRMSNormRope (epilogues.cuh:269-425).  BN == 128 == one head.
-        const int third = p.N / 3;
-        const bool is_q = n0 < third;
-        const bool is_k = !is_q && n0 < 2 * third;
-        if (is_q || is_k) { // block-uniform
-            __syncthreads(); // everyone is out of the main loop: the ring can be reused
-            float *sq = reinterpret_cast<float *>(lds); // [2 (wn)][256 rows]
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                float s = 0.f;
-#pragma unroll
-                for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) s += acc[ni][mi][r] * acc[ni][mi][r];
-                s += __shfl_xor(s, 32);
-                if (h == 0) sq[wn * 256 + wm * 64 + mi * 32 + lr] = s;
-            }
+            npre = min((unsigned)NSTAGE, ncnt);
+            // the epilogue below waits on global loads (bias / low-rank operands) that are younger than the
+            // prefetch DMAs of the next tile: vmcnt retires in order, so those DMAs have landed by then
+            landed = ((p.bias || p.R > 0) && !(p.debug & 2)) ? npre : 0;
+        } else {
+            // ---- reference C++ main loop (variant 1: same arithmetic, compiler-scheduled, no cross-tile
+            //      prefetch); kept for A/B debugging of the hand-scheduled loop
             __syncthreads();
-            const T *nw = (const T *)(is_q ? p.norm_q : p.norm_k);
+            // ---- operand streams: every wave moves whole 1 KiB planes -------------------------------
+            //   waves 0..7: the three planes of A chunk `wave`;  waves 0..3: the three planes of W chunk
+            //   `wave`;  wave 4: activation scales (8 x 128 B);  wave 5: weight scales (4 x 128 B).
+            const uint8_t *a_src = p.act + ((size_t)(bm * 8 + wave) * KP) * F6_CHUNK + lane * 16;
+            const uint8_t *w_src = p.wgt + ((size_t)(bn * 4 + (wave & 3)) * KP) * F6_CHUNK + lane * 16;
+            const uint8_t *as_src = (const uint8_t *)p.ascales + ((size_t)(bm * 8 + (lane >> 3)) * KP) * 128 + (lane & 7) * 16;
+            const uint8_t *ws_src = (const uint8_t *)p.wscales + ((size_t)(bn * 4 + ((lane >> 3) & 3)) * KP) * 128 + (lane & 7) * 16;
+
+            auto fetch = [&](int kp, uint8_t *st) {
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                const int row = wm * 64 + mi * 32 + lr;
-                const float tot = sq[row] + sq[256 + row];
-                const float coef = 1.0f / sqrtf(tot / 128.0f + 1e-6f);
-                const int m_abs = m0 + row;
-                // packed rotary order (models/embeddings.py:100-138): [m/16][d/8][r8*4+p][rh][sin,cos]
-                const size_t rbase = ((size_t)(m_abs >> 4) * 16) * 128 + (size_t)((m_abs & 7) * 4) * 4 + ((m_abs >> 3) & 1) * 2;
+                for (int pl = 0; pl < 3; pl++)
+                    __builtin_amdgcn_global_load_lds((gvoid *)(a_src + (size_t)kp * F6_CHUNK + pl * F6_PLANE),
+                                                     (lds_void *)(st + wave * F6_CHUNK + pl * F6_PLANE), 16, 0, 0);
+                if (wave < 4) {
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
+                    for (int pl = 0; pl < 3; pl++)
+                        __builtin_amdgcn_global_load_lds((gvoid *)(w_src + (size_t)kp * F6_CHUNK + pl * F6_PLANE),
+                                                         (lds_void *)(st + A_BYTES + wave * F6_CHUNK + pl * F6_PLANE), 16, 0, 0);
+                } else if (wave == 4) {
+                    __builtin_amdgcn_global_load_lds((gvoid *)(as_src + (size_t)kp * 128), (lds_void *)(st + A_BYTES + W_BYTES), 16, 0, 0);
+                } else if (wave == 5) {
+                    if (lane < 32)
+                        __builtin_amdgcn_global_load_lds((gvoid *)(ws_src + (size_t)kp * 128),
+                                                         (lds_void *)(st + A_BYTES + W_BYTES + AS_BYTES), 16, 0, 0);
+                }
+            };
+
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const int col = wn * 64 + ni * 32 + c * 8 + h * 4; // column inside the head
-                        u16x4 wv = *reinterpret_cast<const u16x4 *>(nw + col);
-                        const int pi = col >> 1; // first pair index
-                        const float *rp = p.rotary_emb + rbase + (size_t)(pi >> 2) * 128 + (size_t)(pi & 3) * 4;
-                        float2 sc0 = *reinterpret_cast<const float2 *>(rp);
-                        float2 sc1 = *reinterpret_cast<const float2 *>(rp + 4);
-                        float v0 = acc[ni][mi][c * 4 + 0] * (coef * h2f(hfrom<T>(wv[0])));
-                        float v1 = acc[ni][mi][c * 4 + 1] * (coef * h2f(hfrom<T>(wv[1])));
-                        float v2 = acc[ni][mi][c * 4 + 2] * (coef * h2f(hfrom<T>(wv[2])));
-                        float v3 = acc[ni][mi][c * 4 + 3] * (coef * h2f(hfrom<T>(wv[3])));
-                        acc[ni][mi][c * 4 + 0] = round16<T>(v0 * sc0.y - v1 * sc0.x);
-                        acc[ni][mi][c * 4 + 1] = round16<T>(v0 * sc0.x + v1 * sc0.y);
-                        acc[ni][mi][c * 4 + 2] = round16<T>(v2 * sc1.y - v3 * sc1.x);
-                        acc[ni][mi][c * 4 + 3] = round16<T>(v2 * sc1.x + v3 * sc1.y);
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+            fetch(0, lds);
+            if (KP > 1) fetch(1, lds + STAGE_BYTES);
+
+            for (int s = 0; s < KP; s++) {
+                // stage s (and, conservatively, s+1) has landed for this wave; the barrier makes every wave's
+                // planes visible and guarantees everyone is done reading stage s-1 before it is refilled
+                __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+                __syncthreads();
+                if (s + 2 < KP) fetch(s + 2, lds + ((s + 2) % NSTAGE) * STAGE_BYTES);
+                const uint8_t *st = lds + (s % NSTAGE) * STAGE_BYTES;
+
+                // fragments of both groups: 3 x 16 B per (tile, lane)
+                int af[2][12], wf[2][12];
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) {
+                        v4i a = *reinterpret_cast<const v4i *>(st + (wm * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
+                        v4i w = *reinterpret_cast<const v4i *>(st + A_BYTES + (wn * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { af[i][pl * 4 + e] = a[e]; wf[i][pl * 4 + e] = w[e]; }
                     }
-            }
-        }
-    }
-
-    if constexpr (FUSE == SVDQ_FUSE_GELU_QUANT) {
-        // EpilogueGelu (epilogues.cuh:22-44) -> 16-bit
+                const unsigned short *as_l = reinterpret_cast<const unsigned short *>(st + A_BYTES + W_BYTES);
+                const unsigned short *ws_l = reinterpret_cast<const unsigned short *>(st + A_BYTES + W_BYTES + AS_BYTES);
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+                for (int grp = 0; grp < 2; grp++) {
+                    v4i sa[2], sw[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
+                    for (int i = 0; i < 2; i++) {
+                        sa[i] = v4i{(int)as_l[(wm * 2 + i) * 64 + grp * 32 + lr], 0, 0, 0};
+                        sw[i] = v4i{(int)ws_l[(wn * 2 + i) * 64 + grp * 32 + lr], 0, 0, 0};
+                    }
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(gelu_tanh_f(acc[ni][mi][r]));
-
-        // EpilogueLoraDown for the NEXT layer on the GELU output, before shift/smooth
-        // (lora.cuh:243-353, launch_impl.cuh:226-262):  D'[r2][m] = sum_n ld[r2][n] * g[n][m].  In the C
-        // layout a lane already holds, for its row m, the 8 columns {16q + 8(j>>2) + 4h + (j&3)} of MFMA
-        // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.
-        if (p.R2 > 0) {
-            const T *ld = (const T *)p.next_lora_down; // rank-major [R2][N]
-            for (int t2 = 0; t2 < p.R2; t2 += 32) {
-                v16f d[2];
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++) d[mi] = zero16;
-                const bool live = t2 + lr < p.R2;
-#pragma unroll
-                for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        V8 wv;
-                        if (live) {
-                            const T *src = ld + (size_t)(t2 + lr) * p.N + nw0 + ni * 32 + q * 16 + h * 4;
-                            u16x4 w0 = *reinterpret_cast<const u16x4 *>(src);
-                            u16x4 w1 = *reinterpret_cast<const u16x4 *>(src + 8);
-#pragma unroll
-                            for (int j = 0; j < 4; j++) { wv[j] = hfrom<T>(w0[j]); wv[4 + j] = hfrom<T>(w1[j]); }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 8; j++) wv[j] = (T)0.f;
-                        }
+                    for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                         for (int mi = 0; mi < 2; mi++) {
-                            V8 gv;
+                            const int o = grp * 6;
+                            v8i A = {wf[ni][o], wf[ni][o + 1], wf[ni][o + 2], wf[ni][o + 3], wf[ni][o + 4], wf[ni][o + 5], 0, 0};
+                            v8i B = {af[mi][o], af[mi][o + 1], af[mi][o + 2], af[mi][o + 3], af[mi][o + 4], af[mi][o + 5], 0, 0};
+                            v16f P = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, FMT_FP6, FMT_FP6, 0, MXS_A, 0, MXS_B);
+                            v16f S = Half<DT>::mfma32(__builtin_bit_cast(V8, sw[ni]), __builtin_bit_cast(V8, sa[mi]), zero16);
 #pragma unroll
-                            for (int j = 0; j < 8; j++) gv[j] = f2h<T>(acc[ni][mi][q * 8 + j]);
-                            d[mi] = Half<DT>::mfma32(wv, gv, d[mi]);
+                            for (int r = 0; r < 16; r++) acc[ni][mi][r] = __builtin_fmaf(P[r], S[r], acc[ni][mi][r]);
                         }
-                    }
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++) {
-                    float *dst = p.lora_act_out + (size_t)(mw0 + mi * 32 + lr) * p.R2 + t2 + h * 4;
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int r2 = (i & 3) + 8 * (i >> 2);
-                        if (t2 + r2 + h * 4 < p.R2) unsafeAtomicAdd(dst + r2, d[mi][i]);
-                    }
                 }
             }
         }
 
-        // EpilogueQuantize<false, unsigned> (gemm_w4a4.cuh:930-1043): 16-bit add of the shift,
-        // fp32 divide by the next layer's smooth factor -> 16-bit, per (row, 64 columns) absmax,
-        // scale = amax/15, unsigned 4-bit codes.  The wave's 64 columns are exactly one group of the
-        // next GEMM and the lane's 32 values (j = 16*ni + r) are exactly its F6 lane record.
-        const int KP2 = p.N / 128;
-        const int g2 = nw0 / GROUP;
-        u16x4 sm[2][4];
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                sm[ni][c] = *reinterpret_cast<const u16x4 *>((const T *)p.next_smooth + nw0 + ni * 32 + c * 8 + h * 4);
-#pragma unroll
-        for (int mi = 0; mi < 2; mi++) {
-            float xh[32];
-            float amax = 0.f;
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    float sh = round16<T>(acc[ni][mi][r] + 0.171875f);
-                    float v = round16<T>(sh / h2f(hfrom<T>(sm[ni][r >> 2][r & 3])));
-                    xh[ni * 16 + r] = v;
-                    amax = fmaxf(amax, fabsf(v));
-                }
-            amax = fmaxf(amax, __shfl_xor(amax, 32));
-            const float scale = amax * (1.0f / 15.0f);
-            const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
-            uint32_t rec[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 32; j++) {
-                const uint32_t code = (uint32_t)fminf(fmaxf(rintf(xh[j] * rscale), 0.f), 15.f);
-                const int bit = 6 * j;
-                rec[bit >> 5] |= code << (bit & 31);
-                if ((bit & 31) > 26) rec[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
-            }
-            const int m_abs = mw0 + mi * 32 + lr;
-            uint8_t *dst = p.qout + ((size_t)(m_abs >> 5) * KP2 + (g2 >> 1)) * F6_CHUNK + (size_t)lane * 16;
-            if ((g2 & 1) == 0) {
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-                *reinterpret_cast<uint2 *>(dst + F6_PLANE) = make_uint2(rec[4], rec[5]);
-            } else {
-                *reinterpret_cast<uint2 *>(dst + F6_PLANE + 8) = make_uint2(rec[0], rec[1]);
-                *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[2], rec[3], rec[4], rec[5]);
-            }
-            if (h == 0) ((T *)p.oscales)[simg_index(m_abs, g2, KP2)] = f2h<T>(scale);
-        }
-        return;
-    }
+        // ------------------------------------------------------------------ epilogue
+        // lane owns rows m = mw0 + 32*mi + lr and columns n = nw0 + 32*ni + 8*c + 4*h + e  (r = 4c + e)
+        const int nw0 = n0 + wn * 64;
+        const int mw0 = m0 + wm * 64;
 
-    // EpilogueDefault (gemm_base.cuh:667-698): store rows < M; fp16 clamps to +-65504
-#pragma unroll
-    for (int mi = 0; mi < 2; mi++) {
-        const int m_abs = mw0 + mi * 32 + lr;
-        if (m_abs < p.M) {
-            T *orow = (T *)p.out + (size_t)m_abs * p.ldo + nw0 + h * 4;
+        // bias (reference EpilogueBias, gemm_base.cuh:710-781)
+        if (p.bias && !(p.debug & 2)) {
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    u16x4 o;
+                    u16x4 b = *reinterpret_cast<const u16x4 *>((const T *)p.bias + nw0 + ni * 32 + c * 8 + h * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float v = acc[ni][mi][c * 4 + e];
-                        if constexpr (DT == SVDQ_FP16) v = fminf(fmaxf(v, -65504.f), 65504.f);
-                        o[e] = hbits(f2h<T>(v));
-                    }
-                    *reinterpret_cast<u16x4 *>(orow + ni * 32 + c * 8) = o;
+                    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[ni][mi][c * 4 + e] += h2f(hfrom<T>(b[e]));
                 }
         }
+
+        // low-rank up projection (reference EpilogueLoraUp, lora.cuh:110-241): fp32 activations are
+        // scaled per 16 ranks and rounded to 16-bit (:145-158), multiplied on the matrix cores and
+        // accumulated in fp32 -- here straight onto the GEMM accumulators.
+        if (p.R > 0 && !(p.debug & 2)) {
+            for (int rc = 0; rc < p.R; rc += 16) {
+                const float sc = p.lora_scales[rc >> 4];
+                V8 la[2], lu[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++) {
+                    const float *src = p.lora_act_in + (size_t)(mw0 + mi * 32 + lr) * p.R + rc + h * 8;
+                    v4f x0 = *reinterpret_cast<const v4f *>(src);
+                    v4f x1 = *reinterpret_cast<const v4f *>(src + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        la[mi][j] = f2h<T>(x0[j] * sc);
+                        la[mi][4 + j] = f2h<T>(x1[j] * sc);
+                    }
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+                    lu[ni] = *reinterpret_cast<const V8 *>((const T *)p.lora_up + (size_t)(nw0 + ni * 32 + lr) * p.R + rc + h * 8);
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(lu[ni], la[mi], acc[ni][mi]);
+            }
+        }
+
+        // the single rounding to the 16-bit model dtype (the reference's tile is 16-bit from here on)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(acc[ni][mi][r]);
+
+        if constexpr (FUSE == SVDQ_FUSE_SILU) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(silu_f(acc[ni][mi][r]));
+        }
+
+        if constexpr (FUSE == SVDQ_FUSE_RMSNORM_ROPE) {
+            // reference EpilogueRMSNormRope (epilogues.cuh:269-425).  BN == 128 == one head.
+            const int third = p.N / 3;
+            const bool is_q = n0 < third;
+            const bool is_k = !is_q && n0 < 2 * third;
+            if (is_q || is_k) { // block-uniform
+                __syncthreads(); // the previous tile's readers of the epilogue scratch are done
+                float *sq = reinterpret_cast<float *>(lds_epi); // [2 (wn)][256 rows]
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) s += acc[ni][mi][r] * acc[ni][mi][r];
+                    s += __shfl_xor(s, 32);
+                    if (h == 0) sq[wn * 256 + wm * 64 + mi * 32 + lr] = s;
+                }
+                __syncthreads();
+                const T *nw = (const T *)(is_q ? p.norm_q : p.norm_k);
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++) {
+                    const int row = wm * 64 + mi * 32 + lr;
+                    const float tot = sq[row] + sq[256 + row];
+                    const float coef = 1.0f / sqrtf(tot / 128.0f + 1e-6f);
+                    const int m_abs = m0 + row;
+                    // packed rotary order (models/embeddings.py:100-138): [m/16][d/8][r8*4+p][rh][sin,cos]
+                    const size_t rbase = ((size_t)(m_abs >> 4) * 16) * 128 + (size_t)((m_abs & 7) * 4) * 4 + ((m_abs >> 3) & 1) * 2;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const int col = wn * 64 + ni * 32 + c * 8 + h * 4; // column inside the head
+                            u16x4 wv = *reinterpret_cast<const u16x4 *>(nw + col);
+                            const int pi = col >> 1; // first pair index
+                            const float *rp = p.rotary_emb + rbase + (size_t)(pi >> 2) * 128 + (size_t)(pi & 3) * 4;
+                            float2 sc0 = *reinterpret_cast<const float2 *>(rp);
+                            float2 sc1 = *reinterpret_cast<const float2 *>(rp + 4);
+                            float v0 = acc[ni][mi][c * 4 + 0] * (coef * h2f(hfrom<T>(wv[0])));
+                            float v1 = acc[ni][mi][c * 4 + 1] * (coef * h2f(hfrom<T>(wv[1])));
+                            float v2 = acc[ni][mi][c * 4 + 2] * (coef * h2f(hfrom<T>(wv[2])));
+                            float v3 = acc[ni][mi][c * 4 + 3] * (coef * h2f(hfrom<T>(wv[3])));
+                            acc[ni][mi][c * 4 + 0] = round16<T>(v0 * sc0.y - v1 * sc0.x);
+                            acc[ni][mi][c * 4 + 1] = round16<T>(v0 * sc0.x + v1 * sc0.y);
+                            acc[ni][mi][c * 4 + 2] = round16<T>(v2 * sc1.y - v3 * sc1.x);
+                            acc[ni][mi][c * 4 + 3] = round16<T>(v2 * sc1.x + v3 * sc1.y);
+                        }
+                }
+            }
+        }
+
+        if constexpr (FUSE == SVDQ_FUSE_GELU_QUANT) {
+            // EpilogueGelu (epilogues.cuh:22-44) -> 16-bit
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(gelu_tanh_f(acc[ni][mi][r]));
+
+            // EpilogueLoraDown for the NEXT layer on the GELU output, before shift/smooth
+            // (lora.cuh:243-353, launch_impl.cuh:226-262):  D'[r2][m] = sum_n ld[r2][n] * g[n][m].  In the C
+            // layout a lane already holds, for its row m, the 8 columns {16q + 8(j>>2) + 4h + (j&3)} of MFMA
+            // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.
+            if (p.R2 > 0) {
+                const T *ld = (const T *)p.next_lora_down; // rank-major [R2][N]
+                for (int t2 = 0; t2 < p.R2; t2 += 32) {
+                    v16f d[2];
+#pragma unroll
+                    for (int mi = 0; mi < 2; mi++) d[mi] = zero16;
+                    const bool live = t2 + lr < p.R2;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            V8 wv;
+                            if (live) {
+                                const T *src = ld + (size_t)(t2 + lr) * p.N + nw0 + ni * 32 + q * 16 + h * 4;
+                                u16x4 w0 = *reinterpret_cast<const u16x4 *>(src);
+                                u16x4 w1 = *reinterpret_cast<const u16x4 *>(src + 8);
+#pragma unroll
+                                for (int j = 0; j < 4; j++) { wv[j] = hfrom<T>(w0[j]); wv[4 + j] = hfrom<T>(w1[j]); }
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 8; j++) wv[j] = (T)0.f;
+                            }
+#pragma unroll
+                            for (int mi = 0; mi < 2; mi++) {
+                                V8 gv;
+#pragma unroll
+                                for (int j = 0; j < 8; j++) gv[j] = f2h<T>(acc[ni][mi][q * 8 + j]);
+                                d[mi] = Half<DT>::mfma32(wv, gv, d[mi]);
+                            }
+                        }
+#pragma unroll
+                    for (int mi = 0; mi < 2; mi++) {
+                        float *dst = p.lora_act_out + (size_t)(mw0 + mi * 32 + lr) * p.R2 + t2 + h * 4;
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const int r2 = (i & 3) + 8 * (i >> 2);
+                            if (t2 + r2 + h * 4 < p.R2) unsafeAtomicAdd(dst + r2, d[mi][i]);
+                        }
+                    }
+                }
+            }
+
+            // EpilogueQuantize<false, unsigned> (gemm_w4a4.cuh:930-1043): 16-bit add of the shift,
+            // fp32 divide by the next layer's smooth factor -> 16-bit, per (row, 64 columns) absmax,
+            // scale = amax/15, unsigned 4-bit codes.  The wave's 64 columns are exactly one group of the
+            // next GEMM and the lane's 32 values (j = 16*ni + r) are exactly its F6 lane record.
+            const int KP2 = p.N / 128;
+            const int g2 = nw0 / GROUP;
+            u16x4 sm[2][4];
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    sm[ni][c] = *reinterpret_cast<const u16x4 *>((const T *)p.next_smooth + nw0 + ni * 32 + c * 8 + h * 4);
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+                float xh[32];
+                float amax = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float sh = round16<T>(acc[ni][mi][r] + 0.171875f);
+                        float v = round16<T>(sh / h2f(hfrom<T>(sm[ni][r >> 2][r & 3])));
+                        xh[ni * 16 + r] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                const float scale = amax * (1.0f / 15.0f);
+                const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
+                uint32_t rec[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const uint32_t code = (uint32_t)fminf(fmaxf(rintf(xh[j] * rscale), 0.f), 15.f);
+                    const int bit = 6 * j;
+                    rec[bit >> 5] |= code << (bit & 31);
+                    if ((bit & 31) > 26) rec[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                }
+                const int m_abs = mw0 + mi * 32 + lr;
+                uint8_t *dst = p.qout + ((size_t)(m_abs >> 5) * KP2 + (g2 >> 1)) * F6_CHUNK + (size_t)lane * 16;
+                if ((g2 & 1) == 0) {
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+                    *reinterpret_cast<uint2 *>(dst + F6_PLANE) = make_uint2(rec[4], rec[5]);
+                } else {
+                    *reinterpret_cast<uint2 *>(dst + F6_PLANE + 8) = make_uint2(rec[0], rec[1]);
+                    *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[2], rec[3], rec[4], rec[5]);
+                }
+                if (h == 0) ((T *)p.oscales)[simg_index(m_abs, g2, KP2)] = f2h<T>(scale);
+            }
+        }
+
+        // EpilogueDefault (gemm_base.cuh:667-698): store rows < M; fp16 clamps to +-65504.
+        // A lane holds 4 consecutive columns per (tile, c); the partner lane (lane ^ 32) holds the next 4.
+        // One v_permlane32_swap per dword turns two 8-byte pieces per lane into one 16-byte piece, so a
+        // wave store writes 32 contiguous bytes per row with dwordx4 stores (8 instead of 32 per wave).
+        if constexpr (FUSE != SVDQ_FUSE_GELU_QUANT) {
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+            const int m_abs = mw0 + mi * 32 + lr;
+            T *orow = (T *)p.out + (size_t)m_abs * p.ldo + nw0 + h * 8;
+            const bool ok = m_abs < p.M && !(p.debug & 1);
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    unsigned x[2], y[2]; // x: piece c = 2j, y: piece c = 2j + 1 (4 x 16-bit each)
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        float v0 = acc[ni][mi][(2 * j) * 4 + 2 * d], v1 = acc[ni][mi][(2 * j) * 4 + 2 * d + 1];
+                        float w0 = acc[ni][mi][(2 * j + 1) * 4 + 2 * d], w1 = acc[ni][mi][(2 * j + 1) * 4 + 2 * d + 1];
+                        if constexpr (DT == SVDQ_FP16) {
+                            v0 = fminf(fmaxf(v0, -65504.f), 65504.f); v1 = fminf(fmaxf(v1, -65504.f), 65504.f);
+                            w0 = fminf(fmaxf(w0, -65504.f), 65504.f); w1 = fminf(fmaxf(w1, -65504.f), 65504.f);
+                        }
+                        x[d] = (unsigned)hbits(f2h<T>(v0)) | ((unsigned)hbits(f2h<T>(v1)) << 16);
+                        y[d] = (unsigned)hbits(f2h<T>(w0)) | ((unsigned)hbits(f2h<T>(w1)) << 16);
+                        // x.hi-lanes <-> y.lo-lanes: lo lanes end up with (own x, partner x), hi lanes (partner y, own y)
+                        auto sw = __builtin_amdgcn_permlane32_swap(x[d], y[d], false, false);
+                        x[d] = sw[0];
+                        y[d] = sw[1];
+                    }
+                    if (ok) {
+                        v4i o = {(int)x[0], (int)x[1], (int)y[0], (int)y[1]};
+                        if (p.debug & 4) __builtin_nontemporal_store(o, reinterpret_cast<v4i *>(orow + ni * 32 + j * 16));
+                        else *reinterpret_cast<v4i *>(orow + ni * 32 + j * 16) = o;
+                    }
+                }
+        }
+        } // FUSE != GELU_QUANT
+        seg_tile = next_tile;
+        bm = nbm;
+        bn = nbn;
     }
+}
+
+// number of workgroups of the persistent grid: one per CU (the kernel needs 114 KiB of LDS and 8 waves
+// of 230 VGPRs, so exactly one workgroup is resident per CU)
+static int persistent_grid(int tiles) {
+    static int cus = 0; // benign race: every thread computes the same value
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n >= 8 ? (n / 8) * 8 : n;
+    }
+    return tiles < cus ? tiles : cus;
 }
 
 template <int DT, int FUSE, int LOOPV>
 static void launch_one(const GemmParams &p, hipStream_t st) {
-    dim3 grid((p.M_pad / BM) * (p.N / BN)), block(512);
+    dim3 grid(persistent_grid((p.M_pad / BM) * (p.N / BN))), block(512);
     hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, LOOPV>), grid, block, 0, st, p);
 }
 
@@ -566,7 +648,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     }
     if (a->R > 0 && (!a->lora_act_in || !a->lora_up)) { set_error("svdq_gemm_w4a4: R > 0 needs lora_act_in and lora_up"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemm_w4a4: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
-    if (a->variant < 0 || a->variant > 10) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
+    if (a->variant < 0 || a->variant > 13) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
     if (a->variant >= 2 && (a->dtype != SVDQ_BF16 || a->fuse != SVDQ_FUSE_NONE)) {
         set_error("svdq_gemm_w4a4: ablation variants (tools only, WRONG results) exist for bf16 / FUSE_NONE only");
         return SVDQ_E_INVALID;
@@ -617,6 +699,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.norm_q = a->norm_q;
     p.norm_k = a->norm_k;
     p.rotary_emb = a->rotary_emb;
+    p.debug = a->reserved;
     p.M = a->M; p.M_pad = a->M_pad; p.N = a->N; p.K = a->K; p.R = a->R; p.R2 = a->R2; p.ldo = a->ldo;
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;
 
@@ -639,7 +722,10 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         case 7: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 7>(p, st); break;
         case 8: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 8>(p, st); break;
         case 9: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 9>(p, st); break;
-        default: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 10>(p, st); break;
+        case 10: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 10>(p, st); break;
+        case 11: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 11>(p, st); break;
+        case 12: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 12>(p, st); break;
+        default: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 13>(p, st); break;
         }
     }
     prof_end(prof, st);

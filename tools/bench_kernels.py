@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--json", default=None)
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="M K N: time a single shape")
+    ap.add_argument("--zero", action="store_true", help="all-zero codes (power/clock experiment)")
     args = ap.parse_args()
     rows = []
     shapes = [(3072, 9216), (3072, 3072), (3072, 12288), (12288, 3072)]
@@ -60,6 +61,8 @@ def main():
             lin = rand_layer(K, N, act_unsigned=False)
             x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
             qx, asc, la = lin.quantize(x)
+            if args.zero:
+                qx.zero_(); lin.qweight.data.zero_()
             out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             tq = timeit(lambda: lin.quantize(x), args.iters)
             tg = timeit(lambda: lin.forward_quant(qx, asc, la, out), args.iters)

@@ -25,12 +25,23 @@ operands to the same physical registers):
   v217..v220 LDS addresses of the current stage, v221..v224 of the next stage
   s[40:41] s[42:43] s[44:45]  inputs: global base of streams A, X1, X2 (advanced here)
   s46 KP   s47 s48 s49 LDS destinations (stage-relative) of A, X1, X2   s50 s51 step of X1, X2
-  s52 number of X streams (1 or 2)     s53.. scratch
+  s52 number of X streams (1 or 2)     s53..s57, s61 scratch
+  s58 ring position = LDS stage offset of this segment's K-step 0 (in/out: segments chain)
+  s59 number of this segment's K-steps whose DMA is already in flight (issued by the previous segment)
+  s60 K-steps of the NEXT segment (0 = none); s[62:63] s[64:65] s[66:67] its stream bases A, X1, X2
+  s68 number of leading K-steps of this segment whose DMA is KNOWN to have landed (the caller waited on
+      a younger global load of its own: vmcnt retires in order), so neither the prologue nor those
+      steps wait on vmcnt -- which lets the previous tile's output stores drain under this tile's loop
+
+A "segment" is a run of K-steps [kp0, kp1) of one output tile (a whole tile, or a slice of one when
+the tail of the tile list is split along K).  The DMA stream runs ahead across segment boundaries: the
+last K-steps of a segment already fetch the first three K-steps of the next one, so the epilogue of a
+tile overlaps the HBM/L2 latency of the next tile's first operands.
 """
 import os
 
 STAGE = 24576 + 12288 + 1024 + 1024  # A, W, as, ws(+pad)
-NSTAGE = 3
+NSTAGE = int(os.environ.get('SVDQ_GEN_NSTAGE', '4'))
 CHUNK, PLANE = 3072, 1024
 
 ACC = 0
@@ -45,7 +56,10 @@ CUR = [217, 218, 219, 220]   # A, W, SA, SW address of the current stage
 NXT = [221, 222, 223, 224]
 S_PA, S_PX1, S_PX2 = 40, 42, 44
 S_KP, S_DA, S_DX1, S_DX2, S_IX1, S_IX2, S_NX = 46, 47, 48, 49, 50, 51, 52
-S_STEP, S_CUR, S_NEXT, S_TMP, S_DMASTEP = 53, 54, 55, 56, 57
+S_STEP, S_NEXT, S_TMP, S_DMASTEP, S_TOT = 53, 55, 56, 57, 61
+S_CUR, S_NPRE, S_NCNT = 58, 59, 60
+S_PA_N, S_PX1_N, S_PX2_N = 62, 64, 66
+S_LANDED = 68
 
 
 def vr(a, n=1):
@@ -154,6 +168,21 @@ class Gen:
         ]
         return o
 
+    def issue_step(self, stage_reg):
+        """DMA of K-step S_DMASTEP (counted from the start of this segment) into the stage in stage_reg:
+        from this segment while S_DMASTEP < count, from the next one while < count + next count."""
+        Lskip, Lnosw = self.new_label(), self.new_label()
+        return [
+            f"s_cmp_lt_u32 {sr(S_DMASTEP)}, {sr(S_TOT)}",
+            f"s_cbranch_scc0 {Lskip}",
+            f"s_cmp_eq_u32 {sr(S_DMASTEP)}, {sr(S_KP)}",
+            f"s_cbranch_scc0 {Lnosw}",
+            f"s_mov_b64 {sr(S_PA, 2)}, {sr(S_PA_N, 2)}",
+            f"s_mov_b64 {sr(S_PX1, 2)}, {sr(S_PX1_N, 2)}",
+            f"s_mov_b64 {sr(S_PX2, 2)}, {sr(S_PX2_N, 2)}",
+            f"{Lnosw}:",
+        ] + self.dma_issue(stage_reg) + [f"{Lskip}:"]
+
     def stage_addrs(self, dst, stage_reg):
         return [f"v_add_u32 {vr(dst[i])}, {sr(stage_reg)}, {vr(src)}"
                 for i, src in enumerate((IN_LA, IN_LW, IN_LSA, IN_LSW))]
@@ -171,22 +200,33 @@ class Gen:
         e(f"v_mov_b32 {vr(MXA)}, 0x82828282")
         e(f"v_mov_b32 {vr(MXB)}, 0x81818181")
         e(f"s_mov_b32 {sr(S_STEP)}, 0")
-        e(f"s_mov_b32 {sr(S_CUR)}, 0")
-        # prologue: DMA of K-steps 0, 1, 2 into stages 0, 1, 2
+        e(f"s_add_u32 {sr(S_TOT)}, {sr(S_KP)}, {sr(S_NCNT)}")
+        # prologue: top the DMA stream up to three K-steps in flight (all three for the first segment of a
+        # workgroup, normally none afterwards: the previous segment already fetched them)
+        e(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_CUR)}")
         for j in range(NSTAGE):
             L = self.new_label()
-            if j > 0:
-                e(f"s_cmp_gt_u32 {sr(S_KP)}, {j}")
-                e(f"s_cbranch_scc0 {L}")
-            e(f"s_mov_b32 {sr(S_TMP)}, {j * STAGE}")
-            for ln in self.dma_issue(S_TMP):
+            e(f"s_mov_b32 {sr(S_DMASTEP)}, {j}")
+            e(f"s_cmp_le_u32 {sr(S_NPRE)}, {j}")
+            e(f"s_cbranch_scc0 {L}")
+            for ln in self.issue_step(S_NEXT):
                 e(ln)
             e(f"{L}:")
+            e(f"s_add_u32 {sr(S_NEXT)}, {sr(S_NEXT)}, {STAGE}")
+            e(f"s_cmp_lt_u32 {sr(S_NEXT)}, {NSTAGE * STAGE}")
+            e(f"s_cselect_b32 {sr(S_NEXT)}, {sr(S_NEXT)}, 0")
         e(f"s_mov_b32 {sr(S_DMASTEP)}, {NSTAGE}")
-        e(f"s_mov_b32 {sr(S_NEXT)}, {STAGE}")
+        # S_NEXT has gone once round the ring: back at S_CUR; advance to the stage of K-step 1
+        e(f"s_add_u32 {sr(S_NEXT)}, {sr(S_CUR)}, {STAGE}")
+        e(f"s_cmp_lt_u32 {sr(S_NEXT)}, {NSTAGE * STAGE}")
+        e(f"s_cselect_b32 {sr(S_NEXT)}, {sr(S_NEXT)}, 0")
         for ln in self.stage_addrs(CUR, S_CUR) + self.stage_addrs(NXT, S_NEXT):
             e(ln)
+        Lpw = self.new_label()
+        e(f"s_cmp_gt_u32 {sr(S_LANDED)}, 0")
+        e(f"s_cbranch_scc1 {Lpw}")
         e("s_waitcnt vmcnt(0)")
+        e(f"{Lpw}:")
         e("s_barrier")
         for ln in self.frag_reads(0, 0, CUR):
             e(ln)
@@ -216,25 +256,28 @@ class Gen:
             elif q == 4:
                 # stage s+1 must have landed (own DMAs), then rendezvous: afterwards every wave's planes
                 # of stage s+1 are visible and nobody reads stage s any more -> refill it with step s+3
-                Lw0, Lw4, Lwd, Lnd = self.new_label(), self.new_label(), self.new_label(), self.new_label()
+                Lwd = self.new_label()
                 misc = [
-                    f"s_add_u32 {sr(S_TMP)}, {sr(S_STEP)}, 2",
-                    f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_KP)}",
-                    f"s_cbranch_scc0 {Lw0}",
-                    f"s_cmp_eq_u32 {sr(S_NX)}, 2",
-                    f"s_cbranch_scc0 {Lw4}",
-                    "s_waitcnt vmcnt(5)",
-                    f"s_branch {Lwd}",
-                    f"{Lw4}:",
-                    "s_waitcnt vmcnt(4)",
-                    f"s_branch {Lwd}",
-                    f"{Lw0}:",
-                    "s_waitcnt vmcnt(0)",
+                    f"s_add_u32 {sr(S_TMP)}, {sr(S_STEP)}, 1",
+                    f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_LANDED)}",
+                    f"s_cbranch_scc1 {Lwd}",
+                ]
+                # own DMAs of K-step s+1 must have landed; the younger ones (K-steps s+2 .. s+NSTAGE-1, as far
+                # as they exist) may stay in flight: vmcnt retires in order, nd DMA instructions per K-step
+                misc += [f"s_sub_u32 {sr(S_TMP)}, {sr(S_TOT)}, {sr(S_STEP)}"]
+                klabels = {kk: self.new_label() for kk in range(1, NSTAGE - 1)}
+                for kk in range(NSTAGE - 2, 0, -1):
+                    misc += [f"s_cmp_ge_u32 {sr(S_TMP)}, {kk + 2}", f"s_cbranch_scc1 {klabels[kk]}"]
+                misc += ["s_waitcnt vmcnt(0)", f"s_branch {Lwd}"]
+                for kk in range(1, NSTAGE - 1):
+                    L4 = self.new_label()
+                    misc += [f"{klabels[kk]}:", f"s_cmp_eq_u32 {sr(S_NX)}, 2", f"s_cbranch_scc0 {L4}",
+                             f"s_waitcnt vmcnt({5 * kk})", f"s_branch {Lwd}", f"{L4}:", f"s_waitcnt vmcnt({4 * kk})",
+                             f"s_branch {Lwd}"]
+                misc += [
                     f"{Lwd}:",
                     "s_barrier",
-                    f"s_cmp_lt_u32 {sr(S_DMASTEP)}, {sr(S_KP)}",
-                    f"s_cbranch_scc0 {Lnd}",
-                ] + self.dma_issue(S_CUR) + [f"{Lnd}:"] + reads_n0[0:4]
+                ] + self.issue_step(S_CUR) + reads_n0[0:4]
             elif q in (5, 6):
                 misc = reads_n0[4 * (q - 4):4 * (q - 4) + 4]
             else:  # q == 7: rotate the ring
@@ -246,15 +289,20 @@ class Gen:
                     f"s_add_u32 {sr(S_DMASTEP)}, {sr(S_DMASTEP)}, 1",
                     f"s_add_u32 {sr(S_STEP)}, {sr(S_STEP)}, 1",
                 ] + [f"v_mov_b32 {vr(CUR[i])}, {vr(NXT[i])}" for i in range(4)]
+            order = int(os.environ.get("SVDQ_GEN_ORDER", "0"))
+            split = {0: 8, 1: 0, 2: 4, 3: 12}[order]
+            if order == 1:
+                e(self.s_mfma(pb ^ 1, nbuf, nt))
             for ln in misc:
                 e(ln)
-            for ln in self.fma(t, pb, 0, 8):
+            for ln in self.fma(t, pb, 0, split):
                 e(ln)
-            e(self.s_mfma(pb ^ 1, nbuf, nt))
+            if order != 1:
+                e(self.s_mfma(pb ^ 1, nbuf, nt))
             if q == 7:
                 for ln in self.stage_addrs(NXT, S_NEXT):
                     e(ln)
-            for ln in self.fma(t, pb, 8, 16):
+            for ln in self.fma(t, pb, split, 16):
                 e(ln)
         e(f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_KP)}")
         e(f"s_cbranch_scc1 {loop}")
@@ -281,6 +329,7 @@ if __name__ == "__main__":
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nunchaku_amd", "csrc")
     n = emit(os.path.join(root, "gemm_loop_bf16.inc"), "v_mfma_f32_32x32x16_bf16")
     emit(os.path.join(root, "gemm_loop_fp16.inc"), "v_mfma_f32_32x32x16_f16")
-    for ab in ("dma", "lds", "fma", "smfma", "barrier", "dma+lds", "fma+smfma", "dma+barrier", "dma+lds+barrier"):
+    for ab in ("dma", "lds", "fma", "smfma", "barrier", "dma+lds", "fma+smfma", "dma+barrier", "dma+lds+barrier",
+               "pmfma+smfma+fma", "pmfma+smfma+fma+lds", "pmfma+smfma+fma+lds+barrier"):
         emit(os.path.join(root, "ablate", f"gemm_loop_bf16_{ab.replace('+', '_')}.inc"), "v_mfma_f32_32x32x16_bf16", ab)
     print(f"wrote gemm_loop_{{bf16,fp16}}.inc ({n} lines each)")
