@@ -457,9 +457,11 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                     for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(gelu_tanh_f(acc[ni][mi][r]));
 
             // EpilogueLoraDown for the NEXT layer on the GELU output, before shift/smooth
-            // (lora.cuh:243-353, launch_impl.cuh:226-262):  D'[r2][m] = sum_n ld[r2][n] * g[n][m].  In the C
+            // (lora.cuh:243-353, launch_impl.cuh:226-262):  D'[m][r2] = sum_n g[m][n] * ld[n][r2].  In the C
             // layout a lane already holds, for its row m, the 8 columns {16q + 8(j>>2) + 4h + (j&3)} of MFMA
-            // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.
+            // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.  With
+            // the activations as the A operand the result tile has the RANK along the lanes, so every fp32
+            // atomic instruction hits two 128-byte lines instead of 64 different ones.
             if (p.R2 > 0) {
                 const T *ld = (const T *)p.next_lora_down; // rank-major [R2][N]
                 for (int t2 = 0; t2 < p.R2; t2 += 32) {
@@ -487,16 +489,15 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                                 V8 gv;
 #pragma unroll
                                 for (int j = 0; j < 8; j++) gv[j] = f2h<T>(acc[ni][mi][q * 8 + j]);
-                                d[mi] = Half<DT>::mfma32(wv, gv, d[mi]);
+                                d[mi] = Half<DT>::mfma32(gv, wv, d[mi]);
                             }
                         }
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) {
-                        float *dst = p.lora_act_out + (size_t)(mw0 + mi * 32 + lr) * p.R2 + t2 + h * 4;
+                        float *dst = p.lora_act_out + (size_t)(mw0 + mi * 32 + h * 4) * p.R2 + t2 + lr;
+                        if (live) {
 #pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            const int r2 = (i & 3) + 8 * (i >> 2);
-                            if (t2 + r2 + h * 4 < p.R2) unsafeAtomicAdd(dst + r2, d[mi][i]);
+                            for (int i = 0; i < 16; i++) unsafeAtomicAdd(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.R2, d[mi][i]);
                         }
                     }
                 }

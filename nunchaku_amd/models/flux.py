@@ -172,8 +172,8 @@ class FluxTransformerAMD(nn.Module):
     @torch.no_grad()
     def init_synthetic_(self, seed: int = 0):
         """Random-init weights of FLUX shape (no checkpoints in this environment): int4 codes uniform,
-        scales/low-rank factors small so activations stay O(1).  Parameters are written directly in
-        the kernel layout (a permutation of random data is random data)."""
+        scales/low-rank factors small so activations stay O(1).  Parameters are written in the
+        checkpoint layout (random nibbles are random int4 codes) and repacked like a real checkpoint."""
         dev = self.proj_out.weight.device
         g = torch.Generator(device=dev).manual_seed(seed)
 
@@ -195,7 +195,8 @@ class FluxTransformerAMD(nn.Module):
                 m.smooth_factor_orig.copy_(m.smooth_factor)
                 m.proj_down.copy_(rnd(m.proj_down.shape, 0.5 / math.sqrt(K)))
                 m.proj_up.copy_(rnd(m.proj_up.shape, 0.5 / math.sqrt(m.rank)))
-                m._amd_layout = True
+                m._amd_layout = False
+                m.repack_()
             elif isinstance(m, nn.Linear):
                 m.weight.copy_(rnd(m.weight.shape, 1.0 / math.sqrt(m.in_features)))
                 m.bias.zero_()
