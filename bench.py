@@ -15,7 +15,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the dominant kernel (gemm_w4a4): algorithmic ops / summed kernel time, measured
                   live with HIP events recorded around every launch on the launch stream
                   (svdq_prof_*, include/svdq_amd.h) during the timed steps, against the dense INT8
-                  MFMA peak of MI355X;
+                  MFMA peak of MI355X (BASELINE.json's yardstick; the kernel itself runs the 4-bit
+                  codes on the FP6 matrix path, DESIGN.md section 2);
   cpu_baseline -- the CPU oracle (a numpy port; the reference ships no CPU path) timed on a bounded
                   sample of the same workload on this box's host cores (rank 0, N=1 only).
 """
@@ -155,7 +156,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int4 x int4 -> int32 on INT8 MFMA, fp32 accumulate, bf16 I/O",
+            "dtype": "int4 codes as FP6 (e2m3) operands of the MX-scaled MFMA (exact), fp32 accumulate, bf16 I/O",
             "data": "synthetic",
             "config": {
                 "workload": f"FLUX.1-dev-shaped transformer step, {args.resolution}x{args.resolution} "
