@@ -649,7 +649,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     }
     if (a->R > 0 && (!a->lora_act_in || !a->lora_up)) { set_error("svdq_gemm_w4a4: R > 0 needs lora_act_in and lora_up"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemm_w4a4: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
-    if (a->variant < 0 || a->variant > 13) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
+    if (a->variant < 0 || a->variant > 18) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
     if (a->variant >= 2 && (a->dtype != SVDQ_BF16 || a->fuse != SVDQ_FUSE_NONE)) {
         set_error("svdq_gemm_w4a4: ablation variants (tools only, WRONG results) exist for bf16 / FUSE_NONE only");
         return SVDQ_E_INVALID;
@@ -726,7 +726,11 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         case 10: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 10>(p, st); break;
         case 11: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 11>(p, st); break;
         case 12: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 12>(p, st); break;
-        default: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 13>(p, st); break;
+        case 13: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 13>(p, st); break;
+        case 15: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 15>(p, st); break;
+        case 16: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 16>(p, st); break;
+        case 17: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 17>(p, st); break;
+        default: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 18>(p, st); break;
         }
     }
     prof_end(prof, st);

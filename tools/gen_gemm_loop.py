@@ -77,6 +77,7 @@ class Gen:
         self.lines = []
         self.label = 0
         self.in_loop = False
+        self.keep_all = False
 
     def e(self, s):
         a = self.ablate
@@ -93,6 +94,19 @@ class Gen:
                 return
             if "barrier" in a and s.startswith("s_barrier"):
                 return
+            if "bare" in a:  # keep only the MFMAs, the fmas and the loop control
+                keep = s.startswith("v_mfma") or s.startswith("v_fmac") or s.startswith("v_pk_fma") or \
+                    f"s_add_u32 {sr(S_STEP)}, {sr(S_STEP)}, 1" in s or self.keep_all
+                if "bare2" in a and s.startswith("s_waitcnt lgkmcnt"):
+                    keep = True
+                if "bare3" in a and (s.startswith("v_mov") or s.startswith("v_add") or s.startswith("s_nop")):
+                    keep = True
+                if "bare4" in a and s.startswith("s_") and not s.startswith("s_barrier") and not s.startswith("s_waitcnt vmcnt") and "m0" not in s:
+                    keep = True
+                if "bare4" in a and s.endswith(":"):
+                    keep = True
+                if not keep:
+                    return
         self.lines.append(s)
 
     def new_label(self):
@@ -304,8 +318,10 @@ class Gen:
                     e(ln)
             for ln in self.fma(t, pb, split, 16):
                 e(ln)
+        self.keep_all = True
         e(f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_KP)}")
         e(f"s_cbranch_scc1 {loop}")
+        self.keep_all = False
         self.in_loop = False
         # drain: the speculative MFMAs / fragment reads of the non-existent next step
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -330,6 +346,7 @@ if __name__ == "__main__":
     n = emit(os.path.join(root, "gemm_loop_bf16.inc"), "v_mfma_f32_32x32x16_bf16")
     emit(os.path.join(root, "gemm_loop_fp16.inc"), "v_mfma_f32_32x32x16_f16")
     for ab in ("dma", "lds", "fma", "smfma", "barrier", "dma+lds", "fma+smfma", "dma+barrier", "dma+lds+barrier",
-               "pmfma+smfma+fma", "pmfma+smfma+fma+lds", "pmfma+smfma+fma+lds+barrier"):
+               "pmfma+smfma+fma", "pmfma+smfma+fma+lds", "pmfma+smfma+fma+lds+barrier",
+               "bare", "bare+bare2", "bare+bare3", "bare+bare4"):
         emit(os.path.join(root, "ablate", f"gemm_loop_bf16_{ab.replace('+', '_')}.inc"), "v_mfma_f32_32x32x16_bf16", ab)
     print(f"wrote gemm_loop_{{bf16,fp16}}.inc ({n} lines each)")
