@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 2
+#define SVDQ_ABI_VERSION 3
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -136,9 +136,15 @@ typedef struct svdq_gemm_args {
     int32_t fuse;             /* SVDQ_FUSE_*                                                    */
     int32_t variant;          /* 0 = hand-scheduled main loop; 1 = compiler-scheduled (debug)   */
     int32_t reserved;
+    /* optional scratch for the stream-K tail (svdq_gemm_workspace_bytes() bytes, zero-filled ONCE by the
+     * caller, then reusable by every later call on the same stream; NULL = whole-tile schedule only)     */
+    void *workspace;
+    int64_t workspace_bytes;
 } svdq_gemm_args;
 
 int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
+/* size of the stream-K workspace for the current device (256 arrival counters + 2 fp32 tiles per CU) */
+int64_t svdq_gemm_workspace_bytes(void);
 
 /* ------------------------------------------------------------------------------------------
  * Load-time re-layout of reference checkpoint tensors (NVIDIA fragment order -> CDNA4 order).

@@ -36,6 +36,21 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_workspaces: dict[int, torch.Tensor] = {}
+
+
+def _workspace(device: torch.device) -> torch.Tensor:
+    """Per-device scratch of the GEMM's stream-K tail (arrival counters + fp32 partial tiles).  Allocated
+    once from the torch caching allocator, zero-filled once; the kernel leaves the counters at zero."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _workspaces.get(idx)
+    if ws is None:
+        with torch.cuda.device(idx):
+            ws = torch.zeros(int(_lib.load().svdq_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
+        _workspaces[idx] = ws
+    return ws
+
+
 class _Ops:
     @staticmethod
     def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False):
@@ -115,6 +130,8 @@ class _Ops:
         a.dtype = _DT[ascales.dtype]
         a.act_unsigned = int(bool(act_unsigned))
         a.reserved = int(os.environ.get("SVDQ_GEMM_DEBUG", "0"))  # timing experiments only
+        ws = _workspace(act.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         a.variant = int(os.environ.get("SVDQ_GEMM_VARIANT", "0"))  # 1 = compiler-scheduled loop (debug/A-B only)
 
         if qout is not None and oscales is not None:

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class QuantizeArgs(C.Structure):
@@ -35,12 +35,14 @@ class GemmArgs(C.Structure):
         ("M", C.c_int32), ("M_pad", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("R", C.c_int32), ("R2", C.c_int32), ("ldo", C.c_int32), ("dtype", C.c_int32),
         ("act_unsigned", C.c_int32), ("fuse", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
 EXPORTS = {
     "svdq_quantize_w4a4_act_fuse_lora": (C.c_int, [C.POINTER(QuantizeArgs), C.c_void_p]),
     "svdq_gemm_w4a4": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "svdq_gemm_workspace_bytes": (C.c_int64, []),
     "svdq_repack_qweight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_repack_wscales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_repack_vec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -60,6 +60,9 @@ struct GemmParams {
     const void *norm_k;
     const float *rotary_emb;
     int M, M_pad, N, K, R, R2, ldo;
+    uint8_t *workspace;      // stream-K: [256 int32 flags][2*G slabs of BM*BN fp32] or NULL
+    long long workspace_bytes;
+    int sk_gs;               // stream-K: workgroups sharing the remainder tiles (0 = whole tiles only); host heuristic
     int debug; // timing experiments (tools/): bit0 skip output stores, bit1 skip bias + low-rank up
     float lora_scales[MAX_LORA_TILES];
 };
@@ -111,7 +114,6 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 
     v16f acc[2][2]; // [n tile][m tile]
     const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint8_t *const lds_epi = lds + NSTAGE * STAGE_BYTES;
 
     // ---- per-wave DMA roles (constant over the kernel) ---------------------------------------------
     //   every wave: the three planes of A chunk `wave` of the tile;  waves 0..3: W planes 2w, 2w+1;
@@ -152,26 +154,63 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         else x2 = x1;
     };
 
-    int seg_tile = pos; // segment i of this workgroup = tile pos + i*G, all of K
+    // ---- segments of this workgroup ----------------------------------------------------------------
+    // F = NT / G whole tiles each (tile i*G + pos), then the R = NT % G remainder tiles.  With a workspace
+    // the remainder is split along K ("stream-K"): its R*KP K-steps are dealt evenly to Gs workgroups, a
+    // workgroup's run of K-steps is cut at tile boundaries into segments, the workgroup holding a tile's LAST
+    // K-steps owns it: it adds the other segments' fp32 partial tiles (published through the workspace) and
+    // runs the epilogue.  Without a workspace the first R workgroups take one remainder tile each.
+    const int F = NT / G, R = NT - F * G;
+    constexpr long long SLAB_BYTES = (long long)BM * BN * 4;
+    const bool sk = R > 0 && p.sk_gs >= R && p.sk_gs <= G && p.workspace != nullptr && p.workspace_bytes >= 1024 + 2LL * G * SLAB_BYTES;
+    const long long RU = (long long)R * KP;
+    const int Gs = sk ? p.sk_gs : 0;
+    auto ubound = [&](int q) -> long long { return (long long)q * RU / Gs; };          // first K-step of position q
+    auto pos_of = [&](long long u) -> int { return (int)(((u + 1) * Gs - 1) / RU); };   // position holding K-step u
+    long long su = 0, su_end = 0, su_begin = 0;
+    if (sk && pos < Gs) { su = su_begin = ubound(pos); su_end = ubound(pos + 1); }
+    int it_full = 0;
+    struct Seg { int tile, kp0, kp1; long long u0; };
+    auto next_seg = [&](Seg &sg) -> bool {
+        if (it_full < F) { sg = Seg{it_full * G + pos, 0, KP, 0}; it_full++; return true; }
+        if (!sk) {
+            if (it_full == F && pos < R) { sg = Seg{F * G + pos, 0, KP, 0}; it_full++; return true; }
+            return false;
+        }
+        if (su < su_end) {
+            // LAST segment of the run first: it is the head of a tile that a later workgroup owns, and that owner
+            // waits for it; our own owner duty (the tail of the tile begun by the previous workgroup) comes after,
+            // so no workgroup ever waits on a partial that is itself queued behind a wait
+            const long long t = (su_end - 1) / KP;
+            const long long u0 = max(su, t * KP);
+            sg = Seg{F * G + (int)t, (int)(u0 - t * KP), (int)(su_end - t * KP), u0};
+            su_end = u0;
+            return true;
+        }
+        return false;
+    };
+
     unsigned ring = 0, npre = 0, landed = 0;
     unsigned long long pA = 0, pX1 = 0, pX2 = 0;
     int bm = 0, bn = 0;
-    if (seg_tile < NT) {
-        tile_coords(seg_tile, bm, bn);
-        stream_ptrs(bm, bn, 0, pA, pX1, pX2);
+    Seg cur{0, 0, 0, 0}, nxt{0, 0, 0, 0};
+    bool have = next_seg(cur);
+    if (have) {
+        tile_coords(cur.tile, bm, bn);
+        stream_ptrs(bm, bn, cur.kp0, pA, pX1, pX2);
     }
-    while (seg_tile < NT) {
-        const int kp0 = 0, kp1 = KP;
+    while (have) {
+        const int kp0 = cur.kp0, kp1 = cur.kp1;
         const int m0 = bm * BM, n0 = bn * BN;
         // the next segment (its first operands are prefetched by the tail of this one)
-        const int next_tile = seg_tile + G;
+        const bool have_next = next_seg(nxt);
         int nbm = 0, nbn = 0;
         unsigned ncnt = 0;
         unsigned long long nA = 0, nX1 = 0, nX2 = 0;
-        if (next_tile < NT) {
-            tile_coords(next_tile, nbm, nbn);
-            stream_ptrs(nbm, nbn, 0, nA, nX1, nX2);
-            ncnt = KP;
+        if (have_next) {
+            tile_coords(nxt.tile, nbm, nbn);
+            stream_ptrs(nbm, nbn, nxt.kp0, nA, nX1, nX2);
+            ncnt = nxt.kp1 - nxt.kp0;
         }
 
         if constexpr (LOOPV != 1) {
@@ -245,8 +284,9 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             npre = min((unsigned)NSTAGE, ncnt);
             // the epilogue below waits on global loads (bias / low-rank operands) that are younger than the
             // prefetch DMAs of the next tile: vmcnt retires in order, so those DMAs have landed by then
-            landed = ((p.bias || p.R > 0) && !(p.debug & 2)) ? npre : 0;
+            landed = ((p.bias || p.R > 0) && !(p.debug & 2) && kp1 == KP) ? npre : 0;
         } else {
+            npre = 0;
             // ---- reference C++ main loop (variant 1: same arithmetic, compiler-scheduled, no cross-tile
             //      prefetch); kept for A/B debugging of the hand-scheduled loop
             __syncthreads();
@@ -258,7 +298,11 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             const uint8_t *as_src = (const uint8_t *)p.ascales + ((size_t)(bm * 8 + (lane >> 3)) * KP) * 128 + (lane & 7) * 16;
             const uint8_t *ws_src = (const uint8_t *)p.wscales + ((size_t)(bn * 4 + ((lane >> 3) & 3)) * KP) * 128 + (lane & 7) * 16;
 
-            auto fetch = [&](int kp, uint8_t *st) {
+            typedef __attribute__((address_space(3))) uint8_t lds_u8; // LDS-typed pointers only: no flat casts
+            typedef __attribute__((address_space(3))) v4i lds_v4i;
+            typedef __attribute__((address_space(3))) unsigned short lds_u16;
+            lds_u8 *const L = (lds_u8 *)lds;
+            auto fetch = [&](int kp, lds_u8 *st) {
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
                     __builtin_amdgcn_global_load_lds((gvoid *)(a_src + (size_t)kp * F6_CHUNK + pl * F6_PLANE),
@@ -284,16 +328,17 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-            fetch(0, lds);
-            if (KP > 1) fetch(1, lds + STAGE_BYTES);
+            const int cnt = kp1 - kp0;
+            fetch(kp0, L);
+            if (cnt > 1) fetch(kp0 + 1, L + STAGE_BYTES);
 
-            for (int s = 0; s < KP; s++) {
+            for (int s = 0; s < cnt; s++) {
                 // stage s (and, conservatively, s+1) has landed for this wave; the barrier makes every wave's
                 // planes visible and guarantees everyone is done reading stage s-1 before it is refilled
                 __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
                 __syncthreads();
-                if (s + 2 < KP) fetch(s + 2, lds + ((s + 2) % NSTAGE) * STAGE_BYTES);
-                const uint8_t *st = lds + (s % NSTAGE) * STAGE_BYTES;
+                if (s + 2 < cnt) fetch(kp0 + s + 2, L + ((s + 2) % NSTAGE) * STAGE_BYTES);
+                const lds_u8 *st = L + (s % NSTAGE) * STAGE_BYTES;
 
                 // fragments of both groups: 3 x 16 B per (tile, lane)
                 int af[2][12], wf[2][12];
@@ -301,13 +346,13 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int pl = 0; pl < 3; pl++) {
-                        v4i a = *reinterpret_cast<const v4i *>(st + (wm * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
-                        v4i w = *reinterpret_cast<const v4i *>(st + A_BYTES + (wn * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
+                        v4i a = *(const lds_v4i *)(st + (wm * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
+                        v4i w = *(const lds_v4i *)(st + A_BYTES + (wn * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
 #pragma unroll
                         for (int e = 0; e < 4; e++) { af[i][pl * 4 + e] = a[e]; wf[i][pl * 4 + e] = w[e]; }
                     }
-                const unsigned short *as_l = reinterpret_cast<const unsigned short *>(st + A_BYTES + W_BYTES);
-                const unsigned short *ws_l = reinterpret_cast<const unsigned short *>(st + A_BYTES + W_BYTES + AS_BYTES);
+                const lds_u16 *as_l = (const lds_u16 *)(st + A_BYTES + W_BYTES);
+                const lds_u16 *ws_l = (const lds_u16 *)(st + A_BYTES + W_BYTES + AS_BYTES);
 #pragma unroll
                 for (int grp = 0; grp < 2; grp++) {
                     v4i sa[2], sw[2];
@@ -332,6 +377,57 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             }
         }
 
+        // ---- stream-K: publish or collect partial tiles -----------------------------------------------
+        bool run_epilogue = true;
+        if (sk && (kp0 > 0 || kp1 < KP)) {
+            typedef __attribute__((address_space(1))) int gint;
+            gint *flags = (gint *)reinterpret_cast<int *>(p.workspace); // explicit global address space: no flat aperture checks
+            typedef __attribute__((address_space(1))) float gfloat;
+            typedef __attribute__((address_space(1))) v4f gv4f;
+            gfloat *slabs = (gfloat *)reinterpret_cast<float *>(p.workspace + 1024);
+            const int trel = cur.tile - F * G;                 // remainder tile index = flag index
+            const long long ut0 = (long long)trel * KP;        // first K-step of this tile in the remainder stream
+            if (kp1 < KP) {
+                // not the owner: store the raw fp32 accumulators (16 coalesced 1 KiB wave stores per wave),
+                // make them visible at agent scope, then bump the tile's arrival counter
+                gfloat *slab = slabs + (size_t)(pos * 2 + (cur.u0 > su_begin ? 1 : 0)) * (BM * BN);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    v4f v = {acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 0], acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 1],
+                             acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 2], acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 3]};
+                    *(gv4f *)(slab + ((size_t)(j * 8 + wave) * 64 + lane) * 4) = v;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(flags + trel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                run_epilogue = false;
+            } else {
+                // owner of the tile: wait for the segments [ut0, ut0 + kp0) of the workgroups before us
+                const int first = pos_of(ut0);
+                const int needed = pos - first;
+                if (tid == 0) {
+                    while (__hip_atomic_load(flags + trel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < needed)
+                        __builtin_amdgcn_s_sleep(8);
+                    __hip_atomic_store(flags + trel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                for (int q = first; q < pos; q++) {
+                    const gfloat *slab = slabs + (size_t)(q * 2 + (ubound(q) < ut0 ? 1 : 0)) * (BM * BN);
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)(j * 8 + wave) * 64 + lane) * 4));
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + e] += v[e];
+                    }
+                }
+            }
+        }
+
+        if (run_epilogue) {
         // ------------------------------------------------------------------ epilogue
         // lane owns rows m = mw0 + 32*mi + lr and columns n = nw0 + 32*ni + 8*c + 4*h + e  (r = 4c + e)
         const int nw0 = n0 + wn * 64;
@@ -403,7 +499,8 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             const bool is_k = !is_q && n0 < 2 * third;
             if (is_q || is_k) { // block-uniform
                 __syncthreads(); // the previous tile's readers of the epilogue scratch are done
-                float *sq = reinterpret_cast<float *>(lds_epi); // [2 (wn)][256 rows]
+                // LDS-address-space pointer (no flat cast: the aperture compare it needs trips an LLVM verifier bug here)
+                __attribute__((address_space(3))) float *sq = (__attribute__((address_space(3))) float *)(lds + NSTAGE * STAGE_BYTES); // [2 (wn)][256 rows]
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++) {
                     float s = 0.f;
@@ -590,7 +687,9 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 }
         }
         } // FUSE != GELU_QUANT
-        seg_tile = next_tile;
+        } // run_epilogue
+        have = have_next;
+        cur = nxt;
         bm = nbm;
         bn = nbn;
     }
@@ -598,7 +697,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 
 // number of workgroups of the persistent grid: one per CU (the kernel needs 114 KiB of LDS and 8 waves
 // of 230 VGPRs, so exactly one workgroup is resident per CU)
-static int persistent_grid(int tiles) {
+static int device_cus() {
     static int cus = 0; // benign race: every thread computes the same value
     if (cus == 0) {
         int dev = 0, n = 0;
@@ -606,12 +705,34 @@ static int persistent_grid(int tiles) {
             n = 256;
         cus = n >= 8 ? (n / 8) * 8 : n;
     }
+    return cus;
+}
+static long long workspace_bytes_needed() { return 1024 + 2LL * device_cus() * BM * BN * 4; }
+// Stream-K heuristic.  The remainder R = tiles % CUs of the last round leaves CUs idle for a whole tile time;
+// splitting those tiles along K costs every split ~2 x 128 KiB of fp32 partial traffic plus a prologue
+// (measured ~10 K-steps worth), so it only pays for long K or nearly empty last rounds.  At most two pieces
+// per tile, at least 8 K-steps per piece.  Returns the number of workgroups sharing the remainder (0 = off).
+static int streamk_groups(const GemmParams &p, int tiles, int KP) {
+    const int cus = device_cus();
+    if (!p.workspace || p.workspace_bytes < workspace_bytes_needed() || (p.debug & 8)) return 0;
+    const int R = tiles % cus;
+    if (R == 0) return 0;
+    long long gs = (long long)R * 2;
+    if (gs > cus) gs = cus;
+    while (gs > R && (long long)R * KP / gs < 8) gs--;
+    if (gs <= R) return 0;
+    const double with_sk = (double)R * KP / gs + 10.0, without = (double)KP;
+    return with_sk < 0.85 * without ? (int)gs : 0;
+}
+static int persistent_grid(const GemmParams &p, int tiles) {
+    const int cus = device_cus();
+    if (p.sk_gs > 0) return tiles < cus ? max(tiles, p.sk_gs) : cus;
     return tiles < cus ? tiles : cus;
 }
 
 template <int DT, int FUSE, int LOOPV>
 static void launch_one(const GemmParams &p, hipStream_t st) {
-    dim3 grid(persistent_grid((p.M_pad / BM) * (p.N / BN))), block(512);
+    dim3 grid(persistent_grid(p, (p.M_pad / BM) * (p.N / BN))), block(512);
     hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, LOOPV>), grid, block, 0, st, p);
 }
 
@@ -628,6 +749,8 @@ static void launch_fuse(const GemmParams &p, int fuse, hipStream_t st) {
 } // namespace svdq
 
 using namespace svdq;
+
+extern "C" int64_t svdq_gemm_workspace_bytes(void) { return workspace_bytes_needed(); }
 
 extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     if (!a) { set_error("svdq_gemm_w4a4: args is NULL"); return SVDQ_E_INVALID; }
@@ -677,6 +800,10 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         set_error("svdq_gemm_w4a4: act, wgt, ascales, wscales, lora_up, lora_act_in, qout, rotary_emb must be 16-byte aligned");
         return SVDQ_E_INVALID;
     }
+    if (a->workspace && (((uintptr_t)a->workspace & 15) || a->workspace_bytes < 0)) {
+        set_error("svdq_gemm_w4a4: workspace must be 16-byte aligned with a non-negative size");
+        return SVDQ_E_INVALID;
+    }
     if (((uintptr_t)a->out | (uintptr_t)a->bias | (uintptr_t)a->next_smooth | (uintptr_t)a->next_lora_down |
          (uintptr_t)a->norm_q | (uintptr_t)a->norm_k) & 7) {
         set_error("svdq_gemm_w4a4: out, bias, next_smooth, next_lora_down, norm_q, norm_k must be 8-byte aligned");
@@ -701,9 +828,12 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.norm_k = a->norm_k;
     p.rotary_emb = a->rotary_emb;
     p.debug = a->reserved;
+    p.workspace = (uint8_t *)a->workspace;
+    p.workspace_bytes = a->workspace_bytes;
     p.M = a->M; p.M_pad = a->M_pad; p.N = a->N; p.K = a->K; p.R = a->R; p.R2 = a->R2; p.ldo = a->ldo;
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;
 
+    p.sk_gs = streamk_groups(p, (p.M_pad / BM) * (p.N / BN), p.K / 128);
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(0, 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
     // variant 0: hand-scheduled main loop; variant 1: the compiler-scheduled C++ loop (same arithmetic)

@@ -35,7 +35,7 @@ def test_abi_version(built_lib):
 def test_struct_sizes_match_header(built_lib):
     # 6 pointers + 8 int32 ; 17 pointers + 12 int32
     assert C.sizeof(_lib.QuantizeArgs) == 6 * 8 + 8 * 4
-    assert C.sizeof(_lib.GemmArgs) == 17 * 8 + 12 * 4
+    assert C.sizeof(_lib.GemmArgs) == 17 * 8 + 12 * 4 + 2 * 8  # + workspace, workspace_bytes
 
 
 def test_validation_errors_are_returned_not_aborted(built_lib):
