@@ -68,10 +68,24 @@ struct GemmParams {
 };
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // reference: gemm_utils.cuh:305-312 (tanh.approx there; exact tanhf here)
-    float x3 = x * x * x;
-    float t = 0.5f + 0.5f * tanhf(0.79788456f * (x + 0.044715f * x3));
-    return x * t;
+    // reference: gemm_utils.cuh:305-312: x * (0.5 + 0.5 * tanh.approx(0.79788456 * (x + 0.044715 x^3))).
+    // tanh(u) = 1 - 2 / (exp(2u) + 1) on the hardware exp2 / rcp (|error| ~1e-6, the class of tanh.approx);
+    // libm tanhf costs ~40 VALU instructions per element and made this epilogue VALU-bound.
+    const float x3 = x * x * x;
+    const float u = 0.79788456f * (x + 0.044715f * x3);
+    const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f); // exp(2u); inf / 0 saturate correctly
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return x * (0.5f + 0.5f * t);
+}
+// a / b rounded to nearest for normal-range operands: two Newton steps on the hardware reciprocal rb ~ 1/b
+// (the quotient of the v_div_scale / v_div_fmas / v_div_fixup sequence without its ~7 scaling instructions;
+// activations and smoothing factors are far from the fp32 exponent limits those instructions guard)
+__device__ __forceinline__ float div_rn(float a, float b, float rb) {
+    float q = a * rb;
+    float e = __builtin_fmaf(-q, b, a);
+    q = __builtin_fmaf(e, rb, q);
+    e = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(e, rb, q);
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
@@ -606,12 +620,18 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             // next GEMM and the lane's 32 values (j = 16*ni + r) are exactly its F6 lane record.
             const int KP2 = p.N / 128;
             const int g2 = nw0 / GROUP;
-            u16x4 sm[2][4];
+            float smf[2][16], smr[2][16]; // next layer's smoothing factors of this lane's 32 columns and their reciprocals
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                for (int c = 0; c < 4; c++)
-                    sm[ni][c] = *reinterpret_cast<const u16x4 *>((const T *)p.next_smooth + nw0 + ni * 32 + c * 8 + h * 4);
+                for (int c = 0; c < 4; c++) {
+                    u16x4 sv = *reinterpret_cast<const u16x4 *>((const T *)p.next_smooth + nw0 + ni * 32 + c * 8 + h * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        smf[ni][c * 4 + e] = h2f(hfrom<T>(sv[e]));
+                        smr[ni][c * 4 + e] = __builtin_amdgcn_rcpf(smf[ni][c * 4 + e]);
+                    }
+                }
 #pragma unroll
             for (int mi = 0; mi < 2; mi++) {
                 float xh[32];
@@ -621,7 +641,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         float sh = round16<T>(acc[ni][mi][r] + 0.171875f);
-                        float v = round16<T>(sh / h2f(hfrom<T>(sm[ni][r >> 2][r & 3])));
+                        float v = round16<T>(div_rn(sh, smf[ni][r], smr[ni][r]));
                         xh[ni * 16 + r] = v;
                         amax = fmaxf(amax, fabsf(v));
                     }
