@@ -77,16 +77,6 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
     return x * (0.5f + 0.5f * t);
 }
-// a / b rounded to nearest for normal-range operands: two Newton steps on the hardware reciprocal rb ~ 1/b
-// (the quotient of the v_div_scale / v_div_fmas / v_div_fixup sequence without its ~7 scaling instructions;
-// activations and smoothing factors are far from the fp32 exponent limits those instructions guard)
-__device__ __forceinline__ float div_rn(float a, float b, float rb) {
-    float q = a * rb;
-    float e = __builtin_fmaf(-q, b, a);
-    q = __builtin_fmaf(e, rb, q);
-    e = __builtin_fmaf(-q, b, a);
-    return __builtin_fmaf(e, rb, q);
-}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 typedef __attribute__((address_space(3))) void lds_void;

@@ -53,15 +53,36 @@ __global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::
 #pragma unroll
         for (int i = 0; i < 12; i++) rec[i] = 0;
         T sc16[2];
+        // ---- every global load of the chunk is issued before anything is consumed (the kernel is
+        //      latency-bound otherwise: two dependent round trips per chunk): activations, smoothing factors
+        //      and the first 32 ranks of lora_down for both groups
+        u16x4 xv[2][8], sv[2][8], bv[2][4][2];
 #pragma unroll
         for (int grp = 0; grp < 2; grp++) {
             const int kbase = kp * 128 + grp * 64 + 4 * h; // + 32t + 8c + e
-            u16x4 xv[8];
 #pragma unroll
             for (int tc = 0; tc < 8; tc++) {
-                if (valid) xv[tc] = *reinterpret_cast<const u16x4 *>(xrow + kbase + 8 * tc);
-                else xv[tc] = u16x4{0, 0, 0, 0};
+                if (valid) xv[grp][tc] = *reinterpret_cast<const u16x4 *>(xrow + kbase + 8 * tc);
+                else xv[grp][tc] = u16x4{0, 0, 0, 0};
+                if (smooth) sv[grp][tc] = *reinterpret_cast<const u16x4 *>(smooth + kbase + 8 * tc);
             }
+            if constexpr (RT32 > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (r < R) {
+                        const T *ld = lora_down + (size_t)r * K + kbase + 16 * q;
+                        bv[grp][q][0] = *reinterpret_cast<const u16x4 *>(ld);
+                        bv[grp][q][1] = *reinterpret_cast<const u16x4 *>(ld + 8);
+                    } else {
+                        bv[grp][q][0] = u16x4{0, 0, 0, 0};
+                        bv[grp][q][1] = u16x4{0, 0, 0, 0};
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+            const int kbase = kp * 128 + grp * 64 + 4 * h;
             if constexpr (RT32 > 0) {
                 // D[m][rank] += x[m][k] * lora_down[k][rank]; MFMA q consumes pieces tc = 2q, 2q+1 of every
                 // lane as k-slots 8h .. 8h+7 (any k order works as long as both operands agree)
@@ -70,15 +91,21 @@ __global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::
                     V8 a;
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        a[e] = hfrom<T>(xv[2 * q][e]);
-                        a[4 + e] = hfrom<T>(xv[2 * q + 1][e]);
+                        a[e] = hfrom<T>(xv[grp][2 * q][e]);
+                        a[4 + e] = hfrom<T>(xv[grp][2 * q + 1][e]);
                     }
 #pragma unroll
                     for (int t32 = 0; t32 < RT32; t32++) {
                         if (t32 * 32 < R) { // wave-uniform
                             const int rank = t32 * 32 + r;
                             V8 b;
-                            if (rank < R) {
+                            if (t32 == 0) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    b[e] = hfrom<T>(bv[grp][q][0][e]);
+                                    b[4 + e] = hfrom<T>(bv[grp][q][1][e]);
+                                }
+                            } else if (rank < R) {
                                 const T *ld = lora_down + (size_t)rank * K + kbase + 16 * q;
                                 u16x4 b0 = *reinterpret_cast<const u16x4 *>(ld);
                                 u16x4 b1 = *reinterpret_cast<const u16x4 *>(ld + 8);
@@ -101,13 +128,14 @@ __global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::
 #pragma unroll
             for (int tc = 0; tc < 8; tc++) {
                 if (smooth) {
-                    u16x4 sv = *reinterpret_cast<const u16x4 *>(smooth + kbase + 8 * tc);
 #pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        xh[4 * tc + e] = round16<T>(h2f(hfrom<T>(xv[tc][e])) / h2f(hfrom<T>(sv[e])));
+                    for (int e = 0; e < 4; e++) {
+                        const float sm = h2f(hfrom<T>(sv[grp][tc][e]));
+                        xh[4 * tc + e] = round16<T>(div_rn(h2f(hfrom<T>(xv[grp][tc][e])), sm, __builtin_amdgcn_rcpf(sm)));
+                    }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) xh[4 * tc + e] = h2f(hfrom<T>(xv[tc][e]));
+                    for (int e = 0; e < 4; e++) xh[4 * tc + e] = h2f(hfrom<T>(xv[grp][tc][e]));
                 }
             }
             float amax = 0.f;
@@ -167,8 +195,8 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     using T = typename Half<DT>::T;
     const int KP = a->K / 128, tiles = a->M_pad / 32;
     // enough workgroups to fill 256 CUs several times over, but at least one chunk per wave
-    int cpw = 4;
-    while ((long)tiles * ((KP + cpw - 1) / cpw) > 4096) cpw *= 2;
+    int cpw = 4; // chunks per workgroup = 4 waves x 1 chunk: many short waves hide the HBM round trip
+    while ((long)tiles * ((KP + cpw - 1) / cpw) > 8192) cpw *= 2;
     if (cpw > KP) cpw = ((KP + 3) / 4) * 4;
     const int slices = (KP + cpw - 1) / cpw;
     const int atomics = slices > 1;

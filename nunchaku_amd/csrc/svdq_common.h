@@ -76,6 +76,17 @@ template <typename T> __device__ __forceinline__ T hfrom(unsigned short b) { ret
 // epilogue stages; this reproduces those rounding points)
 template <typename T> __device__ __forceinline__ float round16(float v) { return (float)(T)v; }
 
+// a / b rounded to nearest for normal-range operands: two Newton steps on the hardware reciprocal rb ~ 1/b
+// (the quotient of the v_div_scale / v_div_fmas / v_div_fixup sequence without its ~7 scaling instructions;
+// activations and smoothing factors are far from the fp32 exponent limits those instructions guard)
+__device__ __forceinline__ float div_rn(float a, float b, float rb) {
+    float q = a * rb;
+    float e = __builtin_fmaf(-q, b, a);
+    q = __builtin_fmaf(e, rb, q);
+    e = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(e, rb, q);
+}
+
 // ---- F6 / S image addressing ----------------------------------------------------------------
 constexpr int F6_CHUNK = 3072; // bytes of one (32 rows x 128 k) chunk
 constexpr int F6_PLANE = 1024;
