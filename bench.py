@@ -38,6 +38,11 @@ import torch  # noqa: E402
 INT8_PEAK_TOPS = 256 * 4 * 1024 * 2 * 2.4e9 / 1e12
 # W4A4 + low-rank work of one FLUX.1-dev 1024^2 step: 59.5 TOP + 0.83 TFLOP
 FLUX_STEP_GOP = 59.5e3 + 0.83e3
+# HBM-side traffic of the dominant kernel, bytes per launch averaged over the gemm_w4a4 dispatches of THIS
+# command: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_profile_bench.sh ->
+# profiles/r1_bench_gemm_hbm_counters.json), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.
+# PMC counters cannot be read from inside the timed run, so this is the committed measurement, not a live one.
+GEMM_HBM_TRAFFIC_BYTES = (2 * 117307.98 + 85849.90) * 1024
 
 
 def cpu_baseline(max_seconds: float = 30.0):
@@ -173,7 +178,9 @@ def main():
                 "peak": INT8_PEAK_TOPS,
                 "unit": "TOP/s",
                 "frac": achieved / INT8_PEAK_TOPS,
-                "traffic": None,
+                "traffic": GEMM_HBM_TRAFFIC_BYTES,
+                "traffic_note": "HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, profiles/r1_bench_gemm_hbm_counters.json); "
+                                "the L2-side operand stream is ~5x larger (83 % L2 hit rate)",
                 "launches": n_g,
                 "avg_launch_us": ms_g * 1e3 / max(n_g, 1),
                 "gemm_ms_per_step": ms_g / args.steps,
