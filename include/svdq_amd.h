@@ -145,6 +145,10 @@ typedef struct svdq_gemm_args {
 int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
 /* size of the stream-K workspace for the current device (256 arrival counters + 2 fp32 tiles per CU) */
 int64_t svdq_gemm_workspace_bytes(void);
+/* Host-side replay of the kernel's persistent / stream-K schedule (test helper; no GPU needed): writes up to
+ * `cap` records of 6 int32 {position, tile, kp0, kp1, partial slot or -1, contributors the owner waits for}
+ * and returns the number of segments, or -1 for invalid shapes. */
+int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t *out, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * Load-time re-layout of reference checkpoint tensors (NVIDIA fragment order -> CDNA4 order).

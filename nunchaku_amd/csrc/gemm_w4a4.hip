@@ -164,35 +164,14 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     // workgroup's run of K-steps is cut at tile boundaries into segments, the workgroup holding a tile's LAST
     // K-steps owns it: it adds the other segments' fp32 partial tiles (published through the workspace) and
     // runs the epilogue.  Without a workspace the first R workgroups take one remainder tile each.
-    const int F = NT / G, R = NT - F * G;
     constexpr long long SLAB_BYTES = (long long)BM * BN * 4;
-    const bool sk = R > 0 && p.sk_gs >= R && p.sk_gs <= G && p.workspace != nullptr && p.workspace_bytes >= 1024 + 2LL * G * SLAB_BYTES;
-    const long long RU = (long long)R * KP;
-    const int Gs = sk ? p.sk_gs : 0;
-    auto ubound = [&](int q) -> long long { return (long long)q * RU / Gs; };          // first K-step of position q
-    auto pos_of = [&](long long u) -> int { return (int)(((u + 1) * Gs - 1) / RU); };   // position holding K-step u
-    long long su = 0, su_end = 0, su_begin = 0;
-    if (sk && pos < Gs) { su = su_begin = ubound(pos); su_end = ubound(pos + 1); }
-    int it_full = 0;
-    struct Seg { int tile, kp0, kp1; long long u0; };
-    auto next_seg = [&](Seg &sg) -> bool {
-        if (it_full < F) { sg = Seg{it_full * G + pos, 0, KP, 0}; it_full++; return true; }
-        if (!sk) {
-            if (it_full == F && pos < R) { sg = Seg{F * G + pos, 0, KP, 0}; it_full++; return true; }
-            return false;
-        }
-        if (su < su_end) {
-            // LAST segment of the run first: it is the head of a tile that a later workgroup owns, and that owner
-            // waits for it; our own owner duty (the tail of the tile begun by the previous workgroup) comes after,
-            // so no workgroup ever waits on a partial that is itself queued behind a wait
-            const long long t = (su_end - 1) / KP;
-            const long long u0 = max(su, t * KP);
-            sg = Seg{F * G + (int)t, (int)(u0 - t * KP), (int)(su_end - t * KP), u0};
-            su_end = u0;
-            return true;
-        }
-        return false;
-    };
+    const bool ws_ok = p.workspace != nullptr && p.workspace_bytes >= 1024 + 2LL * G * SLAB_BYTES;
+    GemmSchedule sched;
+    sched.init(NT, KP, G, ws_ok ? p.sk_gs : 0, pos);
+    const bool sk = sched.gs > 0;
+    const int F = sched.F;
+    typedef GemmSegment Seg;
+    auto next_seg = [&](Seg &sg) -> bool { return sched.next(sg); };
 
     unsigned ring = 0, npre = 0, landed = 0;
     unsigned long long pA = 0, pX1 = 0, pX2 = 0;
@@ -390,11 +369,10 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             typedef __attribute__((address_space(1))) v4f gv4f;
             gfloat *slabs = (gfloat *)reinterpret_cast<float *>(p.workspace + 1024);
             const int trel = cur.tile - F * G;                 // remainder tile index = flag index
-            const long long ut0 = (long long)trel * KP;        // first K-step of this tile in the remainder stream
             if (kp1 < KP) {
                 // not the owner: store the raw fp32 accumulators (16 coalesced 1 KiB wave stores per wave),
                 // make them visible at agent scope, then bump the tile's arrival counter
-                gfloat *slab = slabs + (size_t)(pos * 2 + (cur.u0 > su_begin ? 1 : 0)) * (BM * BN);
+                gfloat *slab = slabs + (size_t)sched.slot(cur) * (BM * BN);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     v4f v = {acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 0], acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 1],
@@ -410,7 +388,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 run_epilogue = false;
             } else {
                 // owner of the tile: wait for the segments [ut0, ut0 + kp0) of the workgroups before us
-                const int first = pos_of(ut0);
+                const int first = sched.first_contributor(cur);
                 const int needed = pos - first;
                 if (tid == 0) {
                     while (__hip_atomic_load(flags + trel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < needed)
@@ -420,7 +398,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 }
                 __syncthreads();
                 for (int q = first; q < pos; q++) {
-                    const gfloat *slab = slabs + (size_t)(q * 2 + (ubound(q) < ut0 ? 1 : 0)) * (BM * BN);
+                    const gfloat *slab = slabs + (size_t)sched.contributor_slot(cur, q) * (BM * BN);
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
                         v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)(j * 8 + wave) * 64 + lane) * 4));
@@ -761,6 +739,42 @@ static void launch_fuse(const GemmParams &p, int fuse, hipStream_t st) {
 using namespace svdq;
 
 extern "C" int64_t svdq_gemm_workspace_bytes(void) { return workspace_bytes_needed(); }
+
+// Host-side replay of the persistent schedule (the same GemmSchedule code the kernel runs): for the problem
+// (M_pad, N, K) on `cus` compute units, with or without a stream-K workspace, write up to `cap` records
+// {position, tile, kp0, kp1, slot-or-minus-one, contributors} and return the number of segments (or -1).
+extern "C" int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t *out, int32_t cap) {
+    if (M_pad <= 0 || N <= 0 || K <= 0 || M_pad % BM || N % BN || K % 128 || cus <= 0) return -1;
+    const int tiles = (M_pad / BM) * (N / BN), KP = K / 128;
+    int gs = 0;
+    if (with_workspace) { // streamk_groups() with an explicit CU count
+        const int R = tiles % cus;
+        if (R) {
+            long long g = (long long)R * 2;
+            if (g > cus) g = cus;
+            while (g > R && (long long)R * KP / g < 8) g--;
+            if (g > R && (double)R * KP / g + 10.0 < 0.85 * KP) gs = (int)g;
+        }
+    }
+    const int G = gs > 0 ? (tiles < cus ? (tiles > gs ? tiles : gs) : cus) : (tiles < cus ? tiles : cus);
+    int n = 0;
+    for (int pos = 0; pos < G; pos++) {
+        GemmSchedule sc;
+        sc.init(tiles, KP, G, gs, pos);
+        GemmSegment sg;
+        while (sc.next(sg)) {
+            if (out && n < cap) {
+                int32_t *r = out + 6 * n;
+                const bool partial = sc.gs > 0 && (sg.kp0 > 0 || sg.kp1 < KP);
+                r[0] = pos; r[1] = sg.tile; r[2] = sg.kp0; r[3] = sg.kp1;
+                r[4] = partial && sg.kp1 < KP ? sc.slot(sg) : -1;
+                r[5] = partial && sg.kp1 == KP ? pos - sc.first_contributor(sg) : 0;
+            }
+            n++;
+        }
+    }
+    return n;
+}
 
 extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     if (!a) { set_error("svdq_gemm_w4a4: args is NULL"); return SVDQ_E_INVALID; }

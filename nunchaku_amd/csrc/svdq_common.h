@@ -119,6 +119,54 @@ __host__ __device__ __forceinline__ int f6_dec(unsigned c, int is_unsigned) {
     return is_unsigned ? (int)(c & 31) : ((c & 32) ? -(int)(c & 15) : (int)(c & 15));
 }
 
+// ---- persistent GEMM schedule (shared by the kernel and by svdq_gemm_schedule, which the CPU tests use) --
+// A grid of G workgroups walks NT output tiles of KP K-steps each.  Every workgroup first takes F = NT / G
+// whole tiles (tile i*G + pos), then the R = NT % G remainder tiles are either handed out whole (gs == 0: the
+// first R positions take one each) or split along K ("stream-K", gs >= R): their R*KP K-steps are dealt evenly
+// to the positions 0..gs-1, a position's run is cut at tile boundaries into segments and handed out LAST
+// SEGMENT FIRST (the head of a tile somebody else owns is published before our own owner duty can wait).
+// The segment with kp1 == KP owns its tile: it collects the fp32 partials of the `contributors()` other
+// segments and runs the epilogue.
+struct GemmSegment { int tile, kp0, kp1; long long u0; };
+struct GemmSchedule {
+    int NT, KP, G, gs, pos, F, R;
+    long long RU, su, su_end, su_begin;
+    int it_full;
+    __host__ __device__ void init(int NT_, int KP_, int G_, int gs_, int pos_) {
+        NT = NT_; KP = KP_; G = G_; pos = pos_;
+        F = NT / G; R = NT - F * G;
+        gs = (R > 0 && gs_ >= R && gs_ <= G) ? gs_ : 0;
+        RU = (long long)R * KP;
+        su = su_end = su_begin = 0;
+        if (gs && pos < gs) { su = su_begin = ubound(pos); su_end = ubound(pos + 1); }
+        it_full = 0;
+    }
+    __host__ __device__ long long ubound(int q) const { return (long long)q * RU / gs; }             // first K-step of position q
+    __host__ __device__ int pos_of(long long u) const { return (int)(((u + 1) * gs - 1) / RU); }     // position holding K-step u
+    __host__ __device__ bool next(GemmSegment &sg) {
+        if (it_full < F) { sg = GemmSegment{it_full * G + pos, 0, KP, 0}; it_full++; return true; }
+        if (!gs) {
+            if (it_full == F && pos < R) { sg = GemmSegment{F * G + pos, 0, KP, 0}; it_full++; return true; }
+            return false;
+        }
+        if (su < su_end) {
+            const long long t = (su_end - 1) / KP;
+            const long long u0 = su > t * KP ? su : t * KP;
+            sg = GemmSegment{F * G + (int)t, (int)(u0 - t * KP), (int)(su_end - t * KP), u0};
+            su_end = u0;
+            return true;
+        }
+        return false;
+    }
+    // partial-tile slot of a non-owner segment: 2 slots per position (a run spans at most two tiles)
+    __host__ __device__ int slot(const GemmSegment &sg) const { return pos * 2 + (sg.u0 > su_begin ? 1 : 0); }
+    // owner side: positions [first_contributor, pos) hold the earlier K-steps of sg.tile; slot of contributor q
+    __host__ __device__ int first_contributor(const GemmSegment &sg) const { return pos_of((long long)(sg.tile - F * G) * KP); }
+    __host__ __device__ int contributor_slot(const GemmSegment &sg, int q) const {
+        return q * 2 + (ubound(q) < (long long)(sg.tile - F * G) * KP ? 1 : 0);
+    }
+};
+
 // ---- host-side error plumbing --------------------------------------------------------------
 void set_error(const char *fmt, ...);
 int hip_check(hipError_t e, const char *what);
