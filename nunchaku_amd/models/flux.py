@@ -66,10 +66,13 @@ class FluxAttentionAMD(nn.Module):
     def forward(self, hidden, encoder_hidden=None, rotary=None):
         B = hidden.shape[0]
         if self.joint:
+            # both projections write straight into one [txt; img] buffer (B == 1): no torch.cat round trip
             rot_img, rot_txt = rotary
-            qkv = fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rot_img)
-            qkv_c = fused_qkv_norm_rottary(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, rot_txt)
-            qkv = torch.cat([qkv_c, qkv], dim=1)
+            t_txt, t_img = encoder_hidden.shape[1], hidden.shape[1]
+            qkv = torch.empty(B, t_txt + t_img, 3 * self.heads * self.head_dim, dtype=hidden.dtype, device=hidden.device)
+            fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rot_img, output=qkv[0, t_txt:])
+            fused_qkv_norm_rottary(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, rot_txt,
+                                   output=qkv[0, :t_txt])
         else:
             qkv = fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary)
         q, k, v = qkv.chunk(3, dim=-1)
@@ -108,8 +111,9 @@ class FluxJointBlockAMD(nn.Module):
         self.dim = dim
 
     @staticmethod
-    def _ln(x):
-        return F.layer_norm(x, (x.shape[-1],), eps=1e-6)
+    def _ln_mod(x, scale, shift):
+        # AdaLayerNormZero: LN(x) * (1 + scale) + shift as LN + one fused multiply-add
+        return torch.addcmul(shift[:, None], F.layer_norm(x, (x.shape[-1],), eps=1e-6), 1 + scale[:, None])
 
     def forward(self, hidden, encoder_hidden, temb_act, rotary):
         # normalization.py:85-98 -- emb.view(B, -1, 6).permute(2, 0, 1): interleaved chunks
@@ -117,15 +121,15 @@ class FluxJointBlockAMD(nn.Module):
         c = self.mod_context(temb_act).view(temb_act.shape[0], -1, 6).permute(2, 0, 1)
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = m
         c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c
-        n_h = self._ln(hidden) * (1 + scale_msa[:, None]) + shift_msa[:, None]
-        n_e = self._ln(encoder_hidden) * (1 + c_scale_msa[:, None]) + c_shift_msa[:, None]
+        n_h = self._ln_mod(hidden, scale_msa, shift_msa)
+        n_e = self._ln_mod(encoder_hidden, c_scale_msa, c_shift_msa)
         a, ca = self.attn(n_h, n_e, rotary)
-        hidden = hidden + gate_msa[:, None] * a
-        n_h = self._ln(hidden) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
-        hidden = hidden + gate_mlp[:, None] * self.ff(n_h)
-        encoder_hidden = encoder_hidden + c_gate_msa[:, None] * ca
-        n_e = self._ln(encoder_hidden) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
-        encoder_hidden = encoder_hidden + c_gate_mlp[:, None] * self.ff_context(n_e)
+        hidden = torch.addcmul(hidden, gate_msa[:, None], a)
+        n_h = self._ln_mod(hidden, scale_mlp, shift_mlp)
+        hidden = torch.addcmul(hidden, gate_mlp[:, None], self.ff(n_h))
+        encoder_hidden = torch.addcmul(encoder_hidden, c_gate_msa[:, None], ca)
+        n_e = self._ln_mod(encoder_hidden, c_scale_mlp, c_shift_mlp)
+        encoder_hidden = torch.addcmul(encoder_hidden, c_gate_mlp[:, None], self.ff_context(n_e))
         return encoder_hidden, hidden
 
 
@@ -140,10 +144,10 @@ class FluxSingleBlockAMD(nn.Module):
 
     def forward(self, hidden, temb_act, rotary):
         shift, scale, gate = self.mod(temb_act).view(temb_act.shape[0], -1, 3).permute(2, 0, 1)
-        n = F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]
+        n = torch.addcmul(shift[:, None], F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6), 1 + scale[:, None])
         mlp = fused_gelu_mlp(n, self.mlp_fc1, self.mlp_fc2)
         att = self.attn(n, rotary=rotary)
-        return hidden + gate[:, None] * (att + mlp)
+        return torch.addcmul(hidden, gate[:, None], att.add_(mlp))
 
 
 class FluxTransformerAMD(nn.Module):
