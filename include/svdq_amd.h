@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 3
+#define SVDQ_ABI_VERSION 4
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -140,6 +140,13 @@ typedef struct svdq_gemm_args {
      * caller, then reusable by every later call on the same stream; NULL = whole-tile schedule only)     */
     void *workspace;
     int64_t workspace_bytes;
+    /* SVDQ_FUSE_RMSNORM_ROPE only, optional: the V third of the output (columns [2N/3, N)) is written
+     * TRANSPOSED, element (m, n) -> out_vt[(n - 2N/3) * ldvt + m], and NOT to `out` -- the key-contiguous
+     * operand svdq_attention reads (role of the reference's packed out_v, epilogues.cuh:427-550).  A joint
+     * (text + image) attention passes the same buffer to both GEMMs with out_vt offset by the token start. */
+    void *out_vt;
+    int32_t ldvt;             /* row stride of out_vt in elements (>= total tokens)              */
+    int32_t reserved2;
 } svdq_gemm_args;
 
 int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
@@ -149,6 +156,31 @@ int64_t svdq_gemm_workspace_bytes(void);
  * `cap` records of 6 int32 {position, tile, kp0, kp1, partial slot or -1, contributors the owner waits for}
  * and returns the number of segments, or -1 for invalid shapes. */
 int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t *out, int32_t cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention over the packed QKV (reference: ops.attention_fp16, nunchaku/csrc/ops.h:114-121,
+ * src/kernels/zgemm/attention.cu:11-94).  Non-causal, no mask,
+ * head_dim 128, one batch element per call:
+ *   O[l, h, :] = softmax_j(scale * Q[l, h, :] . K[j, h, :]) V[j, h, :]
+ * element addresses (in 16-bit elements):
+ *   Q (l,h,d): q  + l*ldq  + h*q_hs  + d        K (j,h,d): k + j*ldk + h*k_hs + d
+ *   V (j,h,d): vt + d*ldvt + h*vt_hs + j        (V TRANSPOSED: keys contiguous)
+ *   O (l,h,d): out + l*ldo + h*o_hs  + d
+ * With the fused QKV GEMM output [L, 3*H*128] (+ out_vt [H*128, L]): q = qkv, k = qkv + H*128,
+ * ldq = ldk = 3*H*128, q_hs = k_hs = 128, vt_hs = 128*ldvt, out [L, H*128]: o_hs = 128, ldo = H*128.
+ * L (queries = keys) must be a multiple of 128 (the models pad tokens to 256: fused.py:140-152).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct svdq_attention_args {
+    const void *q, *k, *vt;
+    void *out;
+    int64_t q_hs, k_hs, vt_hs, o_hs; /* head strides in elements */
+    int32_t ldq, ldk, ldvt, ldo;     /* token (q, k, out) / channel (vt) strides in elements */
+    int32_t L, H, head_dim, dtype;
+    float scale;                     /* softmax scale, e.g. 1/sqrt(head_dim) */
+    int32_t reserved;
+} svdq_attention_args;
+
+int svdq_attention(const svdq_attention_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Load-time re-layout of reference checkpoint tensors (NVIDIA fragment order -> CDNA4 order).
@@ -173,7 +205,7 @@ int svdq_unpack_scales(const void *simg, void *natural, int32_t ROWS, int32_t G,
  * Launch profiler (used by bench.py for the roofline line).  While enabled, every
  * svdq_gemm_w4a4 / svdq_quantize call brackets its kernel launch with two hipEvents recorded on
  * the launch stream.  svdq_prof_read synchronises the recorded events and returns, per kernel
- * class (0 = gemm_w4a4, 1 = quantize), the number of launches, the summed kernel time in
+ * class (0 = gemm_w4a4, 1 = quantize, 2 = attention: 4*L*L*H*128 flops), the number of launches, the summed kernel time in
  * milliseconds and the summed ALGORITHMIC work (gemm: 2*M_pad*N*K + 2*M_pad*N*R operations;
  * quantize: bytes read + written).  Process-global state, guarded by a mutex; off by default.
  * ------------------------------------------------------------------------------------------ */

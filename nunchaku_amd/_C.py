@@ -91,10 +91,14 @@ class _Ops:
     def gemm_w4a4(
         act, wgt, out, qout, ascales, wscales, oscales, poolout, lora_act_in, lora_up, lora_down, lora_act_out,
         norm_q, norm_k, rotary_emb, bias, smooth_factor, out_vk, out_linearattn, act_unsigned, lora_scales,
-        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens,
+        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens, out_vt=None,
     ):
         """reference: csrc/ops.h:10-81 -> kernels::gemm_w4a4 (zgemm.h:8-36).  The epilogue is inferred
-        from which optional tensors are present, exactly as gemm_w4a4_launch_impl.cuh:282-423 does."""
+        from which optional tensors are present, exactly as gemm_w4a4_launch_impl.cuh:282-423 does.
+
+        ``out_vt`` (extension, RMSNorm+RoPE epilogue only): a ``[N/3, tokens]`` view with unit column stride
+        that receives V transposed instead of the V columns of ``out`` -- the operand ``ops.attention`` reads
+        (role of the reference's packed out_q/out_k/out_v, epilogues.cuh:427-550)."""
         lib = _lib.load()
         if fp4:
             raise NotImplementedError("gemm_w4a4: fp4 (NVFP4) is Blackwell-only; use int4 checkpoints")
@@ -103,7 +107,10 @@ class _Ops:
         if out_linearattn is not None or out_vk is not None:
             raise NotImplementedError("gemm_w4a4: the SANA LiteLA epilogue is out of scope")
         if out_q is not None or out_k is not None or out_v is not None:
-            raise NotImplementedError("gemm_w4a4: packed Q/K/V for nunchaku-fp16 attention is not implemented yet")
+            raise NotImplementedError(
+                "gemm_w4a4: the reference's packed out_q/out_k/out_v tile order is NVIDIA-fragment specific; "
+                "pass out_vt= and use ops.attention on the [tokens, 3*H*128] output instead"
+            )
         if act is None or wgt is None or ascales is None or wscales is None:
             raise ValueError("gemm_w4a4: act, wgt, ascales and wscales are required")
         if ascales.dtype not in _DT:
@@ -148,6 +155,12 @@ class _Ops:
                 raise ValueError("gemm_w4a4: rotary_emb must be float32 [M_pad, 128] (pack_rotemb order)")
             a.fuse = _lib.FUSE_RMSNORM_ROPE
             a.norm_q, a.norm_k, a.rotary_emb = _ptr(norm_q), _ptr(norm_k), _ptr(rotary_emb)
+            if out_vt is not None:
+                if out_vt.dim() != 2 or out_vt.stride(1) != 1 or out_vt.shape[0] * 3 != N or out_vt.dtype != ascales.dtype:
+                    raise ValueError("gemm_w4a4: out_vt must be a [N/3, tokens] view with unit column stride in the model dtype")
+                if not out_vt.is_cuda:
+                    raise RuntimeError("nunchaku_amd ops need GPU tensors (there is no CPU path)")
+                a.out_vt, a.ldvt = out_vt.data_ptr(), out_vt.stride(0)
         elif out is not None:
             a.fuse = _lib.FUSE_SILU if fuse_silu else _lib.FUSE_NONE
         else:
@@ -160,8 +173,39 @@ class _Ops:
                 raise ValueError("gemm_w4a4: out.shape[-1] must equal N")
             if a.M > M_pad or M_pad - a.M >= 256:
                 raise ValueError("gemm_w4a4: out rows must satisfy M <= M_pad < M + 256 (launch_impl.cuh:55)")
+        if out_vt is not None and a.fuse != _lib.FUSE_RMSNORM_ROPE:
+            raise ValueError("gemm_w4a4: out_vt needs the RMSNorm+RoPE epilogue (rotary_emb, norm_q, norm_k)")
+        if out_vt is not None and out_vt.shape[1] < a.M:
+            raise ValueError("gemm_w4a4: out_vt has fewer columns than out has rows")
         _lib.check(lib.svdq_gemm_w4a4(C.byref(a), _stream()), "gemm_w4a4")
         del keep
+
+    @staticmethod
+    def attention(q, k, vt, out, scale):
+        """Non-causal attention, head_dim 128 (role of the reference's ``ops.attention_fp16``, csrc/ops.h:114-121
+        -> attention.cu:11-94).  Strided views, no copies: ``q``/``k``/``out`` are ``[L, H, 128]`` (any token and head
+        stride, unit channel stride), ``vt`` is ``[H, 128, L]`` with unit token stride (V transposed, as the QKV
+        GEMM's ``out_vt`` writes it).  L must be a multiple of 128."""
+        lib = _lib.load()
+        for name, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
+            if t is None or t.dim() != 3 or t.stride(2) != 1:
+                raise ValueError(f"attention: {name} must be a 3-D view with unit innermost stride")
+            if not t.is_cuda:
+                raise RuntimeError("nunchaku_amd ops need GPU tensors (there is no CPU path)")
+        if q.dtype not in _DT or k.dtype != q.dtype or vt.dtype != q.dtype or out.dtype != q.dtype:
+            raise ValueError("attention: q, k, vt, out must share one 16-bit dtype")
+        L, H, D = q.shape
+        if tuple(k.shape) != (L, H, D) or tuple(out.shape) != (L, H, D) or tuple(vt.shape) != (H, D, L):
+            raise ValueError("attention: expected q/k/out [L, H, D] and vt [H, D, L]")
+        a = _lib.AttentionArgs()
+        a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+        a.ldq, a.q_hs = q.stride(0), q.stride(1)
+        a.ldk, a.k_hs = k.stride(0), k.stride(1)
+        a.ldo, a.o_hs = out.stride(0), out.stride(1)
+        a.vt_hs, a.ldvt = vt.stride(0), vt.stride(1)
+        a.L, a.H, a.head_dim, a.dtype = L, H, D, _DT[q.dtype]
+        a.scale = float(scale)
+        _lib.check(lib.svdq_attention(C.byref(a), _stream()), "attention")
 
 
 class _Utils:

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class QuantizeArgs(C.Structure):
@@ -36,12 +36,24 @@ class GemmArgs(C.Structure):
         ("R", C.c_int32), ("R2", C.c_int32), ("ldo", C.c_int32), ("dtype", C.c_int32),
         ("act_unsigned", C.c_int32), ("fuse", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("out_vt", C.c_void_p), ("ldvt", C.c_int32), ("reserved2", C.c_int32),
+    ]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
+        ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("vt_hs", C.c_int64), ("o_hs", C.c_int64),
+        ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldvt", C.c_int32), ("ldo", C.c_int32),
+        ("L", C.c_int32), ("H", C.c_int32), ("head_dim", C.c_int32), ("dtype", C.c_int32),
+        ("scale", C.c_float), ("reserved", C.c_int32),
     ]
 
 
 EXPORTS = {
     "svdq_quantize_w4a4_act_fuse_lora": (C.c_int, [C.POINTER(QuantizeArgs), C.c_void_p]),
     "svdq_gemm_w4a4": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "svdq_attention": (C.c_int, [C.POINTER(AttentionArgs), C.c_void_p]),
     "svdq_gemm_workspace_bytes": (C.c_int64, []),
     "svdq_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_repack_qweight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -1,0 +1,233 @@
+// svdq_attention: bf16/fp16 flash attention over the packed QKV the fused QKV GEMM epilogue emits
+// (role of the reference's EpiloguePackQKV + attention_fp16: epilogues.cuh:427-550, attention.cu:11-94,
+//  nunchaku/ops/fused.py:82-178 with output=(q,k,v)).
+//
+// Layouts (no transposes anywhere in the model):
+//   Q, K : token-major rows of the QKV GEMM output, element (l, h, d) at base + l*ld + h*128 + d
+//   V^T  : channel-major, element (h, d, l) at base + (h*128 + d)*ldvt + l   (written by the RMSNORM_ROPE
+//          epilogue of svdq_gemm_w4a4 when out_vt is given) -- the PV MFMA needs 8 consecutive KEYS per lane
+//   O    : token-major [L, H*128], directly the input of the output projection's quantiser
+//
+// Kernel (DESIGN.md "Attention"): workgroup = 4 waves = 128 query rows of one head, wave = 32 query rows;
+// KV tiles of 64 keys, double-buffered in LDS with XOR-swizzled 16-byte pieces (conflict-free ds_read_b128);
+// the score MFMA is issued swapped (S^T = K Q^T) so a lane holds 32 of the 64 scores of ONE query row: the
+// online softmax is lane-local plus one lane^32 exchange; P is packed to 16-bit with v_cvt_pk + one
+// v_permlane32_swap per dword into exactly the B-operand fragments of the PV MFMA (O^T = V^T P^T), whose
+// accumulator again has the query along the lanes -- the running rescale is a per-lane scalar.
+#include "svdq_common.h"
+
+namespace svdq {
+
+constexpr int ATT_D = 128;     // head dimension (FLUX; the reference's attention kernel is also fixed to 128)
+constexpr int ATT_QB = 128;    // query rows per workgroup
+constexpr int ATT_KB = 64;     // keys per tile
+constexpr int ATT_TILE = ATT_KB * ATT_D * 2; // bytes of one K tile (= one V^T tile)
+#ifndef ATT_DEFER
+#define ATT_DEFER 0.0f
+#endif
+
+struct AttnParams {
+    const uint16_t *q, *k, *vt;
+    uint16_t *out;
+    long long q_hs, k_hs, vt_hs, o_hs;
+    int L, H, ldq, ldk, ldvt, ldo;
+    float scale_log2e; // softmax scale * log2(e)
+};
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
+    using T = typename Half<DT>::T;
+    using V8 = typename Half<DT>::V8;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * ATT_TILE]; // [buf][K | V^T]
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef __attribute__((address_space(3))) v4i lds_v4i;
+    lds_u8 *const L8 = (lds_u8 *)lds;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const int q0 = blockIdx.x * ATT_QB + wave * 32;
+    const uint16_t *kbase = p.k + (size_t)head * p.k_hs;
+    const uint16_t *vtbase = p.vt + (size_t)head * p.vt_hs;
+
+    // ---- Q fragments: B operand of S^T = K Q^T, lane (q = lr, d = 16*ds + 8h .. +7) -----------------------
+    V8 qf[8];
+    {
+        const uint16_t *qrow = p.q + (size_t)(q0 + lr) * p.ldq + (size_t)head * p.q_hs + 8 * h;
+#pragma unroll
+        for (int ds = 0; ds < 8; ds++) qf[ds] = *reinterpret_cast<const V8 *>(qrow + 16 * ds);
+    }
+
+    // ---- tile staging: 1024 16-byte pieces per tile, 4 per thread; swizzled so that the 16 lanes a
+    //      ds_read_b128 serves per cycle hit 16 different 16-byte columns ------------------------------------
+    v4i kreg[4], vreg[4];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + 256 * i;
+            const int kr = idx >> 4, kc = idx & 15;          // K: row (key), 16-byte column
+            kreg[i] = *reinterpret_cast<const v4i *>(kbase + (size_t)(kv0 + kr) * p.ldk + kc * 8);
+            const int vd = idx >> 3, vc = idx & 7;            // V^T: row (channel), 16-byte column (8 keys)
+            vreg[i] = *reinterpret_cast<const v4i *>(vtbase + (size_t)vd * p.ldvt + kv0 + vc * 8);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        lds_u8 *kb = L8 + buf * 2 * ATT_TILE, *vb = kb + ATT_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + 256 * i;
+            const int kr = idx >> 4, kc = idx & 15;
+            *(lds_v4i *)(kb + kr * 256 + ((kc ^ (kr & 15)) << 4)) = kreg[i];
+            const int vd = idx >> 3, vc = idx & 7;
+            *(lds_v4i *)(vb + vd * 128 + ((vc ^ ((vd >> 1) & 7)) << 4)) = vreg[i];
+        }
+    };
+
+    v16f o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f; // running max (in raw score units) and this lane's share of the row sum
+    const float c = p.scale_log2e;
+
+    const int ntiles = p.L / ATT_KB;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int j = 0; j < ntiles; j++) {
+        const int buf = j & 1;
+        const lds_u8 *kb = L8 + buf * 2 * ATT_TILE, *vb = kb + ATT_TILE;
+
+        // ---- S^T[k][q] = sum_d K[k][d] Q[q][d]: two 32-key tiles x 8 d-steps ------------------------------
+        v16f s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) s[kt][r] = 0.f;
+            const int kr = 32 * kt + lr;
+#pragma unroll
+            for (int ds = 0; ds < 8; ds++) {
+                const int pc = 2 * ds + h;
+                v4i kw = *(const lds_v4i *)(kb + kr * 256 + ((pc ^ (kr & 15)) << 4));
+                s[kt] = Half<DT>::mfma32(__builtin_bit_cast(V8, kw), qf[ds], s[kt]);
+            }
+        }
+
+        if (j + 1 < ntiles) load_tile((j + 1) * ATT_KB); // in flight under the softmax and the PV MFMAs
+
+        // ---- online softmax: lane holds 32 of the 64 scores of query row lr (the partner lane the others) --
+        float mloc = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; r += 2) { // v_max3_f32 chains
+            mloc = fmaxf(fmaxf(mloc, s[0][r]), r + 1 < 16 ? s[0][r + 1] : s[0][r]);
+            mloc = fmaxf(fmaxf(mloc, s[1][r]), r + 1 < 16 ? s[1][r + 1] : s[1][r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        // deferred rescale: keep the old running max while no row of this wave grew by more than 2^ATT_DEFER
+        // (P stays <= 2^ATT_DEFER, exact in the 16-bit formats' range); the common case skips 64 multiplies
+        if (__builtin_amdgcn_ballot_w64((mloc - m_run) * c > ATT_DEFER) != 0) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c); // 0 on the first tile (m_run = -inf)
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[dt][r] *= alpha;
+        }
+        const float mc = m_run * c;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, -mc));
+                psum += s[kt][r];
+            }
+        l_run += psum;
+
+        // ---- P -> 16-bit B-operand fragments of the PV MFMA: lane (q = lr, keys 16*ks + 8h .. +7) ------------
+        // regs 8*(ks&1) + {0..3} hold keys 4h + {0..3}, regs + {4..7} keys 8 + 4h + {0..3} of that 16-key step
+        V8 pf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int kt = ks >> 1, r0 = 8 * (ks & 1);
+            unsigned x[2], y[2];
+#pragma unroll
+            for (int d2 = 0; d2 < 2; d2++) {
+                x[d2] = (unsigned)hbits(f2h<T>(s[kt][r0 + 2 * d2])) | ((unsigned)hbits(f2h<T>(s[kt][r0 + 2 * d2 + 1])) << 16);
+                y[d2] = (unsigned)hbits(f2h<T>(s[kt][r0 + 4 + 2 * d2])) | ((unsigned)hbits(f2h<T>(s[kt][r0 + 4 + 2 * d2 + 1])) << 16);
+                auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
+                x[d2] = sw[0];
+                y[d2] = sw[1];
+            }
+            pf[ks] = __builtin_bit_cast(V8, v4i{(int)x[0], (int)x[1], (int)y[0], (int)y[1]});
+        }
+
+        // ---- O^T[d][q] += sum_k V^T[d][k] P^T[k][q]: 4 channel tiles x 4 key steps ----------------------------
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+            const int vd = 32 * dt + lr;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const int pc = 2 * ks + h;
+                v4i vw = *(const lds_v4i *)(vb + vd * 128 + ((pc ^ ((vd >> 1) & 7)) << 4));
+                o[dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw), pf[ks], o[dt]);
+            }
+        }
+
+        if (j + 1 < ntiles) store_tile(buf ^ 1); // the other buffer was last read in iteration j-1
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane owns query row q0 + lr and channels 32*dt + 8c + 4h + e ------------------
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    uint16_t *orow = p.out + (size_t)(q0 + lr) * p.ldo + (size_t)head * p.o_hs + 8 * h;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; j2++) {
+            unsigned x[2], y[2];
+#pragma unroll
+            for (int d2 = 0; d2 < 2; d2++) {
+                x[d2] = (unsigned)hbits(f2h<T>(o[dt][8 * j2 + 2 * d2] * inv)) | ((unsigned)hbits(f2h<T>(o[dt][8 * j2 + 2 * d2 + 1] * inv)) << 16);
+                y[d2] = (unsigned)hbits(f2h<T>(o[dt][8 * j2 + 4 + 2 * d2] * inv)) | ((unsigned)hbits(f2h<T>(o[dt][8 * j2 + 4 + 2 * d2 + 1] * inv)) << 16);
+                auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
+                x[d2] = sw[0];
+                y[d2] = sw[1];
+            }
+            *reinterpret_cast<v4i *>(orow + 32 * dt + 16 * j2) = v4i{(int)x[0], (int)x[1], (int)y[0], (int)y[1]};
+        }
+}
+
+} // namespace svdq
+
+using namespace svdq;
+
+extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
+    if (!a) { set_error("svdq_attention: args is NULL"); return SVDQ_E_INVALID; }
+    if (!a->q || !a->k || !a->vt || !a->out) { set_error("svdq_attention: q, k, vt and out are required"); return SVDQ_E_INVALID; }
+    if (a->head_dim != ATT_D) { set_error("svdq_attention: head_dim=%d (only 128 is implemented, as in the reference kernel)", a->head_dim); return SVDQ_E_UNSUPPORTED; }
+    if (a->L <= 0 || a->L % ATT_QB || a->H <= 0) { set_error("svdq_attention: L=%d must be a positive multiple of %d and H=%d positive", a->L, ATT_QB, a->H); return SVDQ_E_INVALID; }
+    if (a->ldq % 8 || a->ldk % 8 || a->ldvt % 8 || a->ldo % 8 || a->q_hs % 8 || a->k_hs % 8 || a->vt_hs % 8 || a->o_hs % 8 ||
+        a->ldvt < a->L || a->ldq < ATT_D || a->ldk < ATT_D || a->ldo < ATT_D) {
+        set_error("svdq_attention: strides must be multiples of 8 elements, ldq/ldk/ldo >= 128 and ldvt >= L");
+        return SVDQ_E_INVALID;
+    }
+    if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->vt | (uintptr_t)a->out) & 15) { set_error("svdq_attention: q, k, vt, out must be 16-byte aligned"); return SVDQ_E_INVALID; }
+    if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_attention: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
+    AttnParams p;
+    p.q = (const uint16_t *)a->q; p.k = (const uint16_t *)a->k; p.vt = (const uint16_t *)a->vt; p.out = (uint16_t *)a->out;
+    p.q_hs = a->q_hs; p.k_hs = a->k_hs; p.vt_hs = a->vt_hs; p.o_hs = a->o_hs;
+    p.L = a->L; p.H = a->H; p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;
+    p.scale_log2e = a->scale * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+    const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
+    dim3 grid(a->L / ATT_QB, a->H), block(256);
+    if (a->dtype == SVDQ_BF16) hipLaunchKernelGGL((attention_kernel<SVDQ_BF16>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attention_kernel<SVDQ_FP16>), grid, block, 0, st, p);
+    prof_end(prof, st);
+    return hip_check(hipGetLastError(), "svdq_attention launch");
+}

@@ -59,6 +59,8 @@ struct GemmParams {
     const void *norm_q;
     const void *norm_k;
     const float *rotary_emb;
+    void *out_vt;            // RMSNORM_ROPE: transposed V output or NULL
+    int ldvt;
     int M, M_pad, N, K, R, R2, ldo;
     uint8_t *workspace;      // stream-K: [256 int32 flags][2*G slabs of BM*BN fp32] or NULL
     long long workspace_bytes;
@@ -641,6 +643,34 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         // A lane holds 4 consecutive columns per (tile, c); the partner lane (lane ^ 32) holds the next 4.
         // One v_permlane32_swap per dword turns two 8-byte pieces per lane into one 16-byte piece, so a
         // wave store writes 32 contiguous bytes per row with dwordx4 stores (8 instead of 32 per wave).
+        bool vt_tile = false;
+        if constexpr (FUSE == SVDQ_FUSE_RMSNORM_ROPE) vt_tile = p.out_vt != nullptr && n0 >= 2 * (p.N / 3); // block-uniform
+        if (vt_tile) {
+            // V^T for svdq_attention: element (m, n) -> out_vt[(n - 2N/3) * ldvt + m].  A lane owns one row m, so
+            // a register is 32 consecutive m of one channel across the half-wave: neighbouring lanes trade halves
+            // (one DPP quad_perm) and every lane stores one dword = (m even, m odd) of one channel.
+            const int nv0 = nw0 - 2 * (p.N / 3);
+            const int odd = lr & 1;
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+                const int m_base = (mw0 + mi * 32 + lr) & ~1;
+                uint16_t *vcol = (uint16_t *)p.out_vt + m_base;
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        float v0 = acc[ni][mi][r], v1 = acc[ni][mi][r + 1];
+                        if constexpr (DT == SVDQ_FP16) { v0 = fminf(fmaxf(v0, -65504.f), 65504.f); v1 = fminf(fmaxf(v1, -65504.f), 65504.f); }
+                        const unsigned own = (unsigned)hbits(f2h<T>(v0)) | ((unsigned)hbits(f2h<T>(v1)) << 16);
+                        const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, true); // lane ^ 1
+                        const unsigned val = odd ? ((oth >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (oth << 16));
+                        const int n = nv0 + ni * 32 + (r >> 2) * 8 + h * 4 + (r & 3) + odd;
+                        uint16_t *dst = vcol + (size_t)n * p.ldvt;
+                        if (m_base + 1 < p.M) *reinterpret_cast<unsigned *>(dst) = val;
+                        else if (m_base < p.M) *dst = (uint16_t)val;
+                    }
+            }
+        } else
         if constexpr (FUSE != SVDQ_FUSE_GELU_QUANT) {
 #pragma unroll
         for (int mi = 0; mi < 2; mi++) {
@@ -813,6 +843,10 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     case SVDQ_FUSE_RMSNORM_ROPE:
         if (!a->out || !a->norm_q || !a->norm_k || !a->rotary_emb) { set_error("svdq_gemm_w4a4: RMSNORM_ROPE needs out, norm_q, norm_k and rotary_emb"); return SVDQ_E_INVALID; }
         if (a->N % 384) { set_error("svdq_gemm_w4a4: RMSNORM_ROPE needs N=%d to be a multiple of 3*128", a->N); return SVDQ_E_INVALID; }
+        if (a->out_vt && (a->ldvt < a->M || a->ldvt % 2 || ((uintptr_t)a->out_vt & 3))) {
+            set_error("svdq_gemm_w4a4: out_vt needs an even ldvt=%d >= M=%d and a 4-byte aligned pointer", a->ldvt, a->M);
+            return SVDQ_E_INVALID;
+        }
         break;
     default:
         set_error("svdq_gemm_w4a4: unknown fuse mode %d", a->fuse);
@@ -851,6 +885,8 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.norm_q = a->norm_q;
     p.norm_k = a->norm_k;
     p.rotary_emb = a->rotary_emb;
+    p.out_vt = a->fuse == SVDQ_FUSE_RMSNORM_ROPE ? a->out_vt : nullptr;
+    p.ldvt = a->ldvt;
     p.debug = a->reserved;
     p.workspace = (uint8_t *)a->workspace;
     p.workspace_bytes = a->workspace_bytes;

@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..ops.attention import attention_packed
 from ..ops.fused import fused_gelu_mlp, fused_qkv_norm_rottary
 from ..utils import pad_tensor
 from .embeddings import flux_pos_embed, pack_rotemb
@@ -63,26 +64,42 @@ class FluxAttentionAMD(nn.Module):
             self.norm_added_k = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=kw["torch_dtype"], device=kw["device"])
             self.to_add_out = SVDQW4A4Linear(dim, dim, **kw)
 
+    # "svdq": this library's attention kernel on the packed QKV (+ V^T side output of the QKV GEMM);
+    # "sdpa": torch's scaled_dot_product_attention (the reference's "flashattn2" processor role,
+    # models/attention_processors/flux.py:24-59).  "svdq" needs B == 1, head_dim 128, tokens % 128 == 0.
+    attention_impl = "svdq"
+
+    def _use_svdq(self, B, tokens):
+        return self.attention_impl == "svdq" and B == 1 and self.head_dim == 128 and tokens % 128 == 0
+
     def forward(self, hidden, encoder_hidden=None, rotary=None):
         B = hidden.shape[0]
+        hd = self.heads * self.head_dim
+        t_txt = encoder_hidden.shape[1] if self.joint else 0
+        tokens = t_txt + hidden.shape[1]
+        svdq = self._use_svdq(B, tokens)
+        qkv = torch.empty(B, tokens, 3 * hd, dtype=hidden.dtype, device=hidden.device)
+        vt = torch.empty(hd, tokens, dtype=hidden.dtype, device=hidden.device) if svdq else None
         if self.joint:
             # both projections write straight into one [txt; img] buffer (B == 1): no torch.cat round trip
             rot_img, rot_txt = rotary
-            t_txt, t_img = encoder_hidden.shape[1], hidden.shape[1]
-            qkv = torch.empty(B, t_txt + t_img, 3 * self.heads * self.head_dim, dtype=hidden.dtype, device=hidden.device)
-            fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rot_img, output=qkv[0, t_txt:])
+            fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rot_img, output=qkv[0, t_txt:],
+                                   out_vt=vt[:, t_txt:] if svdq else None)
             fused_qkv_norm_rottary(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, rot_txt,
-                                   output=qkv[0, :t_txt])
+                                   output=qkv[0, :t_txt], out_vt=vt[:, :t_txt] if svdq else None)
         else:
-            qkv = fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary)
-        q, k, v = qkv.chunk(3, dim=-1)
-        shp = (B, -1, self.heads, self.head_dim)
-        o = F.scaled_dot_product_attention(q.view(shp).transpose(1, 2), k.view(shp).transpose(1, 2),
-                                           v.view(shp).transpose(1, 2), dropout_p=0.0, is_causal=False)
-        o = o.transpose(1, 2).reshape(B, -1, self.heads * self.head_dim)
+            fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary, output=qkv.view(B * tokens, -1),
+                                   out_vt=vt)
+        if svdq:
+            o = attention_packed(qkv[0], vt, self.heads).unsqueeze(0)
+        else:
+            q, k, v = qkv.chunk(3, dim=-1)
+            shp = (B, -1, self.heads, self.head_dim)
+            o = F.scaled_dot_product_attention(q.view(shp).transpose(1, 2), k.view(shp).transpose(1, 2),
+                                               v.view(shp).transpose(1, 2), dropout_p=0.0, is_causal=False)
+            o = o.transpose(1, 2).reshape(B, -1, hd)
         if self.joint:
-            t = encoder_hidden.shape[1]
-            return self.to_out(o[:, t:]), self.to_add_out(o[:, :t])
+            return self.to_out(o[:, t_txt:]), self.to_add_out(o[:, :t_txt])
         return self.to_out(o)
 
 

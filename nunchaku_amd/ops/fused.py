@@ -34,15 +34,17 @@ def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256) -> torch.Tens
 
 
 def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rotary_emb: torch.Tensor | None = None,
-                           output=None, attn_tokens: int = 0):
+                           output=None, attn_tokens: int = 0, out_vt: torch.Tensor | None = None):
     """QKV projection with RMSNorm(q), RMSNorm(k) and rotary embedding applied in the GEMM epilogue.
-    ``rotary_emb`` is the ``pack_rotemb`` tensor of the reference ([1, M_pad, 128] float32)."""
+    ``rotary_emb`` is the ``pack_rotemb`` tensor of the reference ([1, M_pad, 128] float32).
+    ``out_vt`` ([out_features/3, tokens] view): V is written transposed there for ``ops.attention`` instead of
+    into ``output`` (this library's form of the reference's ``output=(q, k, v)`` packed mode)."""
     B, S, C_in = x.shape
     M = B * S
     x2 = x.reshape(M, C_in)
     qx, ascales, lora_act = proj.quantize(x2)
     if isinstance(output, tuple):
-        raise NotImplementedError("packed Q/K/V outputs (nunchaku-fp16 attention) are not implemented yet")
+        raise NotImplementedError("the reference's packed (q, k, v) tuple is NVIDIA-fragment ordered; pass out_vt= instead")
     if output is None:
         output = torch.empty(M, proj.out_features, dtype=x.dtype, device=x.device)
     proj._ensure_layout()
@@ -53,6 +55,6 @@ def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rota
         act=qx, wgt=proj.qweight, out=output, ascales=ascales, wscales=proj.wscales, lora_act_in=lora_act,
         lora_up=proj.proj_up, bias=proj.bias, fp4=False, alpha=proj.wtscale, wcscales=proj.wcscales,
         norm_q=None if norm_q is None else norm_q.weight, norm_k=None if norm_k is None else norm_k.weight,
-        rotary_emb=rot,
+        rotary_emb=rot, out_vt=out_vt,
     )
     return output.view(B, S, -1)

@@ -39,6 +39,7 @@ def svdq_gemm_w4a4_cuda(
     out_k: torch.Tensor | None = None,
     out_v: torch.Tensor | None = None,
     attn_tokens: int = 0,
+    out_vt: torch.Tensor | None = None,
 ) -> None:
     """Fused W4A4 GEMM + low-rank correction; results are written in place into ``out`` or, for the
     GELU+requantise fusion, into ``qout`` / ``oscales`` / ``lora_act_out``."""
@@ -50,5 +51,5 @@ def svdq_gemm_w4a4_cuda(
     ops.gemm_w4a4(
         act, wgt, out, qout, ascales, wscales, oscales, poolout, lora_act_in, lora_up, lora_down, lora_act_out,
         norm_q, norm_k, rotary_emb, bias, smooth_factor, out_vk, out_linearattn, act_unsigned, lora_scales,
-        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens,
+        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens, out_vt,
     )

@@ -35,7 +35,21 @@ def test_abi_version(built_lib):
 def test_struct_sizes_match_header(built_lib):
     # 6 pointers + 8 int32 ; 17 pointers + 12 int32
     assert C.sizeof(_lib.QuantizeArgs) == 6 * 8 + 8 * 4
-    assert C.sizeof(_lib.GemmArgs) == 17 * 8 + 12 * 4 + 2 * 8  # + workspace, workspace_bytes
+    assert C.sizeof(_lib.GemmArgs) == 17 * 8 + 12 * 4 + 2 * 8 + 8 + 2 * 4  # + workspace, workspace_bytes, out_vt, ldvt, reserved2
+    assert C.sizeof(_lib.AttentionArgs) == 4 * 8 + 4 * 8 + 8 * 4 + 4 + 4
+
+
+def test_attention_validation(built_lib):
+    lib = _lib.load()
+    assert lib.svdq_attention(None, None) == 1
+    a = _lib.AttentionArgs()
+    a.q = a.k = a.vt = a.out = 4096
+    a.L, a.H, a.head_dim, a.ldq, a.ldk, a.ldo, a.ldvt = 256, 2, 64, 768, 768, 256, 256
+    assert lib.svdq_attention(C.byref(a), None) == 2 and b"head_dim" in lib.svdq_last_error()
+    a.head_dim, a.L = 128, 200
+    assert lib.svdq_attention(C.byref(a), None) == 1 and b"multiple of 128" in lib.svdq_last_error()
+    a.L, a.ldvt = 256, 128
+    assert lib.svdq_attention(C.byref(a), None) == 1 and b"ldvt" in lib.svdq_last_error()
 
 
 def test_validation_errors_are_returned_not_aborted(built_lib):

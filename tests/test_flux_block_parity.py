@@ -113,7 +113,7 @@ def test_small_flux_transformer_matches_oracle_forward():
             elif isinstance(mod, torch.nn.RMSNorm):
                 mod.weight.copy_(1 + 0.1 * torch.randn_like(mod.weight, dtype=torch.float32))
     model.eval()
-    side, t_txt = 16, 64  # 256 image tokens + 64 text tokens
+    side, t_txt = 16, 128  # 256 image tokens + 128 text tokens (a multiple of 128 in total: the svdq attention path)
     g = torch.Generator().manual_seed(1)
     lat = r16(torch.randn(side * side, 64, generator=g))
     enc = r16(torch.randn(t_txt, 128, generator=g))

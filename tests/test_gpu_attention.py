@@ -1,0 +1,138 @@
+"""GPU tests of the attention path: the QKV GEMM's transposed-V side output
+and svdq_attention against a float32 torch restatement of softmax(QK^T/sqrt(d)) V on the same 16-bit inputs.
+
+Floating-point tolerance (written here as the task demands): the kernel rounds the probabilities to the 16-bit
+dtype before the PV MFMA (as flash attention implementations do, including the reference's attention_fp16),
+so |err| <= 3 * 2^-8 (bf16) / 3 * 2^-11 (fp16) relative to max|out| is the bar, and it must not be worse than
+1.5x the error of torch's own 16-bit SDPA on the same inputs."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svdq_oracle as O
+from tests.helpers import TORCH_DT, f32, make_module, t16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu(built_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def _ref_attention(q, k, v):
+    """q, k, v: [L, H, D] 16-bit -> float32 [L, H, D]"""
+    qf, kf, vf = (t.float().permute(1, 0, 2) for t in (q, k, v))
+    s = qf @ kf.transpose(1, 2) / math.sqrt(q.shape[-1])
+    return (torch.softmax(s, dim=-1) @ vf).permute(1, 0, 2)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("L,H", [(128, 1), (384, 3), (1152, 2)])
+def test_attention_matches_fp32_reference(dtype, L, H):
+    from nunchaku_amd.ops.attention import attention_packed
+
+    td = TORCH_DT[dtype]
+    g = torch.Generator(device="cuda").manual_seed(L + H)
+    qkv = torch.randn(L, 3 * H * 128, device="cuda", generator=g).to(td)
+    # peaky rows too: scale some queries so the softmax is far from uniform
+    qkv[: L // 2, : H * 128] *= 4.0
+    q, k, v = (qkv[:, i * H * 128:(i + 1) * H * 128].unflatten(1, (H, 128)) for i in range(3))
+    vt = v.permute(1, 2, 0).contiguous().view(H * 128, L)
+    out = attention_packed(qkv, vt, H)
+    ref = _ref_attention(q, k, v).reshape(L, H * 128)
+    err = (out.float() - ref).abs().max().item()
+    sd = torch.nn.functional.scaled_dot_product_attention(q.permute(1, 0, 2)[None], k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None])
+    err_sdpa = (sd[0].permute(1, 0, 2).reshape(L, H * 128).float() - ref).abs().max().item()
+    tol = 3 * (2.0 ** -8 if dtype == "bf16" else 2.0 ** -11) * ref.abs().max().item()
+    assert err <= tol, f"attention error {err:.3g} > {tol:.3g}"
+    assert err <= 1.5 * err_sdpa + 1e-6, f"attention error {err:.3g} vs torch 16-bit SDPA {err_sdpa:.3g}"
+
+
+def test_attention_strided_heads_and_errors():
+    from nunchaku_amd._C import ops
+
+    L, H = 256, 2
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn(H, L, 128, device="cuda", generator=g).bfloat16()  # head-major storage (the reference's [B, H, L, D])
+    k = torch.randn(H, L, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(H, L, 128, device="cuda", generator=g).bfloat16()
+    out = torch.empty(L, H, 128, device="cuda", dtype=torch.bfloat16)
+    ops.attention(q.permute(1, 0, 2), k.permute(1, 0, 2), v.transpose(1, 2).contiguous(), out, 1 / math.sqrt(128))
+    ref = _ref_attention(q.permute(1, 0, 2), k.permute(1, 0, 2), v.permute(1, 0, 2))
+    assert (out.float() - ref).abs().max().item() <= 3 * 2.0 ** -8 * ref.abs().max().item()
+    with pytest.raises(ValueError):
+        ops.attention(q.permute(1, 0, 2)[:200], k.permute(1, 0, 2)[:200], v.transpose(1, 2)[:, :, :200].contiguous(), out[:200], 0.1)
+    with pytest.raises(ValueError):
+        ops.attention(q.permute(1, 0, 2), k.permute(1, 0, 2), v, out, 0.1)  # V not transposed
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [256, 300, 301])
+def test_qkv_gemm_transposed_v_output(dtype, M):
+    """out_vt receives exactly the V columns the plain epilogue would have stored, transposed; the V third of
+    `out`, the padding columns of out_vt and the neighbouring token range are not touched."""
+    from nunchaku_amd.ops.fused import fused_qkv_norm_rottary
+    from tests.test_gpu_parity import _gemm_inputs
+
+    K, H = 256, 2
+    N = 3 * H * 128
+    Lyr, x = _gemm_inputs(M, K, N, 32, dtype, seed=21)
+    rng = np.random.default_rng(22)
+    M_pad = O.ceil_div(M, 256) * 256
+    ang = rng.uniform(0, 6.28, (M_pad, 64)).astype(np.float32)
+    rot = np.stack([np.sin(ang), np.cos(ang)], axis=-1).astype(np.float32)
+    packed = torch.from_numpy(O.pack_rotemb_ref(rot)).cuda().view(1, M_pad, 128)
+    mod = make_module(Lyr, dtype)
+
+    class W:
+        def __init__(self):
+            self.weight = torch.ones(128, device="cuda", dtype=TORCH_DT[dtype])
+
+    xin = t16(x, dtype).view(1, M, K)
+    torch.manual_seed(0)
+    full = fused_qkv_norm_rottary(xin, mod, W(), W(), packed)[0]
+    sentinel = 7.0
+    out = torch.full((M, N), sentinel, device="cuda", dtype=TORCH_DT[dtype])
+    off = 6  # even token offset inside a wider joint buffer
+    vt = torch.full((H * 128, off + M + 10 + (M & 1)), sentinel, device="cuda", dtype=TORCH_DT[dtype])
+    fused_qkv_norm_rottary(xin, mod, W(), W(), packed, output=out, out_vt=vt[:, off:off + M])
+    # lora_act comes from fp32 atomics only when K is sliced; K = 256 is one slice -> both runs are identical
+    assert torch.equal(out[:, : 2 * N // 3], full[:, : 2 * N // 3])
+    assert torch.equal(vt[:, off:off + M], full[:, 2 * N // 3:].t())
+    assert (out[:, 2 * N // 3:] == sentinel).all()
+    assert (vt[:, :off] == sentinel).all() and (vt[:, off + M:] == sentinel).all()
+
+
+def test_flux_transformer_svdq_attention_vs_sdpa():
+    """The small FLUX-shaped transformer with this library's attention vs torch SDPA on the same weights."""
+    from nunchaku_amd.models.flux import FluxAttentionAMD, FluxTransformerAMD
+
+    torch.manual_seed(3)
+    model = FluxTransformerAMD(num_layers=1, num_single_layers=2, dim=256, heads=2, in_channels=64, joint_attention_dim=128,
+                               pooled_projection_dim=64, device="cuda")
+    model.init_synthetic_(seed=1)
+    model.eval()
+    side, t_txt = 16, 128
+    lat = torch.randn(1, side * side, 64, device="cuda").bfloat16()
+    enc = torch.randn(1, t_txt, 128, device="cuda").bfloat16()
+    pooled = torch.randn(1, 64, device="cuda").bfloat16()
+    img_ids = torch.zeros(side * side, 3, device="cuda")
+    img_ids[:, 1] = torch.arange(side, device="cuda").repeat_interleave(side)
+    img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
+    txt_ids = torch.zeros(t_txt, 3, device="cuda")
+    t, gd = torch.tensor([0.7], device="cuda"), torch.tensor([3.5], device="cuda")
+    outs = {}
+    try:
+        for impl in ("svdq", "sdpa"):
+            FluxAttentionAMD.attention_impl = impl
+            with torch.no_grad():
+                outs[impl] = model(lat, enc, pooled, t, img_ids, txt_ids, gd)[0].float()
+    finally:
+        FluxAttentionAMD.attention_impl = "svdq"
+    rel = ((outs["svdq"] - outs["sdpa"]).norm() / outs["sdpa"].norm()).item()
+    assert torch.isfinite(outs["svdq"]).all() and rel < 5e-2, f"svdq vs sdpa attention: relative L2 {rel:.3g}"
