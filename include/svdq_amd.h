@@ -183,6 +183,29 @@ typedef struct svdq_attention_args {
 int svdq_attention(const svdq_attention_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * AWQ W4A16 GEMV (reference: ops.gemv_awq, nunchaku/csrc/ops.h:123-145 -> src/kernels/awq/gemv_awq.cu:100-286;
+ * module nunchaku/models/linear.py:277-414).  The AdaLayerNormZero modulation projections of every block.
+ *   out[m, n] = round16( sum_k round16( round16(q[n,k]*scales[k/64,n] + zeros[k/64,n]) * x[m,k] ) ) (+ bias[n])
+ * qweight is the CHECKPOINT tensor as stored ([N/4, K/2] int32, tinychat pack_w4 order,
+ * text_encoders/tinychat_utils.py:76-107) -- no load-time repack.  scales / zeros are [K/64, N] 16-bit,
+ * zeros already scaled and negated (w = q*scale + zeros).  1 <= M <= 8 as in the reference.
+ * bias (optional, [N] 16-bit) fuses AWQW4A16Linear.forward's output.add_(bias) (one more 16-bit rounding).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct svdq_gemv_awq_args {
+    const void *x;        /* [M, K] 16-bit, row stride ldx */
+    const void *qweight;  /* [N/4, K/2] int32 */
+    const void *scales;   /* [K/64, N] 16-bit */
+    const void *zeros;    /* [K/64, N] 16-bit */
+    const void *bias;     /* [N] 16-bit or NULL */
+    void *out;            /* [M, N] 16-bit, contiguous */
+    int32_t M, N, K, ldx;
+    int32_t group_size;   /* must be 64 */
+    int32_t dtype;        /* SVDQ_BF16 | SVDQ_FP16 */
+} svdq_gemv_awq_args;
+
+int svdq_gemv_awq(const svdq_gemv_awq_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Load-time re-layout of reference checkpoint tensors (NVIDIA fragment order -> CDNA4 order).
  * src and dst must not alias.  All but svdq_repack_qweight are pure permutations of equal size.
  * ------------------------------------------------------------------------------------------ */
@@ -205,7 +228,7 @@ int svdq_unpack_scales(const void *simg, void *natural, int32_t ROWS, int32_t G,
  * Launch profiler (used by bench.py for the roofline line).  While enabled, every
  * svdq_gemm_w4a4 / svdq_quantize call brackets its kernel launch with two hipEvents recorded on
  * the launch stream.  svdq_prof_read synchronises the recorded events and returns, per kernel
- * class (0 = gemm_w4a4, 1 = quantize, 2 = attention: 4*L*L*H*128 flops), the number of launches, the summed kernel time in
+ * class (0 = gemm_w4a4, 1 = quantize, 2 = attention: 4*L*L*H*128 flops, 3 = gemv_awq: bytes read), the number of launches, the summed kernel time in
  * milliseconds and the summed ALGORITHMIC work (gemm: 2*M_pad*N*K + 2*M_pad*N*R operations;
  * quantize: bytes read + written).  Process-global state, guarded by a mutex; off by default.
  * ------------------------------------------------------------------------------------------ */

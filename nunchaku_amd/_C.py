@@ -181,6 +181,36 @@ class _Ops:
         del keep
 
     @staticmethod
+    def gemv_awq(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size, bias=None):
+        """reference: csrc/ops.h:123-145 -> gemv_awq (src/kernels/awq/gemv_awq.cu:253-286): allocates and returns
+        the output, shape ``in_feats.shape[:-1] + (n,)``.  ``kernel`` is the checkpoint's ``qweight`` as stored
+        ([n/4, k/2] int32); ``zeros`` are the scaled zeros.  ``bias`` (extension) fuses the module's 16-bit
+        ``output.add_(bias)``."""
+        lib = _lib.load()
+        if in_feats.dtype not in _DT or scaling_factors.dtype != in_feats.dtype or zeros.dtype != in_feats.dtype:
+            raise ValueError("gemv_awq: in_feats, scaling_factors and zeros must share one 16-bit dtype")
+        if in_feats.shape[-1] != k or in_feats.numel() != m * k:
+            raise ValueError("gemv_awq: in_feats must hold m rows of k features")
+        if kernel.numel() * kernel.element_size() * 2 != n * k:
+            raise ValueError("gemv_awq: kernel must hold n*k 4-bit codes")
+        G = (k + group_size - 1) // group_size
+        if scaling_factors.dim() != 2 or scaling_factors.shape[1] != n or scaling_factors.shape[0] < G or zeros.shape != scaling_factors.shape:
+            raise ValueError("gemv_awq: scaling_factors / zeros must be [>= k/group_size, n]")
+        x2 = in_feats.reshape(m, k)
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        out = torch.empty(*in_feats.shape[:-1], n, dtype=in_feats.dtype, device=in_feats.device)
+        a = _lib.GemvAwqArgs()
+        a.x, a.qweight, a.scales, a.zeros = x2.data_ptr(), _ptr(kernel), _ptr(scaling_factors), _ptr(zeros)
+        a.bias, a.out = _ptr(bias), out.data_ptr()
+        if not x2.is_cuda:
+            raise RuntimeError("nunchaku_amd ops need GPU tensors (there is no CPU path)")
+        a.M, a.N, a.K, a.ldx = m, n, k, x2.stride(0) if m > 1 else k
+        a.group_size, a.dtype = group_size, _DT[in_feats.dtype]
+        _lib.check(lib.svdq_gemv_awq(C.byref(a), _stream()), "gemv_awq")
+        return out
+
+    @staticmethod
     def attention(q, k, vt, out, scale):
         """Non-causal attention, head_dim 128 (role of the reference's ``ops.attention_fp16``, csrc/ops.h:114-121
         -> attention.cu:11-94).  Strided views, no copies: ``q``/``k``/``out`` are ``[L, H, 128]`` (any token and head
@@ -205,6 +235,7 @@ class _Ops:
         a.vt_hs, a.ldvt = vt.stride(0), vt.stride(1)
         a.L, a.H, a.head_dim, a.dtype = L, H, D, _DT[q.dtype]
         a.scale = float(scale)
+        a.reserved = int(os.environ.get("SVDQ_ATT_DEBUG", "0"))  # timing experiments only
         _lib.check(lib.svdq_attention(C.byref(a), _stream()), "attention")
 
 

@@ -50,10 +50,20 @@ class AttentionArgs(C.Structure):
     ]
 
 
+class GemvAwqArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("qweight", C.c_void_p), ("scales", C.c_void_p), ("zeros", C.c_void_p),
+        ("bias", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32),
+        ("group_size", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
 EXPORTS = {
     "svdq_quantize_w4a4_act_fuse_lora": (C.c_int, [C.POINTER(QuantizeArgs), C.c_void_p]),
     "svdq_gemm_w4a4": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "svdq_attention": (C.c_int, [C.POINTER(AttentionArgs), C.c_void_p]),
+    "svdq_gemv_awq": (C.c_int, [C.POINTER(GemvAwqArgs), C.c_void_p]),
     "svdq_gemm_workspace_bytes": (C.c_int64, []),
     "svdq_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_repack_qweight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -15,16 +15,13 @@
 // v_permlane32_swap per dword into exactly the B-operand fragments of the PV MFMA (O^T = V^T P^T), whose
 // accumulator again has the query along the lanes -- the running rescale is a per-lane scalar.
 #include "svdq_common.h"
+#include <type_traits>
 
 namespace svdq {
 
 constexpr int ATT_D = 128;     // head dimension (FLUX; the reference's attention kernel is also fixed to 128)
-constexpr int ATT_QB = 128;    // query rows per workgroup
 constexpr int ATT_KB = 64;     // keys per tile
 constexpr int ATT_TILE = ATT_KB * ATT_D * 2; // bytes of one K tile (= one V^T tile)
-#ifndef ATT_DEFER
-#define ATT_DEFER 0.0f
-#endif
 
 struct AttnParams {
     const uint16_t *q, *k, *vt;
@@ -32,12 +29,24 @@ struct AttnParams {
     long long q_hs, k_hs, vt_hs, o_hs;
     int L, H, ldq, ldk, ldvt, ldo;
     float scale_log2e; // softmax scale * log2(e)
+    int debug;         // timing experiments (tools/bench_attention.py): results are WRONG when non-zero
 };
 
-template <int DT>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
-    using T = typename Half<DT>::T;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two RNE-rounded 16-bit values (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+template <int DT> __device__ __forceinline__ unsigned pack2(float a, float b) {
+    if constexpr (DT == SVDQ_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a, b}, bf16x2));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a, b}, f16x2));
+}
+
+// NW waves = NW * 32 query rows of one head per workgroup.  DBG: ablation bits (bench only).
+template <int DT, int NW, int DBG>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnParams p) {
     using V8 = typename Half<DT>::V8;
+    constexpr int NT = NW * 64;          // threads
+    constexpr int PIECES = 1024 / NT;    // 16-byte pieces of each of K and V^T a thread stages per tile
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * ATT_TILE]; // [buf][K | V^T]
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     typedef __attribute__((address_space(3))) v4i lds_v4i;
@@ -46,9 +55,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
     const int head = blockIdx.y;
-    const int q0 = blockIdx.x * ATT_QB + wave * 32;
-    const uint16_t *kbase = p.k + (size_t)head * p.k_hs;
-    const uint16_t *vtbase = p.vt + (size_t)head * p.vt_hs;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    const uint8_t *kbase = (const uint8_t *)(p.k + (size_t)head * p.k_hs);
+    const uint8_t *vtbase = (const uint8_t *)(p.vt + (size_t)head * p.vt_hs);
 
     // ---- Q fragments: B operand of S^T = K Q^T, lane (q = lr, d = 16*ds + 8h .. +7) -----------------------
     V8 qf[8];
@@ -58,28 +67,42 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         for (int ds = 0; ds < 8; ds++) qf[ds] = *reinterpret_cast<const V8 *>(qrow + 16 * ds);
     }
 
-    // ---- tile staging: 1024 16-byte pieces per tile, 4 per thread; swizzled so that the 16 lanes a
-    //      ds_read_b128 serves per cycle hit 16 different 16-byte columns ------------------------------------
-    v4i kreg[4], vreg[4];
-    auto load_tile = [&](int kv0) {
+    // ---- tile staging: 1024 16-byte pieces per matrix per tile, PIECES per thread; XOR-swizzled so that the
+    //      16 lanes a ds_read_b128 serves per LDS cycle hit 16 different 16-byte columns.  All per-thread
+    //      offsets are loop invariants (32-bit, relative to a wave-uniform tile base / the LDS buffer) ----------
+    unsigned koff[PIECES], voff[PIECES], kst[PIECES], vst[PIECES];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = tid + 256 * i;
-            const int kr = idx >> 4, kc = idx & 15;          // K: row (key), 16-byte column
-            kreg[i] = *reinterpret_cast<const v4i *>(kbase + (size_t)(kv0 + kr) * p.ldk + kc * 8);
-            const int vd = idx >> 3, vc = idx & 7;            // V^T: row (channel), 16-byte column (8 keys)
-            vreg[i] = *reinterpret_cast<const v4i *>(vtbase + (size_t)vd * p.ldvt + kv0 + vc * 8);
+    for (int i = 0; i < PIECES; i++) {
+        const int idx = tid + NT * i;
+        const int kr = idx >> 4, kc = idx & 15; // K: row (key), 16-byte column
+        koff[i] = (unsigned)kr * (unsigned)p.ldk * 2u + kc * 16;
+        kst[i] = kr * 256 + ((kc ^ (kr & 15)) << 4);
+        const int vd = idx >> 3, vc = idx & 7;  // V^T: row (channel), 16-byte column (8 keys)
+        voff[i] = (unsigned)vd * (unsigned)p.ldvt * 2u + vc * 16;
+        vst[i] = ATT_TILE + vd * 128 + ((vc ^ ((vd >> 1) & 7)) << 4);
+    }
+    // fragment read offsets: K rows 32*kt + lr (+8192 per kt), V^T rows 32*dt + lr (+4096 per dt)
+    unsigned ka[8], va[4];
+#pragma unroll
+    for (int ds = 0; ds < 8; ds++) ka[ds] = lr * 256 + (((2 * ds + h) ^ (lr & 15)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) va[ks] = ATT_TILE + lr * 128 + (((2 * ks + h) ^ ((lr >> 1) & 7)) << 4);
+
+    v4i kreg[PIECES], vreg[PIECES];
+    auto load_tile = [&](int kv0) {
+        const uint8_t *kt = kbase + (size_t)kv0 * p.ldk * 2; // wave-uniform
+        const uint8_t *vt = vtbase + (size_t)kv0 * 2;
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) {
+            kreg[i] = *reinterpret_cast<const v4i *>(kt + koff[i]);
+            vreg[i] = *reinterpret_cast<const v4i *>(vt + voff[i]);
         }
     };
-    auto store_tile = [&](int buf) {
-        lds_u8 *kb = L8 + buf * 2 * ATT_TILE, *vb = kb + ATT_TILE;
+    auto store_tile = [&](int bufoff) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = tid + 256 * i;
-            const int kr = idx >> 4, kc = idx & 15;
-            *(lds_v4i *)(kb + kr * 256 + ((kc ^ (kr & 15)) << 4)) = kreg[i];
-            const int vd = idx >> 3, vc = idx & 7;
-            *(lds_v4i *)(vb + vd * 128 + ((vc ^ ((vd >> 1) & 7)) << 4)) = vreg[i];
+        for (int i = 0; i < PIECES; i++) {
+            *(lds_v4i *)(L8 + (kst[i] + bufoff)) = kreg[i];
+            *(lds_v4i *)(L8 + (vst[i] + bufoff)) = vreg[i];
         }
     };
 
@@ -88,17 +111,18 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
     for (int dt = 0; dt < 4; dt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) o[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f; // running max (in raw score units) and this lane's share of the row sum
+    float m_run = -INFINITY; // running row max, raw score units (shared by the two lanes of a query row)
+    v2f l2 = {0.f, 0.f};     // this lane's share of the row sum, as two partial sums (v_pk_add_f32)
     const float c = p.scale_log2e;
 
-    const int ntiles = p.L / ATT_KB;
+    const int ntiles = p.L / ATT_KB; // even: L is a multiple of 128
     load_tile(0);
     store_tile(0);
     __syncthreads();
 
-    for (int j = 0; j < ntiles; j++) {
-        const int buf = j & 1;
-        const lds_u8 *kb = L8 + buf * 2 * ATT_TILE, *vb = kb + ATT_TILE;
+    auto step = [&](auto bufc, int j) {
+        constexpr int BUF = (DBG & 2) ? 0 : decltype(bufc)::value;
+        constexpr int BO = BUF * 2 * ATT_TILE;
 
         // ---- S^T[k][q] = sum_d K[k][d] Q[q][d]: two 32-key tiles x 8 d-steps ------------------------------
         v16f s[2];
@@ -106,16 +130,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         for (int kt = 0; kt < 2; kt++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) s[kt][r] = 0.f;
-            const int kr = 32 * kt + lr;
 #pragma unroll
             for (int ds = 0; ds < 8; ds++) {
-                const int pc = 2 * ds + h;
-                v4i kw = *(const lds_v4i *)(kb + kr * 256 + ((pc ^ (kr & 15)) << 4));
-                s[kt] = Half<DT>::mfma32(__builtin_bit_cast(V8, kw), qf[ds], s[kt]);
+                v4i kw = *(const lds_v4i *)(L8 + (ka[ds] + (BO + kt * 8192)));
+                if constexpr (!(DBG & 16)) s[kt] = Half<DT>::mfma32(__builtin_bit_cast(V8, kw), qf[ds], s[kt]);
+                else s[kt][ds] += (float)kw[0];
             }
         }
 
-        if (j + 1 < ntiles) load_tile((j + 1) * ATT_KB); // in flight under the softmax and the PV MFMAs
+        if (j + 1 < ntiles && !(DBG & 2)) load_tile((j + 1) * ATT_KB); // in flight under the softmax and the PV MFMAs
 
         // ---- online softmax: lane holds 32 of the 64 scores of query row lr (the partner lane the others) --
         float mloc = fmaxf(s[0][0], s[1][0]);
@@ -125,28 +148,28 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
             mloc = fmaxf(fmaxf(mloc, s[1][r]), r + 1 < 16 ? s[1][r + 1] : s[1][r]);
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        // deferred rescale: keep the old running max while no row of this wave grew by more than 2^ATT_DEFER
-        // (P stays <= 2^ATT_DEFER, exact in the 16-bit formats' range); the common case skips 64 multiplies
-        if (__builtin_amdgcn_ballot_w64((mloc - m_run) * c > ATT_DEFER) != 0) {
+        // rescale only when some row of this wave has a new maximum (exactly equivalent to rescaling always:
+        // alpha = 1 otherwise); later tiles mostly skip the 64 multiplies
+        if (__builtin_amdgcn_ballot_w64(mloc > m_run) != 0) {
             const float m_new = fmaxf(m_run, mloc);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c); // 0 on the first tile (m_run = -inf)
             m_run = m_new;
-            l_run *= alpha;
+            l2 = l2 * alpha;
 #pragma unroll
-            for (int dt = 0; dt < 4; dt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[dt][r] *= alpha;
+            for (int dt = 0; dt < 4; dt++) o[dt] = o[dt] * alpha;
         }
         const float mc = m_run * c;
-        float psum = 0.f;
+        const v2f c2 = {c, c}, mc2 = {-mc, -mc};
 #pragma unroll
         for (int kt = 0; kt < 2; kt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, -mc));
-                psum += s[kt][r];
+            for (int r = 0; r < 16; r += 2) {
+                v2f t = __builtin_elementwise_fma((v2f){s[kt][r], s[kt][r + 1]}, c2, mc2);
+                if constexpr (!(DBG & 1)) { t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]); }
+                l2 += t;
+                s[kt][r] = t[0];
+                s[kt][r + 1] = t[1];
             }
-        l_run += psum;
 
         // ---- P -> 16-bit B-operand fragments of the PV MFMA: lane (q = lr, keys 16*ks + 8h .. +7) ------------
         // regs 8*(ks&1) + {0..3} hold keys 4h + {0..3}, regs + {4..7} keys 8 + 4h + {0..3} of that 16-key step
@@ -157,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
             unsigned x[2], y[2];
 #pragma unroll
             for (int d2 = 0; d2 < 2; d2++) {
-                x[d2] = (unsigned)hbits(f2h<T>(s[kt][r0 + 2 * d2])) | ((unsigned)hbits(f2h<T>(s[kt][r0 + 2 * d2 + 1])) << 16);
-                y[d2] = (unsigned)hbits(f2h<T>(s[kt][r0 + 4 + 2 * d2])) | ((unsigned)hbits(f2h<T>(s[kt][r0 + 4 + 2 * d2 + 1])) << 16);
+                x[d2] = pack2<DT>(s[kt][r0 + 2 * d2], s[kt][r0 + 2 * d2 + 1]);
+                y[d2] = pack2<DT>(s[kt][r0 + 4 + 2 * d2], s[kt][r0 + 4 + 2 * d2 + 1]);
                 auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
                 x[d2] = sw[0];
                 y[d2] = sw[1];
@@ -169,20 +192,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
         // ---- O^T[d][q] += sum_k V^T[d][k] P^T[k][q]: 4 channel tiles x 4 key steps ----------------------------
 #pragma unroll
         for (int dt = 0; dt < 4; dt++) {
-            const int vd = 32 * dt + lr;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
-                const int pc = 2 * ks + h;
-                v4i vw = *(const lds_v4i *)(vb + vd * 128 + ((pc ^ ((vd >> 1) & 7)) << 4));
-                o[dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw), pf[ks], o[dt]);
+                v4i vw = *(const lds_v4i *)(L8 + (va[ks] + (BO + dt * 4096)));
+                if constexpr (!(DBG & 8)) o[dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw), pf[ks], o[dt]);
+                else o[dt][ks] += (float)vw[0] * (float)__builtin_bit_cast(v4i, pf[ks])[0];
             }
         }
 
-        if (j + 1 < ntiles) store_tile(buf ^ 1); // the other buffer was last read in iteration j-1
-        __syncthreads();
+        if (j + 1 < ntiles && !(DBG & 2)) store_tile((BUF ^ 1) * 2 * ATT_TILE); // that buffer was last read in iteration j-1
+        if constexpr (!(DBG & 4)) __syncthreads();
+    };
+    for (int j = 0; j < ntiles; j += 2) {
+        step(std::integral_constant<int, 0>{}, j);
+        step(std::integral_constant<int, 1>{}, j + 1);
     }
 
     // ---- normalise and store: lane owns query row q0 + lr and channels 32*dt + 8c + 4h + e ------------------
+    const float l_run = l2[0] + l2[1];
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
     uint16_t *orow = p.out + (size_t)(q0 + lr) * p.ldo + (size_t)head * p.o_hs + 8 * h;
 #pragma unroll
@@ -192,14 +219,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnParams p) {
             unsigned x[2], y[2];
 #pragma unroll
             for (int d2 = 0; d2 < 2; d2++) {
-                x[d2] = (unsigned)hbits(f2h<T>(o[dt][8 * j2 + 2 * d2] * inv)) | ((unsigned)hbits(f2h<T>(o[dt][8 * j2 + 2 * d2 + 1] * inv)) << 16);
-                y[d2] = (unsigned)hbits(f2h<T>(o[dt][8 * j2 + 4 + 2 * d2] * inv)) | ((unsigned)hbits(f2h<T>(o[dt][8 * j2 + 4 + 2 * d2 + 1] * inv)) << 16);
+                x[d2] = pack2<DT>(o[dt][8 * j2 + 2 * d2] * inv, o[dt][8 * j2 + 2 * d2 + 1] * inv);
+                y[d2] = pack2<DT>(o[dt][8 * j2 + 4 + 2 * d2] * inv, o[dt][8 * j2 + 4 + 2 * d2 + 1] * inv);
                 auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
                 x[d2] = sw[0];
                 y[d2] = sw[1];
             }
             *reinterpret_cast<v4i *>(orow + 32 * dt + 16 * j2) = v4i{(int)x[0], (int)x[1], (int)y[0], (int)y[1]};
         }
+}
+
+template <int DT, int NW, int DBG> static void launch_attention(const AttnParams &p, hipStream_t st) {
+    dim3 grid(p.L / (NW * 32), p.H), block(NW * 64);
+    hipLaunchKernelGGL((attention_kernel<DT, NW, DBG>), grid, block, 0, st, p);
 }
 
 } // namespace svdq
@@ -210,7 +242,7 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     if (!a) { set_error("svdq_attention: args is NULL"); return SVDQ_E_INVALID; }
     if (!a->q || !a->k || !a->vt || !a->out) { set_error("svdq_attention: q, k, vt and out are required"); return SVDQ_E_INVALID; }
     if (a->head_dim != ATT_D) { set_error("svdq_attention: head_dim=%d (only 128 is implemented, as in the reference kernel)", a->head_dim); return SVDQ_E_UNSUPPORTED; }
-    if (a->L <= 0 || a->L % ATT_QB || a->H <= 0) { set_error("svdq_attention: L=%d must be a positive multiple of %d and H=%d positive", a->L, ATT_QB, a->H); return SVDQ_E_INVALID; }
+    if (a->L <= 0 || a->L % 128 || a->H <= 0) { set_error("svdq_attention: L=%d must be a positive multiple of 128 and H=%d positive", a->L, a->H); return SVDQ_E_INVALID; }
     if (a->ldq % 8 || a->ldk % 8 || a->ldvt % 8 || a->ldo % 8 || a->q_hs % 8 || a->k_hs % 8 || a->vt_hs % 8 || a->o_hs % 8 ||
         a->ldvt < a->L || a->ldq < ATT_D || a->ldk < ATT_D || a->ldo < ATT_D) {
         set_error("svdq_attention: strides must be multiples of 8 elements, ldq/ldk/ldo >= 128 and ldvt >= L");
@@ -223,11 +255,34 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.q_hs = a->q_hs; p.k_hs = a->k_hs; p.vt_hs = a->vt_hs; p.o_hs = a->o_hs;
     p.L = a->L; p.H = a->H; p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;
     p.scale_log2e = a->scale * 1.4426950408889634f;
+    p.debug = a->reserved;
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
-    dim3 grid(a->L / ATT_QB, a->H), block(256);
-    if (a->dtype == SVDQ_BF16) hipLaunchKernelGGL((attention_kernel<SVDQ_BF16>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attention_kernel<SVDQ_FP16>), grid, block, 0, st, p);
+    const int nw = (a->reserved >> 8) & 0xf ? (a->reserved >> 8) & 0xf : (a->L % 256 == 0 ? 8 : 4);
+    if ((nw != 4 && nw != 8) || a->L % (nw * 32)) { set_error("svdq_attention: bad wave-count override %d", nw); return SVDQ_E_INVALID; }
+    p.debug = a->reserved & 0xff;
+    if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8, 0>(p, st); else launch_attention<SVDQ_FP16, 4, 0>(p, st); }
+    else if (nw == 4) {
+        switch (p.debug) { // non-zero: ablations (bf16 only), timing experiments, results are garbage
+        case 0: launch_attention<SVDQ_BF16, 4, 0>(p, st); break;
+        case 1: launch_attention<SVDQ_BF16, 4, 1>(p, st); break;
+        case 2: launch_attention<SVDQ_BF16, 4, 2>(p, st); break;
+        case 8: launch_attention<SVDQ_BF16, 4, 8>(p, st); break;
+        case 16: launch_attention<SVDQ_BF16, 4, 16>(p, st); break;
+        case 24: launch_attention<SVDQ_BF16, 4, 24>(p, st); break;
+        default: set_error("svdq_attention: unknown debug variant %d", p.debug); return SVDQ_E_INVALID;
+        }
+    } else {
+        switch (p.debug) {
+        case 0: launch_attention<SVDQ_BF16, 8, 0>(p, st); break;
+        case 1: launch_attention<SVDQ_BF16, 8, 1>(p, st); break;
+        case 2: launch_attention<SVDQ_BF16, 8, 2>(p, st); break;
+        case 8: launch_attention<SVDQ_BF16, 8, 8>(p, st); break;
+        case 16: launch_attention<SVDQ_BF16, 8, 16>(p, st); break;
+        case 24: launch_attention<SVDQ_BF16, 8, 24>(p, st); break;
+        default: set_error("svdq_attention: unknown debug variant %d", p.debug); return SVDQ_E_INVALID;
+        }
+    }
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_attention launch");
 }

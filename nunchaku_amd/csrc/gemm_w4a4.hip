@@ -576,9 +576,14 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) {
                         float *dst = p.lora_act_out + (size_t)(mw0 + mi * 32 + h * 4) * p.R2 + t2 + lr;
-                        if (live) {
+                        if (live && !(p.debug & 16)) {
+                            if (p.debug & 32) {
+#pragma unroll
+                                for (int i = 0; i < 16; i++) __hip_atomic_fetch_add(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.R2, d[mi][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            } else {
 #pragma unroll
                             for (int i = 0; i < 16; i++) unsafeAtomicAdd(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.R2, d[mi][i]);
+                            }
                         }
                     }
                 }

@@ -8,9 +8,9 @@ MLP x4; every 3072-wide projection is an ``SVDQW4A4Linear`` driven through
 ``fused_qkv_norm_rottary`` / ``fused_gelu_mlp`` / ``forward``.
 
 ``diffusers`` is not a dependency: the few non-quantised pieces it would provide (embedders,
-AdaLayerNorm modulation, SDPA) are restated here with plain torch ops.  The AdaLN modulation
-projections, which the reference runs as AWQ W4A16 GEMVs, are 16-bit ``nn.Linear`` for now
-(SURVEY.md section 8f item 1).  Used by bench.py with synthetic weights and by the GPU tests; a
+AdaLayerNorm modulation) are restated here with plain torch ops.  The AdaLN modulation projections are
+AWQ W4A16 GEMVs (``AWQW4A16Linear``) and attention runs on this library's kernel, as in the reference
+(SURVEY.md section 8f items 1 and 3).  Used by bench.py with synthetic weights and by the GPU tests; a
 reference checkpoint's SVDQ tensors load into the ``SVDQW4A4Linear`` members unchanged.
 """
 
@@ -26,7 +26,7 @@ from ..ops.attention import attention_packed
 from ..ops.fused import fused_gelu_mlp, fused_qkv_norm_rottary
 from ..utils import pad_tensor
 from .embeddings import flux_pos_embed, pack_rotemb
-from .linear import SVDQW4A4Linear
+from .linear import AWQW4A16Linear, SVDQW4A4Linear
 
 
 def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 10000.0) -> torch.Tensor:
@@ -120,8 +120,9 @@ class FluxJointBlockAMD(nn.Module):
     def __init__(self, dim, heads, kw):
         super().__init__()
         dt, dev = kw["torch_dtype"], kw["device"]
-        self.mod = nn.Linear(dim, 6 * dim, dtype=dt, device=dev)  # AdaLayerNormZero.linear
-        self.mod_context = nn.Linear(dim, 6 * dim, dtype=dt, device=dev)
+        # AdaLayerNormZero.linear: AWQ W4A16 GEMV as in the reference (normalization.py:85-98, linear.py:277-414)
+        self.mod = AWQW4A16Linear(dim, 6 * dim, torch_dtype=dt, device=dev)
+        self.mod_context = AWQW4A16Linear(dim, 6 * dim, torch_dtype=dt, device=dev)
         self.attn = FluxAttentionAMD(dim, heads, True, kw)
         self.ff = _FeedForward(dim, kw)
         self.ff_context = _FeedForward(dim, kw)
@@ -154,7 +155,7 @@ class FluxSingleBlockAMD(nn.Module):
     def __init__(self, dim, heads, kw):
         super().__init__()
         dt, dev = kw["torch_dtype"], kw["device"]
-        self.mod = nn.Linear(dim, 3 * dim, dtype=dt, device=dev)  # AdaLayerNormZeroSingle.linear
+        self.mod = AWQW4A16Linear(dim, 3 * dim, torch_dtype=dt, device=dev)  # AdaLayerNormZeroSingle.linear (:155-165)
         self.mlp_fc1 = SVDQW4A4Linear(dim, 4 * dim, **kw)
         self.mlp_fc2 = SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})
         self.attn = FluxAttentionAMD(dim, heads, False, kw)
@@ -218,6 +219,13 @@ class FluxTransformerAMD(nn.Module):
                 m.proj_up.copy_(rnd(m.proj_up.shape, 0.5 / math.sqrt(m.rank)))
                 m._amd_layout = False
                 m.repack_()
+            elif isinstance(m, AWQW4A16Linear):
+                # uniform 4-bit codes (std 4.6) centred by the zero point: weights ~ 1/sqrt(K)
+                sc = 1.0 / (4.6 * math.sqrt(m.in_features))
+                m.qweight.copy_(torch.randint(-2 ** 31, 2 ** 31, m.qweight.shape, generator=g, device=dev, dtype=torch.int64))
+                m.wscales.copy_((uni(m.wscales.shape) * 0.5 + 0.75) * sc)
+                m.wzeros.copy_(m.wscales.float() * -7.5)
+                m.bias.zero_()
             elif isinstance(m, nn.Linear):
                 m.weight.copy_(rnd(m.weight.shape, 1.0 / math.sqrt(m.in_features)))
                 m.bias.zero_()

@@ -155,3 +155,43 @@ class SVDQW4A4Linear(nn.Module):
             f"SVDQW4A4Linear(in_features={self.in_features}, out_features={self.out_features}, "
             f"rank={self.rank}, precision={self.precision}, act_unsigned={self.act_unsigned})"
         )
+
+
+class AWQW4A16Linear(nn.Module):
+    """AWQ W4A16 linear for M <= 8 rows (reference: nunchaku/models/linear.py:277-414): the AdaLayerNormZero
+    modulation projections.  Same constructor, parameter names, shapes and dtypes, so checkpoints load unchanged:
+    ``qweight`` int32 [out/4, in/2] (tinychat ``pack_w4`` order, consumed as stored -- no repack),
+    ``wscales`` / ``wzeros`` [in/group, out] (zeros pre-scaled: w = q * scale + zero), ``bias`` [out] or None.
+    ``forward`` is one launch: the reference's separate ``output.add_(bias)`` is fused into the GEMV
+    (same 16-bit rounding point)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, group_size: int = 64,
+                 torch_dtype: torch.dtype = torch.bfloat16, device: str | torch.device | None = None):
+        super().__init__()
+        if device is None:
+            device = torch.device("cpu")
+        self.in_features, self.out_features, self.group_size = in_features, out_features, group_size
+        self.qweight = nn.Parameter(torch.empty(out_features // 4, in_features // 2, dtype=torch.int32, device=device),
+                                    requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_features, dtype=torch_dtype, device=device), requires_grad=True) if bias else None
+        self.wscales = nn.Parameter(torch.empty(in_features // group_size, out_features, dtype=torch_dtype, device=device),
+                                    requires_grad=False)
+        self.wzeros = nn.Parameter(torch.empty(in_features // group_size, out_features, dtype=torch_dtype, device=device),
+                                   requires_grad=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from ..ops.gemv import awq_gemv_w4a16_cuda
+
+        m = x.numel() // x.shape[-1]
+        return awq_gemv_w4a16_cuda(in_feats=x, kernel=self.qweight, scaling_factors=self.wscales, zeros=self.wzeros,
+                                   m=m, n=self.out_features, k=self.in_features, group_size=self.group_size, bias=self.bias)
+
+    @classmethod
+    def from_linear(cls, linear: nn.Linear, group_size: int = 64, torch_dtype: torch.dtype = torch.bfloat16,
+                    device: str = "cpu", **kwargs):
+        """Uninitialised layer of the same shape (reference :379-411)."""
+        return cls(in_features=linear.in_features, out_features=linear.out_features, bias=linear.bias is not None,
+                   group_size=group_size, torch_dtype=torch_dtype, device=device)
+
+    def __repr__(self):
+        return f"AWQW4A16Linear(in_features={self.in_features}, out_features={self.out_features}, group_size={self.group_size})"

@@ -600,3 +600,83 @@ def make_activations(M: int, K: int, seed: int = 0, dtype: str = "bf16", positiv
     if positive:
         x = np.abs(x)
     return round16(x, dtype)
+
+
+# --------------------------------------------------------------------------
+# AWQ W4A16 GEMV: the AdaLayerNormZero modulation projections.
+# Layout: nunchaku/models/text_encoders/tinychat_utils.py:76-107 (pack_w4), consumed by
+# src/kernels/awq/gemv_awq.cu:100-286; Python surface nunchaku/models/linear.py:277-414.
+# Layout pinned against the reference's pack_w4 / convert_to_tinychat_w4x16y16_linear_weight
+# (tests/golden/awq_*.npz, tools/make_golden.py); arithmetic restated from gemv_awq.cu (unpinned).
+# --------------------------------------------------------------------------
+AWQ_GROUP = 64  # gemv_awq.cu:278 (GROUP_SIZE; asserted against the group_size argument)
+
+
+def _awq_index(N: int, K: int):
+    """(int16 index, nibble) of logical weight (n, k) in the reference's packed AWQ tensor.
+
+    pack_w4 (tinychat_utils.py:97-107): 32 consecutive input channels -> 8 int16, int16 j holds channels
+    (j, 8+j, 16+j, 24+j) in nibbles 0..3; then rows are interleaved 4 at a time per 64-channel chunk:
+    [N/4][K/64][4 rows][16 int16].  The kernel reads exactly this: gemv_awq.cu:161-176 (row / chunk / half
+    of a thread), dequantize.cuh:17-77 + the shuffle at gemv_awq.cu:192-205 (nibble -> channel)."""
+    n = np.arange(N)[:, None]
+    k = np.arange(K)[None, :]
+    rg, i = n // 4, n % 4
+    c, half, kk = k // 64, (k % 64) // 32, k % 32
+    e, j = kk // 8, kk % 8
+    idx = (rg * (K // 64) + c) * 64 + i * 16 + half * 8 + j  # int16 units; a row group holds K int16
+    return np.broadcast_to(idx, (N, K)), np.broadcast_to(e, (N, K))
+
+
+def pack_awq_w4_ref(q: np.ndarray) -> np.ndarray:
+    """unsigned 4-bit codes [N, K] -> the reference's qweight parameter, int32 [N/4, K/2] (linear.py:328-330)."""
+    N, K = q.shape
+    assert N % 4 == 0 and K % 64 == 0
+    assert q.min() >= 0 and q.max() <= 15
+    idx, nib = _awq_index(N, K)
+    words = np.zeros(N * K // 4, dtype=np.uint16)
+    np.bitwise_or.at(words, idx.ravel(), (q.astype(np.uint16) << (4 * nib).astype(np.uint16)).ravel())
+    return words.view(np.int32).reshape(N // 4, K // 2)
+
+
+def unpack_awq_w4_ref(packed: np.ndarray) -> np.ndarray:
+    """int32 [N/4, K/2] -> codes [N, K] (uint8)."""
+    N, K = packed.shape[0] * 4, packed.shape[1] * 2
+    w = np.ascontiguousarray(packed).view(np.uint16).ravel()
+    idx, nib = _awq_index(N, K)
+    return ((w[idx] >> (4 * nib).astype(np.uint16)) & 0xF).astype(np.uint8)
+
+
+def awq_quantize_ref(w: np.ndarray, dtype: str):
+    """Asymmetric 4-bit group-64 quantisation as the reference converter does it
+    (tinychat_utils.py:165-188): q = round((w + zero)/scale) in [0, 15]; returns
+    (codes [N, K], scales [K/64, N], scaled zeros [K/64, N] = -zero, both 16-bit carriers)."""
+    N, K = w.shape
+    g = w.reshape(N, K // AWQ_GROUP, AWQ_GROUP).astype(F32)  # the converter works in float32
+    lo, hi = g.min(-1), g.max(-1)
+    scale = round16(np.maximum((hi - lo) / F32(15.0), F32(1e-8)), dtype)
+    zero = round16(-lo, dtype)
+    q = np.clip(np.rint((g + zero[..., None]) / scale[..., None]), 0, 15).astype(np.uint8).reshape(N, K)
+    return q, scale.T.copy(), (-zero).T.copy()
+
+
+def awq_gemv_w4a16(x: np.ndarray, q: np.ndarray, scales: np.ndarray, zeros: np.ndarray, dtype: str,
+                   bias: np.ndarray | None = None) -> np.ndarray:
+    """y[b, n] = sum_k x[b, k] * w16[n, k], gemv_awq.cu:181-236:
+      w16 = fma16(q, scale[g, n], scaled_zero[g, n])   one 16-bit rounding (__hfma2, :201)
+      p   = round16(w16 * x16)                         16-bit product (__hmul2, :222-224)
+      y   = round16(sum_k float(p))                    fp32 accumulate, order unspecified (:225-226, warp_reduce)
+    then the 16-bit bias add of AWQW4A16Linear.forward (linear.py:375-377: output.add_(bias)).
+    x [B, K], q [N, K] codes, scales / zeros [K/64, N]; returns [B, N] float32 carrier."""
+    B, K = x.shape
+    N = q.shape[0]
+    s = np.repeat(scales.T.astype(np.float64), AWQ_GROUP, axis=1)  # [N, K]
+    z = np.repeat(zeros.T.astype(np.float64), AWQ_GROUP, axis=1)
+    w16 = round16((q.astype(np.float64) * s + z).astype(np.float64), dtype).astype(np.float64)  # exact fma, then one rounding
+    y = np.empty((B, N), dtype=F32)
+    for b in range(B):
+        p = round16((w16 * x[b].astype(np.float64)[None, :]), dtype).astype(np.float64)
+        y[b] = round16(p.sum(axis=1).astype(F32), dtype)
+    if bias is not None:
+        y = round16(y + bias[None, :].astype(F32), dtype)
+    return y

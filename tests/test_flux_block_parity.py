@@ -28,6 +28,10 @@ class Ref:
     def lin(self, mod, x):  # nn.Linear with 16-bit weights, fp32 accumulate, 16-bit output
         return r16(F.linear(x, mod.weight.float().cpu(), mod.bias.float().cpu()))
 
+    def awq(self, name, x):  # AWQW4A16Linear (modulation): oracle GEMV with the fused 16-bit bias add
+        L = self.L[name]
+        return torch.from_numpy(O.awq_gemv_w4a16(x.numpy(), L["q"], L["s"], L["z"], DT, bias=L["bias"]))
+
     def svdq(self, name, x):
         return torch.from_numpy(O.svdq_linear(x.numpy(), self.L[name], DT, "fp32")["out"])
 
@@ -69,8 +73,8 @@ class Ref:
         rot = flux_pos_embed(torch.cat([txt_ids, img_ids], 0), m.axes)[0, :, :, 0].numpy()  # [T, 64, (sin, cos)]
         tt = e.shape[0]
         b = m.blocks[0]
-        mm = self.lin(b.mod, ta).view(-1, 6).T
-        cc = self.lin(b.mod_context, ta).view(-1, 6).T
+        mm = self.awq("blocks.0.mod", ta).view(-1, 6).T
+        cc = self.awq("blocks.0.mod_context", ta).view(-1, 6).T
         n_h, n_e = self.ln_mod(hidden, mm[1], mm[0]), self.ln_mod(e, cc[1], cc[0])
         qkv = torch.cat([self.qkv("blocks.0.attn.add_qkv_proj", n_e, b.attn.norm_added_q.weight, b.attn.norm_added_k.weight, rot[:tt]),
                          self.qkv("blocks.0.attn.to_qkv", n_h, b.attn.norm_q.weight, b.attn.norm_k.weight, rot[tt:])])
@@ -82,7 +86,7 @@ class Ref:
         e = r16(e + r16(cc[5])[None] * self.mlp("blocks.0.ff_context.fc1", "blocks.0.ff_context.fc2", self.ln_mod(e, cc[4], cc[3])))
         x = torch.cat([e, hidden])
         s = m.single_blocks[0]
-        sm = self.lin(s.mod, ta).view(-1, 3).T
+        sm = self.awq("single_blocks.0.mod", ta).view(-1, 3).T
         n = self.ln_mod(x, sm[1], sm[0])
         mlp = self.mlp("single_blocks.0.mlp_fc1", "single_blocks.0.mlp_fc2", n)
         att = self.svdq("single_blocks.0.attn.to_out",
@@ -95,7 +99,7 @@ class Ref:
 
 def test_small_flux_transformer_matches_oracle_forward():
     from nunchaku_amd.models.flux import FluxTransformerAMD
-    from nunchaku_amd.models.linear import SVDQW4A4Linear
+    from nunchaku_amd.models.linear import AWQW4A16Linear, SVDQW4A4Linear
 
     torch.manual_seed(0)
     model = FluxTransformerAMD(num_layers=1, num_single_layers=1, dim=256, heads=2, in_channels=64, joint_attention_dim=128,
@@ -107,6 +111,14 @@ def test_small_flux_transformer_matches_oracle_forward():
                 L = O.make_svdq_layer(mod.in_features, mod.out_features, 32, seed=len(layers), dtype=DT, cheap=True)
                 layers[name] = L
                 mod.load_state_dict({k: v.cuda() for k, v in reference_state_dict(L, DT).items()})
+            elif isinstance(mod, AWQW4A16Linear):
+                rng = np.random.default_rng(1000 + len(layers))
+                w = O.round16(rng.standard_normal((mod.out_features, mod.in_features)).astype(np.float32) / mod.in_features ** 0.5, DT)
+                q, s_, z_ = O.awq_quantize_ref(w, DT)
+                bias = O.round16(rng.standard_normal(mod.out_features).astype(np.float32) * 0.02, DT)
+                layers[name] = {"q": q, "s": s_, "z": z_, "bias": bias}
+                mod.load_state_dict({"qweight": torch.from_numpy(O.pack_awq_w4_ref(q)).cuda(), "wscales": torch.from_numpy(s_).cuda().bfloat16(),
+                                     "wzeros": torch.from_numpy(z_).cuda().bfloat16(), "bias": torch.from_numpy(bias).cuda().bfloat16()})
             elif isinstance(mod, torch.nn.Linear):
                 mod.weight.copy_(torch.randn_like(mod.weight, dtype=torch.float32) / mod.in_features ** 0.5)
                 mod.bias.copy_(torch.randn_like(mod.bias, dtype=torch.float32) * 0.02)

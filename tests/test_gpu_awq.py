@@ -1,0 +1,63 @@
+"""GPU parity of the AWQ W4A16 GEMV against the numpy oracle.
+
+Tolerance (floating point, stated as the task demands): the 16-bit roundings of the dequantised weight and
+of every product are reproduced exactly; only the fp32 summation ORDER differs (the reference's own order is
+thread-layout dependent, gemv_awq.cu:225-236), so outputs may differ by one 16-bit ulp where the fp32 sum
+lands next to a rounding boundary: |err| <= 1 ulp, and <= 2 % of the elements may differ at all."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import svdq_oracle as O
+from tests.helpers import TORCH_DT, assert_close_16, f32, t16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu(built_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def _layer(N, K, dtype, seed):
+    rng = np.random.default_rng(seed)
+    w = O.round16(rng.standard_normal((N, K)).astype(np.float32) * 0.05, dtype)
+    q, s, z = O.awq_quantize_ref(w, dtype)
+    bias = O.round16(rng.standard_normal(N).astype(np.float32) * 0.1, dtype)
+    return q, s, z, bias
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("m,N,K", [(1, 64, 128), (3, 256, 576), (8, 128, 1024), (1, 1536, 3072)])
+def test_gemv_awq_matches_oracle(dtype, m, N, K):
+    from nunchaku_amd.models.linear import AWQW4A16Linear
+
+    q, s, z, bias = _layer(N, K, dtype, seed=N + K + m)
+    rng = np.random.default_rng(7)
+    x = O.round16(rng.standard_normal((m, K)).astype(np.float32), dtype)
+    lin = AWQW4A16Linear(K, N, torch_dtype=TORCH_DT[dtype], device="cuda")
+    lin.load_state_dict({"qweight": torch.from_numpy(O.pack_awq_w4_ref(q)), "wscales": t16(s, dtype), "wzeros": t16(z, dtype),
+                         "bias": t16(bias, dtype)})
+    y = lin(t16(x, dtype))
+    assert y.shape == (m, N) and y.dtype == TORCH_DT[dtype]
+    ref = O.awq_gemv_w4a16(x, q, s, z, dtype, bias=bias)
+    got = f32(y)
+    assert (got != ref).mean() <= 0.02
+    assert_close_16(got, ref, dtype, "gemv_awq")
+
+
+def test_gemv_awq_op_surface_and_errors():
+    from nunchaku_amd._C import ops
+    from nunchaku_amd.ops.gemv import awq_gemv_w4a16_cuda
+
+    q, s, z, _ = _layer(64, 128, "bf16", 1)
+    x = t16(np.ones((2, 128), np.float32), "bf16")
+    kern = torch.from_numpy(O.pack_awq_w4_ref(q)).cuda()
+    y = awq_gemv_w4a16_cuda(x, kern, t16(s, "bf16"), t16(z, "bf16"), 2, 64, 128)  # no bias: the reference op
+    ref = O.awq_gemv_w4a16(np.ones((2, 128), np.float32), q, s, z, "bf16")
+    assert_close_16(f32(y), ref, "bf16", "gemv_awq(no bias)")
+    with pytest.raises(NotImplementedError):
+        ops.gemv_awq(x, kern, t16(s, "bf16"), t16(z, "bf16"), 2, 64, 128, 128)
+    with pytest.raises(ValueError):
+        ops.gemv_awq(x.repeat(5, 1)[:9], kern, t16(s, "bf16"), t16(z, "bf16"), 9, 64, 128, 64)

@@ -102,6 +102,22 @@ def main():
     np.savez_compressed(
         f"{OUT}/rotemb_{M}.npz", logical=rot.numpy().reshape(M, D // 2, 2), packed=prot.numpy().reshape(M, D)
     )
+    # --- AWQ W4A16 (tinychat) weights: the reference's own converter -------------------------
+    tc = _load("tinychat_utils_ref", f"{REF}/nunchaku/models/text_encoders/tinychat_utils.py")
+    for (N, K) in ((16, 128), (64, 256)):
+        w = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).to(torch.bfloat16)
+        g = w.float().view(N, K // 64, 64)
+        lo, hi = g.amin(-1), g.amax(-1)
+        scale = ((hi - lo) / 15).clamp_min(1e-8).to(torch.bfloat16)
+        zero = (-lo).to(torch.bfloat16)
+        pw, ps, pz = tc.convert_to_tinychat_w4x16y16_linear_weight(w.clone(), scale, zero, group_size=64)
+        # logical codes as the converter computes them (tinychat_utils.py:180)
+        q = (g + zero.float()[..., None]).div(scale.float()[..., None]).round().view(N, K).to(torch.int32)
+        assert torch.equal(tc.pack_w4(q), pw)
+        np.savez_compressed(
+            f"{OUT}/awq_{N}x{K}.npz", weight=w.float().numpy(), codes=q.numpy().astype(np.uint8),
+            packed_int16=pw.numpy(), scales=ps.float().numpy(), zeros=pz.float().numpy(),
+        )
     print("golden fixtures written to", os.path.abspath(OUT))
 
 
