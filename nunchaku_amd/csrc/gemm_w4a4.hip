@@ -70,14 +70,13 @@ struct GemmParams {
 };
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // reference: gemm_utils.cuh:305-312: x * (0.5 + 0.5 * tanh.approx(0.79788456 * (x + 0.044715 x^3))).
-    // tanh(u) = 1 - 2 / (exp(2u) + 1) on the hardware exp2 / rcp (|error| ~1e-6, the class of tanh.approx);
-    // libm tanhf costs ~40 VALU instructions per element and made this epilogue VALU-bound.
-    const float x3 = x * x * x;
-    const float u = 0.79788456f * (x + 0.044715f * x3);
-    const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f); // exp(2u); inf / 0 saturate correctly
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    return x * (0.5f + 0.5f * t);
+    // reference: gemm_utils.cuh:305-312: x * (0.5 + 0.5 * tanh.approx(u)), u = 0.79788456 * (x + 0.044715 x^3).
+    // 0.5 + 0.5 tanh(u) = 1 / (1 + exp(-2u)): one hardware exp2 and one rcp (|error| ~1e-6, the class of
+    // tanh.approx), 7 VALU operations per element; -2 u log2(e) = x * (A + B x^2).  exp2 overflow gives
+    // x * rcp(inf) = 0 for very negative x, underflow gives x * 1 for very positive x.
+    constexpr float A = -2.0f * 0.79788456f * 1.4426950408889634f, B = A * 0.044715f;
+    const float t = x * __builtin_fmaf(x * x, B, A);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
@@ -535,15 +534,70 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(gelu_tanh_f(acc[ni][mi][r]));
+                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = (p.debug & 128) ? acc[ni][mi][r] : round16<T>(gelu_tanh_f(acc[ni][mi][r]));
 
+            // EpilogueQuantize<false, unsigned> (gemm_w4a4.cuh:930-1043): 16-bit add of the shift,
+            // fp32 divide by the next layer's smooth factor -> 16-bit, per (row, 64 columns) absmax,
+            // scale = amax/15, unsigned 4-bit codes.  The wave's 64 columns are exactly one group of the
+            // next GEMM and the lane's 32 values (j = 16*ni + r) are exactly its F6 lane record.
+            const int KP2 = p.N / 128;
+            const int g2 = nw0 / GROUP;
+            // 1 / smooth of this lane's 32 columns.  The reference divides with __fdividef (gemm_w4a4.cuh:990-993,
+            // gemm_utils.cuh:329-344: an approximate reciprocal times the numerator); so does this epilogue
+            // (the stand-alone quantiser keeps the exactly rounded division).
+            float smr[2][16];
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    u16x4 sv = *reinterpret_cast<const u16x4 *>((const T *)p.next_smooth + nw0 + ni * 32 + c * 8 + h * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) smr[ni][c * 4 + e] = __builtin_amdgcn_rcpf(h2f(hfrom<T>(sv[e])));
+                }
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+                float xh[32];
+                float amax = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float sh = round16<T>(acc[ni][mi][r] + 0.171875f);
+                        float v = (p.debug & 256) ? sh : round16<T>(sh * smr[ni][r]);
+                        xh[ni * 16 + r] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                const float scale = amax * (1.0f / 15.0f);
+                const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
+                uint32_t rec[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const uint32_t code = (uint32_t)fminf(fmaxf(rintf(xh[j] * rscale), 0.f), 15.f);
+                    const int bit = 6 * j;
+                    rec[bit >> 5] |= code << (bit & 31);
+                    if ((bit & 31) > 26) rec[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                }
+                const int m_abs = mw0 + mi * 32 + lr;
+                uint8_t *dst = p.qout + ((size_t)(m_abs >> 5) * KP2 + (g2 >> 1)) * F6_CHUNK + (size_t)lane * 16;
+                if ((g2 & 1) == 0) {
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+                    *reinterpret_cast<uint2 *>(dst + F6_PLANE) = make_uint2(rec[4], rec[5]);
+                } else {
+                    *reinterpret_cast<uint2 *>(dst + F6_PLANE + 8) = make_uint2(rec[0], rec[1]);
+                    *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[2], rec[3], rec[4], rec[5]);
+                }
+                if (h == 0) ((T *)p.oscales)[simg_index(m_abs, g2, KP2)] = f2h<T>(scale);
+            }
             // EpilogueLoraDown for the NEXT layer on the GELU output, before shift/smooth
+            // (issued AFTER the requantisation below in program order: vmcnt retires in order on CDNA, so any load
+            //  that followed these fp32 atomics would wait for their memory-side round trip)
             // (lora.cuh:243-353, launch_impl.cuh:226-262):  D'[m][r2] = sum_n g[m][n] * ld[n][r2].  In the C
             // layout a lane already holds, for its row m, the 8 columns {16q + 8(j>>2) + 4h + (j&3)} of MFMA
             // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.  With
             // the activations as the A operand the result tile has the RANK along the lanes, so every fp32
             // atomic instruction hits two 128-byte lines instead of 64 different ones.
-            if (p.R2 > 0) {
+            if (p.R2 > 0 && !(p.debug & 64)) {
                 const T *ld = (const T *)p.next_lora_down; // rank-major [R2][N]
                 for (int t2 = 0; t2 < p.R2; t2 += 32) {
                     v16f d[2];
@@ -589,59 +643,6 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 }
             }
 
-            // EpilogueQuantize<false, unsigned> (gemm_w4a4.cuh:930-1043): 16-bit add of the shift,
-            // fp32 divide by the next layer's smooth factor -> 16-bit, per (row, 64 columns) absmax,
-            // scale = amax/15, unsigned 4-bit codes.  The wave's 64 columns are exactly one group of the
-            // next GEMM and the lane's 32 values (j = 16*ni + r) are exactly its F6 lane record.
-            const int KP2 = p.N / 128;
-            const int g2 = nw0 / GROUP;
-            float smf[2][16], smr[2][16]; // next layer's smoothing factors of this lane's 32 columns and their reciprocals
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    u16x4 sv = *reinterpret_cast<const u16x4 *>((const T *)p.next_smooth + nw0 + ni * 32 + c * 8 + h * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        smf[ni][c * 4 + e] = h2f(hfrom<T>(sv[e]));
-                        smr[ni][c * 4 + e] = __builtin_amdgcn_rcpf(smf[ni][c * 4 + e]);
-                    }
-                }
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                float xh[32];
-                float amax = 0.f;
-#pragma unroll
-                for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        float sh = round16<T>(acc[ni][mi][r] + 0.171875f);
-                        float v = round16<T>(div_rn(sh, smf[ni][r], smr[ni][r]));
-                        xh[ni * 16 + r] = v;
-                        amax = fmaxf(amax, fabsf(v));
-                    }
-                amax = fmaxf(amax, __shfl_xor(amax, 32));
-                const float scale = amax * (1.0f / 15.0f);
-                const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
-                uint32_t rec[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    const uint32_t code = (uint32_t)fminf(fmaxf(rintf(xh[j] * rscale), 0.f), 15.f);
-                    const int bit = 6 * j;
-                    rec[bit >> 5] |= code << (bit & 31);
-                    if ((bit & 31) > 26) rec[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
-                }
-                const int m_abs = mw0 + mi * 32 + lr;
-                uint8_t *dst = p.qout + ((size_t)(m_abs >> 5) * KP2 + (g2 >> 1)) * F6_CHUNK + (size_t)lane * 16;
-                if ((g2 & 1) == 0) {
-                    *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-                    *reinterpret_cast<uint2 *>(dst + F6_PLANE) = make_uint2(rec[4], rec[5]);
-                } else {
-                    *reinterpret_cast<uint2 *>(dst + F6_PLANE + 8) = make_uint2(rec[0], rec[1]);
-                    *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[2], rec[3], rec[4], rec[5]);
-                }
-                if (h == 0) ((T *)p.oscales)[simg_index(m_abs, g2, KP2)] = f2h<T>(scale);
-            }
         }
 
         // EpilogueDefault (gemm_base.cuh:667-698): store rows < M; fp16 clamps to +-65504.

@@ -32,7 +32,7 @@ def _ref_attention(q, k, v):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("L,H", [(128, 1), (384, 3), (1152, 2)])
+@pytest.mark.parametrize("L,H", [(128, 1), (384, 3), (1152, 2), (256, 2), (1024, 3)])  # L % 256 == 0: pipelined kernel
 def test_attention_matches_fp32_reference(dtype, L, H):
     from nunchaku_amd.ops.attention import attention_packed
 
