@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 4
+#define SVDQ_ABI_VERSION 5
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -90,6 +90,14 @@ typedef struct svdq_quantize_args {
     int32_t dtype;         /* SVDQ_BF16 | SVDQ_FP16                                           */
     int32_t fuse_glu;      /* must be 0 (SVDQ_E_UNSUPPORTED otherwise; not on the FLUX path)  */
     int32_t fp4;           /* must be 0 (NVFP4 is Blackwell-only)                             */
+    /* Optional fused AdaLayerNormZero front end (extension; all three or none).  The quantiser then reads
+     *   x' = round16(mod_shift + round16((x - mean) * rstd) * round16(1 + mod_scale))
+     * in place of x -- bit for bit what F.layer_norm(x) (no affine) followed by the 16-bit
+     * torch.addcmul(shift, ln, 1 + scale) of the reference's blocks produces
+     * (nunchaku/models/normalization.py:85-98,155-165) -- for the low-rank projection and the codes alike. */
+    const float *ln_stats; /* [M, 2] fp32 (mean, rstd) per row, e.g. from svdq_residual_gate_stats     */
+    const void *mod_scale; /* [K] 16-bit                                                              */
+    const void *mod_shift; /* [K] 16-bit                                                              */
 } svdq_quantize_args;
 
 int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *args, void *stream);
@@ -181,6 +189,29 @@ typedef struct svdq_attention_args {
 } svdq_attention_args;
 
 int svdq_attention(const svdq_attention_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gated residual + LayerNorm statistics (extension; the element-wise glue between the operators of a block,
+ * transformer_flux_v2.py:118-342):
+ *   t = b ? round16(a + b) : a;      y = a ? round16(res + (gate ? gate[c] : 1) * t) : res;
+ *   out[m, :] = y (if out);          stats[m] = (mean(y), 1/sqrt(var(y) + eps)) over the 16-bit values (if stats)
+ * i.e. torch.addcmul(res, gate, a) (or with a.add_(b) first) with the statistics the next LayerNorm needs
+ * produced in the same pass.  out may alias res.  C must be a multiple of 8 with ceil(C/512) in {1..8, 12, 16, 24, 32}.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct svdq_residual_args {
+    const void *res;   /* [M, C] 16-bit, row stride ld */
+    const void *a;     /* [M, C] or NULL (statistics of res only) */
+    const void *b;     /* [M, C] or NULL */
+    const void *gate;  /* [C] 16-bit or NULL */
+    void *out;         /* [M, C] or NULL */
+    float *stats;      /* [M, 2] fp32 or NULL */
+    int32_t M, C, ld;  /* ld: common row stride of res / a / b / out in elements */
+    int32_t dtype;
+    float eps;
+    int32_t reserved;
+} svdq_residual_args;
+
+int svdq_residual_gate_stats(const svdq_residual_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * AWQ W4A16 GEMV (reference: ops.gemv_awq, nunchaku/csrc/ops.h:123-145 -> src/kernels/awq/gemv_awq.cu:100-286;

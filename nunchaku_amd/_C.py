@@ -53,8 +53,13 @@ def _workspace(device: torch.device) -> torch.Tensor:
 
 class _Ops:
     @staticmethod
-    def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False):
-        """reference: csrc/ops.h:83-112 -> kernels::quantize_w4a4_act_fuse_lora (zgemm.h:39-46)."""
+    def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False,
+                                    ln_stats=None, mod_scale=None, mod_shift=None):
+        """reference: csrc/ops.h:83-112 -> kernels::quantize_w4a4_act_fuse_lora (zgemm.h:39-46).
+
+        ``ln_stats`` / ``mod_scale`` / ``mod_shift`` (extension, all or none): quantise
+        ``addcmul(shift, layer_norm(input), 1 + scale)`` instead of ``input`` without materialising it;
+        ``ln_stats`` is the ``[M, 2]`` float32 (mean, rstd) tensor ``ops.residual_gate_stats`` returns."""
         lib = _lib.load()
         if input is None or output is None or oscales is None:
             raise ValueError("quantize_w4a4_act_fuse_lora: input, output and oscales are required")
@@ -78,6 +83,14 @@ class _Ops:
         a.ldx = input.stride(0)
         a.dtype = _DT[input.dtype]
         a.fuse_glu, a.fp4 = int(bool(fuse_glu)), int(bool(fp4))
+        if ln_stats is not None or mod_scale is not None or mod_shift is not None:
+            if ln_stats is None or mod_scale is None or mod_shift is None:
+                raise ValueError("quantize_w4a4_act_fuse_lora: ln_stats, mod_scale and mod_shift go together")
+            if ln_stats.dtype != torch.float32 or ln_stats.numel() != 2 * M:
+                raise ValueError("quantize_w4a4_act_fuse_lora: ln_stats must be float32 [M, 2]")
+            if mod_scale.numel() != K or mod_shift.numel() != K or mod_scale.dtype != input.dtype or mod_shift.dtype != input.dtype:
+                raise ValueError("quantize_w4a4_act_fuse_lora: mod_scale / mod_shift must be [K] in the input dtype")
+            a.ln_stats, a.mod_scale, a.mod_shift = _ptr(ln_stats), _ptr(mod_scale), _ptr(mod_shift)
         if output.shape[-1] * 4 != K * 3 or oscales.numel() != (K // 64) * M_pad:
             raise ValueError(
                 "quantize_w4a4_act_fuse_lora: output must be the [M_pad, 3K/4] byte FP6 operand image of this "
@@ -179,6 +192,31 @@ class _Ops:
             raise ValueError("gemm_w4a4: out_vt has fewer columns than out has rows")
         _lib.check(lib.svdq_gemm_w4a4(C.byref(a), _stream()), "gemm_w4a4")
         del keep
+
+    @staticmethod
+    def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6):
+        """Extension: ``out = res + gate * (a [+ b])`` (the 16-bit ``torch.addcmul`` of a block's gated residual)
+        and/or the LayerNorm statistics ``stats[m] = (mean, rstd)`` of the result, in one pass.  2-D row-major
+        views with a common row stride; ``a`` None = statistics of ``res`` itself; ``out`` may be ``res``."""
+        lib = _lib.load()
+        if res.dim() != 2 or res.stride(1) != 1 or res.dtype not in _DT:
+            raise ValueError("residual_gate_stats: res must be a 2-D 16-bit view with unit column stride")
+        M, Cc = res.shape
+        args = _lib.ResidualArgs()
+        for name, t in (("a", a), ("b", b), ("out", out)):
+            if t is not None and (tuple(t.shape) != (M, Cc) or t.stride() != res.stride() or t.dtype != res.dtype):
+                raise ValueError(f"residual_gate_stats: {name} must match res in shape, strides and dtype")
+        if gate is not None and (gate.numel() != Cc or gate.dtype != res.dtype or not gate.is_contiguous()):
+            raise ValueError("residual_gate_stats: gate must be a contiguous [C] tensor in the dtype of res")
+        if stats is not None and (stats.dtype != torch.float32 or stats.numel() != 2 * M or not stats.is_contiguous()):
+            raise ValueError("residual_gate_stats: stats must be contiguous float32 [M, 2]")
+        for t in (res, a, b, gate, out, stats):
+            if t is not None and not t.is_cuda:
+                raise RuntimeError("nunchaku_amd ops need GPU tensors (there is no CPU path)")
+        dp = lambda t: None if t is None else t.data_ptr()
+        args.res, args.a, args.b, args.gate, args.out, args.stats = dp(res), dp(a), dp(b), dp(gate), dp(out), dp(stats)
+        args.M, args.C, args.ld, args.dtype, args.eps = M, Cc, res.stride(0), _DT[res.dtype], float(eps)
+        _lib.check(lib.svdq_residual_gate_stats(C.byref(args), _stream()), "residual_gate_stats")
 
     @staticmethod
     def gemv_awq(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size, bias=None):

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class QuantizeArgs(C.Structure):
@@ -21,6 +21,15 @@ class QuantizeArgs(C.Structure):
         ("act", C.c_void_p), ("ascales", C.c_void_p), ("lora_act", C.c_void_p),
         ("M", C.c_int32), ("M_pad", C.c_int32), ("K", C.c_int32), ("R", C.c_int32),
         ("ldx", C.c_int32), ("dtype", C.c_int32), ("fuse_glu", C.c_int32), ("fp4", C.c_int32),
+        ("ln_stats", C.c_void_p), ("mod_scale", C.c_void_p), ("mod_shift", C.c_void_p),
+    ]
+
+
+class ResidualArgs(C.Structure):
+    _fields_ = [
+        ("res", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("gate", C.c_void_p), ("out", C.c_void_p),
+        ("stats", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("ld", C.c_int32), ("dtype", C.c_int32),
+        ("eps", C.c_float), ("reserved", C.c_int32),
     ]
 
 
@@ -64,6 +73,7 @@ EXPORTS = {
     "svdq_gemm_w4a4": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "svdq_attention": (C.c_int, [C.POINTER(AttentionArgs), C.c_void_p]),
     "svdq_gemv_awq": (C.c_int, [C.POINTER(GemvAwqArgs), C.c_void_p]),
+    "svdq_residual_gate_stats": (C.c_int, [C.POINTER(ResidualArgs), C.c_void_p]),
     "svdq_gemm_workspace_bytes": (C.c_int64, []),
     "svdq_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_repack_qweight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

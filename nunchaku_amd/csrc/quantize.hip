@@ -26,7 +26,10 @@ __global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::
                                                        uint8_t *__restrict__ act,
                                                        typename Half<DT>::T *__restrict__ ascales,
                                                        float *__restrict__ lora_act, int M, int K, int R, int ldx,
-                                                       int chunks_per_wg, int use_atomics) {
+                                                       int chunks_per_wg, int use_atomics,
+                                                       const float *__restrict__ ln_stats,
+                                                       const typename Half<DT>::T *__restrict__ mod_scale,
+                                                       const typename Half<DT>::T *__restrict__ mod_shift) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     const int tid = threadIdx.x;
@@ -47,6 +50,13 @@ __global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::
         for (int j = 0; j < 16; j++) accL[i][j] = 0.f;
 
     const T *xrow = x + (size_t)row * ldx;
+    // fused AdaLayerNormZero front end: per-row statistics of the LayerNorm this projection follows
+    float ln_mean = 0.f, ln_rstd = 0.f;
+    if (ln_stats && valid) {
+        const float2 st = *reinterpret_cast<const float2 *>(ln_stats + 2 * (size_t)row);
+        ln_mean = st.x;
+        ln_rstd = st.y;
+    }
 
     for (int kp = slice * chunks_per_wg + wave; kp < kp_end; kp += 4) {
         uint32_t rec[12];
@@ -65,6 +75,20 @@ __global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::
                 if (valid) xv[grp][tc] = *reinterpret_cast<const u16x4 *>(xrow + kbase + 8 * tc);
                 else xv[grp][tc] = u16x4{0, 0, 0, 0};
                 if (smooth) sv[grp][tc] = *reinterpret_cast<const u16x4 *>(smooth + kbase + 8 * tc);
+            }
+            if (ln_stats) { // x <- round16(shift + round16((x - mean) * rstd) * round16(1 + scale)); padded rows stay 0
+#pragma unroll
+                for (int tc = 0; tc < 8; tc++) {
+                    const u16x4 ms = *reinterpret_cast<const u16x4 *>(mod_scale + kbase + 8 * tc);
+                    const u16x4 mh = *reinterpret_cast<const u16x4 *>(mod_shift + kbase + 8 * tc);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float ln = round16<T>((h2f(hfrom<T>(xv[grp][tc][e])) - ln_mean) * ln_rstd);
+                        const float s1 = round16<T>(1.0f + h2f(hfrom<T>(ms[e])));
+                        const float y = __builtin_fmaf(ln, s1, h2f(hfrom<T>(mh[e])));
+                        if (valid) xv[grp][tc][e] = hbits(f2h<T>(y));
+                    }
+                }
             }
             if constexpr (RT32 > 0) {
 #pragma unroll
@@ -210,7 +234,7 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
 #define SVDQ_LAUNCH_Q(RT)                                                                                            \
     hipLaunchKernelGGL((quantize_kernel<DT, RT>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,          \
                        (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
-                       a->ldx, cpw, atomics)
+                       a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift)
     if (rt32 == 0) SVDQ_LAUNCH_Q(0);
     else if (rt32 <= 1) SVDQ_LAUNCH_Q(1);
     else if (rt32 <= 2) SVDQ_LAUNCH_Q(2);
@@ -244,6 +268,14 @@ extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, voi
     }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) {
         set_error("svdq_quantize: unknown dtype %d", a->dtype);
+        return SVDQ_E_INVALID;
+    }
+    if ((a->ln_stats != nullptr) != (a->mod_scale != nullptr) || (a->ln_stats != nullptr) != (a->mod_shift != nullptr)) {
+        set_error("svdq_quantize: ln_stats, mod_scale and mod_shift must be given together");
+        return SVDQ_E_INVALID;
+    }
+    if (((uintptr_t)a->ln_stats | (uintptr_t)a->mod_scale | (uintptr_t)a->mod_shift) & 7) {
+        set_error("svdq_quantize: ln_stats, mod_scale and mod_shift must be 8-byte aligned");
         return SVDQ_E_INVALID;
     }
     hipStream_t st = (hipStream_t)stream;

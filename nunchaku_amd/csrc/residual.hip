@@ -1,0 +1,117 @@
+// svdq_residual_gate_stats: the element-wise glue between the operators of a FLUX block, with the statistics of the
+// NEXT LayerNorm produced in the same pass (extension; reference blocks: transformer_flux_v2.py:118-342 use
+// torch ops: hidden + gate * attn_out, LayerNorm, (1 + scale) * x + shift).
+//
+//   t = b ? round16(a + b) : a;   y = a ? round16(res + gate * t) : res;   out = y;   stats = (mean, rstd) of y
+//
+// HBM-bound: one pass over the row (3 reads + 1 write of 2 bytes per element); one wave per row keeps the whole
+// row in registers (C <= 16384), so mean and variance are the exact two-pass formulas on the stored 16-bit values
+// and the LayerNorm itself disappears into the quantiser (svdq_quantize_args.ln_stats).
+#include "svdq_common.h"
+
+namespace svdq {
+
+template <int DT, int NV /* 16-byte pieces per lane */>
+__global__ __launch_bounds__(256) void residual_kernel(const uint16_t *__restrict__ res, const uint16_t *__restrict__ a,
+                                                        const uint16_t *__restrict__ b, const uint16_t *__restrict__ gate,
+                                                        uint16_t *__restrict__ out, float *__restrict__ stats, int M, int C, int ld,
+                                                        float eps) {
+    using T = typename Half<DT>::T;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const size_t base = (size_t)row * ld;
+    float y[NV][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const int c = (v * 64 + lane) * 8; // a wave instruction covers 1 KiB of the row
+        if (c >= C) { // ragged tail of the last pass (C is a multiple of 8, not necessarily of 512)
+#pragma unroll
+            for (int e = 0; e < 8; e++) y[v][e] = 0.f;
+            continue;
+        }
+        const u16x8 rv = *reinterpret_cast<const u16x8 *>(res + base + c);
+        if (a) {
+            const u16x8 av = *reinterpret_cast<const u16x8 *>(a + base + c);
+            u16x8 bv, gv;
+            if (b) bv = *reinterpret_cast<const u16x8 *>(b + base + c);
+            if (gate) gv = *reinterpret_cast<const u16x8 *>(gate + c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float t = h2f(hfrom<T>(av[e]));
+                if (b) t = round16<T>(t + h2f(hfrom<T>(bv[e])));
+                const float g = gate ? h2f(hfrom<T>(gv[e])) : 1.0f;
+                y[v][e] = round16<T>(__builtin_fmaf(g, t, h2f(hfrom<T>(rv[e]))));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) y[v][e] = h2f(hfrom<T>(rv[e]));
+        }
+        if (out && a) {
+            u16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; e++) ov[e] = hbits(f2h<T>(y[v][e]));
+            *reinterpret_cast<u16x8 *>(out + base + c) = ov;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) sum += y[v][e];
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float d = (v * 64 + lane) * 8 < C ? y[v][e] - mean : 0.f;
+            sq = __builtin_fmaf(d, d, sq);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) {
+        stats[2 * (size_t)row] = mean;
+        stats[2 * (size_t)row + 1] = 1.0f / sqrtf(sq / (float)C + eps);
+    }
+}
+
+template <int DT> static int launch_residual(const svdq_residual_args *p, hipStream_t st) {
+    dim3 grid((p->M + 3) / 4), block(256);
+#define SVDQ_RES_CASE(NV)                                                                                                       \
+    case NV:                                                                                                                    \
+        hipLaunchKernelGGL((residual_kernel<DT, NV>), grid, block, 0, st, (const uint16_t *)p->res, (const uint16_t *)p->a,      \
+                           (const uint16_t *)p->b, (const uint16_t *)p->gate, (uint16_t *)p->out, p->stats, p->M, p->C, p->ld,   \
+                           p->eps);                                                                                             \
+        return 0;
+    switch ((p->C + 511) / 512) {
+        SVDQ_RES_CASE(1) SVDQ_RES_CASE(2) SVDQ_RES_CASE(3) SVDQ_RES_CASE(4) SVDQ_RES_CASE(5) SVDQ_RES_CASE(6) SVDQ_RES_CASE(7) SVDQ_RES_CASE(8)
+        SVDQ_RES_CASE(12) SVDQ_RES_CASE(16) SVDQ_RES_CASE(24) SVDQ_RES_CASE(32)
+    default: return -1;
+    }
+#undef SVDQ_RES_CASE
+}
+
+} // namespace svdq
+
+using namespace svdq;
+
+extern "C" int svdq_residual_gate_stats(const svdq_residual_args *a, void *stream) {
+    if (!a) { set_error("svdq_residual_gate_stats: args is NULL"); return SVDQ_E_INVALID; }
+    if (!a->res || (!a->out && !a->stats)) { set_error("svdq_residual_gate_stats: res and one of out / stats are required"); return SVDQ_E_INVALID; }
+    if ((a->b || a->gate || a->out) && !a->a) { set_error("svdq_residual_gate_stats: b, gate and out need a"); return SVDQ_E_INVALID; }
+    if (a->M <= 0 || a->C <= 0 || a->C % 8 || a->ld < a->C || a->ld % 8) {
+        set_error("svdq_residual_gate_stats: need M=%d > 0, C=%d a multiple of 8, ld=%d >= C and a multiple of 8", a->M, a->C, a->ld);
+        return SVDQ_E_INVALID;
+    }
+    if (((uintptr_t)a->res | (uintptr_t)a->a | (uintptr_t)a->b | (uintptr_t)a->gate | (uintptr_t)a->out) & 15 || ((uintptr_t)a->stats & 7)) {
+        set_error("svdq_residual_gate_stats: tensors must be 16-byte aligned (stats 8-byte)");
+        return SVDQ_E_INVALID;
+    }
+    if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_residual_gate_stats: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = a->dtype == SVDQ_BF16 ? launch_residual<SVDQ_BF16>(a, st) : launch_residual<SVDQ_FP16>(a, st);
+    if (rc) { set_error("svdq_residual_gate_stats: C=%d: ceil(C/512) must be one of {1..8, 12, 16, 24, 32}", a->C); return SVDQ_E_UNSUPPORTED; }
+    return hip_check(hipGetLastError(), "svdq_residual_gate_stats launch");
+}

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..ops.attention import attention_packed
+from ..ops.elementwise import residual_gate_stats
 from ..ops.fused import fused_gelu_mlp, fused_qkv_norm_rottary
 from ..utils import pad_tensor
 from .embeddings import flux_pos_embed, pack_rotemb
@@ -72,7 +73,9 @@ class FluxAttentionAMD(nn.Module):
     def _use_svdq(self, B, tokens):
         return self.attention_impl == "svdq" and B == 1 and self.head_dim == 128 and tokens % 128 == 0
 
-    def forward(self, hidden, encoder_hidden=None, rotary=None):
+    def forward(self, hidden, encoder_hidden=None, rotary=None, ln=None, ln_ctx=None):
+        """``ln`` / ``ln_ctx`` = (stats, scale, shift): the inputs are the UN-normalised streams and the
+        AdaLayerNormZero front end runs inside the QKV projections' quantiser."""
         B = hidden.shape[0]
         hd = self.heads * self.head_dim
         t_txt = encoder_hidden.shape[1] if self.joint else 0
@@ -84,12 +87,12 @@ class FluxAttentionAMD(nn.Module):
             # both projections write straight into one [txt; img] buffer (B == 1): no torch.cat round trip
             rot_img, rot_txt = rotary
             fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rot_img, output=qkv[0, t_txt:],
-                                   out_vt=vt[:, t_txt:] if svdq else None)
+                                   out_vt=vt[:, t_txt:] if svdq else None, ln=ln)
             fused_qkv_norm_rottary(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, rot_txt,
-                                   output=qkv[0, :t_txt], out_vt=vt[:, :t_txt] if svdq else None)
+                                   output=qkv[0, :t_txt], out_vt=vt[:, :t_txt] if svdq else None, ln=ln_ctx)
         else:
             fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary, output=qkv.view(B * tokens, -1),
-                                   out_vt=vt)
+                                   out_vt=vt, ln=ln)
         if svdq:
             o = attention_packed(qkv[0], vt, self.heads).unsqueeze(0)
         else:
@@ -112,8 +115,8 @@ class _FeedForward(nn.Module):
         self.fc1 = SVDQW4A4Linear(dim, 4 * dim, **kw)
         self.fc2 = SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})
 
-    def forward(self, x):
-        return fused_gelu_mlp(x, self.fc1, self.fc2)
+    def forward(self, x, ln=None):
+        return fused_gelu_mlp(x, self.fc1, self.fc2, ln=ln)
 
 
 class FluxJointBlockAMD(nn.Module):
@@ -133,22 +136,35 @@ class FluxJointBlockAMD(nn.Module):
         # AdaLayerNormZero: LN(x) * (1 + scale) + shift as LN + one fused multiply-add
         return torch.addcmul(shift[:, None], F.layer_norm(x, (x.shape[-1],), eps=1e-6), 1 + scale[:, None])
 
-    def forward(self, hidden, encoder_hidden, temb_act, rotary):
+    def forward(self, hidden, encoder_hidden, temb_act, rotary, stats=None):
+        """``stats`` = (image-stream, text-stream) LayerNorm statistics of the inputs: the fused path -- LayerNorm and
+        modulation inside the quantisers, gated residual + next statistics in one element-wise pass (B == 1).
+        Returns (encoder_hidden, hidden, stats)."""
         # normalization.py:85-98 -- emb.view(B, -1, 6).permute(2, 0, 1): interleaved chunks
-        m = self.mod(temb_act).view(temb_act.shape[0], -1, 6).permute(2, 0, 1)
-        c = self.mod_context(temb_act).view(temb_act.shape[0], -1, 6).permute(2, 0, 1)
-        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = m
-        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c
-        n_h = self._ln_mod(hidden, scale_msa, shift_msa)
-        n_e = self._ln_mod(encoder_hidden, c_scale_msa, c_shift_msa)
-        a, ca = self.attn(n_h, n_e, rotary)
-        hidden = torch.addcmul(hidden, gate_msa[:, None], a)
-        n_h = self._ln_mod(hidden, scale_mlp, shift_mlp)
-        hidden = torch.addcmul(hidden, gate_mlp[:, None], self.ff(n_h))
-        encoder_hidden = torch.addcmul(encoder_hidden, c_gate_msa[:, None], ca)
-        n_e = self._ln_mod(encoder_hidden, c_scale_mlp, c_shift_mlp)
-        encoder_hidden = torch.addcmul(encoder_hidden, c_gate_mlp[:, None], self.ff_context(n_e))
-        return encoder_hidden, hidden
+        if stats is None:
+            m = self.mod(temb_act).view(temb_act.shape[0], -1, 6).permute(2, 0, 1)
+            c = self.mod_context(temb_act).view(temb_act.shape[0], -1, 6).permute(2, 0, 1)
+            shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = m
+            c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c
+            n_h = self._ln_mod(hidden, scale_msa, shift_msa)
+            n_e = self._ln_mod(encoder_hidden, c_scale_msa, c_shift_msa)
+            a, ca = self.attn(n_h, n_e, rotary)
+            hidden = torch.addcmul(hidden, gate_msa[:, None], a)
+            n_h = self._ln_mod(hidden, scale_mlp, shift_mlp)
+            hidden = torch.addcmul(hidden, gate_mlp[:, None], self.ff(n_h))
+            encoder_hidden = torch.addcmul(encoder_hidden, c_gate_msa[:, None], ca)
+            n_e = self._ln_mod(encoder_hidden, c_scale_mlp, c_shift_mlp)
+            encoder_hidden = torch.addcmul(encoder_hidden, c_gate_mlp[:, None], self.ff_context(n_e))
+            return encoder_hidden, hidden, None
+        h_stats, e_stats = stats
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.mod(temb_act).view(-1, 6).t().contiguous()
+        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.mod_context(temb_act).view(-1, 6).t().contiguous()
+        a, ca = self.attn(hidden, encoder_hidden, rotary, ln=(h_stats, scale_msa, shift_msa), ln_ctx=(e_stats, c_scale_msa, c_shift_msa))
+        hidden, h_stats = residual_gate_stats(hidden, a, gate_msa)
+        hidden, h_stats = residual_gate_stats(hidden, self.ff(hidden, ln=(h_stats, scale_mlp, shift_mlp)), gate_mlp)
+        encoder_hidden, e_stats = residual_gate_stats(encoder_hidden, ca, c_gate_msa)
+        encoder_hidden, e_stats = residual_gate_stats(encoder_hidden, self.ff_context(encoder_hidden, ln=(e_stats, c_scale_mlp, c_shift_mlp)), c_gate_mlp)
+        return encoder_hidden, hidden, (h_stats, e_stats)
 
 
 class FluxSingleBlockAMD(nn.Module):
@@ -160,16 +176,26 @@ class FluxSingleBlockAMD(nn.Module):
         self.mlp_fc2 = SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})
         self.attn = FluxAttentionAMD(dim, heads, False, kw)
 
-    def forward(self, hidden, temb_act, rotary):
-        shift, scale, gate = self.mod(temb_act).view(temb_act.shape[0], -1, 3).permute(2, 0, 1)
-        n = torch.addcmul(shift[:, None], F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6), 1 + scale[:, None])
-        mlp = fused_gelu_mlp(n, self.mlp_fc1, self.mlp_fc2)
-        att = self.attn(n, rotary=rotary)
-        return torch.addcmul(hidden, gate[:, None], att.add_(mlp))
+    def forward(self, hidden, temb_act, rotary, stats=None):
+        if stats is None:
+            shift, scale, gate = self.mod(temb_act).view(temb_act.shape[0], -1, 3).permute(2, 0, 1)
+            n = torch.addcmul(shift[:, None], F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6), 1 + scale[:, None])
+            mlp = fused_gelu_mlp(n, self.mlp_fc1, self.mlp_fc2)
+            att = self.attn(n, rotary=rotary)
+            return torch.addcmul(hidden, gate[:, None], att.add_(mlp)), None
+        shift, scale, gate = self.mod(temb_act).view(-1, 3).t().contiguous()
+        ln = (stats, scale, shift)  # one LayerNorm + modulation, consumed by both projections' quantisers
+        mlp = fused_gelu_mlp(hidden, self.mlp_fc1, self.mlp_fc2, ln=ln)
+        att = self.attn(hidden, rotary=rotary, ln=ln)
+        return residual_gate_stats(hidden, att, gate, b=mlp)  # hidden + gate * (att + mlp), and the next statistics
 
 
 class FluxTransformerAMD(nn.Module):
     """One denoising step: ``forward(latents, text states, pooled text, timestep, guidance, ids)``."""
+
+    # True: AdaLayerNormZero runs inside the quantisers and the gated residuals are one fused pass each
+    # (svdq_quantize_args.ln_stats, svdq_residual_gate_stats); False: the reference's torch-op sequence.
+    fused_norm = True
 
     def __init__(self, num_layers=19, num_single_layers=38, dim=3072, heads=24, in_channels=64,
                  joint_attention_dim=4096, pooled_projection_dim=768, rank=32, guidance_embeds=True,
@@ -253,11 +279,14 @@ class FluxTransformerAMD(nn.Module):
         rot_img = pack_rotemb(pad_tensor(rot[:, t_txt:], 256, 1))
         rot_all = pack_rotemb(pad_tensor(rot, 256, 1))
 
+        fused = self.fused_norm and hidden.shape[0] == 1
+        stats = (residual_gate_stats(hidden)[1], residual_gate_stats(enc)[1]) if fused else None
         for blk in self.blocks:
-            enc, hidden = blk(hidden, enc, temb_act, (rot_img, rot_txt))
+            enc, hidden, stats = blk(hidden, enc, temb_act, (rot_img, rot_txt), stats)
         hidden = torch.cat([enc, hidden], dim=1)
+        stats = torch.cat([stats[1], stats[0]], dim=0) if fused else None
         for blk in self.single_blocks:
-            hidden = blk(hidden, temb_act, rot_all)
+            hidden, stats = blk(hidden, temb_act, rot_all, stats)
         hidden = hidden[:, t_txt:]
         scale, shift = self.norm_out_mod(temb_act).chunk(2, dim=-1)  # AdaLayerNormContinuous
         hidden = F.layer_norm(hidden, (self.dim,), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]

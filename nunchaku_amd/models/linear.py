@@ -119,21 +119,22 @@ class SVDQW4A4Linear(nn.Module):
             **kwargs,
         )
 
-    def forward(self, x: torch.Tensor, output: torch.Tensor | None = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, output: torch.Tensor | None = None, ln=None) -> torch.Tensor:
         """x [B, S, in] 16-bit -> [B, S, out]: quantise (+ low-rank down) then the fused GEMM."""
         B, S, C_in = x.shape
         x2 = x.reshape(B * S, C_in)
         if output is None:
             output = torch.empty(B * S, self.out_features, dtype=x.dtype, device=x.device)
-        qx, ascales, lora_act = self.quantize(x2)
+        qx, ascales, lora_act = self.quantize(x2, ln=ln)
         output = self.forward_quant(qx, ascales, lora_act, output)
         return output.reshape(B, S, -1)
 
-    def quantize(self, x: torch.Tensor, pad_size: int = 256):
-        """x [N, in] -> (FP6 code image [N_pad, 3*in/4] uint8, ascales [in/64, N_pad], lora_act [N_pad, rank] f32)."""
+    def quantize(self, x: torch.Tensor, pad_size: int = 256, ln=None):
+        """x [N, in] -> (FP6 code image [N_pad, 3*in/4] uint8, ascales [in/64, N_pad], lora_act [N_pad, rank] f32).
+        ``ln = (stats, scale, shift)``: quantise ``layer_norm(x) * (1 + scale) + shift`` (fused AdaLayerNormZero)."""
         self._ensure_layout()
         return svdq_quantize_w4a4_act_fuse_lora_cuda(
-            x, lora_down=self.proj_down, smooth=self.smooth_factor, fp4=False, pad_size=pad_size
+            x, lora_down=self.proj_down, smooth=self.smooth_factor, fp4=False, pad_size=pad_size, ln=ln
         )
 
     def forward_quant(self, quantized_x, ascales, lora_act, output: torch.Tensor | None = None) -> torch.Tensor:

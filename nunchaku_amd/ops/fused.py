@@ -8,14 +8,14 @@ from ..utils import ceil_divide
 from .gemm import svdq_gemm_w4a4_cuda
 
 
-def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256) -> torch.Tensor:
+def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256, ln=None) -> torch.Tensor:
     """MLP ``fc2(gelu(fc1(x)))`` in three launches: quantise, fc1 GEMM whose epilogue applies GELU,
     re-quantises to unsigned 4-bit (shift 0.171875) and computes fc2's low-rank down projection,
     then the fc2 GEMM on those codes."""
     B, S, C_in = x.shape
     M = B * S
     x2 = x.reshape(M, C_in)
-    qx, ascales, lora_act = fc1.quantize(x2)
+    qx, ascales, lora_act = fc1.quantize(x2, ln=ln)  # ln: fused AdaLayerNormZero front end (extension)
     M_pad = ceil_divide(M, pad_size) * pad_size
     dev = x.device
     q_hidden = torch.empty(M_pad, fc1.out_features * 3 // 4, dtype=torch.uint8, device=dev)  # FP6 operand image
@@ -34,7 +34,7 @@ def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256) -> torch.Tens
 
 
 def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rotary_emb: torch.Tensor | None = None,
-                           output=None, attn_tokens: int = 0, out_vt: torch.Tensor | None = None):
+                           output=None, attn_tokens: int = 0, out_vt: torch.Tensor | None = None, ln=None):
     """QKV projection with RMSNorm(q), RMSNorm(k) and rotary embedding applied in the GEMM epilogue.
     ``rotary_emb`` is the ``pack_rotemb`` tensor of the reference ([1, M_pad, 128] float32).
     ``out_vt`` ([out_features/3, tokens] view): V is written transposed there for ``ops.attention`` instead of
@@ -42,7 +42,7 @@ def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rota
     B, S, C_in = x.shape
     M = B * S
     x2 = x.reshape(M, C_in)
-    qx, ascales, lora_act = proj.quantize(x2)
+    qx, ascales, lora_act = proj.quantize(x2, ln=ln)
     if isinstance(output, tuple):
         raise NotImplementedError("the reference's packed (q, k, v) tuple is NVIDIA-fragment ordered; pass out_vt= instead")
     if output is None:

@@ -18,6 +18,7 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     fuse_glu: bool = False,
     fp4: bool = False,
     pad_size: int = 256,
+    ln: tuple[torch.Tensor, torch.Tensor, torch.Tensor] | None = None,
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """4-bit quantisation of ``input`` [M, K] plus the low-rank down projection.
 
@@ -25,6 +26,8 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     with ``M_pad = ceil(M / pad_size) * pad_size``.  ``output`` and ``oscales`` are opaque (the FP6
     operand image / scale image of this library: 6 bits per 4-bit code, so the code buffer is 1.5x the
     reference's ``[M_pad, K/2]``); ``lora_act_out`` holds the true fp32 projection.
+    ``ln = (stats, scale, shift)`` (extension): quantise ``layer_norm(input) * (1 + scale) + shift`` computed on
+    the fly from the row statistics of ``ops.elementwise.residual_gate_stats`` -- the AdaLayerNormZero front end.
     """
     if fp4:
         raise NotImplementedError("NVFP4 is not available on MI355X")
@@ -40,5 +43,9 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
         oscales = torch.empty(K // 64, M_pad, dtype=input.dtype, device=dev)
     if lora_act_out is None:
         lora_act_out = torch.empty(M_pad, R, dtype=torch.float32, device=dev)
-    ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4)
+    if ln is None:
+        ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4)
+    else:
+        ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4,
+                                        ln_stats=ln[0], mod_scale=ln[1], mod_shift=ln[2])
     return output, oscales, lora_act_out

@@ -680,3 +680,43 @@ def awq_gemv_w4a16(x: np.ndarray, q: np.ndarray, scales: np.ndarray, zeros: np.n
     if bias is not None:
         y = round16(y + bias[None, :].astype(F32), dtype)
     return y
+
+
+# --------------------------------------------------------------------------
+# Element-wise glue of a block (extension kernels svdq_residual_gate_stats / svdq_quantize_args.ln_stats).
+# The reference's V2 blocks do this with torch ops (transformer_flux_v2.py:118-342, normalization.py:85-98):
+# hidden = addcmul(hidden, gate, out); n = addcmul(shift, layer_norm(hidden), 1 + scale)  -- restated with the
+# same 16-bit rounding points.
+# --------------------------------------------------------------------------
+def _round16_fma(exact64: np.ndarray, dtype: str) -> np.ndarray:
+    """16-bit result of an fp32 fused multiply-add whose exact value is ``exact64``: bf16 goes through the fp32
+    result (two roundings, as torch and the bf16 kernels do); fp16 is rounded ONCE -- gfx950 fuses the fma and the
+    conversion into v_fma_mix*_f16, and torch's half addcmul agrees with it bit for bit (tests)."""
+    if dtype == "fp16":
+        with np.errstate(over="ignore"):
+            return exact64.astype(np.float16).astype(F32)
+    return round16(exact64.astype(F32), dtype)
+
+
+def residual_gate_ref(res: np.ndarray, a: np.ndarray, gate: np.ndarray | None, b: np.ndarray | None, dtype: str) -> np.ndarray:
+    """round16(res + gate * t), t = round16(a + b) if b is given else a (torch.addcmul: fp32 fma, 16-bit result)."""
+    t = a.astype(np.float64) if b is None else round16((a.astype(np.float64) + b.astype(np.float64)).astype(F32), dtype).astype(np.float64)
+    g = 1.0 if gate is None else gate.astype(np.float64)[None, :]
+    return _round16_fma(res.astype(np.float64) + g * t, dtype)
+
+
+def ln_stats_ref(y: np.ndarray, eps: float = RMS_EPS) -> np.ndarray:
+    """[M, 2] float32 (mean, 1/sqrt(var + eps)), population variance, float64 accumulation."""
+    y64 = y.astype(np.float64)
+    mean = y64.mean(axis=1)
+    var = ((y64 - mean[:, None]) ** 2).mean(axis=1)
+    return np.stack([mean, 1.0 / np.sqrt(var + eps)], axis=1).astype(F32)
+
+
+def ln_mod_ref(x: np.ndarray, stats: np.ndarray, scale: np.ndarray, shift: np.ndarray, dtype: str) -> np.ndarray:
+    """round16(shift + round16((x - mean) * rstd) * round16(1 + scale)): F.layer_norm without affine (fp32 math,
+    16-bit output) followed by the 16-bit torch.addcmul(shift, ln, 1 + scale); (x - mean) * rstd in float32."""
+    # (x - mean) rounds to fp32, the product with rstd is then exact in float64 (24 x 24 bits); see _round16_fma for fp16
+    ln = _round16_fma((x.astype(F32) - stats[:, 0:1]).astype(np.float64) * stats[:, 1:2].astype(np.float64), dtype)
+    s1 = round16(F32(1.0) + scale.astype(F32), dtype)
+    return _round16_fma(ln.astype(np.float64) * s1.astype(np.float64)[None, :] + shift.astype(np.float64)[None, :], dtype)

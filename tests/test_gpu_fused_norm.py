@@ -1,0 +1,97 @@
+"""GPU tests of the fused AdaLayerNormZero front end (LayerNorm + modulation inside the quantiser) and of the gated
+residual + statistics pass, against the numpy restatement of the torch-op sequence the reference blocks use."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import svdq_oracle as O
+from tests.helpers import TORCH_DT, f32, make_module, t16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu(built_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,C,with_b", [(5, 256, False), (300, 3072, True), (64, 1536, False)])
+def test_residual_gate_stats(dtype, M, C, with_b):
+    from nunchaku_amd.ops.elementwise import residual_gate_stats
+
+    rng = np.random.default_rng(M + C)
+    res = O.round16(rng.standard_normal((M, C)).astype(np.float32) * 3, dtype)
+    a = O.round16(rng.standard_normal((M, C)).astype(np.float32), dtype)
+    b = O.round16(rng.standard_normal((M, C)).astype(np.float32), dtype) if with_b else None
+    gate = O.round16(rng.standard_normal(C).astype(np.float32), dtype)
+    ref = O.residual_gate_ref(res, a, gate, b, dtype)
+    tr = t16(res, dtype)
+    y, st = residual_gate_stats(tr, t16(a, dtype), t16(gate, dtype), None if b is None else t16(b, dtype))
+    assert y.data_ptr() == tr.data_ptr()  # in place
+    assert np.array_equal(f32(y), ref)  # same fp32 fma, same rounding: bit exact
+    sref = O.ln_stats_ref(ref)
+    np.testing.assert_allclose(st.cpu().numpy(), sref, rtol=2e-6, atol=2e-6)
+    # statistics only
+    y2, st2 = residual_gate_stats(t16(res, dtype))
+    np.testing.assert_allclose(st2.cpu().numpy(), O.ln_stats_ref(res), rtol=2e-6, atol=2e-6)
+    # the torch-op sequence it replaces
+    t = t16(a, dtype) if b is None else t16(a, dtype) + t16(b, dtype)
+    assert torch.equal(y, torch.addcmul(t16(res, dtype), t16(gate, dtype)[None], t))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,K", [(256, 256), (300, 384), (512, 3072)])
+def test_quantize_with_fused_layernorm_modulation(dtype, M, K):
+    from tests.test_gpu_parity import _gemm_inputs
+
+    L, x = _gemm_inputs(M, K, 128, 32, dtype, seed=M + K)
+    rng = np.random.default_rng(3)
+    x = O.round16(x * 2 + 0.5, dtype)
+    scale = O.round16(rng.standard_normal(K).astype(np.float32) * 0.3, dtype)
+    shift = O.round16(rng.standard_normal(K).astype(np.float32) * 0.2, dtype)
+    stats = O.ln_stats_ref(x)
+    mod = make_module(L, dtype)
+    q, asc, la = mod.quantize(t16(x, dtype), ln=(torch.from_numpy(stats).cuda(), t16(scale, dtype), t16(shift, dtype)))
+    xn = O.ln_mod_ref(x, stats, scale, shift, dtype)
+    rq, ra, rl = O.quantize_w4a4_act_fuse_lora(xn, L["smooth"], L["proj_down"], dtype)
+    from nunchaku_amd import layout
+    assert np.array_equal(layout.unpack_act(q, K).cpu().numpy(), rq)
+    assert np.array_equal(f32(layout.unpack_scales(asc, q.shape[0])), ra)
+    np.testing.assert_allclose(la.cpu().numpy()[:M], rl[:M], rtol=2e-3, atol=2e-3 * float(np.abs(rl).max()))
+    # and it is what the unfused torch sequence produces
+    tx = t16(x, dtype)
+    n = torch.addcmul(t16(shift, dtype)[None], torch.nn.functional.layer_norm(tx, (K,), eps=1e-6), 1 + t16(scale, dtype)[None])
+    q2, _, _ = mod.quantize(n)
+    agree = (layout.unpack_act(q2, K) == layout.unpack_act(q, K)).float().mean().item()
+    assert agree > 0.999, f"fused vs torch LayerNorm + addcmul: {agree:.5f} of the codes agree"
+
+
+def test_flux_transformer_fused_norm_vs_torch_ops():
+    from nunchaku_amd.models.flux import FluxTransformerAMD
+
+    torch.manual_seed(3)
+    model = FluxTransformerAMD(num_layers=1, num_single_layers=2, dim=256, heads=2, in_channels=64, joint_attention_dim=128,
+                               pooled_projection_dim=64, device="cuda")
+    model.init_synthetic_(seed=1)
+    model.eval()
+    side, t_txt = 16, 128
+    lat = torch.randn(1, side * side, 64, device="cuda").bfloat16()
+    enc = torch.randn(1, t_txt, 128, device="cuda").bfloat16()
+    pooled = torch.randn(1, 64, device="cuda").bfloat16()
+    img_ids = torch.zeros(side * side, 3, device="cuda")
+    img_ids[:, 1] = torch.arange(side, device="cuda").repeat_interleave(side)
+    img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
+    txt_ids = torch.zeros(t_txt, 3, device="cuda")
+    t, gd = torch.tensor([0.7], device="cuda"), torch.tensor([3.5], device="cuda")
+    outs = {}
+    try:
+        for fused in (True, False):
+            FluxTransformerAMD.fused_norm = fused
+            with torch.no_grad():
+                outs[fused] = model(lat, enc, pooled, t, img_ids, txt_ids, gd)[0].float()
+    finally:
+        FluxTransformerAMD.fused_norm = True
+    rel = ((outs[True] - outs[False]).norm() / outs[False].norm()).item()
+    assert torch.isfinite(outs[True]).all() and rel < 5e-2, f"fused vs torch-op AdaLayerNormZero: relative L2 {rel:.3g}"
