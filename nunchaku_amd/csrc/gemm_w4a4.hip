@@ -570,14 +570,20 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 amax = fmaxf(amax, __shfl_xor(amax, 32));
                 const float scale = amax * (1.0f / 15.0f);
                 const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
-                uint32_t rec[6] = {0, 0, 0, 0, 0, 0};
+                // codes 0..15 as FP6 e2m3 (= code/8 <= 1.875, exact), 32 x 6 bits in one v_cvt_scalef32_2xpk16_fp6_f32
+                // (quantize.hip; element 2i from the first source, 2i+1 from the second; RNE).  The shifted GELU
+                // output is >= 0 up to rounding; a negative x_hat (possible when smooth < 0 is not: smooth > 0) is
+                // clamped to 0 first as the reference's unsigned saturation does.
+                v16f ev, od;
 #pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    const uint32_t code = (uint32_t)fminf(fmaxf(rintf(xh[j] * rscale), 0.f), 15.f);
-                    const int bit = 6 * j;
-                    rec[bit >> 5] |= code << (bit & 31);
-                    if ((bit & 31) > 26) rec[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                for (int i = 0; i < 16; i++) {
+                    ev[i] = fmaxf(xh[2 * i] * rscale, 0.f);
+                    od[i] = fmaxf(xh[2 * i + 1] * rscale, 0.f);
                 }
+                const v6i pk = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, 8.0f);
+                uint32_t rec[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) rec[i] = (uint32_t)pk[i];
                 const int m_abs = mw0 + mi * 32 + lr;
                 uint8_t *dst = p.qout + ((size_t)(m_abs >> 5) * KP2 + (g2 >> 1)) * F6_CHUNK + (size_t)lane * 16;
                 if ((g2 & 1) == 0) {

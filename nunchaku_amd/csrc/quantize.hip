@@ -16,11 +16,12 @@
 // in LDS in a fixed order and added to lora_act with fp32 atomics when K is split over several
 // workgroups (the reference reduces K/128 CTAs the same way, lora.cuh:253-339).
 #include "svdq_common.h"
+#include <stdlib.h>
 
 namespace svdq {
 
-template <int DT, int RT32 /* 32-rank tiles held in registers */>
-__global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::T *__restrict__ x,
+template <int DT, int RT32 /* 32-rank tiles held in registers */, int OCC /* workgroups per CU the register budget allows */>
+__global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<DT>::T *__restrict__ x,
                                                        const typename Half<DT>::T *__restrict__ smooth,
                                                        const typename Half<DT>::T *__restrict__ lora_down, // [R][K]
                                                        uint8_t *__restrict__ act,
@@ -170,14 +171,19 @@ __global__ __launch_bounds__(256) void quantize_kernel(const typename Half<DT>::
             const float scale = amax * (1.0f / 7.0f);
             const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
             sc16[grp] = f2h<T>(scale);
+            // q = rne(x_hat / scale) as FP6 e2m3 = q/8, packed 32 x 6 bits: ONE v_cvt_scalef32_2xpk16_fp6_f32 (scale 8 =
+            // divide by 2^3; element 2i from the first source, 2i+1 from the second; RNE; |x_hat/scale| <= 7 by
+            // construction so the -8..7 clamp never fires; probed on gfx950 with tools/ubench5.hip) instead of
+            // rint / clamp / sign-magnitude encode / shift / or per element
+            v16f ev, od;
 #pragma unroll
-            for (int j = 0; j < 32; j++) {
-                const int q = (int)fminf(fmaxf(rintf(xh[j] * rscale), -8.f), 7.f);
-                const uint32_t code = f6_enc_s4(q);
-                const int bit = 192 * grp + 6 * j;
-                rec[bit >> 5] |= code << (bit & 31);
-                if ((bit & 31) > 26) rec[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+            for (int i = 0; i < 16; i++) {
+                ev[i] = xh[2 * i] * rscale;
+                od[i] = xh[2 * i + 1] * rscale;
             }
+            const v6i pk = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, 8.0f);
+#pragma unroll
+            for (int i = 0; i < 6; i++) rec[6 * grp + i] = (uint32_t)pk[i];
         }
         uint8_t *dst = act + ((size_t)rt * KP + kp) * F6_CHUNK + (size_t)lane * 16;
         *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
@@ -219,7 +225,8 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     using T = typename Half<DT>::T;
     const int KP = a->K / 128, tiles = a->M_pad / 32;
     // enough workgroups to fill 256 CUs several times over, but at least one chunk per wave
-    int cpw = 4; // chunks per workgroup = 4 waves x 1 chunk: many short waves hide the HBM round trip
+    static const int cpw_env = getenv("SVDQ_QUANT_CPW") ? atoi(getenv("SVDQ_QUANT_CPW")) : 0; // experiment knob
+    int cpw = cpw_env > 0 ? cpw_env : 4; // chunks per workgroup = 4 waves x 1 chunk: many short waves hide the HBM round trip
     while ((long)tiles * ((KP + cpw - 1) / cpw) > 8192) cpw *= 2;
     if (cpw > KP) cpw = ((KP + 3) / 4) * 4;
     const int slices = (KP + cpw - 1) / cpw;
@@ -231,8 +238,14 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     }
     dim3 grid(tiles * slices), block(256);
     const int rt32 = (a->R + 31) / 32;
+    static const int occ_env = getenv("SVDQ_QUANT_OCC") ? atoi(getenv("SVDQ_QUANT_OCC")) : 0; // experiment knob
 #define SVDQ_LAUNCH_Q(RT)                                                                                            \
-    hipLaunchKernelGGL((quantize_kernel<DT, RT>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,          \
+    if (RT <= 2 && occ_env != 1)                                                                                     \
+    hipLaunchKernelGGL((quantize_kernel<DT, RT, (RT <= 2 ? 4 : 1)>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth, \
+                       (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
+                       a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift);          \
+    else                                                                                                             \
+    hipLaunchKernelGGL((quantize_kernel<DT, RT, 1>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,          \
                        (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
                        a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift)
     if (rt32 == 0) SVDQ_LAUNCH_Q(0);
