@@ -91,10 +91,11 @@ typedef struct svdq_quantize_args {
     int32_t fuse_glu;      /* must be 0 (SVDQ_E_UNSUPPORTED otherwise; not on the FLUX path)  */
     int32_t fp4;           /* must be 0 (NVFP4 is Blackwell-only)                             */
     /* Optional fused AdaLayerNormZero front end (extension; all three or none).  The quantiser then reads
-     *   x' = round16(mod_shift + round16((x - mean) * rstd) * round16(1 + mod_scale))
-     * in place of x -- bit for bit what F.layer_norm(x) (no affine) followed by the 16-bit
-     * torch.addcmul(shift, ln, 1 + scale) of the reference's blocks produces
-     * (nunchaku/models/normalization.py:85-98,155-165) -- for the low-rank projection and the codes alike. */
+     *   x' = round16(round16(round16((x - mean) * rstd) * mod_scale) + mod_shift)
+     * in place of x -- the rounding points of the reference's 16-bit torch ops `norm(x) * scale[:, None] +
+     * shift[:, None]` (nunchaku/models/normalization.py:85-98,155-165, transformer_flux_v2.py:233-234; nunchaku
+     * checkpoints carry the +1 of the scale inside the modulation bias, scale_shift = 0) -- for the low-rank
+     * projection and the codes alike. */
     const float *ln_stats; /* [M, 2] fp32 (mean, rstd) per row, e.g. from svdq_residual_gate_stats     */
     const void *mod_scale; /* [K] 16-bit                                                              */
     const void *mod_shift; /* [K] 16-bit                                                              */
@@ -193,10 +194,10 @@ int svdq_attention(const svdq_attention_args *args, void *stream);
 /* ------------------------------------------------------------------------------------------
  * Gated residual + LayerNorm statistics (extension; the element-wise glue between the operators of a block,
  * transformer_flux_v2.py:118-342):
- *   t = b ? round16(a + b) : a;      y = a ? round16(res + (gate ? gate[c] : 1) * t) : res;
+ *   t = b ? round16(a + b) : a;      if (gate) t = round16(gate[c] * t);      y = a ? round16(res + t) : res;
  *   out[m, :] = y (if out);          stats[m] = (mean(y), 1/sqrt(var(y) + eps)) over the 16-bit values (if stats)
- * i.e. torch.addcmul(res, gate, a) (or with a.add_(b) first) with the statistics the next LayerNorm needs
- * produced in the same pass.  out may alias res.  C must be a multiple of 8 with ceil(C/512) in {1..8, 12, 16, 24, 32}.
+ * i.e. the reference's 16-bit torch ops `residual + gate.unsqueeze(1) * (attn [+ mlp])`
+ * (transformer_flux_v2.py:230-251,332-335) with the statistics the next LayerNorm needs produced in the same pass.  out may alias res.  C must be a multiple of 8 with ceil(C/512) in {1..8, 12, 16, 24, 32}.
  * ------------------------------------------------------------------------------------------ */
 typedef struct svdq_residual_args {
     const void *res;   /* [M, C] 16-bit, row stride ld */

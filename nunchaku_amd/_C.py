@@ -58,7 +58,7 @@ class _Ops:
         """reference: csrc/ops.h:83-112 -> kernels::quantize_w4a4_act_fuse_lora (zgemm.h:39-46).
 
         ``ln_stats`` / ``mod_scale`` / ``mod_shift`` (extension, all or none): quantise
-        ``addcmul(shift, layer_norm(input), 1 + scale)`` instead of ``input`` without materialising it;
+        ``layer_norm(input) * scale + shift`` (16-bit torch-op rounding, scale with the +1 included) instead of ``input``;
         ``ln_stats`` is the ``[M, 2]`` float32 (mean, rstd) tensor ``ops.residual_gate_stats`` returns."""
         lib = _lib.load()
         if input is None or output is None or oscales is None:
@@ -195,7 +195,7 @@ class _Ops:
 
     @staticmethod
     def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6):
-        """Extension: ``out = res + gate * (a [+ b])`` (the 16-bit ``torch.addcmul`` of a block's gated residual)
+        """Extension: ``out = res + gate * (a [+ b])`` (16-bit torch-op rounding of a block's gated residual)
         and/or the LayerNorm statistics ``stats[m] = (mean, rstd)`` of the result, in one pass.  2-D row-major
         views with a common row stride; ``a`` None = statistics of ``res`` itself; ``out`` may be ``res``."""
         lib = _lib.load()

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
                 else xv[grp][tc] = u16x4{0, 0, 0, 0};
                 if (smooth) sv[grp][tc] = *reinterpret_cast<const u16x4 *>(smooth + kbase + 8 * tc);
             }
-            if (ln_stats) { // x <- round16(shift + round16((x - mean) * rstd) * round16(1 + scale)); padded rows stay 0
+            if (ln_stats) { // x <- round16(round16(round16((x - mean) * rstd) * scale) + shift); padded rows stay 0
 #pragma unroll
                 for (int tc = 0; tc < 8; tc++) {
                     const u16x4 ms = *reinterpret_cast<const u16x4 *>(mod_scale + kbase + 8 * tc);
@@ -85,8 +85,7 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const float ln = round16<T>((h2f(hfrom<T>(xv[grp][tc][e])) - ln_mean) * ln_rstd);
-                        const float s1 = round16<T>(1.0f + h2f(hfrom<T>(ms[e])));
-                        const float y = __builtin_fmaf(ln, s1, h2f(hfrom<T>(mh[e])));
+                        const float y = round16<T>(ln * h2f(hfrom<T>(ms[e]))) + h2f(hfrom<T>(mh[e]));
                         if (valid) xv[grp][tc][e] = hbits(f2h<T>(y));
                     }
                 }

@@ -2,7 +2,9 @@
 // NEXT LayerNorm produced in the same pass (extension; reference blocks: transformer_flux_v2.py:118-342 use
 // torch ops: hidden + gate * attn_out, LayerNorm, (1 + scale) * x + shift).
 //
-//   t = b ? round16(a + b) : a;   y = a ? round16(res + gate * t) : res;   out = y;   stats = (mean, rstd) of y
+//   t = b ? round16(a + b) : a;   y = a ? round16(res + round16(gate * t)) : res;   out = y;   stats = (mean, rstd) of y
+// (the rounding points of the reference's 16-bit torch ops: `attn + mlp`, `gate * x`, `residual + x`,
+//  transformer_flux_v2.py:230-251,332-335)
 //
 // HBM-bound: one pass over the row (3 reads + 1 write of 2 bytes per element); one wave per row keeps the whole
 // row in registers (C <= 16384), so mean and variance are the exact two-pass formulas on the stored 16-bit values
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint16_t *__restric
             for (int e = 0; e < 8; e++) {
                 float t = h2f(hfrom<T>(av[e]));
                 if (b) t = round16<T>(t + h2f(hfrom<T>(bv[e])));
-                const float g = gate ? h2f(hfrom<T>(gv[e])) : 1.0f;
-                y[v][e] = round16<T>(__builtin_fmaf(g, t, h2f(hfrom<T>(rv[e]))));
+                if (gate) t = round16<T>(h2f(hfrom<T>(gv[e])) * t);
+                y[v][e] = round16<T>(h2f(hfrom<T>(rv[e])) + t);
             }
         } else {
 #pragma unroll

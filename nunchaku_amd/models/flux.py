@@ -133,8 +133,9 @@ class FluxJointBlockAMD(nn.Module):
 
     @staticmethod
     def _ln_mod(x, scale, shift):
-        # AdaLayerNormZero: LN(x) * (1 + scale) + shift as LN + one fused multiply-add
-        return torch.addcmul(shift[:, None], F.layer_norm(x, (x.shape[-1],), eps=1e-6), 1 + scale[:, None])
+        # NunchakuAdaLayerNormZero with scale_shift = 0 (normalization.py:85-98): the checkpoint's modulation bias
+        # already carries the +1 of the scale
+        return F.layer_norm(x, (x.shape[-1],), eps=1e-6) * scale[:, None] + shift[:, None]
 
     def forward(self, hidden, encoder_hidden, temb_act, rotary, stats=None):
         """``stats`` = (image-stream, text-stream) LayerNorm statistics of the inputs: the fused path -- LayerNorm and
@@ -149,12 +150,12 @@ class FluxJointBlockAMD(nn.Module):
             n_h = self._ln_mod(hidden, scale_msa, shift_msa)
             n_e = self._ln_mod(encoder_hidden, c_scale_msa, c_shift_msa)
             a, ca = self.attn(n_h, n_e, rotary)
-            hidden = torch.addcmul(hidden, gate_msa[:, None], a)
+            hidden = hidden + gate_msa[:, None] * a  # transformer_flux_v2.py:230-251, op for op
             n_h = self._ln_mod(hidden, scale_mlp, shift_mlp)
-            hidden = torch.addcmul(hidden, gate_mlp[:, None], self.ff(n_h))
-            encoder_hidden = torch.addcmul(encoder_hidden, c_gate_msa[:, None], ca)
+            hidden = hidden + gate_mlp[:, None] * self.ff(n_h)
+            encoder_hidden = encoder_hidden + c_gate_msa[:, None] * ca
             n_e = self._ln_mod(encoder_hidden, c_scale_mlp, c_shift_mlp)
-            encoder_hidden = torch.addcmul(encoder_hidden, c_gate_mlp[:, None], self.ff_context(n_e))
+            encoder_hidden = encoder_hidden + c_gate_mlp[:, None] * self.ff_context(n_e)
             return encoder_hidden, hidden, None
         h_stats, e_stats = stats
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.mod(temb_act).view(-1, 6).t().contiguous()
@@ -179,10 +180,10 @@ class FluxSingleBlockAMD(nn.Module):
     def forward(self, hidden, temb_act, rotary, stats=None):
         if stats is None:
             shift, scale, gate = self.mod(temb_act).view(temb_act.shape[0], -1, 3).permute(2, 0, 1)
-            n = torch.addcmul(shift[:, None], F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6), 1 + scale[:, None])
+            n = F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6) * scale[:, None] + shift[:, None]
             mlp = fused_gelu_mlp(n, self.mlp_fc1, self.mlp_fc2)
             att = self.attn(n, rotary=rotary)
-            return torch.addcmul(hidden, gate[:, None], att.add_(mlp)), None
+            return hidden + gate[:, None] * (att + mlp), None  # transformer_flux_v2.py:332-335
         shift, scale, gate = self.mod(temb_act).view(-1, 3).t().contiguous()
         ln = (stats, scale, shift)  # one LayerNorm + modulation, consumed by both projections' quantisers
         mlp = fused_gelu_mlp(hidden, self.mlp_fc1, self.mlp_fc2, ln=ln)
@@ -251,7 +252,11 @@ class FluxTransformerAMD(nn.Module):
                 m.qweight.copy_(torch.randint(-2 ** 31, 2 ** 31, m.qweight.shape, generator=g, device=dev, dtype=torch.int64))
                 m.wscales.copy_((uni(m.wscales.shape) * 0.5 + 0.75) * sc)
                 m.wzeros.copy_(m.wscales.float() * -7.5)
+                # nunchaku checkpoints carry the +1 of every modulation scale in the bias (scale_shift = 0,
+                # normalization.py:24-25): chunks (shift, SCALE, gate[, shift, SCALE, gate]) are interleaved per channel
                 m.bias.zero_()
+                chunks = m.out_features // m.in_features
+                m.bias.view(-1, chunks)[:, 1::3] = 1.0
             elif isinstance(m, nn.Linear):
                 m.weight.copy_(rnd(m.weight.shape, 1.0 / math.sqrt(m.in_features)))
                 m.bias.zero_()

@@ -131,7 +131,7 @@ class SVDQW4A4Linear(nn.Module):
 
     def quantize(self, x: torch.Tensor, pad_size: int = 256, ln=None):
         """x [N, in] -> (FP6 code image [N_pad, 3*in/4] uint8, ascales [in/64, N_pad], lora_act [N_pad, rank] f32).
-        ``ln = (stats, scale, shift)``: quantise ``layer_norm(x) * (1 + scale) + shift`` (fused AdaLayerNormZero)."""
+        ``ln = (stats, scale, shift)``: quantise ``layer_norm(x) * scale + shift`` (fused AdaLayerNormZero, scale incl. +1)."""
         self._ensure_layout()
         return svdq_quantize_w4a4_act_fuse_lora_cuda(
             x, lora_down=self.proj_down, smooth=self.smooth_factor, fp4=False, pad_size=pad_size, ln=ln

@@ -10,7 +10,7 @@ from .._C import ops
 
 def residual_gate_stats(res: torch.Tensor, a: torch.Tensor | None = None, gate: torch.Tensor | None = None,
                         b: torch.Tensor | None = None, inplace: bool = True, want_stats: bool = True, eps: float = 1e-6):
-    """``y = res + gate * (a [+ b])`` (16-bit ``torch.addcmul`` semantics; ``a`` None: ``y = res``) and the row
+    """``y = res + gate * (a [+ b])`` (one 16-bit rounding per torch op, as the reference's blocks; ``a`` None: ``y = res``) and the row
     statistics ``[rows, 2]`` float32 (mean, rstd) of ``y`` for a following ``quantize(..., ln=...)``.
     Tensors are ``[..., C]`` contiguous; returns ``(y, stats)``."""
     C = res.shape[-1]

@@ -26,7 +26,7 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     with ``M_pad = ceil(M / pad_size) * pad_size``.  ``output`` and ``oscales`` are opaque (the FP6
     operand image / scale image of this library: 6 bits per 4-bit code, so the code buffer is 1.5x the
     reference's ``[M_pad, K/2]``); ``lora_act_out`` holds the true fp32 projection.
-    ``ln = (stats, scale, shift)`` (extension): quantise ``layer_norm(input) * (1 + scale) + shift`` computed on
+    ``ln = (stats, scale, shift)`` (extension): quantise ``layer_norm(input) * scale + shift`` computed on
     the fly from the row statistics of ``ops.elementwise.residual_gate_stats`` -- the AdaLayerNormZero front end.
     """
     if fp4:

@@ -685,13 +685,13 @@ def awq_gemv_w4a16(x: np.ndarray, q: np.ndarray, scales: np.ndarray, zeros: np.n
 # --------------------------------------------------------------------------
 # Element-wise glue of a block (extension kernels svdq_residual_gate_stats / svdq_quantize_args.ln_stats).
 # The reference's V2 blocks do this with torch ops (transformer_flux_v2.py:118-342, normalization.py:85-98):
-# hidden = addcmul(hidden, gate, out); n = addcmul(shift, layer_norm(hidden), 1 + scale)  -- restated with the
-# same 16-bit rounding points.
+# hidden = hidden + gate * out; n = layer_norm(hidden) * scale + shift  -- restated with the same 16-bit rounding points.
 # --------------------------------------------------------------------------
 def _round16_fma(exact64: np.ndarray, dtype: str) -> np.ndarray:
-    """16-bit result of an fp32 fused multiply-add whose exact value is ``exact64``: bf16 goes through the fp32
-    result (two roundings, as torch and the bf16 kernels do); fp16 is rounded ONCE -- gfx950 fuses the fma and the
-    conversion into v_fma_mix*_f16, and torch's half addcmul agrees with it bit for bit (tests)."""
+    """16-bit result of ONE fp32 operation (add / mul / fma of 16-bit operands) whose exact value is ``exact64``:
+    bf16 goes through the fp32 result (two roundings, as torch and the bf16 kernels do); fp16 is rounded ONCE --
+    the gfx950 backend folds the fp32 operation and the conversion into v_fma_mix*_f16, in torch's half kernels
+    and in ours alike (the GPU tests compare both bit for bit)."""
     if dtype == "fp16":
         with np.errstate(over="ignore"):
             return exact64.astype(np.float16).astype(F32)
@@ -699,10 +699,12 @@ def _round16_fma(exact64: np.ndarray, dtype: str) -> np.ndarray:
 
 
 def residual_gate_ref(res: np.ndarray, a: np.ndarray, gate: np.ndarray | None, b: np.ndarray | None, dtype: str) -> np.ndarray:
-    """round16(res + gate * t), t = round16(a + b) if b is given else a (torch.addcmul: fp32 fma, 16-bit result)."""
-    t = a.astype(np.float64) if b is None else round16((a.astype(np.float64) + b.astype(np.float64)).astype(F32), dtype).astype(np.float64)
-    g = 1.0 if gate is None else gate.astype(np.float64)[None, :]
-    return _round16_fma(res.astype(np.float64) + g * t, dtype)
+    """round16(res + round16(gate * t)), t = round16(a + b) if b is given else a: the reference's 16-bit torch ops
+    ``residual + gate.unsqueeze(1) * (attn [+ mlp])`` (transformer_flux_v2.py:230-251, 332-335), one rounding each."""
+    t = a.astype(np.float64) if b is None else _round16_fma(a.astype(np.float64) + b.astype(np.float64), dtype).astype(np.float64)
+    if gate is not None:
+        t = round16((gate.astype(np.float64)[None, :] * t).astype(F32), dtype).astype(np.float64)  # product exact in fp32
+    return _round16_fma(res.astype(np.float64) + t, dtype)
 
 
 def ln_stats_ref(y: np.ndarray, eps: float = RMS_EPS) -> np.ndarray:
@@ -714,9 +716,10 @@ def ln_stats_ref(y: np.ndarray, eps: float = RMS_EPS) -> np.ndarray:
 
 
 def ln_mod_ref(x: np.ndarray, stats: np.ndarray, scale: np.ndarray, shift: np.ndarray, dtype: str) -> np.ndarray:
-    """round16(shift + round16((x - mean) * rstd) * round16(1 + scale)): F.layer_norm without affine (fp32 math,
-    16-bit output) followed by the 16-bit torch.addcmul(shift, ln, 1 + scale); (x - mean) * rstd in float32."""
+    """round16(round16(round16((x - mean) * rstd) * scale) + shift): F.layer_norm without affine (fp32 math, 16-bit
+    output) followed by the reference's 16-bit ``norm_x * scale[:, None] + shift[:, None]`` (normalization.py:96,164;
+    the checkpoint's scale already contains the +1, scale_shift = 0); (x - mean) * rstd in float32."""
     # (x - mean) rounds to fp32, the product with rstd is then exact in float64 (24 x 24 bits); see _round16_fma for fp16
     ln = _round16_fma((x.astype(F32) - stats[:, 0:1]).astype(np.float64) * stats[:, 1:2].astype(np.float64), dtype)
-    s1 = round16(F32(1.0) + scale.astype(F32), dtype)
-    return _round16_fma(ln.astype(np.float64) * s1.astype(np.float64)[None, :] + shift.astype(np.float64)[None, :], dtype)
+    m = round16((ln.astype(np.float64) * scale.astype(np.float64)[None, :]).astype(F32), dtype)  # exact in fp32
+    return _round16_fma(m.astype(np.float64) + shift.astype(np.float64)[None, :], dtype)

@@ -50,7 +50,8 @@ class Ref:
 
     @staticmethod
     def ln_mod(x, scale, shift):
-        return r16(shift[None] + r16(F.layer_norm(x, (x.shape[-1],), eps=1e-6)) * r16(1 + scale)[None])
+        # NunchakuAdaLayerNormZero, scale_shift = 0: norm(x) * scale + shift, one 16-bit rounding per torch op
+        return r16(r16(r16(F.layer_norm(x, (x.shape[-1],), eps=1e-6)) * scale[None]) + shift[None])
 
     @staticmethod
     def attend(qkv, heads):
@@ -80,10 +81,10 @@ class Ref:
                          self.qkv("blocks.0.attn.to_qkv", n_h, b.attn.norm_q.weight, b.attn.norm_k.weight, rot[tt:])])
         o = self.attend(qkv, b.attn.heads)
         a, ca = self.svdq("blocks.0.attn.to_out", o[tt:]), self.svdq("blocks.0.attn.to_add_out", o[:tt])
-        hidden = r16(hidden + r16(mm[2])[None] * a)
-        hidden = r16(hidden + r16(mm[5])[None] * self.mlp("blocks.0.ff.fc1", "blocks.0.ff.fc2", self.ln_mod(hidden, mm[4], mm[3])))
-        e = r16(e + r16(cc[2])[None] * ca)
-        e = r16(e + r16(cc[5])[None] * self.mlp("blocks.0.ff_context.fc1", "blocks.0.ff_context.fc2", self.ln_mod(e, cc[4], cc[3])))
+        hidden = r16(hidden + r16(mm[2][None] * a))
+        hidden = r16(hidden + r16(mm[5][None] * self.mlp("blocks.0.ff.fc1", "blocks.0.ff.fc2", self.ln_mod(hidden, mm[4], mm[3]))))
+        e = r16(e + r16(cc[2][None] * ca))
+        e = r16(e + r16(cc[5][None] * self.mlp("blocks.0.ff_context.fc1", "blocks.0.ff_context.fc2", self.ln_mod(e, cc[4], cc[3]))))
         x = torch.cat([e, hidden])
         s = m.single_blocks[0]
         sm = self.awq("single_blocks.0.mod", ta).view(-1, 3).T
@@ -91,7 +92,7 @@ class Ref:
         mlp = self.mlp("single_blocks.0.mlp_fc1", "single_blocks.0.mlp_fc2", n)
         att = self.svdq("single_blocks.0.attn.to_out",
                         self.attend(self.qkv("single_blocks.0.attn.to_qkv", n, s.attn.norm_q.weight, s.attn.norm_k.weight, rot), s.attn.heads))
-        x = r16(x + r16(sm[2])[None] * r16(att + mlp))[tt:]
+        x = r16(x + r16(sm[2][None] * r16(att + mlp)))[tt:]
         sc, sh = self.lin(m.norm_out_mod, ta).chunk(2, dim=-1)
         x = r16(r16(F.layer_norm(x, (x.shape[-1],), eps=1e-6)) * r16(1 + sc) + sh)
         return self.lin(m.proj_out, x)
@@ -115,7 +116,9 @@ def test_small_flux_transformer_matches_oracle_forward():
                 rng = np.random.default_rng(1000 + len(layers))
                 w = O.round16(rng.standard_normal((mod.out_features, mod.in_features)).astype(np.float32) / mod.in_features ** 0.5, DT)
                 q, s_, z_ = O.awq_quantize_ref(w, DT)
-                bias = O.round16(rng.standard_normal(mod.out_features).astype(np.float32) * 0.02, DT)
+                bias = rng.standard_normal(mod.out_features).astype(np.float32) * 0.02
+                bias.reshape(-1, mod.out_features // mod.in_features)[:, 1::3] += 1.0  # scale chunks carry the +1 (scale_shift = 0)
+                bias = O.round16(bias, DT)
                 layers[name] = {"q": q, "s": s_, "z": z_, "bias": bias}
                 mod.load_state_dict({"qweight": torch.from_numpy(O.pack_awq_w4_ref(q)).cuda(), "wscales": torch.from_numpy(s_).cuda().bfloat16(),
                                      "wzeros": torch.from_numpy(z_).cuda().bfloat16(), "bias": torch.from_numpy(bias).cuda().bfloat16()})

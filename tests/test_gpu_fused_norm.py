@@ -36,9 +36,9 @@ def test_residual_gate_stats(dtype, M, C, with_b):
     # statistics only
     y2, st2 = residual_gate_stats(t16(res, dtype))
     np.testing.assert_allclose(st2.cpu().numpy(), O.ln_stats_ref(res), rtol=2e-6, atol=2e-6)
-    # the torch-op sequence it replaces
+    # the reference's torch-op sequence it replaces (transformer_flux_v2.py:332-335)
     t = t16(a, dtype) if b is None else t16(a, dtype) + t16(b, dtype)
-    assert torch.equal(y, torch.addcmul(t16(res, dtype), t16(gate, dtype)[None], t))
+    assert torch.equal(y, t16(res, dtype) + t16(gate, dtype)[None] * t)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
@@ -49,7 +49,7 @@ def test_quantize_with_fused_layernorm_modulation(dtype, M, K):
     L, x = _gemm_inputs(M, K, 128, 32, dtype, seed=M + K)
     rng = np.random.default_rng(3)
     x = O.round16(x * 2 + 0.5, dtype)
-    scale = O.round16(rng.standard_normal(K).astype(np.float32) * 0.3, dtype)
+    scale = O.round16(1 + rng.standard_normal(K).astype(np.float32) * 0.3, dtype)  # checkpoint convention: +1 included
     shift = O.round16(rng.standard_normal(K).astype(np.float32) * 0.2, dtype)
     stats = O.ln_stats_ref(x)
     mod = make_module(L, dtype)
@@ -62,10 +62,10 @@ def test_quantize_with_fused_layernorm_modulation(dtype, M, K):
     np.testing.assert_allclose(la.cpu().numpy()[:M], rl[:M], rtol=2e-3, atol=2e-3 * float(np.abs(rl).max()))
     # and it is what the unfused torch sequence produces
     tx = t16(x, dtype)
-    n = torch.addcmul(t16(shift, dtype)[None], torch.nn.functional.layer_norm(tx, (K,), eps=1e-6), 1 + t16(scale, dtype)[None])
+    n = torch.nn.functional.layer_norm(tx, (K,), eps=1e-6) * t16(scale, dtype)[None] + t16(shift, dtype)[None]
     q2, _, _ = mod.quantize(n)
     agree = (layout.unpack_act(q2, K) == layout.unpack_act(q, K)).float().mean().item()
-    assert agree > 0.999, f"fused vs torch LayerNorm + addcmul: {agree:.5f} of the codes agree"
+    assert agree > 0.999, f"fused vs torch LayerNorm * scale + shift: {agree:.5f} of the codes agree"
 
 
 def test_flux_transformer_fused_norm_vs_torch_ops():
