@@ -219,7 +219,7 @@ class FluxTransformerAMD(nn.Module):
         return [m for m in self.modules() if isinstance(m, SVDQW4A4Linear)]
 
     @torch.no_grad()
-    def init_synthetic_(self, seed: int = 0):
+    def init_synthetic_(self, seed: int = 0, repack: bool = True):
         """Random-init weights of FLUX shape (no checkpoints in this environment): int4 codes uniform,
         scales/low-rank factors small so activations stay O(1).  Parameters are written in the
         checkpoint layout (random nibbles are random int4 codes) and repacked like a real checkpoint."""
@@ -245,7 +245,8 @@ class FluxTransformerAMD(nn.Module):
                 m.proj_down.copy_(rnd(m.proj_down.shape, 0.5 / math.sqrt(K)))
                 m.proj_up.copy_(rnd(m.proj_up.shape, 0.5 / math.sqrt(m.rank)))
                 m._amd_layout = False
-                m.repack_()
+                if repack:  # False: stay in the checkpoint layout (repacked lazily on first use, like a loaded checkpoint)
+                    m.repack_()
             elif isinstance(m, AWQW4A16Linear):
                 # uniform 4-bit codes (std 4.6) centred by the zero point: weights ~ 1/sqrt(K)
                 sc = 1.0 / (4.6 * math.sqrt(m.in_features))

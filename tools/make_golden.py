@@ -118,6 +118,34 @@ def main():
             f"{OUT}/awq_{N}x{K}.npz", weight=w.float().numpy(), codes=q.numpy().astype(np.uint8),
             packed_int16=pw.numpy(), scales=ps.float().numpy(), zeros=pz.float().numpy(),
         )
+    # --- FLUX checkpoint key conversion: the reference's convert_flux_state_dict on every legacy key name ----------
+    src = open(f"{REF}/nunchaku/models/transformers/transformer_flux_v2.py").read()
+    ns = {"torch": torch}
+    exec(compile(src[src.index("def convert_flux_state_dict"):], "convert_flux_state_dict", "exec"), ns)
+    svdq = ["qweight", "wscales", "bias", "lora_down", "lora_up", "smooth", "smooth_orig", "wtscale", "wcscales"]
+    awq = ["qweight", "wscales", "wzeros", "bias"]
+    keys = []
+    for i in (0, 18):
+        b = f"transformer_blocks.{i}."
+        for mod in ("qkv_proj", "qkv_proj_context", "out_proj", "out_proj_context", "mlp_fc1", "mlp_fc2", "mlp_context_fc1", "mlp_context_fc2"):
+            keys += [f"{b}{mod}.{p}" for p in svdq]
+        for mod in ("norm1.linear", "norm1_context.linear"):
+            keys += [f"{b}{mod}.{p}" for p in awq]
+        keys += [f"{b}{n}.weight" for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k")]
+    for i in (0, 37):
+        b = f"single_transformer_blocks.{i}."
+        for mod in ("qkv_proj", "out_proj", "mlp_fc1", "mlp_fc2"):
+            keys += [f"{b}{mod}.{p}" for p in svdq]
+        keys += [f"{b}norm.linear.{p}" for p in awq] + [f"{b}norm_q.weight", f"{b}norm_k.weight"]
+    for top in ("x_embedder", "context_embedder", "proj_out", "norm_out.linear", "time_text_embed.timestep_embedder.linear_1",
+                "time_text_embed.timestep_embedder.linear_2", "time_text_embed.guidance_embedder.linear_1",
+                "time_text_embed.guidance_embedder.linear_2", "time_text_embed.text_embedder.linear_1",
+                "time_text_embed.text_embedder.linear_2"):
+        keys += [f"{top}.weight", f"{top}.bias"]
+    conv = ns["convert_flux_state_dict"]({k: i for i, k in enumerate(keys)})
+    inv = {v: k for k, v in conv.items()}
+    import json
+    json.dump({k: inv[i] for i, k in enumerate(keys)}, open(f"{OUT}/flux_keys.json", "w"), indent=0, sort_keys=True)
     print("golden fixtures written to", os.path.abspath(OUT))
 
 
