@@ -218,6 +218,26 @@ class FluxTransformerAMD(nn.Module):
     def svdq_layers(self):
         return [m for m in self.modules() if isinstance(m, SVDQW4A4Linear)]
 
+    # runtime LoRA (reference: NunchakuFluxTransformer2dModel.update_lora_params / set_lora_strength,
+    # transformer_flux.py:783-855): per-layer factors in logical layout widen the low-rank branch of that layer
+    def update_lora_params(self, lora: dict, strength: float = 1.0):
+        """``lora``: module name (e.g. ``"blocks.0.attn.to_qkv"``) -> ``(down [r, in], up [out, r])``."""
+        mods = dict(self.named_modules())
+        self.reset_lora()
+        for name, (down, up) in lora.items():
+            if not isinstance(mods.get(name), SVDQW4A4Linear):
+                raise KeyError(f"update_lora_params: {name} is not an SVDQW4A4Linear of this model")
+            mods[name].set_lora(down, up, strength)
+
+    def set_lora_strength(self, strength: float):
+        for m in self.svdq_layers():
+            if m._base_lowrank is not None:
+                m.set_lora_strength(strength)
+
+    def reset_lora(self):
+        for m in self.svdq_layers():
+            m.reset_lora()
+
     @torch.no_grad()
     def init_synthetic_(self, seed: int = 0, repack: bool = True):
         """Random-init weights of FLUX shape (no checkpoints in this environment): int4 codes uniform,

@@ -65,6 +65,10 @@ class SVDQW4A4Linear(nn.Module):
         self.wtscale = None  # nvfp4 only
         self.wcscales = None  # nvfp4 only
         self.act_unsigned = act_unsigned
+        # runtime LoRA (set_lora): one scale per 16 ranks, applied to lora_act in the GEMM epilogue
+        # (reference: GEMM_W4A4::lora_scales, src/Linear.h:98, Linear.cpp:131; ops/gemm.py:125-127)
+        self.lora_scales: list[float] | None = None
+        self._base_lowrank = None
 
         # False while the parameters hold the reference (checkpoint) layout
         self._amd_layout = False
@@ -78,7 +82,8 @@ class SVDQW4A4Linear(nn.Module):
 
     @staticmethod
     def _restore_checkpoint_shapes(module, state_dict, prefix, local_metadata, strict, missing, unexpected, errors):
-        # after repack_() qweight holds the FP6 image; a checkpoint brings [out, in/2] int8 again
+        # a checkpoint brings the base rank and [out, in/2] int8 again: drop a runtime LoRA, undo the FP6 image shape
+        module.reset_lora()
         qw = module.qweight
         if qw.shape[-1] != module.in_features // 2:
             qw.data = torch.empty(module.out_features, module.in_features // 2, dtype=torch.int8, device=qw.device)
@@ -147,9 +152,50 @@ class SVDQW4A4Linear(nn.Module):
         svdq_gemm_w4a4_cuda(
             act=quantized_x, wgt=self.qweight, out=output, ascales=ascales, wscales=self.wscales,
             lora_act_in=lora_act, lora_up=self.proj_up, bias=self.bias, fp4=False, alpha=self.wtscale,
-            wcscales=self.wcscales, act_unsigned=self.act_unsigned,
+            wcscales=self.wcscales, act_unsigned=self.act_unsigned, lora_scales=self.lora_scales,
         )
         return output
+
+    # ------------------------------------------------------------------ runtime LoRA
+    @torch.no_grad()
+    def set_lora(self, down: torch.Tensor, up: torch.Tensor, strength: float = 1.0) -> "SVDQW4A4Linear":
+        """Attach a user LoRA ``W += strength * up @ down`` (``down`` [r, in], ``up`` [out, r], logical layout) by
+        widening the low-rank branch to rank ``R + r`` -- the mechanism of the reference's ``update_lora_params`` /
+        ``set_lora_strength`` (transformer_flux.py:783-855: concatenate along the rank axis, per-16-rank scales).
+        The 4-bit weights are untouched; ``strength`` can be changed later with :meth:`set_lora_strength` for free."""
+        self._ensure_layout()
+        self.reset_lora()
+        r, K = down.shape
+        if K != self.in_features or tuple(up.shape) != (self.out_features, r):
+            raise ValueError("set_lora: expected down [r, in_features] and up [out_features, r]")
+        rp = (r + 15) // 16 * 16
+        R = self.rank
+        if R + rp > 256:
+            raise ValueError(f"set_lora: total rank {R + rp} exceeds 256")
+        dt, dev = self.proj_up.dtype, self.proj_up.device
+        d = torch.zeros(rp, K, dtype=dt, device=dev)
+        d[:r] = down.to(dt)
+        u = torch.zeros(self.out_features, rp, dtype=dt, device=dev)
+        u[:, :r] = up.to(dt)
+        self._base_lowrank = (self.proj_down.data, self.proj_up.data, R)
+        # kernel layouts: proj_down rank-major [R][K] behind a [K, R]-shaped parameter, proj_up natural [N][R]
+        self.proj_down.data = torch.cat([self.proj_down.data.view(R, K), d], dim=0).reshape(K, R + rp)
+        self.proj_up.data = torch.cat([self.proj_up.data, u], dim=1).contiguous()
+        self.rank = R + rp
+        self.lora_scales = [1.0] * (R // 16) + [float(strength)] * (rp // 16)
+        return self
+
+    def set_lora_strength(self, strength: float):
+        if self._base_lowrank is None:
+            raise RuntimeError("set_lora_strength: no LoRA attached")
+        R = self._base_lowrank[2]
+        self.lora_scales = [1.0] * (R // 16) + [float(strength)] * ((self.rank - R) // 16)
+
+    @torch.no_grad()
+    def reset_lora(self):
+        if self._base_lowrank is not None:
+            self.proj_down.data, self.proj_up.data, self.rank = self._base_lowrank
+            self._base_lowrank, self.lora_scales = None, None
 
     def __repr__(self):
         return (

@@ -27,6 +27,7 @@ def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256, ln=None) -> t
         act=qx, wgt=fc1.qweight, qout=q_hidden, ascales=ascales, wscales=fc1.wscales, oscales=s_hidden,
         lora_act_in=lora_act, lora_up=fc1.proj_up, lora_down=fc2.proj_down, lora_act_out=l_hidden,
         bias=fc1.bias, smooth_factor=fc2.smooth_factor, fp4=False, alpha=fc1.wtscale, wcscales=fc1.wcscales,
+        lora_scales=getattr(fc1, "lora_scales", None),
     )
     out = torch.empty(M, fc2.out_features, dtype=x.dtype, device=dev)
     out = fc2.forward_quant(q_hidden, s_hidden, l_hidden, output=out)
@@ -55,6 +56,6 @@ def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rota
         act=qx, wgt=proj.qweight, out=output, ascales=ascales, wscales=proj.wscales, lora_act_in=lora_act,
         lora_up=proj.proj_up, bias=proj.bias, fp4=False, alpha=proj.wtscale, wcscales=proj.wcscales,
         norm_q=None if norm_q is None else norm_q.weight, norm_k=None if norm_k is None else norm_k.weight,
-        rotary_emb=rot, out_vt=out_vt,
+        rotary_emb=rot, out_vt=out_vt, lora_scales=getattr(proj, "lora_scales", None),
     )
     return output.view(B, S, -1)

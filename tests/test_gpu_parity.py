@@ -267,3 +267,35 @@ def test_errors_surface_as_exceptions():
     mod = make_module(O.make_svdq_layer(128, 128, 32, seed=1, cheap=True), "bf16")
     with pytest.raises(ValueError):
         mod(torch.zeros(1, 4, 192, dtype=torch.bfloat16, device="cuda"))  # K mismatch / not a multiple of 128
+
+
+def test_runtime_lora_widens_the_low_rank_branch():
+    """set_lora / set_lora_strength / reset_lora: y(lora) - y(base) = strength * (x down^T) up^T."""
+    dtype, M, K, N, r = "bf16", 300, 256, 384, 24
+    L, x = _gemm_inputs(M, K, N, 32, dtype, seed=31)
+    rng = np.random.default_rng(32)
+    down = O.round16(rng.standard_normal((r, K)).astype(np.float32) / np.sqrt(K), dtype)
+    up = O.round16(rng.standard_normal((N, r)).astype(np.float32) * 0.5, dtype)
+    mod = make_module(L, dtype)
+    tx = t16(x, dtype).view(1, M, K)
+    base = f32(mod(tx))[0]
+    mod.set_lora(t16(down, dtype), t16(up, dtype), strength=0.75)
+    assert mod.rank == 64 and mod.lora_scales == [1.0, 1.0, 0.75, 0.75]
+    got = f32(mod(tx))[0]
+    # oracle with the widened branch: extra ranks, per-16-rank scale on lora_act (lora.cuh:145-158)
+    L2 = dict(L)
+    pad = np.zeros((32 - r, K), np.float32)
+    L2["proj_down"] = np.concatenate([L["proj_down"], np.concatenate([down, pad]).T], axis=1)
+    L2["proj_up"] = np.concatenate([L["proj_up"], up, np.zeros((N, 32 - r), np.float32)], axis=1)
+    q, a, la = O.quantize_w4a4_act_fuse_lora(x, L2["smooth"], L2["proj_down"], dtype)
+    ref = O.gemm_w4a4(q, a, L2["qweight"], L2["wscales"], dtype=dtype, bias=L2["bias"], lora_act_in=la, lora_up=L2["proj_up"],
+                      lora_scales=[1.0, 1.0, 0.75, 0.75])["out"][:M]
+    assert_close_16(got, ref, dtype, "lora", max_bad_frac=2e-3)
+    assert_close_16(got, ref, dtype, "lora(2ulp)", ulps=2.0)
+    delta = 0.75 * (x @ down.T) @ up.T
+    assert np.abs((got - base) - delta).max() <= 0.03 * np.abs(delta).max() + 2.0 ** -6 * np.abs(base).max()
+    mod.set_lora_strength(0.0)
+    assert_close_16(f32(mod(tx))[0], base, dtype, "strength 0", max_bad_frac=2e-3)
+    mod.reset_lora()
+    assert mod.rank == 32 and mod.lora_scales is None
+    assert_close_16(f32(mod(tx))[0], base, dtype, "reset", max_bad_frac=2e-3)
