@@ -266,6 +266,9 @@ int svdq_unpack_scales(const void *simg, void *natural, int32_t ROWS, int32_t G,
  * ------------------------------------------------------------------------------------------ */
 int svdq_prof_enable(int32_t max_launches); /* 0 disables and frees the event pool */
 int svdq_prof_reset(void);
+/* Restrict the bracketing to the kernel classes whose bit is set (default: all).  An event pair costs ~3 us of
+ * queue serialisation per launch, so bench.py brackets only the kernel its roofline line is about. */
+int svdq_prof_select(uint32_t class_mask);
 int svdq_prof_read(int32_t kernel_class, int64_t *launches, double *total_ms, double *total_work);
 
 /* thread-local message of the last failing call on this thread ("" if none) */

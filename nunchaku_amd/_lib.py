@@ -84,6 +84,7 @@ EXPORTS = {
     "svdq_unpack_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_prof_enable": (C.c_int, [C.c_int32]),
     "svdq_prof_reset": (C.c_int, []),
+    "svdq_prof_select": (C.c_int, [C.c_uint32]),
     "svdq_prof_read": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "svdq_last_error": (C.c_char_p, []),
     "svdq_abi_version": (C.c_int, []),

@@ -18,9 +18,10 @@ static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof_pool;
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
+static uint32_t g_prof_mask = 0xffffffffu; // kernel classes that are bracketed (svdq_prof_select)
 
 int prof_begin(int cls, double work, hipStream_t st) {
-    if (!g_prof_on) return -1;
+    if (!g_prof_on || !((g_prof_mask >> cls) & 1u)) return -1;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return -1;
     int i = (int)g_prof_used++;
@@ -249,6 +250,12 @@ int svdq_prof_enable(int32_t max_launches) {
         }
     }
     g_prof_on = true;
+    return SVDQ_OK;
+}
+
+int svdq_prof_select(uint32_t class_mask) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_mask = class_mask;
     return SVDQ_OK;
 }
 
