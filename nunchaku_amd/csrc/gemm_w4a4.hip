@@ -29,6 +29,7 @@
 //     and the low-rank up projection (a 16-bit MFMA issued straight onto the fp32 accumulators) are
 //     added before the single rounding to 16-bit that precedes the activation epilogues.
 #include "svdq_common.h"
+#include <stdlib.h>
 
 namespace svdq {
 
@@ -747,9 +748,11 @@ static int streamk_groups(const GemmParams &p, int tiles, int KP) {
     if (!p.workspace || p.workspace_bytes < workspace_bytes_needed() || (p.debug & 8)) return 0;
     const int R = tiles % cus;
     if (R == 0) return 0;
-    long long gs = (long long)R * 2;
+    static const int max_pieces = getenv("SVDQ_SK_MAXPIECES") ? atoi(getenv("SVDQ_SK_MAXPIECES")) : 2; // experiment knobs
+    static const int min_steps = getenv("SVDQ_SK_MINSTEPS") ? atoi(getenv("SVDQ_SK_MINSTEPS")) : 8;
+    long long gs = (long long)R * max_pieces;
     if (gs > cus) gs = cus;
-    while (gs > R && (long long)R * KP / gs < 8) gs--;
+    while (gs > R && (long long)R * KP / gs < min_steps) gs--;
     if (gs <= R) return 0;
     const double with_sk = (double)R * KP / gs + 10.0, without = (double)KP;
     return with_sk < 0.85 * without ? (int)gs : 0;
