@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
         // ---- every global load of the chunk is issued before anything is consumed (the kernel is
         //      latency-bound otherwise: two dependent round trips per chunk): activations, smoothing factors
         //      and the first 32 ranks of lora_down for both groups
-        u16x4 xv[2][8], sv[2][8], bv[2][4][2];
+        u16x4 xv[2][8], sv[2][8], bv[2][4][2], msv[2][8], mhv[2][8];
 #pragma unroll
         for (int grp = 0; grp < 2; grp++) {
             const int kbase = kp * 128 + grp * 64 + 4 * h; // + 32t + 8c + e
@@ -77,17 +77,11 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
                 else xv[grp][tc] = u16x4{0, 0, 0, 0};
                 if (smooth) sv[grp][tc] = *reinterpret_cast<const u16x4 *>(smooth + kbase + 8 * tc);
             }
-            if (ln_stats) { // x <- round16(round16(round16((x - mean) * rstd) * scale) + shift); padded rows stay 0
+            if (ln_stats) { // modulation vectors of this group: requested with everything else, consumed below
 #pragma unroll
                 for (int tc = 0; tc < 8; tc++) {
-                    const u16x4 ms = *reinterpret_cast<const u16x4 *>(mod_scale + kbase + 8 * tc);
-                    const u16x4 mh = *reinterpret_cast<const u16x4 *>(mod_shift + kbase + 8 * tc);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float ln = round16<T>((h2f(hfrom<T>(xv[grp][tc][e])) - ln_mean) * ln_rstd);
-                        const float y = round16<T>(ln * h2f(hfrom<T>(ms[e]))) + h2f(hfrom<T>(mh[e]));
-                        if (valid) xv[grp][tc][e] = hbits(f2h<T>(y));
-                    }
+                    msv[grp][tc] = *reinterpret_cast<const u16x4 *>(mod_scale + kbase + 8 * tc);
+                    mhv[grp][tc] = *reinterpret_cast<const u16x4 *>(mod_shift + kbase + 8 * tc);
                 }
             }
             if constexpr (RT32 > 0) {
@@ -103,6 +97,18 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
                     }
                 }
             }
+        }
+        if (ln_stats) { // x <- round16(round16(round16((x - mean) * rstd) * scale) + shift); padded rows stay 0
+#pragma unroll
+            for (int grp = 0; grp < 2; grp++)
+#pragma unroll
+                for (int tc = 0; tc < 8; tc++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float ln = round16<T>((h2f(hfrom<T>(xv[grp][tc][e])) - ln_mean) * ln_rstd);
+                        const float y = round16<T>(ln * h2f(hfrom<T>(msv[grp][tc][e]))) + h2f(hfrom<T>(mhv[grp][tc][e]));
+                        if (valid) xv[grp][tc][e] = hbits(f2h<T>(y));
+                    }
         }
 #pragma unroll
         for (int grp = 0; grp < 2; grp++) {
@@ -239,7 +245,7 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     const int rt32 = (a->R + 31) / 32;
     static const int occ_env = getenv("SVDQ_QUANT_OCC") ? atoi(getenv("SVDQ_QUANT_OCC")) : 0; // experiment knob
 #define SVDQ_LAUNCH_Q(RT)                                                                                            \
-    if (RT <= 2 && occ_env != 1)                                                                                     \
+    if (RT <= 2 && occ_env == 4)                                                                                     \
     hipLaunchKernelGGL((quantize_kernel<DT, RT, (RT <= 2 ? 4 : 1)>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth, \
                        (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
                        a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift);          \
