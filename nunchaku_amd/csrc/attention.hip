@@ -132,7 +132,9 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             for (int r = 0; r < 16; r++) s[kt][r] = 0.f;
 #pragma unroll
             for (int ds = 0; ds < 8; ds++) {
-                v4i kw = *(const lds_v4i *)(L8 + (ka[ds] + (BO + kt * 8192)));
+                v4i kw;
+                if constexpr (DBG & 32) kw = __builtin_bit_cast(v4i, qf[(ds + kt) & 7]);
+                else kw = *(const lds_v4i *)(L8 + (ka[ds] + (BO + kt * 8192)));
                 if constexpr (!(DBG & 16)) s[kt] = Half<DT>::mfma32(__builtin_bit_cast(V8, kw), qf[ds], s[kt]);
                 else s[kt][ds] += (float)kw[0];
             }
@@ -194,7 +196,9 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
         for (int dt = 0; dt < 4; dt++) {
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
-                v4i vw = *(const lds_v4i *)(L8 + (va[ks] + (BO + dt * 4096)));
+                v4i vw;
+                if constexpr (DBG & 64) vw = __builtin_bit_cast(v4i, qf[(ks + dt) & 7]);
+                else vw = *(const lds_v4i *)(L8 + (va[ks] + (BO + dt * 4096)));
                 if constexpr (!(DBG & 8)) o[dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw), pf[ks], o[dt]);
                 else o[dt][ks] += (float)vw[0] * (float)__builtin_bit_cast(v4i, pf[ks])[0];
             }
@@ -280,6 +284,13 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
         case 8: launch_attention<SVDQ_BF16, 8, 8>(p, st); break;
         case 16: launch_attention<SVDQ_BF16, 8, 16>(p, st); break;
         case 24: launch_attention<SVDQ_BF16, 8, 24>(p, st); break;
+        case 4: launch_attention<SVDQ_BF16, 8, 4>(p, st); break;
+        case 6: launch_attention<SVDQ_BF16, 8, 6>(p, st); break;
+        case 32: launch_attention<SVDQ_BF16, 8, 32>(p, st); break;
+        case 96: launch_attention<SVDQ_BF16, 8, 96>(p, st); break;
+        case 98: launch_attention<SVDQ_BF16, 8, 98>(p, st); break;
+        case 102: launch_attention<SVDQ_BF16, 8, 102>(p, st); break;
+        case 103: launch_attention<SVDQ_BF16, 8, 103>(p, st); break;
         default: set_error("svdq_attention: unknown debug variant %d", p.debug); return SVDQ_E_INVALID;
         }
     }
