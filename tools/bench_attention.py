@@ -4,7 +4,9 @@ import math, sys, torch, torch.nn.functional as F
 from nunchaku_amd.ops.attention import attention_packed
 
 L, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4608, 24)
+import os
 qkv = torch.randn(L, 3 * H * 128, device="cuda").bfloat16()
+if os.environ.get("ATT_ZERO"): qkv.zero_()  # power / clock experiment: same instructions, no toggling
 vt = qkv[:, 2 * H * 128:].t().contiguous()
 out = torch.empty(L, H * 128, device="cuda", dtype=torch.bfloat16)
 
