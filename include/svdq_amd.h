@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 5
+#define SVDQ_ABI_VERSION 6
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -99,6 +99,9 @@ typedef struct svdq_quantize_args {
     const float *ln_stats; /* [M, 2] fp32 (mean, rstd) per row, e.g. from svdq_residual_gate_stats     */
     const void *mod_scale; /* [K] 16-bit                                                              */
     const void *mod_shift; /* [K] 16-bit                                                              */
+    int32_t lora_act_zeroed; /* non-zero: the caller guarantees lora_act is already zero on this stream (e.g. cleared by
+                                svdq_residual_gate_stats' zero_ptr), so the hipMemsetAsync of the K-sliced reduction is skipped */
+    int32_t reserved;
 } svdq_quantize_args;
 
 int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *args, void *stream);
@@ -210,6 +213,10 @@ typedef struct svdq_residual_args {
     int32_t dtype;
     float eps;
     int32_t reserved;
+    /* optional: zero-fill an unrelated scratch buffer in the same pass (the fp32 low-rank accumulators of the
+     * quantiser / GELU_QUANT calls that follow: saves their memset launches).  zero_bytes must be a multiple of 16. */
+    void *zero_ptr;
+    int64_t zero_bytes;
 } svdq_residual_args;
 
 int svdq_residual_gate_stats(const svdq_residual_args *args, void *stream);

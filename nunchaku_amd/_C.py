@@ -54,7 +54,7 @@ def _workspace(device: torch.device) -> torch.Tensor:
 class _Ops:
     @staticmethod
     def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False,
-                                    ln_stats=None, mod_scale=None, mod_shift=None):
+                                    ln_stats=None, mod_scale=None, mod_shift=None, lora_act_zeroed=False):
         """reference: csrc/ops.h:83-112 -> kernels::quantize_w4a4_act_fuse_lora (zgemm.h:39-46).
 
         ``ln_stats`` / ``mod_scale`` / ``mod_shift`` (extension, all or none): quantise
@@ -83,6 +83,7 @@ class _Ops:
         a.ldx = input.stride(0)
         a.dtype = _DT[input.dtype]
         a.fuse_glu, a.fp4 = int(bool(fuse_glu)), int(bool(fp4))
+        a.lora_act_zeroed = int(bool(lora_act_zeroed))  # extension: lora_act_out already cleared on this stream
         if ln_stats is not None or mod_scale is not None or mod_shift is not None:
             if ln_stats is None or mod_scale is None or mod_shift is None:
                 raise ValueError("quantize_w4a4_act_fuse_lora: ln_stats, mod_scale and mod_shift go together")
@@ -104,7 +105,7 @@ class _Ops:
     def gemm_w4a4(
         act, wgt, out, qout, ascales, wscales, oscales, poolout, lora_act_in, lora_up, lora_down, lora_act_out,
         norm_q, norm_k, rotary_emb, bias, smooth_factor, out_vk, out_linearattn, act_unsigned, lora_scales,
-        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens, out_vt=None,
+        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens, out_vt=None, lora_act_zeroed=False,
     ):
         """reference: csrc/ops.h:10-81 -> kernels::gemm_w4a4 (zgemm.h:8-36).  The epilogue is inferred
         from which optional tensors are present, exactly as gemm_w4a4_launch_impl.cuh:282-423 does.
@@ -160,7 +161,8 @@ class _Ops:
             if lora_down is not None and lora_down.numel() > 0:
                 a.R2 = lora_down.shape[-1]
                 a.next_lora_down, a.lora_act_out = _ptr(lora_down), _ptr(lora_act_out)
-                lora_act_out.zero_()  # launch_impl.cuh:252
+                if not lora_act_zeroed:  # extension: the caller cleared it already (residual_gate_stats(..., zero=))
+                    lora_act_out.zero_()  # launch_impl.cuh:252
         elif rotary_emb is not None:
             if out is None or norm_q is None or norm_k is None:
                 raise ValueError("gemm_w4a4: the RMSNorm+RoPE epilogue needs out, norm_q and norm_k")
@@ -194,7 +196,7 @@ class _Ops:
         del keep
 
     @staticmethod
-    def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6):
+    def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6, zero=None):
         """Extension: ``out = res + gate * (a [+ b])`` (16-bit torch-op rounding of a block's gated residual)
         and/or the LayerNorm statistics ``stats[m] = (mean, rstd)`` of the result, in one pass.  2-D row-major
         views with a common row stride; ``a`` None = statistics of ``res`` itself; ``out`` may be ``res``."""
@@ -216,6 +218,10 @@ class _Ops:
         dp = lambda t: None if t is None else t.data_ptr()
         args.res, args.a, args.b, args.gate, args.out, args.stats = dp(res), dp(a), dp(b), dp(gate), dp(out), dp(stats)
         args.M, args.C, args.ld, args.dtype, args.eps = M, Cc, res.stride(0), _DT[res.dtype], float(eps)
+        if zero is not None:  # scratch cleared in the same pass (fp32 low-rank accumulators of the calls that follow)
+            if not zero.is_cuda or not zero.is_contiguous() or (zero.numel() * zero.element_size()) % 16:
+                raise ValueError("residual_gate_stats: zero must be a contiguous GPU tensor of a multiple of 16 bytes")
+            args.zero_ptr, args.zero_bytes = zero.data_ptr(), zero.numel() * zero.element_size()
         _lib.check(lib.svdq_residual_gate_stats(C.byref(args), _stream()), "residual_gate_stats")
 
     @staticmethod

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class QuantizeArgs(C.Structure):
@@ -22,6 +22,7 @@ class QuantizeArgs(C.Structure):
         ("M", C.c_int32), ("M_pad", C.c_int32), ("K", C.c_int32), ("R", C.c_int32),
         ("ldx", C.c_int32), ("dtype", C.c_int32), ("fuse_glu", C.c_int32), ("fp4", C.c_int32),
         ("ln_stats", C.c_void_p), ("mod_scale", C.c_void_p), ("mod_shift", C.c_void_p),
+        ("lora_act_zeroed", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -29,7 +30,7 @@ class ResidualArgs(C.Structure):
     _fields_ = [
         ("res", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("gate", C.c_void_p), ("out", C.c_void_p),
         ("stats", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("ld", C.c_int32), ("dtype", C.c_int32),
-        ("eps", C.c_float), ("reserved", C.c_int32),
+        ("eps", C.c_float), ("reserved", C.c_int32), ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_int64),
     ]
 
 

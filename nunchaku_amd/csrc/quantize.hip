@@ -236,7 +236,7 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     if (cpw > KP) cpw = ((KP + 3) / 4) * 4;
     const int slices = (KP + cpw - 1) / cpw;
     const int atomics = slices > 1;
-    if (a->R > 0 && atomics) {
+    if (a->R > 0 && atomics && !a->lora_act_zeroed) {
         // the reference zeroes the buffer inside the op as well (launch_impl.cuh:487)
         int rc = hip_check(hipMemsetAsync(a->lora_act, 0, (size_t)a->M_pad * a->R * sizeof(float), st), "svdq_quantize memset");
         if (rc) return rc;

@@ -17,8 +17,10 @@ template <int DT, int NV /* 16-byte pieces per lane */>
 __global__ __launch_bounds__(256) void residual_kernel(const uint16_t *__restrict__ res, const uint16_t *__restrict__ a,
                                                         const uint16_t *__restrict__ b, const uint16_t *__restrict__ gate,
                                                         uint16_t *__restrict__ out, float *__restrict__ stats, int M, int C, int ld,
-                                                        float eps) {
+                                                        float eps, v4i *__restrict__ zero_ptr, long long zero_vec) {
     using T = typename Half<DT>::T;
+    // side job: clear the scratch buffer, 16 bytes per thread, grid-strided (before any early return)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_vec; i += (long long)gridDim.x * 256) zero_ptr[i] = v4i{0, 0, 0, 0};
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -85,7 +87,7 @@ template <int DT> static int launch_residual(const svdq_residual_args *p, hipStr
     case NV:                                                                                                                    \
         hipLaunchKernelGGL((residual_kernel<DT, NV>), grid, block, 0, st, (const uint16_t *)p->res, (const uint16_t *)p->a,      \
                            (const uint16_t *)p->b, (const uint16_t *)p->gate, (uint16_t *)p->out, p->stats, p->M, p->C, p->ld,   \
-                           p->eps);                                                                                             \
+                           p->eps, (v4i *)p->zero_ptr, (long long)(p->zero_ptr ? p->zero_bytes / 16 : 0));                                                                                           \
         return 0;
     switch ((p->C + 511) / 512) {
         SVDQ_RES_CASE(1) SVDQ_RES_CASE(2) SVDQ_RES_CASE(3) SVDQ_RES_CASE(4) SVDQ_RES_CASE(5) SVDQ_RES_CASE(6) SVDQ_RES_CASE(7) SVDQ_RES_CASE(8)
@@ -112,6 +114,10 @@ extern "C" int svdq_residual_gate_stats(const svdq_residual_args *a, void *strea
         return SVDQ_E_INVALID;
     }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_residual_gate_stats: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
+    if (a->zero_ptr && (a->zero_bytes < 0 || a->zero_bytes % 16 || ((uintptr_t)a->zero_ptr & 15))) {
+        set_error("svdq_residual_gate_stats: zero_ptr must be 16-byte aligned and zero_bytes a non-negative multiple of 16");
+        return SVDQ_E_INVALID;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int rc = a->dtype == SVDQ_BF16 ? launch_residual<SVDQ_BF16>(a, st) : launch_residual<SVDQ_FP16>(a, st);
     if (rc) { set_error("svdq_residual_gate_stats: C=%d: ceil(C/512) must be one of {1..8, 12, 16, 24, 32}", a->C); return SVDQ_E_UNSUPPORTED; }

@@ -38,6 +38,10 @@ def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 1000
     return torch.cat([args.cos(), args.sin()], dim=-1)
 
 
+def _pad256(n: int) -> int:
+    return (n + 255) // 256 * 256
+
+
 class _MLPEmbedder(nn.Module):
     def __init__(self, d_in, d, dtype, device):
         super().__init__()
@@ -157,15 +161,22 @@ class FluxJointBlockAMD(nn.Module):
             n_e = self._ln_mod(encoder_hidden, c_scale_mlp, c_shift_mlp)
             encoder_hidden = encoder_hidden + c_gate_mlp[:, None] * self.ff_context(n_e)
             return encoder_hidden, hidden, None
-        h_stats, e_stats = stats
+        (h_stats, h_pool), (e_stats, e_pool) = stats  # pools: fp32 zeros for the low-rank accumulators of the next calls
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.mod(temb_act).view(-1, 6).t().contiguous()
         c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.mod_context(temb_act).view(-1, 6).t().contiguous()
-        a, ca = self.attn(hidden, encoder_hidden, rotary, ln=(h_stats, scale_msa, shift_msa), ln_ctx=(e_stats, c_scale_msa, c_shift_msa))
-        hidden, h_stats = residual_gate_stats(hidden, a, gate_msa)
-        hidden, h_stats = residual_gate_stats(hidden, self.ff(hidden, ln=(h_stats, scale_mlp, shift_mlp)), gate_mlp)
-        encoder_hidden, e_stats = residual_gate_stats(encoder_hidden, ca, c_gate_msa)
-        encoder_hidden, e_stats = residual_gate_stats(encoder_hidden, self.ff_context(encoder_hidden, ln=(e_stats, c_scale_mlp, c_shift_mlp)), c_gate_mlp)
-        return encoder_hidden, hidden, (h_stats, e_stats)
+        a, ca = self.attn(hidden, encoder_hidden, rotary, ln=(h_stats, scale_msa, shift_msa, h_pool),
+                          ln_ctx=(e_stats, c_scale_msa, c_shift_msa, e_pool))
+        mp_h, mp_e = _pad256(hidden.shape[1]), _pad256(encoder_hidden.shape[1])
+        r_mlp = self.ff.fc1.rank + self.ff.fc2.rank          # fc1's quantiser + the GELU epilogue's accumulator for fc2
+        r_mlp_c = self.ff_context.fc1.rank + self.ff_context.fc2.rank
+        hidden, h_stats, h_pool = residual_gate_stats(hidden, a, gate_msa, zero_floats=mp_h * r_mlp)
+        hidden, h_stats, h_pool = residual_gate_stats(hidden, self.ff(hidden, ln=(h_stats, scale_mlp, shift_mlp, h_pool)), gate_mlp,
+                                                      zero_floats=mp_h * self.attn.to_qkv.rank)  # next block's QKV quantiser
+        encoder_hidden, e_stats, e_pool = residual_gate_stats(encoder_hidden, ca, c_gate_msa, zero_floats=mp_e * r_mlp_c)
+        encoder_hidden, e_stats, e_pool = residual_gate_stats(
+            encoder_hidden, self.ff_context(encoder_hidden, ln=(e_stats, c_scale_mlp, c_shift_mlp, e_pool)), c_gate_mlp,
+            zero_floats=mp_e * self.attn.add_qkv_proj.rank)
+        return encoder_hidden, hidden, ((h_stats, h_pool), (e_stats, e_pool))
 
 
 class FluxSingleBlockAMD(nn.Module):
@@ -185,10 +196,14 @@ class FluxSingleBlockAMD(nn.Module):
             att = self.attn(n, rotary=rotary)
             return hidden + gate[:, None] * (att + mlp), None  # transformer_flux_v2.py:332-335
         shift, scale, gate = self.mod(temb_act).view(-1, 3).t().contiguous()
-        ln = (stats, scale, shift)  # one LayerNorm + modulation, consumed by both projections' quantisers
+        st, pool = stats
+        ln = (st, scale, shift, pool)  # one LayerNorm + modulation, consumed by both projections' quantisers
         mlp = fused_gelu_mlp(hidden, self.mlp_fc1, self.mlp_fc2, ln=ln)
         att = self.attn(hidden, rotary=rotary, ln=ln)
-        return residual_gate_stats(hidden, att, gate, b=mlp)  # hidden + gate * (att + mlp), and the next statistics
+        # hidden + gate * (att + mlp), the next block's statistics and its three low-rank accumulators, one pass
+        hidden, st, pool = residual_gate_stats(hidden, att, gate, b=mlp, zero_floats=_pad256(hidden.shape[1]) * (
+            self.mlp_fc1.rank + self.mlp_fc2.rank + self.attn.to_qkv.rank))
+        return hidden, (st, pool)
 
 
 class FluxTransformerAMD(nn.Module):
@@ -306,11 +321,11 @@ class FluxTransformerAMD(nn.Module):
         rot_all = pack_rotemb(pad_tensor(rot, 256, 1))
 
         fused = self.fused_norm and hidden.shape[0] == 1
-        stats = (residual_gate_stats(hidden)[1], residual_gate_stats(enc)[1]) if fused else None
+        stats = ((residual_gate_stats(hidden)[1], None), (residual_gate_stats(enc)[1], None)) if fused else None
         for blk in self.blocks:
             enc, hidden, stats = blk(hidden, enc, temb_act, (rot_img, rot_txt), stats)
         hidden = torch.cat([enc, hidden], dim=1)
-        stats = torch.cat([stats[1], stats[0]], dim=0) if fused else None
+        stats = (torch.cat([stats[1][0], stats[0][0]], dim=0), None) if fused else None  # [txt; img] row order
         for blk in self.single_blocks:
             hidden, stats = blk(hidden, temb_act, rot_all, stats)
         hidden = hidden[:, t_txt:]

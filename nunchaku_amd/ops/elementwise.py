@@ -3,23 +3,50 @@ reference surface; the reference's V2 blocks use torch ops here: transformer_flu
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .._C import ops
 
 
+class ZeroPool:
+    """fp32 scratch cleared by a :func:`residual_gate_stats` pass, handed out in pieces to the quantiser /
+    GELU_QUANT calls that follow it on the same stream (their low-rank accumulators need a zeroed buffer: this saves
+    one memset launch each).  ``take`` returns None when the pool is exhausted -- the caller then clears its own."""
+
+    def __init__(self, buf: torch.Tensor):
+        self.buf, self.used = buf, 0
+
+    def take(self, numel: int):
+        n = (numel + 3) // 4 * 4  # keep every piece 16-byte aligned
+        if self.used + n > self.buf.numel():
+            return None
+        piece = self.buf[self.used:self.used + numel]
+        self.used += n
+        return piece
+
+
 def residual_gate_stats(res: torch.Tensor, a: torch.Tensor | None = None, gate: torch.Tensor | None = None,
-                        b: torch.Tensor | None = None, inplace: bool = True, want_stats: bool = True, eps: float = 1e-6):
+                        b: torch.Tensor | None = None, inplace: bool = True, want_stats: bool = True, eps: float = 1e-6,
+                        zero_floats: int = 0):
     """``y = res + gate * (a [+ b])`` (one 16-bit rounding per torch op, as the reference's blocks; ``a`` None: ``y = res``) and the row
     statistics ``[rows, 2]`` float32 (mean, rstd) of ``y`` for a following ``quantize(..., ln=...)``.
-    Tensors are ``[..., C]`` contiguous; returns ``(y, stats)``."""
+    Tensors are ``[..., C]`` contiguous; returns ``(y, stats)`` or, with ``zero_floats`` > 0, ``(y, stats, ZeroPool)``
+    where the pool holds that many fp32 zeros cleared in the same pass."""
     C = res.shape[-1]
     r2 = res.reshape(-1, C)
     out = None
     if a is not None:
         out = r2 if inplace else torch.empty_like(r2)
     stats = torch.empty(r2.shape[0], 2, dtype=torch.float32, device=res.device) if want_stats else None
+    want_pool = zero_floats > 0
+    if os.environ.get("SVDQ_NO_ZEROPOOL"):  # A/B knob: hand out an exhausted pool, every consumer clears its own buffer
+        zero_floats = 0
+    zero = torch.empty((zero_floats + 3) // 4 * 4, dtype=torch.float32, device=res.device) if zero_floats > 0 else None
     ops.residual_gate_stats(r2, None if a is None else a.reshape(-1, C), None if b is None else b.reshape(-1, C),
-                            None if gate is None else gate.reshape(-1), out, stats, eps)
+                            None if gate is None else gate.reshape(-1), out, stats, eps, zero)
     y = res if out is None else out.view(res.shape)
+    if want_pool:
+        return y, stats, ZeroPool(zero if zero is not None else torch.empty(0, dtype=torch.float32, device=res.device))
     return y, stats

@@ -20,14 +20,17 @@ def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256, ln=None) -> t
     dev = x.device
     q_hidden = torch.empty(M_pad, fc1.out_features * 3 // 4, dtype=torch.uint8, device=dev)  # FP6 operand image
     s_hidden = torch.empty(fc1.out_features // 64, M_pad, dtype=x.dtype, device=dev)
-    l_hidden = torch.empty(M_pad, fc2.proj_down.shape[1], dtype=torch.float32, device=dev)
+    pool = ln[3] if ln is not None and len(ln) > 3 else None  # scratch cleared by the preceding element-wise pass
+    l_hidden = pool.take(M_pad * fc2.proj_down.shape[1]) if pool is not None else None
+    l_zeroed = l_hidden is not None
+    l_hidden = l_hidden.view(M_pad, -1) if l_zeroed else torch.empty(M_pad, fc2.proj_down.shape[1], dtype=torch.float32, device=dev)
     fc1._ensure_layout()
     fc2._ensure_layout()
     svdq_gemm_w4a4_cuda(
         act=qx, wgt=fc1.qweight, qout=q_hidden, ascales=ascales, wscales=fc1.wscales, oscales=s_hidden,
         lora_act_in=lora_act, lora_up=fc1.proj_up, lora_down=fc2.proj_down, lora_act_out=l_hidden,
         bias=fc1.bias, smooth_factor=fc2.smooth_factor, fp4=False, alpha=fc1.wtscale, wcscales=fc1.wcscales,
-        lora_scales=getattr(fc1, "lora_scales", None),
+        lora_scales=getattr(fc1, "lora_scales", None), lora_act_zeroed=l_zeroed,
     )
     out = torch.empty(M, fc2.out_features, dtype=x.dtype, device=dev)
     out = fc2.forward_quant(q_hidden, s_hidden, l_hidden, output=out)

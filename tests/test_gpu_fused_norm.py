@@ -33,8 +33,13 @@ def test_residual_gate_stats(dtype, M, C, with_b):
     assert np.array_equal(f32(y), ref)  # same fp32 fma, same rounding: bit exact
     sref = O.ln_stats_ref(ref)
     np.testing.assert_allclose(st.cpu().numpy(), sref, rtol=2e-6, atol=2e-6)
-    # statistics only
-    y2, st2 = residual_gate_stats(t16(res, dtype))
+    # statistics only, plus a scratch buffer cleared in the same pass and handed out in aligned pieces
+    junk = torch.full((1000,), 7.0, device="cuda")  # make sure the allocator hands back dirty memory
+    del junk
+    y2, st2, pool = residual_gate_stats(t16(res, dtype), zero_floats=777)
+    p1, p2 = pool.take(300), pool.take(301)
+    assert p1.numel() == 300 and p2.numel() == 301 and p1.data_ptr() % 16 == 0 and p2.data_ptr() % 16 == 0
+    assert not p1.any() and not p2.any() and pool.take(300) is None
     np.testing.assert_allclose(st2.cpu().numpy(), O.ln_stats_ref(res), rtol=2e-6, atol=2e-6)
     # the reference's torch-op sequence it replaces (transformer_flux_v2.py:332-335)
     t = t16(a, dtype) if b is None else t16(a, dtype) + t16(b, dtype)
