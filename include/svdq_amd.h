@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 6
+#define SVDQ_ABI_VERSION 7
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -190,6 +190,10 @@ typedef struct svdq_attention_args {
     int32_t L, H, head_dim, dtype;
     float scale;                     /* softmax scale, e.g. 1/sqrt(head_dim) */
     int32_t reserved;
+    /* optional: zero-fill an unrelated scratch buffer in the same launch (the fp32 low-rank accumulators of the output
+     * projection's quantiser, see svdq_residual_args.zero_ptr).  zero_bytes must be a multiple of 16. */
+    void *zero_ptr;
+    int64_t zero_bytes;
 } svdq_attention_args;
 
 int svdq_attention(const svdq_attention_args *args, void *stream);
@@ -240,6 +244,11 @@ typedef struct svdq_gemv_awq_args {
     int32_t M, N, K, ldx;
     int32_t group_size;   /* must be 64 */
     int32_t dtype;        /* SVDQ_BF16 | SVDQ_FP16 */
+    int32_t out_chunks;   /* 0 / 1: natural out[m, n].  c > 1 (N % c == 0): de-interleaved, element n is written to
+                             out[m, (n % c) * (N / c) + n / c] -- the modulation vectors of AdaLayerNormZero are stored
+                             interleaved per channel (emb.view(B, -1, 6).permute(2, 0, 1), normalization.py:89) and come
+                             out as c contiguous [N/c] vectors */
+    int32_t reserved;
 } svdq_gemv_awq_args;
 
 int svdq_gemv_awq(const svdq_gemv_awq_args *args, void *stream);

@@ -225,11 +225,12 @@ class _Ops:
         _lib.check(lib.svdq_residual_gate_stats(C.byref(args), _stream()), "residual_gate_stats")
 
     @staticmethod
-    def gemv_awq(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size, bias=None):
+    def gemv_awq(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size, bias=None, out_chunks=1):
         """reference: csrc/ops.h:123-145 -> gemv_awq (src/kernels/awq/gemv_awq.cu:253-286): allocates and returns
         the output, shape ``in_feats.shape[:-1] + (n,)``.  ``kernel`` is the checkpoint's ``qweight`` as stored
         ([n/4, k/2] int32); ``zeros`` are the scaled zeros.  ``bias`` (extension) fuses the module's 16-bit
-        ``output.add_(bias)``."""
+        ``output.add_(bias)``; ``out_chunks`` = c (extension) de-interleaves the output into c contiguous ``[n/c]``
+        vectors (element j goes to ``(j % c) * n/c + j // c``), the order ``emb.view(B, -1, c).permute(2, 0, 1)`` reads."""
         lib = _lib.load()
         if in_feats.dtype not in _DT or scaling_factors.dtype != in_feats.dtype or zeros.dtype != in_feats.dtype:
             raise ValueError("gemv_awq: in_feats, scaling_factors and zeros must share one 16-bit dtype")
@@ -250,12 +251,12 @@ class _Ops:
         if not x2.is_cuda:
             raise RuntimeError("nunchaku_amd ops need GPU tensors (there is no CPU path)")
         a.M, a.N, a.K, a.ldx = m, n, k, x2.stride(0) if m > 1 else k
-        a.group_size, a.dtype = group_size, _DT[in_feats.dtype]
+        a.group_size, a.dtype, a.out_chunks = group_size, _DT[in_feats.dtype], int(out_chunks)
         _lib.check(lib.svdq_gemv_awq(C.byref(a), _stream()), "gemv_awq")
         return out
 
     @staticmethod
-    def attention(q, k, vt, out, scale):
+    def attention(q, k, vt, out, scale, zero=None):
         """Non-causal attention, head_dim 128 (role of the reference's ``ops.attention_fp16``, csrc/ops.h:114-121
         -> attention.cu:11-94).  Strided views, no copies: ``q``/``k``/``out`` are ``[L, H, 128]`` (any token and head
         stride, unit channel stride), ``vt`` is ``[H, 128, L]`` with unit token stride (V transposed, as the QKV
@@ -279,6 +280,10 @@ class _Ops:
         a.vt_hs, a.ldvt = vt.stride(0), vt.stride(1)
         a.L, a.H, a.head_dim, a.dtype = L, H, D, _DT[q.dtype]
         a.scale = float(scale)
+        if zero is not None:  # scratch cleared by the same launch (see residual_gate_stats)
+            if not zero.is_cuda or not zero.is_contiguous() or (zero.numel() * zero.element_size()) % 16:
+                raise ValueError("attention: zero must be a contiguous GPU tensor of a multiple of 16 bytes")
+            a.zero_ptr, a.zero_bytes = zero.data_ptr(), zero.numel() * zero.element_size()
         a.reserved = int(os.environ.get("SVDQ_ATT_DEBUG", "0"))  # timing experiments only
         _lib.check(lib.svdq_attention(C.byref(a), _stream()), "attention")
 

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class QuantizeArgs(C.Structure):
@@ -56,7 +56,7 @@ class AttentionArgs(C.Structure):
         ("q_hs", C.c_int64), ("k_hs", C.c_int64), ("vt_hs", C.c_int64), ("o_hs", C.c_int64),
         ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldvt", C.c_int32), ("ldo", C.c_int32),
         ("L", C.c_int32), ("H", C.c_int32), ("head_dim", C.c_int32), ("dtype", C.c_int32),
-        ("scale", C.c_float), ("reserved", C.c_int32),
+        ("scale", C.c_float), ("reserved", C.c_int32), ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_int64),
     ]
 
 
@@ -65,7 +65,7 @@ class GemvAwqArgs(C.Structure):
         ("x", C.c_void_p), ("qweight", C.c_void_p), ("scales", C.c_void_p), ("zeros", C.c_void_p),
         ("bias", C.c_void_p), ("out", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32),
-        ("group_size", C.c_int32), ("dtype", C.c_int32),
+        ("group_size", C.c_int32), ("dtype", C.c_int32), ("out_chunks", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -30,6 +30,8 @@ struct AttnParams {
     int L, H, ldq, ldk, ldvt, ldo;
     float scale_log2e; // softmax scale * log2(e)
     int debug;         // timing experiments (tools/bench_attention.py): results are WRONG when non-zero
+    v4i *zero_ptr;     // optional scratch cleared by this launch (svdq_attention_args.zero_ptr)
+    long long zero_vec; // its size in 16-byte units
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -56,6 +58,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
     const int lr = lane & 31, h = lane >> 5;
     const int head = blockIdx.y;
     const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * NT + tid; i < p.zero_vec; i += (long long)gridDim.x * gridDim.y * NT)
+        p.zero_ptr[i] = v4i{0, 0, 0, 0}; // side job: clear the next quantiser's low-rank accumulators
     const uint8_t *kbase = (const uint8_t *)(p.k + (size_t)head * p.k_hs);
     const uint8_t *vtbase = (const uint8_t *)(p.vt + (size_t)head * p.vt_hs);
 
@@ -254,11 +258,17 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     }
     if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->vt | (uintptr_t)a->out) & 15) { set_error("svdq_attention: q, k, vt, out must be 16-byte aligned"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_attention: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
+    if (a->zero_ptr && (a->zero_bytes < 0 || a->zero_bytes % 16 || ((uintptr_t)a->zero_ptr & 15))) {
+        set_error("svdq_attention: zero_ptr must be 16-byte aligned and zero_bytes a non-negative multiple of 16");
+        return SVDQ_E_INVALID;
+    }
     AttnParams p;
     p.q = (const uint16_t *)a->q; p.k = (const uint16_t *)a->k; p.vt = (const uint16_t *)a->vt; p.out = (uint16_t *)a->out;
     p.q_hs = a->q_hs; p.k_hs = a->k_hs; p.vt_hs = a->vt_hs; p.o_hs = a->o_hs;
     p.L = a->L; p.H = a->H; p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;
     p.scale_log2e = a->scale * 1.4426950408889634f;
+    p.zero_ptr = (v4i *)a->zero_ptr;
+    p.zero_vec = a->zero_ptr ? a->zero_bytes / 16 : 0;
     p.debug = a->reserved;
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);

@@ -19,7 +19,7 @@ template <int DT, int M>
 __global__ __launch_bounds__(256) void gemv_awq_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ qw,
                                                         const uint16_t *__restrict__ scales, const uint16_t *__restrict__ zeros,
                                                         const uint16_t *__restrict__ bias, uint16_t *__restrict__ out, int K, int N,
-                                                        int ldx) {
+                                                        int ldx, int ochunks) {
     using T = typename Half<DT>::T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rg = blockIdx.x * 4 + wave; // row group: output channels 4*rg .. 4*rg + 3
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void gemv_awq_kernel(const uint16_t *__restric
         if (half == 0 && cl == 0) {
             float y = round16<T>(a);
             if (bias) y = round16<T>(y + h2f(hfrom<T>(bias[n]))); // AWQW4A16Linear.forward: output.add_(bias), 16-bit
-            out[(size_t)m * N + n] = hbits(f2h<T>(y));
+            const int no = ochunks > 1 ? (n % ochunks) * (N / ochunks) + n / ochunks : n; // de-interleave the modulation vectors
+            out[(size_t)m * N + no] = hbits(f2h<T>(y));
         }
     }
 }
@@ -97,7 +98,7 @@ template <int DT> static int launch_gemv(const svdq_gemv_awq_args *a, hipStream_
     case MM:                                                                                                                        \
         hipLaunchKernelGGL((gemv_awq_kernel<DT, MM>), grid, block, 0, st, (const uint16_t *)a->x, (const uint8_t *)a->qweight,        \
                            (const uint16_t *)a->scales, (const uint16_t *)a->zeros, (const uint16_t *)a->bias, (uint16_t *)a->out,  \
-                           a->K, a->N, a->ldx);                                                                                     \
+                           a->K, a->N, a->ldx, a->out_chunks);                                                                                   \
         break;
     switch (a->M) {
         SVDQ_GEMV_CASE(1) SVDQ_GEMV_CASE(2) SVDQ_GEMV_CASE(3) SVDQ_GEMV_CASE(4)
@@ -121,6 +122,7 @@ extern "C" int svdq_gemv_awq(const svdq_gemv_awq_args *a, void *stream) {
     if (a->ldx < a->K || a->ldx % 8) { set_error("svdq_gemv_awq: ldx=%d must be >= K and a multiple of 8", a->ldx); return SVDQ_E_INVALID; }
     if (((uintptr_t)a->x | (uintptr_t)a->qweight) & 15) { set_error("svdq_gemv_awq: x and qweight must be 16-byte aligned"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemv_awq: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
+    if (a->out_chunks < 0 || (a->out_chunks > 1 && a->N % a->out_chunks)) { set_error("svdq_gemv_awq: out_chunks=%d must divide N=%d", a->out_chunks, a->N); return SVDQ_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(3, (double)a->N * a->K / 2 + 4.0 * (a->K / AWQ_GROUP) * a->N, st);
     if (a->dtype == SVDQ_BF16) launch_gemv<SVDQ_BF16>(a, st);

@@ -97,8 +97,11 @@ class FluxAttentionAMD(nn.Module):
         else:
             fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary, output=qkv.view(B * tokens, -1),
                                    out_vt=vt, ln=ln)
-        if svdq:
-            o = attention_packed(qkv[0], vt, self.heads).unsqueeze(0)
+        pool = None
+        if svdq:  # the same launch clears the low-rank accumulators of the output projections' quantisers
+            zf = _pad256(hidden.shape[1]) * self.to_out.rank + (_pad256(t_txt) * self.to_add_out.rank if self.joint else 0)
+            o, pool = attention_packed(qkv[0], vt, self.heads, zero_floats=zf)
+            o = o.unsqueeze(0)
         else:
             q, k, v = qkv.chunk(3, dim=-1)
             shp = (B, -1, self.heads, self.head_dim)
@@ -106,8 +109,8 @@ class FluxAttentionAMD(nn.Module):
                                                v.view(shp).transpose(1, 2), dropout_p=0.0, is_causal=False)
             o = o.transpose(1, 2).reshape(B, -1, hd)
         if self.joint:
-            return self.to_out(o[:, t_txt:]), self.to_add_out(o[:, :t_txt])
-        return self.to_out(o)
+            return self.to_out(o[:, t_txt:], pool=pool), self.to_add_out(o[:, :t_txt], pool=pool)
+        return self.to_out(o, pool=pool)
 
 
 class _FeedForward(nn.Module):
@@ -130,6 +133,7 @@ class FluxJointBlockAMD(nn.Module):
         # AdaLayerNormZero.linear: AWQ W4A16 GEMV as in the reference (normalization.py:85-98, linear.py:277-414)
         self.mod = AWQW4A16Linear(dim, 6 * dim, torch_dtype=dt, device=dev)
         self.mod_context = AWQW4A16Linear(dim, 6 * dim, torch_dtype=dt, device=dev)
+        self.mod.out_chunks = self.mod_context.out_chunks = 6  # the GEMV writes the six [dim] vectors contiguously
         self.attn = FluxAttentionAMD(dim, heads, True, kw)
         self.ff = _FeedForward(dim, kw)
         self.ff_context = _FeedForward(dim, kw)
@@ -147,8 +151,8 @@ class FluxJointBlockAMD(nn.Module):
         Returns (encoder_hidden, hidden, stats)."""
         # normalization.py:85-98 -- emb.view(B, -1, 6).permute(2, 0, 1): interleaved chunks
         if stats is None:
-            m = self.mod(temb_act).view(temb_act.shape[0], -1, 6).permute(2, 0, 1)
-            c = self.mod_context(temb_act).view(temb_act.shape[0], -1, 6).permute(2, 0, 1)
+            m = self.mod(temb_act).view(temb_act.shape[0], 6, -1).permute(1, 0, 2)
+            c = self.mod_context(temb_act).view(temb_act.shape[0], 6, -1).permute(1, 0, 2)
             shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = m
             c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c
             n_h = self._ln_mod(hidden, scale_msa, shift_msa)
@@ -162,8 +166,8 @@ class FluxJointBlockAMD(nn.Module):
             encoder_hidden = encoder_hidden + c_gate_mlp[:, None] * self.ff_context(n_e)
             return encoder_hidden, hidden, None
         (h_stats, h_pool), (e_stats, e_pool) = stats  # pools: fp32 zeros for the low-rank accumulators of the next calls
-        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.mod(temb_act).view(-1, 6).t().contiguous()
-        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.mod_context(temb_act).view(-1, 6).t().contiguous()
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.mod(temb_act).view(6, -1)
+        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.mod_context(temb_act).view(6, -1)
         a, ca = self.attn(hidden, encoder_hidden, rotary, ln=(h_stats, scale_msa, shift_msa, h_pool),
                           ln_ctx=(e_stats, c_scale_msa, c_shift_msa, e_pool))
         mp_h, mp_e = _pad256(hidden.shape[1]), _pad256(encoder_hidden.shape[1])
@@ -184,18 +188,19 @@ class FluxSingleBlockAMD(nn.Module):
         super().__init__()
         dt, dev = kw["torch_dtype"], kw["device"]
         self.mod = AWQW4A16Linear(dim, 3 * dim, torch_dtype=dt, device=dev)  # AdaLayerNormZeroSingle.linear (:155-165)
+        self.mod.out_chunks = 3
         self.mlp_fc1 = SVDQW4A4Linear(dim, 4 * dim, **kw)
         self.mlp_fc2 = SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})
         self.attn = FluxAttentionAMD(dim, heads, False, kw)
 
     def forward(self, hidden, temb_act, rotary, stats=None):
         if stats is None:
-            shift, scale, gate = self.mod(temb_act).view(temb_act.shape[0], -1, 3).permute(2, 0, 1)
+            shift, scale, gate = self.mod(temb_act).view(temb_act.shape[0], 3, -1).permute(1, 0, 2)
             n = F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6) * scale[:, None] + shift[:, None]
             mlp = fused_gelu_mlp(n, self.mlp_fc1, self.mlp_fc2)
             att = self.attn(n, rotary=rotary)
             return hidden + gate[:, None] * (att + mlp), None  # transformer_flux_v2.py:332-335
-        shift, scale, gate = self.mod(temb_act).view(-1, 3).t().contiguous()
+        shift, scale, gate = self.mod(temb_act).view(3, -1)
         st, pool = stats
         ln = (st, scale, shift, pool)  # one LayerNorm + modulation, consumed by both projections' quantisers
         mlp = fused_gelu_mlp(hidden, self.mlp_fc1, self.mlp_fc2, ln=ln)
@@ -292,7 +297,7 @@ class FluxTransformerAMD(nn.Module):
                 # normalization.py:24-25): chunks (shift, SCALE, gate[, shift, SCALE, gate]) are interleaved per channel
                 m.bias.zero_()
                 chunks = m.out_features // m.in_features
-                m.bias.view(-1, chunks)[:, 1::3] = 1.0
+                m.bias.view(-1, chunks)[:, 1::3] = 1.0  # checkpoint (interleaved) order; out_chunks only permutes the OUTPUT
             elif isinstance(m, nn.Linear):
                 m.weight.copy_(rnd(m.weight.shape, 1.0 / math.sqrt(m.in_features)))
                 m.bias.zero_()

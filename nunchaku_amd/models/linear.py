@@ -124,22 +124,23 @@ class SVDQW4A4Linear(nn.Module):
             **kwargs,
         )
 
-    def forward(self, x: torch.Tensor, output: torch.Tensor | None = None, ln=None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, output: torch.Tensor | None = None, ln=None, pool=None) -> torch.Tensor:
         """x [B, S, in] 16-bit -> [B, S, out]: quantise (+ low-rank down) then the fused GEMM."""
         B, S, C_in = x.shape
         x2 = x.reshape(B * S, C_in)
         if output is None:
             output = torch.empty(B * S, self.out_features, dtype=x.dtype, device=x.device)
-        qx, ascales, lora_act = self.quantize(x2, ln=ln)
+        qx, ascales, lora_act = self.quantize(x2, ln=ln, pool=pool)
         output = self.forward_quant(qx, ascales, lora_act, output)
         return output.reshape(B, S, -1)
 
-    def quantize(self, x: torch.Tensor, pad_size: int = 256, ln=None):
+    def quantize(self, x: torch.Tensor, pad_size: int = 256, ln=None, pool=None):
         """x [N, in] -> (FP6 code image [N_pad, 3*in/4] uint8, ascales [in/64, N_pad], lora_act [N_pad, rank] f32).
-        ``ln = (stats, scale, shift)``: quantise ``layer_norm(x) * scale + shift`` (fused AdaLayerNormZero, scale incl. +1)."""
+        ``ln = (stats, scale, shift)``: quantise ``layer_norm(x) * scale + shift`` (fused AdaLayerNormZero, scale incl. +1);
+        ``pool``: a ``ZeroPool`` of pre-cleared fp32 scratch for the low-rank accumulator (ops/elementwise.py)."""
         self._ensure_layout()
         return svdq_quantize_w4a4_act_fuse_lora_cuda(
-            x, lora_down=self.proj_down, smooth=self.smooth_factor, fp4=False, pad_size=pad_size, ln=ln
+            x, lora_down=self.proj_down, smooth=self.smooth_factor, fp4=False, pad_size=pad_size, ln=ln, pool=pool
         )
 
     def forward_quant(self, quantized_x, ascales, lora_act, output: torch.Tensor | None = None) -> torch.Tensor:
@@ -225,13 +226,17 @@ class AWQW4A16Linear(nn.Module):
                                     requires_grad=False)
         self.wzeros = nn.Parameter(torch.empty(in_features // group_size, out_features, dtype=torch_dtype, device=device),
                                    requires_grad=False)
+        # extension: c > 1 makes forward() return the output de-interleaved into c contiguous [out/c] vectors
+        # (what ``emb.view(B, -1, c).permute(2, 0, 1)`` of the AdaLayerNormZero modules reads), saving the copy
+        self.out_chunks = 1
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from ..ops.gemv import awq_gemv_w4a16_cuda
 
         m = x.numel() // x.shape[-1]
         return awq_gemv_w4a16_cuda(in_feats=x, kernel=self.qweight, scaling_factors=self.wscales, zeros=self.wzeros,
-                                   m=m, n=self.out_features, k=self.in_features, group_size=self.group_size, bias=self.bias)
+                                   m=m, n=self.out_features, k=self.in_features, group_size=self.group_size, bias=self.bias,
+                                   out_chunks=self.out_chunks)
 
     @classmethod
     def from_linear(cls, linear: nn.Linear, group_size: int = 64, torch_dtype: torch.dtype = torch.bfloat16,

@@ -17,7 +17,8 @@ def awq_gemv_w4a16_cuda(
     k: int,
     group_size: int = 64,
     bias: torch.Tensor | None = None,
+    out_chunks: int = 1,
 ) -> torch.Tensor:
     """``in_feats`` [m, k] 16-bit, ``kernel`` [n/4, k/2] int32 (checkpoint order), ``scaling_factors`` /
     ``zeros`` [k/group_size, n] -> [m, n].  ``bias`` (extension): fused 16-bit ``output.add_(bias)``."""
-    return ops.gemv_awq(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size, bias)
+    return ops.gemv_awq(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size, bias, out_chunks)

@@ -19,6 +19,7 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     fp4: bool = False,
     pad_size: int = 256,
     ln: tuple | None = None,
+    pool=None,
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """4-bit quantisation of ``input`` [M, K] plus the low-rank down projection.
 
@@ -44,12 +45,14 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     zeroed = False
     if lora_act_out is None:
         # a 4th element of ``ln`` is a ZeroPool of fp32 scratch cleared by the preceding residual_gate_stats pass
-        pool = ln[3] if ln is not None and len(ln) > 3 else None
+        if pool is None:
+            pool = ln[3] if ln is not None and len(ln) > 3 else None
         lora_act_out = pool.take(M_pad * R) if pool is not None else None
         zeroed = lora_act_out is not None
         lora_act_out = lora_act_out.view(M_pad, R) if zeroed else torch.empty(M_pad, R, dtype=torch.float32, device=dev)
     if ln is None:
-        ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4)
+        ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4,
+                                        lora_act_zeroed=zeroed)
     else:
         ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4,
                                         ln_stats=ln[0], mod_scale=ln[1], mod_shift=ln[2], lora_act_zeroed=zeroed)

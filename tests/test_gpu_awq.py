@@ -45,6 +45,10 @@ def test_gemv_awq_matches_oracle(dtype, m, N, K):
     got = f32(y)
     assert (got != ref).mean() <= 0.02
     assert_close_16(got, ref, dtype, "gemv_awq")
+    if N % 6 == 0:  # de-interleaved output (the modulation vectors of AdaLayerNormZero): a pure permutation of the columns
+        lin.out_chunks = 6
+        y6 = lin(t16(x, dtype))
+        assert torch.equal(y6.view(m, 6, N // 6), y.view(m, N // 6, 6).transpose(1, 2))
 
 
 def test_gemv_awq_op_surface_and_errors():
