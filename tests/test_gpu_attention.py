@@ -136,3 +136,33 @@ def test_flux_transformer_svdq_attention_vs_sdpa():
         FluxAttentionAMD.attention_impl = "svdq"
     rel = ((outs["svdq"] - outs["sdpa"]).norm() / outs["sdpa"].norm()).item()
     assert torch.isfinite(outs["svdq"]).all() and rel < 5e-2, f"svdq vs sdpa attention: relative L2 {rel:.3g}"
+
+
+def test_attention_full_size_properties():
+    """FLUX.1 size (24 heads x 4608 tokens), properties that need no oracle: every output is a convex combination of
+    the values (inside their per-channel range), permuting the keys together with the values changes nothing beyond
+    summation order, and a key block repeated twice gives the same answer as once."""
+    from nunchaku_amd.ops.attention import attention_packed
+
+    L, H = 4608, 24
+    g = torch.Generator(device="cuda").manual_seed(11)
+    qkv = torch.randn(L, 3 * H * 128, device="cuda", generator=g).bfloat16()
+    v = qkv[:, 2 * H * 128:]
+    out = attention_packed(qkv, v.t().contiguous(), H)
+    assert torch.isfinite(out.float()).all()
+    lo, hi = v.float().amin(0), v.float().amax(0)
+    eps = 2.0 ** -7 * v.float().abs().amax()
+    assert (out.float() >= lo - eps).all() and (out.float() <= hi + eps).all()
+    perm = torch.randperm(L, device="cuda", generator=g)
+    qkv2 = qkv.clone()
+    qkv2[:, H * 128:] = qkv[perm][:, H * 128:]  # keys and values permuted together, queries in place
+    out2 = attention_packed(qkv2, qkv2[:, 2 * H * 128:].t().contiguous(), H)
+    assert (out.float() - out2.float()).abs().max() <= 2.0 ** -6 * out.float().abs().max()
+    # duplicate keys/values: softmax over [K; K] with [V; V] equals softmax over K with V
+    half = L // 2
+    qkv3 = qkv.clone()
+    qkv3[half:, H * 128:] = qkv[:half, H * 128:]
+    out3 = attention_packed(qkv3, qkv3[:, 2 * H * 128:].t().contiguous(), H)
+    q_small = torch.cat([qkv3[:half], qkv3[:half]])  # same queries twice so that the token count stays a multiple of 256
+    ref = attention_packed(q_small, q_small[:, 2 * H * 128:].t().contiguous(), H)[:half]
+    assert (out3[:half].float() - ref.float()).abs().max() <= 2.0 ** -6 * ref.float().abs().max()
