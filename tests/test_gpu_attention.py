@@ -163,6 +163,6 @@ def test_attention_full_size_properties():
     qkv3 = qkv.clone()
     qkv3[half:, H * 128:] = qkv[:half, H * 128:]
     out3 = attention_packed(qkv3, qkv3[:, 2 * H * 128:].t().contiguous(), H)
-    q_small = torch.cat([qkv3[:half], qkv3[:half]])  # same queries twice so that the token count stays a multiple of 256
-    ref = attention_packed(q_small, q_small[:, 2 * H * 128:].t().contiguous(), H)[:half]
+    first = qkv[:half].contiguous()  # 2304 tokens: the 4-wave kernel, keys once instead of twice
+    ref = attention_packed(first, first[:, 2 * H * 128:].t().contiguous(), H)
     assert (out3[:half].float() - ref.float()).abs().max() <= 2.0 ** -6 * ref.float().abs().max()
