@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 7
+#define SVDQ_ABI_VERSION 8
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -159,6 +159,17 @@ typedef struct svdq_gemm_args {
     void *out_vt;
     int32_t ldvt;             /* row stride of out_vt in elements (>= total tokens)              */
     int32_t reserved2;
+    /* Grouped launch (optional): rows [split_rows, M_pad) use a SECOND weight set of the same shape, rank and
+     * epilogue -- one launch for the text and the image stream of a joint FLUX block (same layer type, different
+     * weights, transformer_flux_v2.py:200-260), whose row-side tensors (act, ascales, lora_act_in, out, qout,
+     * oscales, lora_act_out, rotary_emb, out_vt) are simply the two streams' buffers back to back.  The 48..192
+     * tiles of the 512-token stream then fill the tail of the big GEMM's last round instead of running as a
+     * launch-latency-bound GEMM of their own.  wgt2 == NULL: off.  bias / bias2 must both be given or both NULL. */
+    const void *wgt2, *wscales2, *bias2, *lora_up2;
+    const void *next_smooth2, *next_lora_down2; /* GELU_QUANT */
+    const void *norm_q2, *norm_k2;              /* RMSNORM_ROPE */
+    int32_t split_rows;       /* multiple of 256, 0 < split_rows < M_pad                         */
+    int32_t reserved3;
 } svdq_gemm_args;
 
 int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);

@@ -105,14 +105,19 @@ class _Ops:
     def gemm_w4a4(
         act, wgt, out, qout, ascales, wscales, oscales, poolout, lora_act_in, lora_up, lora_down, lora_act_out,
         norm_q, norm_k, rotary_emb, bias, smooth_factor, out_vk, out_linearattn, act_unsigned, lora_scales,
-        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens, out_vt=None, lora_act_zeroed=False,
+        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens, out_vt=None, lora_act_zeroed=False, second=None, split_rows=0,
     ):
         """reference: csrc/ops.h:10-81 -> kernels::gemm_w4a4 (zgemm.h:8-36).  The epilogue is inferred
         from which optional tensors are present, exactly as gemm_w4a4_launch_impl.cuh:282-423 does.
 
         ``out_vt`` (extension, RMSNorm+RoPE epilogue only): a ``[N/3, tokens]`` view with unit column stride
         that receives V transposed instead of the V columns of ``out`` -- the operand ``ops.attention`` reads
-        (role of the reference's packed out_q/out_k/out_v, epilogues.cuh:427-550)."""
+        (role of the reference's packed out_q/out_k/out_v, epilogues.cuh:427-550).
+
+        ``second`` / ``split_rows`` (extension, grouped launch): rows ``>= split_rows`` use the weight-side tensors
+        of the dict ``second`` (keys ``wgt, wscales, bias, lora_up, smooth_factor, lora_down, norm_q, norm_k``;
+        same shapes as the first set) -- the text and image streams of a joint block in ONE launch; all row-side
+        tensors are the two streams' buffers back to back."""
         lib = _lib.load()
         if fp4:
             raise NotImplementedError("gemm_w4a4: fp4 (NVFP4) is Blackwell-only; use int4 checkpoints")
@@ -188,12 +193,23 @@ class _Ops:
                 raise ValueError("gemm_w4a4: out.shape[-1] must equal N")
             if a.M > M_pad or M_pad - a.M >= 256:
                 raise ValueError("gemm_w4a4: out rows must satisfy M <= M_pad < M + 256 (launch_impl.cuh:55)")
+        keep2 = None
+        if second is not None:
+            g = lambda k: _ptr(second.get(k))
+            if second.get("wgt") is None or tuple(second["wgt"].shape) != tuple(wgt.shape):
+                raise ValueError("gemm_w4a4: second['wgt'] must have the shape of wgt")
+            a.wgt2, a.wscales2, a.bias2 = g("wgt"), g("wscales"), g("bias")
+            a.lora_up2 = g("lora_up") if R else None
+            a.next_smooth2, a.norm_q2, a.norm_k2 = g("smooth_factor"), g("norm_q"), g("norm_k")
+            a.next_lora_down2 = g("lora_down") if a.R2 else None
+            a.split_rows = int(split_rows)
+            keep2 = second  # keeps the tensors alive until the launch has been issued
         if out_vt is not None and a.fuse != _lib.FUSE_RMSNORM_ROPE:
             raise ValueError("gemm_w4a4: out_vt needs the RMSNorm+RoPE epilogue (rotary_emb, norm_q, norm_k)")
         if out_vt is not None and out_vt.shape[1] < a.M:
             raise ValueError("gemm_w4a4: out_vt has fewer columns than out has rows")
         _lib.check(lib.svdq_gemm_w4a4(C.byref(a), _stream()), "gemm_w4a4")
-        del keep
+        del keep, keep2
 
     @staticmethod
     def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6, zero=None):

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class QuantizeArgs(C.Structure):
@@ -47,6 +47,9 @@ class GemmArgs(C.Structure):
         ("act_unsigned", C.c_int32), ("fuse", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("out_vt", C.c_void_p), ("ldvt", C.c_int32), ("reserved2", C.c_int32),
+        ("wgt2", C.c_void_p), ("wscales2", C.c_void_p), ("bias2", C.c_void_p), ("lora_up2", C.c_void_p),
+        ("next_smooth2", C.c_void_p), ("next_lora_down2", C.c_void_p), ("norm_q2", C.c_void_p), ("norm_k2", C.c_void_p),
+        ("split_rows", C.c_int32), ("reserved3", C.c_int32),
     ]
 
 

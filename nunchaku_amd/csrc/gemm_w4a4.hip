@@ -62,6 +62,10 @@ struct GemmParams {
     const float *rotary_emb;
     void *out_vt;            // RMSNORM_ROPE: transposed V output or NULL
     int ldvt;
+    // grouped launch: row blocks >= split_bm use the second weight set (same N, K, R, epilogue); split_bm > TM = off
+    const uint8_t *wgt2;
+    const void *wscales2, *bias2, *lora_up2, *next_smooth2, *next_lora_down2, *norm_q2, *norm_k2;
+    int split_bm;
     int M, M_pad, N, K, R, R2, ldo;
     uint8_t *workspace;      // stream-K: [256 int32 flags][2*G slabs of BM*BN fp32] or NULL
     long long workspace_bytes;
@@ -153,10 +157,12 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     // stream bases of (tile, first K-step)
     auto stream_ptrs = [&](int bm, int bn, int kp0, unsigned long long &a, unsigned long long &x1, unsigned long long &x2) {
         a = (unsigned long long)(p.act + ((size_t)(bm * 8 + wv) * KP + kp0) * F6_CHUNK);
-        x1 = (unsigned long long)(p.wgt + ((size_t)(bn * 4 + px1 / 3) * KP + kp0) * F6_CHUNK + (px1 % 3) * F6_PLANE);
-        if (wv < 4) x2 = (unsigned long long)(p.wgt + ((size_t)(bn * 4 + px2 / 3) * KP + kp0) * F6_CHUNK + (px2 % 3) * F6_PLANE);
+        const uint8_t *wgt = bm >= p.split_bm ? p.wgt2 : p.wgt; // grouped launch: weight set of this row block
+        const void *wscales = bm >= p.split_bm ? p.wscales2 : p.wscales;
+        x1 = (unsigned long long)(wgt + ((size_t)(bn * 4 + px1 / 3) * KP + kp0) * F6_CHUNK + (px1 % 3) * F6_PLANE);
+        if (wv < 4) x2 = (unsigned long long)(wgt + ((size_t)(bn * 4 + px2 / 3) * KP + kp0) * F6_CHUNK + (px2 % 3) * F6_PLANE);
         else if (wv == 4) x2 = (unsigned long long)((const uint8_t *)p.ascales + ((size_t)(bm * 8) * KP + kp0) * 128);
-        else if (wv == 5) x2 = (unsigned long long)((const uint8_t *)p.wscales + ((size_t)(bn * 4) * KP + kp0) * 128);
+        else if (wv == 5) x2 = (unsigned long long)((const uint8_t *)wscales + ((size_t)(bn * 4) * KP + kp0) * 128);
         else x2 = x1;
     };
 
@@ -279,9 +285,9 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             //   waves 0..7: the three planes of A chunk `wave`;  waves 0..3: the three planes of W chunk
             //   `wave`;  wave 4: activation scales (8 x 128 B);  wave 5: weight scales (4 x 128 B).
             const uint8_t *a_src = p.act + ((size_t)(bm * 8 + wave) * KP) * F6_CHUNK + lane * 16;
-            const uint8_t *w_src = p.wgt + ((size_t)(bn * 4 + (wave & 3)) * KP) * F6_CHUNK + lane * 16;
+            const uint8_t *w_src = (bm >= p.split_bm ? p.wgt2 : p.wgt) + ((size_t)(bn * 4 + (wave & 3)) * KP) * F6_CHUNK + lane * 16;
             const uint8_t *as_src = (const uint8_t *)p.ascales + ((size_t)(bm * 8 + (lane >> 3)) * KP) * 128 + (lane & 7) * 16;
-            const uint8_t *ws_src = (const uint8_t *)p.wscales + ((size_t)(bn * 4 + ((lane >> 3) & 3)) * KP) * 128 + (lane & 7) * 16;
+            const uint8_t *ws_src = (const uint8_t *)(bm >= p.split_bm ? p.wscales2 : p.wscales) + ((size_t)(bn * 4 + ((lane >> 3) & 3)) * KP) * 128 + (lane & 7) * 16;
 
             typedef __attribute__((address_space(3))) uint8_t lds_u8; // LDS-typed pointers only: no flat casts
             typedef __attribute__((address_space(3))) v4i lds_v4i;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    u16x4 b = *reinterpret_cast<const u16x4 *>((const T *)p.bias + nw0 + ni * 32 + c * 8 + h * 4);
+                    u16x4 b = *reinterpret_cast<const u16x4 *>((const T *)(bm >= p.split_bm ? p.bias2 : p.bias) + nw0 + ni * 32 + c * 8 + h * 4);
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 }
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++)
-                    lu[ni] = *reinterpret_cast<const V8 *>((const T *)p.lora_up + (size_t)(nw0 + ni * 32 + lr) * p.R + rc + h * 8);
+                    lu[ni] = *reinterpret_cast<const V8 *>((const T *)(bm >= p.split_bm ? p.lora_up2 : p.lora_up) + (size_t)(nw0 + ni * 32 + lr) * p.R + rc + h * 8);
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++)
 #pragma unroll
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                     if (h == 0) sq[wn * 256 + wm * 64 + mi * 32 + lr] = s;
                 }
                 __syncthreads();
-                const T *nw = (const T *)(is_q ? p.norm_q : p.norm_k);
+                const T *nw = (const T *)(bm >= p.split_bm ? (is_q ? p.norm_q2 : p.norm_k2) : (is_q ? p.norm_q : p.norm_k));
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++) {
                     const int row = wm * 64 + mi * 32 + lr;
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    u16x4 sv = *reinterpret_cast<const u16x4 *>((const T *)p.next_smooth + nw0 + ni * 32 + c * 8 + h * 4);
+                    u16x4 sv = *reinterpret_cast<const u16x4 *>((const T *)(bm >= p.split_bm ? p.next_smooth2 : p.next_smooth) + nw0 + ni * 32 + c * 8 + h * 4);
 #pragma unroll
                     for (int e = 0; e < 4; e++) smr[ni][c * 4 + e] = __builtin_amdgcn_rcpf(h2f(hfrom<T>(sv[e])));
                 }
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             // the activations as the A operand the result tile has the RANK along the lanes, so every fp32
             // atomic instruction hits two 128-byte lines instead of 64 different ones.
             if (p.R2 > 0 && !(p.debug & 64)) {
-                const T *ld = (const T *)p.next_lora_down; // rank-major [R2][N]
+                const T *ld = (const T *)(bm >= p.split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
                 for (int t2 = 0; t2 < p.R2; t2 += 32) {
                     v16f d[2];
 #pragma unroll
@@ -867,6 +873,29 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         set_error("svdq_gemm_w4a4: unknown fuse mode %d", a->fuse);
         return SVDQ_E_INVALID;
     }
+    if (a->wgt2) { // grouped launch: a second weight set for rows >= split_rows
+        if (!a->wscales2 || a->split_rows <= 0 || a->split_rows >= a->M_pad || a->split_rows % BM) {
+            set_error("svdq_gemm_w4a4: grouped launch needs wscales2 and 0 < split_rows=%d < M_pad=%d, a multiple of %d", a->split_rows, a->M_pad, BM);
+            return SVDQ_E_INVALID;
+        }
+        if ((a->bias != nullptr) != (a->bias2 != nullptr) || (a->R > 0 && !a->lora_up2)) {
+            set_error("svdq_gemm_w4a4: grouped launch: bias2 / lora_up2 must mirror bias / lora_up");
+            return SVDQ_E_INVALID;
+        }
+        if (a->fuse == SVDQ_FUSE_GELU_QUANT && (!a->next_smooth2 || (a->R2 > 0 && !a->next_lora_down2))) {
+            set_error("svdq_gemm_w4a4: grouped GELU_QUANT launch needs next_smooth2 (and next_lora_down2 when R2 > 0)");
+            return SVDQ_E_INVALID;
+        }
+        if (a->fuse == SVDQ_FUSE_RMSNORM_ROPE && (!a->norm_q2 || !a->norm_k2)) {
+            set_error("svdq_gemm_w4a4: grouped RMSNORM_ROPE launch needs norm_q2 and norm_k2");
+            return SVDQ_E_INVALID;
+        }
+        if (((uintptr_t)a->wgt2 | (uintptr_t)a->wscales2 | (uintptr_t)a->lora_up2) & 15 ||
+            ((uintptr_t)a->bias2 | (uintptr_t)a->next_smooth2 | (uintptr_t)a->next_lora_down2 | (uintptr_t)a->norm_q2 | (uintptr_t)a->norm_k2) & 7) {
+            set_error("svdq_gemm_w4a4: second weight set: wgt2, wscales2, lora_up2 must be 16-byte aligned, the vectors 8-byte");
+            return SVDQ_E_INVALID;
+        }
+    }
     if (a->out && (a->ldo < a->N || a->ldo % 4)) { set_error("svdq_gemm_w4a4: ldo=%d must be >= N and a multiple of 4", a->ldo); return SVDQ_E_INVALID; }
     if (((uintptr_t)a->act | (uintptr_t)a->wgt | (uintptr_t)a->ascales | (uintptr_t)a->wscales | (uintptr_t)a->lora_up |
          (uintptr_t)a->lora_act_in | (uintptr_t)a->qout | (uintptr_t)a->rotary_emb) & 15) {
@@ -900,6 +929,9 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.norm_q = a->norm_q;
     p.norm_k = a->norm_k;
     p.rotary_emb = a->rotary_emb;
+    p.wgt2 = (const uint8_t *)a->wgt2; p.wscales2 = a->wscales2; p.bias2 = a->bias2; p.lora_up2 = a->lora_up2;
+    p.next_smooth2 = a->next_smooth2; p.next_lora_down2 = a->next_lora_down2; p.norm_q2 = a->norm_q2; p.norm_k2 = a->norm_k2;
+    p.split_bm = a->wgt2 ? a->split_rows / BM : 0x7fffffff;
     p.out_vt = a->fuse == SVDQ_FUSE_RMSNORM_ROPE ? a->out_vt : nullptr;
     p.ldvt = a->ldvt;
     p.debug = a->reserved;

@@ -24,7 +24,8 @@ from torch import nn
 
 from ..ops.attention import attention_packed
 from ..ops.elementwise import residual_gate_stats
-from ..ops.fused import fused_gelu_mlp, fused_qkv_norm_rottary
+from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair,
+                         linear_pair)
 from ..utils import pad_tensor
 from .embeddings import flux_pos_embed, pack_rotemb
 from .linear import AWQW4A16Linear, SVDQW4A4Linear
@@ -73,6 +74,8 @@ class FluxAttentionAMD(nn.Module):
     # "sdpa": torch's scaled_dot_product_attention (the reference's "flashattn2" processor role,
     # models/attention_processors/flux.py:24-59).  "svdq" needs B == 1, head_dim 128, tokens % 128 == 0.
     attention_impl = "svdq"
+    # True: the text and image stream's projections of a joint block share one GEMM launch each (svdq_gemm_args.wgt2)
+    grouped = not __import__("os").environ.get("SVDQ_NO_GROUPED")  # A/B knob
 
     def _use_svdq(self, B, tokens):
         return self.attention_impl == "svdq" and B == 1 and self.head_dim == 128 and tokens % 128 == 0
@@ -87,13 +90,19 @@ class FluxAttentionAMD(nn.Module):
         svdq = self._use_svdq(B, tokens)
         qkv = torch.empty(B, tokens, 3 * hd, dtype=hidden.dtype, device=hidden.device)
         vt = torch.empty(hd, tokens, dtype=hidden.dtype, device=hidden.device) if svdq else None
+        grouped = False
         if self.joint:
             # both projections write straight into one [txt; img] buffer (B == 1): no torch.cat round trip
-            rot_img, rot_txt = rotary
-            fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rot_img, output=qkv[0, t_txt:],
-                                   out_vt=vt[:, t_txt:] if svdq else None, ln=ln)
-            fused_qkv_norm_rottary(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, rot_txt,
-                                   output=qkv[0, :t_txt], out_vt=vt[:, :t_txt] if svdq else None, ln=ln_ctx)
+            rot_img, rot_txt = rotary[0], rotary[1]
+            if self.grouped and B == 1 and len(rotary) > 2:  # one launch for both streams (rows: text, then image)
+                grouped = fused_qkv_norm_rottary_pair(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k,
+                                                      hidden, self.to_qkv, self.norm_q, self.norm_k, rotary[2], qkv[0],
+                                                      out_vt=vt, ln_a=ln_ctx, ln_b=ln)
+            if not grouped:
+                fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rot_img, output=qkv[0, t_txt:],
+                                       out_vt=vt[:, t_txt:] if svdq else None, ln=ln)
+                fused_qkv_norm_rottary(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, rot_txt,
+                                       output=qkv[0, :t_txt], out_vt=vt[:, :t_txt] if svdq else None, ln=ln_ctx)
         else:
             fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary, output=qkv.view(B * tokens, -1),
                                    out_vt=vt, ln=ln)
@@ -109,6 +118,9 @@ class FluxAttentionAMD(nn.Module):
                                                v.view(shp).transpose(1, 2), dropout_p=0.0, is_causal=False)
             o = o.transpose(1, 2).reshape(B, -1, hd)
         if self.joint:
+            if self.grouped and B == 1:
+                ca, a = linear_pair(o[:, :t_txt], self.to_add_out, o[:, t_txt:], self.to_out, pool=pool)
+                return a, ca
             return self.to_out(o[:, t_txt:], pool=pool), self.to_add_out(o[:, :t_txt], pool=pool)
         return self.to_out(o, pool=pool)
 
@@ -173,6 +185,16 @@ class FluxJointBlockAMD(nn.Module):
         mp_h, mp_e = _pad256(hidden.shape[1]), _pad256(encoder_hidden.shape[1])
         r_mlp = self.ff.fc1.rank + self.ff.fc2.rank          # fc1's quantiser + the GELU epilogue's accumulator for fc2
         r_mlp_c = self.ff_context.fc1.rank + self.ff_context.fc2.rank
+        if self.attn.grouped and encoder_hidden.shape[1] % 256 == 0:
+            # grouped launches: the text stream's pool carries the scratch of BOTH streams (its rows come first)
+            hidden, h_stats = residual_gate_stats(hidden, a, gate_msa)
+            encoder_hidden, e_stats, e_pool = residual_gate_stats(encoder_hidden, ca, c_gate_msa, zero_floats=(mp_e + mp_h) * r_mlp)
+            ffc, ff = fused_gelu_mlp_pair(encoder_hidden, self.ff_context.fc1, self.ff_context.fc2, hidden, self.ff.fc1, self.ff.fc2,
+                                          ln_a=(e_stats, c_scale_mlp, c_shift_mlp, e_pool), ln_b=(h_stats, scale_mlp, shift_mlp))
+            hidden, h_stats = residual_gate_stats(hidden, ff, gate_mlp)
+            encoder_hidden, e_stats, e_pool = residual_gate_stats(encoder_hidden, ffc, c_gate_mlp,
+                                                                  zero_floats=(mp_e + mp_h) * self.attn.to_qkv.rank)
+            return encoder_hidden, hidden, ((h_stats, None), (e_stats, e_pool))
         hidden, h_stats, h_pool = residual_gate_stats(hidden, a, gate_msa, zero_floats=mp_h * r_mlp)
         hidden, h_stats, h_pool = residual_gate_stats(hidden, self.ff(hidden, ln=(h_stats, scale_mlp, shift_mlp, h_pool)), gate_mlp,
                                                       zero_floats=mp_h * self.attn.to_qkv.rank)  # next block's QKV quantiser
@@ -328,7 +350,7 @@ class FluxTransformerAMD(nn.Module):
         fused = self.fused_norm and hidden.shape[0] == 1
         stats = ((residual_gate_stats(hidden)[1], None), (residual_gate_stats(enc)[1], None)) if fused else None
         for blk in self.blocks:
-            enc, hidden, stats = blk(hidden, enc, temb_act, (rot_img, rot_txt), stats)
+            enc, hidden, stats = blk(hidden, enc, temb_act, (rot_img, rot_txt, rot_all), stats)
         hidden = torch.cat([enc, hidden], dim=1)
         stats = (torch.cat([stats[1][0], stats[0][0]], dim=0), None) if fused else None  # [txt; img] row order
         for blk in self.single_blocks:

@@ -62,3 +62,105 @@ def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rota
         rotary_emb=rot, out_vt=out_vt, lora_scales=getattr(proj, "lora_scales", None),
     )
     return output.view(B, S, -1)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Grouped launches for the two streams of a joint block (extension): stream a (text) owns rows [0, Ma), stream b
+# (image) the rows after it; same layer shapes, different weights.  The row-side buffers of the two streams are
+# allocated back to back, each stream is quantised into its slice, and ONE gemm_w4a4 launch with a second weight set
+# serves both (include/svdq_amd.h: svdq_gemm_args.wgt2 ...).  Ma must be a multiple of 256 and batch 1.
+# --------------------------------------------------------------------------------------------------------------------
+from .quantize import svdq_quantize_w4a4_act_fuse_lora_cuda  # noqa: E402
+
+
+def _pair_ok(la, lb, xa, xb) -> bool:
+    return (xa.shape[0] == 1 and xb.shape[0] == 1 and xa.shape[1] % 256 == 0 and la.in_features == lb.in_features
+            and la.out_features == lb.out_features and la.rank == lb.rank and (la.bias is None) == (lb.bias is None)
+            and la.act_unsigned == lb.act_unsigned and getattr(la, "lora_scales", None) == getattr(lb, "lora_scales", None))
+
+
+def _take(pool, numel):
+    piece = pool.take(numel) if pool is not None else None
+    return piece, piece is not None
+
+
+def _quantize_pair(xa, la, xb, lb, ln_a=None, ln_b=None, pool=None):
+    """Both streams quantised into one set of row-side buffers (stream a first).  Returns (act, ascales, lora_act, Ma)."""
+    la._ensure_layout()
+    lb._ensure_layout()
+    Ma, Mb, K, R = xa.shape[1], xb.shape[1], la.in_features, la.rank
+    Mb_pad = ceil_divide(Mb, 256) * 256
+    Mt, dev = Ma + Mb_pad, xa.device
+    act = torch.empty(Mt, K * 3 // 4, dtype=torch.uint8, device=dev)
+    asc = torch.empty(K // 64, Mt, dtype=xa.dtype, device=dev)  # opaque scale image: row-tile major, so the streams are slices
+    lact, zeroed = _take(pool, Mt * R)
+    lact = lact.view(Mt, R) if zeroed else torch.empty(Mt, R, dtype=torch.float32, device=dev)
+    ascf = asc.view(-1)
+    na = Ma * (K // 64)
+    for x, lin, ln, r0, r1, s0, s1 in ((xa, la, ln_a, 0, Ma, 0, na), (xb, lb, ln_b, Ma, Mt, na, ascf.numel())):
+        svdq_quantize_w4a4_act_fuse_lora_cuda(
+            x.reshape(-1, K), output=act[r0:r1], oscales=ascf[s0:s1].view(K // 64, r1 - r0), lora_down=lin.proj_down,
+            lora_act_out=lact[r0:r1], smooth=lin.smooth_factor, ln=None if ln is None else ln[:3], lora_act_zeroed=zeroed)
+    return act, asc, lact, Ma
+
+
+def _second(lin, **extra):
+    d = dict(wgt=lin.qweight, wscales=lin.wscales, bias=lin.bias, lora_up=lin.proj_up)
+    d.update(extra)
+    return d
+
+
+def linear_pair(xa, la, xb, lb, pool=None):
+    """``(la(xa), lb(xb))`` with one GEMM launch; falls back to two calls when the layers cannot be grouped."""
+    if not _pair_ok(la, lb, xa, xb):
+        return la(xa, pool=pool), lb(xb, pool=pool)
+    act, asc, lact, Ma = _quantize_pair(xa, la, xb, lb, pool=pool)
+    Mb = xb.shape[1]
+    out = torch.empty(Ma + Mb, la.out_features, dtype=xa.dtype, device=xa.device)
+    svdq_gemm_w4a4_cuda(act=act, wgt=la.qweight, out=out, ascales=asc, wscales=la.wscales, lora_act_in=lact, lora_up=la.proj_up,
+                        bias=la.bias, act_unsigned=la.act_unsigned, lora_scales=getattr(la, "lora_scales", None),
+                        second=_second(lb), split_rows=Ma)
+    return out[:Ma].unsqueeze(0), out[Ma:].unsqueeze(0)
+
+
+def fused_gelu_mlp_pair(xa, fc1a, fc2a, xb, fc1b, fc2b, ln_a=None, ln_b=None):
+    """``(fc2a(gelu(fc1a(xa))), fc2b(gelu(fc1b(xb))))`` with two GEMM launches instead of four."""
+    if not (_pair_ok(fc1a, fc1b, xa, xb) and _pair_ok(fc2a, fc2b, xa, xb)):
+        return fused_gelu_mlp(xa, fc1a, fc2a, ln=ln_a), fused_gelu_mlp(xb, fc1b, fc2b, ln=ln_b)
+    pool = ln_a[3] if ln_a is not None and len(ln_a) > 3 else None  # stream a's pool must hold both streams' scratch
+    act, asc, lact, Ma = _quantize_pair(xa, fc1a, xb, fc1b, ln_a, ln_b, pool=pool)
+    for m in (fc2a, fc2b):
+        m._ensure_layout()
+    Mb, Mt, dev = xb.shape[1], act.shape[0], xa.device
+    Nh, R2 = fc1a.out_features, fc2a.rank
+    q_hidden = torch.empty(Mt, Nh * 3 // 4, dtype=torch.uint8, device=dev)
+    s_hidden = torch.empty(Nh // 64, Mt, dtype=xa.dtype, device=dev)
+    l_hidden, l_zeroed = _take(pool, Mt * R2)
+    l_hidden = l_hidden.view(Mt, R2) if l_zeroed else torch.empty(Mt, R2, dtype=torch.float32, device=dev)
+    svdq_gemm_w4a4_cuda(
+        act=act, wgt=fc1a.qweight, qout=q_hidden, ascales=asc, wscales=fc1a.wscales, oscales=s_hidden, lora_act_in=lact,
+        lora_up=fc1a.proj_up, lora_down=fc2a.proj_down, lora_act_out=l_hidden, bias=fc1a.bias, smooth_factor=fc2a.smooth_factor,
+        lora_scales=getattr(fc1a, "lora_scales", None), lora_act_zeroed=l_zeroed,
+        second=_second(fc1b, smooth_factor=fc2b.smooth_factor, lora_down=fc2b.proj_down), split_rows=Ma)
+    out = torch.empty(Ma + Mb, fc2a.out_features, dtype=xa.dtype, device=dev)
+    svdq_gemm_w4a4_cuda(act=q_hidden, wgt=fc2a.qweight, out=out, ascales=s_hidden, wscales=fc2a.wscales, lora_act_in=l_hidden,
+                        lora_up=fc2a.proj_up, bias=fc2a.bias, act_unsigned=fc2a.act_unsigned,
+                        lora_scales=getattr(fc2a, "lora_scales", None), second=_second(fc2b), split_rows=Ma)
+    return out[:Ma].unsqueeze(0), out[Ma:].unsqueeze(0)
+
+
+def fused_qkv_norm_rottary_pair(xa, proj_a, nq_a, nk_a, xb, proj_b, nq_b, nk_b, rotary_emb, output, out_vt=None,
+                                ln_a=None, ln_b=None):
+    """QKV projections of both streams into ``output`` [Ma + Mb, 3*H*128] (rows: stream a, then stream b) with one
+    GEMM launch; ``rotary_emb`` is the packed table of the concatenated token sequence.  Returns False when the
+    layers cannot be grouped (nothing has been written)."""
+    if not _pair_ok(proj_a, proj_b, xa, xb) or xb.shape[1] % 256:
+        return False
+    pool = ln_a[3] if ln_a is not None and len(ln_a) > 3 else None
+    act, asc, lact, Ma = _quantize_pair(xa, proj_a, xb, proj_b, ln_a, ln_b, pool=pool)
+    svdq_gemm_w4a4_cuda(
+        act=act, wgt=proj_a.qweight, out=output, ascales=asc, wscales=proj_a.wscales, lora_act_in=lact, lora_up=proj_a.proj_up,
+        bias=proj_a.bias, norm_q=nq_a.weight, norm_k=nk_a.weight, rotary_emb=rotary_emb.reshape(-1, rotary_emb.shape[-1]),
+        out_vt=out_vt, lora_scales=getattr(proj_a, "lora_scales", None),
+        second=_second(proj_b, norm_q=nq_b.weight, norm_k=nk_b.weight), split_rows=Ma)
+    return True

@@ -41,6 +41,8 @@ def svdq_gemm_w4a4_cuda(
     attn_tokens: int = 0,
     out_vt: torch.Tensor | None = None,
     lora_act_zeroed: bool = False,
+    second: dict | None = None,
+    split_rows: int = 0,
 ) -> None:
     """Fused W4A4 GEMM + low-rank correction; results are written in place into ``out`` or, for the
     GELU+requantise fusion, into ``qout`` / ``oscales`` / ``lora_act_out``."""
@@ -52,5 +54,5 @@ def svdq_gemm_w4a4_cuda(
     ops.gemm_w4a4(
         act, wgt, out, qout, ascales, wscales, oscales, poolout, lora_act_in, lora_up, lora_down, lora_act_out,
         norm_q, norm_k, rotary_emb, bias, smooth_factor, out_vk, out_linearattn, act_unsigned, lora_scales,
-        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens, out_vt, lora_act_zeroed,
+        fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens, out_vt, lora_act_zeroed, second, split_rows,
     )

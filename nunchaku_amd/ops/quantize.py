@@ -20,6 +20,7 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     pad_size: int = 256,
     ln: tuple | None = None,
     pool=None,
+    lora_act_zeroed: bool = False,
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """4-bit quantisation of ``input`` [M, K] plus the low-rank down projection.
 
@@ -42,7 +43,7 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
         if K % 128:
             raise ValueError("K must be a multiple of 128")
         oscales = torch.empty(K // 64, M_pad, dtype=input.dtype, device=dev)
-    zeroed = False
+    zeroed = bool(lora_act_zeroed)  # only meaningful with a caller-provided lora_act_out
     if lora_act_out is None:
         # a 4th element of ``ln`` is a ZeroPool of fp32 scratch cleared by the preceding residual_gate_stats pass
         if pool is None:

@@ -100,3 +100,67 @@ def test_flux_transformer_fused_norm_vs_torch_ops():
         FluxTransformerAMD.fused_norm = True
     rel = ((outs[True] - outs[False]).norm() / outs[False].norm()).item()
     assert torch.isfinite(outs[True]).all() and rel < 5e-2, f"fused vs torch-op AdaLayerNormZero: relative L2 {rel:.3g}"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_grouped_launches_match_separate_calls(dtype):
+    """One GEMM launch with two weight sets (text rows first, image rows after) against the two separate calls."""
+    from nunchaku_amd.ops.fused import fused_gelu_mlp, fused_gelu_mlp_pair, linear_pair
+    from tests.helpers import assert_close_16
+
+    K, N, Ma, Mb = 256, 384, 256, 300
+    La = O.make_svdq_layer(K, N, 32, seed=1, dtype=dtype, cheap=True)
+    Lb = O.make_svdq_layer(K, N, 32, seed=2, dtype=dtype, cheap=True)
+    xa = t16(O.make_activations(Ma, K, seed=3, dtype=dtype), dtype).view(1, Ma, K)
+    xb = t16(O.make_activations(Mb, K, seed=4, dtype=dtype), dtype).view(1, Mb, K)
+    la, lb = make_module(La, dtype), make_module(Lb, dtype)
+    ya, yb = linear_pair(xa, la, xb, lb)
+    assert ya.shape == (1, Ma, N) and yb.shape == (1, Mb, N)
+    assert_close_16(f32(ya), f32(la(xa)), dtype, "pair a", max_bad_frac=2e-3)
+    assert_close_16(f32(yb), f32(lb(xb)), dtype, "pair b", max_bad_frac=2e-3)
+    # and against the oracle directly (stream b uses the SECOND weight set)
+    ref_b = O.svdq_linear(f32(xb)[0], Lb, dtype, "fp32")["out"]
+    assert_close_16(f32(yb)[0], ref_b, dtype, "pair b vs oracle", max_bad_frac=2e-3)
+    # fused MLP pair
+    Nh = 512
+    F1a, F1b = O.make_svdq_layer(K, Nh, 32, seed=5, dtype=dtype, cheap=True), O.make_svdq_layer(K, Nh, 32, seed=6, dtype=dtype, cheap=True)
+    F2a, F2b = O.make_svdq_layer(Nh, K, 32, seed=7, dtype=dtype, cheap=True), O.make_svdq_layer(Nh, K, 32, seed=8, dtype=dtype, cheap=True)
+    f1a, f1b = make_module(F1a, dtype), make_module(F1b, dtype)
+    f2a, f2b = make_module(F2a, dtype, act_unsigned=True), make_module(F2b, dtype, act_unsigned=True)
+    ma, mb = fused_gelu_mlp_pair(xa, f1a, f2a, xb, f1b, f2b)
+    ra, rb = fused_gelu_mlp(xa, f1a, f2a), fused_gelu_mlp(xb, f1b, f2b)
+    for got, ref, nm in ((ma, ra, "mlp a"), (mb, rb, "mlp b")):
+        rel = ((got.float() - ref.float()).norm() / ref.float().norm()).item()
+        assert rel < 1e-2, f"{nm}: grouped vs separate relative L2 {rel:.3g}"  # fp32-atomic noise through the 4-bit requantiser
+    refb = O.fused_gelu_mlp(f32(xb)[0], F1b, F2b, dtype)
+    rel = np.linalg.norm(f32(mb)[0] - refb) / np.linalg.norm(refb)
+    assert rel < 2e-2, f"grouped MLP (second weight set) vs oracle: {rel:.3g}"
+
+
+def test_flux_transformer_grouped_vs_separate_launches():
+    from nunchaku_amd.models.flux import FluxAttentionAMD, FluxTransformerAMD
+
+    torch.manual_seed(5)
+    model = FluxTransformerAMD(num_layers=2, num_single_layers=1, dim=256, heads=2, in_channels=64, joint_attention_dim=128,
+                               pooled_projection_dim=64, device="cuda")
+    model.init_synthetic_(seed=2)
+    model.eval()
+    side, t_txt = 16, 256  # text tokens a multiple of 256: the grouped path is taken
+    lat = torch.randn(1, side * side, 64, device="cuda").bfloat16()
+    enc = torch.randn(1, t_txt, 128, device="cuda").bfloat16()
+    pooled = torch.randn(1, 64, device="cuda").bfloat16()
+    img_ids = torch.zeros(side * side, 3, device="cuda")
+    img_ids[:, 1] = torch.arange(side, device="cuda").repeat_interleave(side)
+    img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
+    txt_ids = torch.zeros(t_txt, 3, device="cuda")
+    t, gd = torch.tensor([0.7], device="cuda"), torch.tensor([3.5], device="cuda")
+    outs = {}
+    try:
+        for grouped in (True, False):
+            FluxAttentionAMD.grouped = grouped
+            with torch.no_grad():
+                outs[grouped] = model(lat, enc, pooled, t, img_ids, txt_ids, gd)[0].float()
+    finally:
+        FluxAttentionAMD.grouped = True
+    rel = ((outs[True] - outs[False]).norm() / outs[False].norm()).item()
+    assert torch.isfinite(outs[True]).all() and rel < 3e-2, f"grouped vs separate launches: relative L2 {rel:.3g}"
