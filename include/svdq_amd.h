@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 8
+#define SVDQ_ABI_VERSION 9
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -99,9 +99,14 @@ typedef struct svdq_quantize_args {
     const float *ln_stats; /* [M, 2] fp32 (mean, rstd) per row, e.g. from svdq_residual_gate_stats     */
     const void *mod_scale; /* [K] 16-bit                                                              */
     const void *mod_shift; /* [K] 16-bit                                                              */
+    /* Grouped launch (optional, x2 != NULL): rows [split_rows, split_rows + M2) of the OUTPUT buffers come from a
+     * second input x2 (row stride ldx2) quantised with a second parameter set -- the text and image stream of a joint
+     * block in one launch, feeding svdq_gemm_args.wgt2.  Then M must equal split_rows (a multiple of 256). */
+    const void *x2, *smooth2, *lora_down2, *mod_scale2, *mod_shift2;
+    const float *ln_stats2;
+    int32_t M2, ldx2, split_rows;
     int32_t lora_act_zeroed; /* non-zero: the caller guarantees lora_act is already zero on this stream (e.g. cleared by
                                 svdq_residual_gate_stats' zero_ptr), so the hipMemsetAsync of the K-sliced reduction is skipped */
-    int32_t reserved;
 } svdq_quantize_args;
 
 int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *args, void *stream);

@@ -54,12 +54,14 @@ def _workspace(device: torch.device) -> torch.Tensor:
 class _Ops:
     @staticmethod
     def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False,
-                                    ln_stats=None, mod_scale=None, mod_shift=None, lora_act_zeroed=False):
+                                    ln_stats=None, mod_scale=None, mod_shift=None, lora_act_zeroed=False, second=None):
         """reference: csrc/ops.h:83-112 -> kernels::quantize_w4a4_act_fuse_lora (zgemm.h:39-46).
 
         ``ln_stats`` / ``mod_scale`` / ``mod_shift`` (extension, all or none): quantise
         ``layer_norm(input) * scale + shift`` (16-bit torch-op rounding, scale with the +1 included) instead of ``input``;
-        ``ln_stats`` is the ``[M, 2]`` float32 (mean, rstd) tensor ``ops.residual_gate_stats`` returns."""
+        ``ln_stats`` is the ``[M, 2]`` float32 (mean, rstd) tensor ``ops.residual_gate_stats`` returns.
+        ``second`` (extension, grouped launch): dict ``input, smooth, lora_down[, ln_stats, mod_scale, mod_shift]`` of a
+        second stream whose rows follow the first stream's (a multiple of 256) in the same output buffers."""
         lib = _lib.load()
         if input is None or output is None or oscales is None:
             raise ValueError("quantize_w4a4_act_fuse_lora: input, output and oscales are required")
@@ -92,6 +94,15 @@ class _Ops:
             if mod_scale.numel() != K or mod_shift.numel() != K or mod_scale.dtype != input.dtype or mod_shift.dtype != input.dtype:
                 raise ValueError("quantize_w4a4_act_fuse_lora: mod_scale / mod_shift must be [K] in the input dtype")
             a.ln_stats, a.mod_scale, a.mod_shift = _ptr(ln_stats), _ptr(mod_scale), _ptr(mod_shift)
+        keep2 = None
+        if second is not None:
+            x2 = second["input"].reshape(-1, K)
+            if x2.stride(-1) != 1:
+                x2 = x2.contiguous()
+            a.x2, a.M2, a.ldx2, a.split_rows = x2.data_ptr(), x2.shape[0], x2.stride(0), M
+            a.smooth2, a.lora_down2 = _ptr(second.get("smooth")), _ptr(second.get("lora_down"))
+            a.ln_stats2, a.mod_scale2, a.mod_shift2 = _ptr(second.get("ln_stats")), _ptr(second.get("mod_scale")), _ptr(second.get("mod_shift"))
+            keep2 = (x2, second)
         if output.shape[-1] * 4 != K * 3 or oscales.numel() != (K // 64) * M_pad:
             raise ValueError(
                 "quantize_w4a4_act_fuse_lora: output must be the [M_pad, 3K/4] byte FP6 operand image of this "
@@ -100,6 +111,7 @@ class _Ops:
         if R and lora_act_out.numel() != M_pad * R:
             raise ValueError("quantize_w4a4_act_fuse_lora: lora_act_out must hold M_pad*R floats")
         _lib.check(lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), _stream()), "quantize_w4a4_act_fuse_lora")
+        del keep2
 
     @staticmethod
     def gemm_w4a4(

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class QuantizeArgs(C.Structure):
@@ -22,7 +22,9 @@ class QuantizeArgs(C.Structure):
         ("M", C.c_int32), ("M_pad", C.c_int32), ("K", C.c_int32), ("R", C.c_int32),
         ("ldx", C.c_int32), ("dtype", C.c_int32), ("fuse_glu", C.c_int32), ("fp4", C.c_int32),
         ("ln_stats", C.c_void_p), ("mod_scale", C.c_void_p), ("mod_shift", C.c_void_p),
-        ("lora_act_zeroed", C.c_int32), ("reserved", C.c_int32),
+        ("x2", C.c_void_p), ("smooth2", C.c_void_p), ("lora_down2", C.c_void_p), ("mod_scale2", C.c_void_p),
+        ("mod_shift2", C.c_void_p), ("ln_stats2", C.c_void_p), ("M2", C.c_int32), ("ldx2", C.c_int32),
+        ("split_rows", C.c_int32), ("lora_act_zeroed", C.c_int32),
     ]
 
 

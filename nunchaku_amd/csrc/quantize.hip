@@ -20,6 +20,13 @@
 
 namespace svdq {
 
+// grouped launch: rows >= split_rows read a second input and use a second parameter set (svdq_quantize_args.x2 ...)
+struct QuantSecond {
+    const void *x, *smooth, *lora_down, *mod_scale, *mod_shift;
+    const float *ln_stats;
+    int M, ldx, split_rows; // M: valid rows of the second stream; x == nullptr: off
+};
+
 template <int DT, int RT32 /* 32-rank tiles held in registers */, int OCC /* workgroups per CU the register budget allows */>
 __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<DT>::T *__restrict__ x,
                                                        const typename Half<DT>::T *__restrict__ smooth,
@@ -30,7 +37,7 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
                                                        int chunks_per_wg, int use_atomics,
                                                        const float *__restrict__ ln_stats,
                                                        const typename Half<DT>::T *__restrict__ mod_scale,
-                                                       const typename Half<DT>::T *__restrict__ mod_shift) {
+                                                       const typename Half<DT>::T *__restrict__ mod_shift, const QuantSecond s2) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     const int tid = threadIdx.x;
@@ -39,7 +46,14 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
     const int KP = K / 128;
     const int slices = (KP + chunks_per_wg - 1) / chunks_per_wg;
     const int rt = blockIdx.x / slices, slice = blockIdx.x % slices;
-    const int row = rt * 32 + r;
+    // grouped launch: this row tile's stream (block-uniform); outputs stay addressed by the joint row tile index rt
+    const bool second = s2.x != nullptr && rt * 32 >= s2.split_rows;
+    if (second) {
+        x = (const T *)s2.x; smooth = (const T *)s2.smooth; lora_down = (const T *)s2.lora_down;
+        ln_stats = s2.ln_stats; mod_scale = (const T *)s2.mod_scale; mod_shift = (const T *)s2.mod_shift;
+        ldx = s2.ldx; M = s2.M;
+    }
+    const int row = rt * 32 + r - (second ? s2.split_rows : 0); // row inside this stream's input
     const bool valid = row < M;
     const int kp_end = min(KP, (slice + 1) * chunks_per_wg);
 
@@ -243,16 +257,17 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     }
     dim3 grid(tiles * slices), block(256);
     const int rt32 = (a->R + 31) / 32;
+    QuantSecond s2{a->x2, a->smooth2, a->lora_down2, a->mod_scale2, a->mod_shift2, a->ln_stats2, a->M2, a->ldx2, a->split_rows};
     static const int occ_env = getenv("SVDQ_QUANT_OCC") ? atoi(getenv("SVDQ_QUANT_OCC")) : 0; // experiment knob
 #define SVDQ_LAUNCH_Q(RT)                                                                                            \
     if (RT <= 2 && occ_env == 4)                                                                                     \
     hipLaunchKernelGGL((quantize_kernel<DT, RT, (RT <= 2 ? 4 : 1)>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth, \
                        (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
-                       a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift);          \
+                       a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift, s2);          \
     else                                                                                                             \
     hipLaunchKernelGGL((quantize_kernel<DT, RT, 1>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,          \
                        (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
-                       a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift)
+                       a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift, s2)
     if (rt32 == 0) SVDQ_LAUNCH_Q(0);
     else if (rt32 <= 1) SVDQ_LAUNCH_Q(1);
     else if (rt32 <= 2) SVDQ_LAUNCH_Q(2);
@@ -296,9 +311,26 @@ extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, voi
         set_error("svdq_quantize: ln_stats, mod_scale and mod_shift must be 8-byte aligned");
         return SVDQ_E_INVALID;
     }
+    if (a->x2) { // grouped launch
+        if (a->split_rows <= 0 || a->split_rows % 256 || a->M != a->split_rows || a->M2 <= 0 || a->split_rows + a->M2 > a->M_pad ||
+            a->ldx2 < a->K || a->ldx2 % 4) {
+            set_error("svdq_quantize: grouped launch needs M == split_rows (a multiple of 256), 0 < M2, split_rows + M2 <= M_pad, ldx2 >= K");
+            return SVDQ_E_INVALID;
+        }
+        if ((a->smooth != nullptr) != (a->smooth2 != nullptr) || (a->R > 0 && !a->lora_down2) ||
+            (a->ln_stats != nullptr) != (a->ln_stats2 != nullptr) || (a->ln_stats2 && (!a->mod_scale2 || !a->mod_shift2))) {
+            set_error("svdq_quantize: grouped launch: the second parameter set must mirror the first");
+            return SVDQ_E_INVALID;
+        }
+        if (((uintptr_t)a->x2 | (uintptr_t)a->lora_down2 | (uintptr_t)a->smooth2 | (uintptr_t)a->ln_stats2 | (uintptr_t)a->mod_scale2 |
+             (uintptr_t)a->mod_shift2) & 7) {
+            set_error("svdq_quantize: second parameter set must be 8-byte aligned");
+            return SVDQ_E_INVALID;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes: x in, codes + scales + lora_act out, lora_down in (once)
-    const double bytes = (double)a->M * a->K * 2 + (double)a->M_pad * a->K * 3 / 4 + (double)a->M_pad * (a->K / 64) * 2 +
+    const double bytes = (double)(a->M + (a->x2 ? a->M2 : 0)) * a->K * 2 + (double)a->M_pad * a->K * 3 / 4 + (double)a->M_pad * (a->K / 64) * 2 +
                          (double)a->M_pad * a->R * 4 + (double)a->K * a->R * 2;
     const int prof = prof_begin(1, bytes, st);
     int rc = a->dtype == SVDQ_BF16 ? launch_quantize<SVDQ_BF16>(a, st) : launch_quantize<SVDQ_FP16>(a, st);

@@ -95,12 +95,13 @@ def _quantize_pair(xa, la, xb, lb, ln_a=None, ln_b=None, pool=None):
     asc = torch.empty(K // 64, Mt, dtype=xa.dtype, device=dev)  # opaque scale image: row-tile major, so the streams are slices
     lact, zeroed = _take(pool, Mt * R)
     lact = lact.view(Mt, R) if zeroed else torch.empty(Mt, R, dtype=torch.float32, device=dev)
-    ascf = asc.view(-1)
-    na = Ma * (K // 64)
-    for x, lin, ln, r0, r1, s0, s1 in ((xa, la, ln_a, 0, Ma, 0, na), (xb, lb, ln_b, Ma, Mt, na, ascf.numel())):
-        svdq_quantize_w4a4_act_fuse_lora_cuda(
-            x.reshape(-1, K), output=act[r0:r1], oscales=ascf[s0:s1].view(K // 64, r1 - r0), lora_down=lin.proj_down,
-            lora_act_out=lact[r0:r1], smooth=lin.smooth_factor, ln=None if ln is None else ln[:3], lora_act_zeroed=zeroed)
+    # ONE quantiser launch: stream a's rows first, stream b read from its own tensor with its own parameter set
+    sec = dict(input=xb, smooth=lb.smooth_factor, lora_down=lb.proj_down)
+    if ln_b is not None:
+        sec.update(ln_stats=ln_b[0], mod_scale=ln_b[1], mod_shift=ln_b[2])
+    svdq_quantize_w4a4_act_fuse_lora_cuda(
+        xa.reshape(-1, K), output=act, oscales=asc, lora_down=la.proj_down, lora_act_out=lact, smooth=la.smooth_factor,
+        ln=None if ln_a is None else ln_a[:3], lora_act_zeroed=zeroed, second=sec)
     return act, asc, lact, Ma
 
 

@@ -21,6 +21,7 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     ln: tuple | None = None,
     pool=None,
     lora_act_zeroed: bool = False,
+    second: dict | None = None,
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """4-bit quantisation of ``input`` [M, K] plus the low-rank down projection.
 
@@ -53,8 +54,8 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
         lora_act_out = lora_act_out.view(M_pad, R) if zeroed else torch.empty(M_pad, R, dtype=torch.float32, device=dev)
     if ln is None:
         ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4,
-                                        lora_act_zeroed=zeroed)
+                                        lora_act_zeroed=zeroed, second=second)
     else:
         ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4,
-                                        ln_stats=ln[0], mod_scale=ln[1], mod_shift=ln[2], lora_act_zeroed=zeroed)
+                                        ln_stats=ln[0], mod_scale=ln[1], mod_shift=ln[2], lora_act_zeroed=zeroed, second=second)
     return output, oscales, lora_act_out
