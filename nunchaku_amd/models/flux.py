@@ -25,7 +25,7 @@ from torch import nn
 from ..ops.attention import attention_packed
 from ..ops.elementwise import residual_gate_stats
 from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair,
-                         linear_pair)
+                         linear_pair, quantize_two)
 from ..utils import pad_tensor
 from .embeddings import flux_pos_embed, pack_rotemb
 from .linear import AWQW4A16Linear, SVDQW4A4Linear
@@ -80,7 +80,7 @@ class FluxAttentionAMD(nn.Module):
     def _use_svdq(self, B, tokens):
         return self.attention_impl == "svdq" and B == 1 and self.head_dim == 128 and tokens % 128 == 0
 
-    def forward(self, hidden, encoder_hidden=None, rotary=None, ln=None, ln_ctx=None):
+    def forward(self, hidden, encoder_hidden=None, rotary=None, ln=None, ln_ctx=None, quantized=None):
         """``ln`` / ``ln_ctx`` = (stats, scale, shift): the inputs are the UN-normalised streams and the
         AdaLayerNormZero front end runs inside the QKV projections' quantiser."""
         B = hidden.shape[0]
@@ -105,7 +105,7 @@ class FluxAttentionAMD(nn.Module):
                                        output=qkv[0, :t_txt], out_vt=vt[:, :t_txt] if svdq else None, ln=ln_ctx)
         else:
             fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary, output=qkv.view(B * tokens, -1),
-                                   out_vt=vt, ln=ln)
+                                   out_vt=vt, ln=ln, quantized=quantized)
         pool = None
         if svdq:  # the same launch clears the low-rank accumulators of the output projections' quantisers
             zf = _pad256(hidden.shape[1]) * self.to_out.rank + (_pad256(t_txt) * self.to_add_out.rank if self.joint else 0)
@@ -225,8 +225,10 @@ class FluxSingleBlockAMD(nn.Module):
         shift, scale, gate = self.mod(temb_act).view(3, -1)
         st, pool = stats
         ln = (st, scale, shift, pool)  # one LayerNorm + modulation, consumed by both projections' quantisers
-        mlp = fused_gelu_mlp(hidden, self.mlp_fc1, self.mlp_fc2, ln=ln)
-        att = self.attn(hidden, rotary=rotary, ln=ln)
+        both = quantize_two(hidden, self.mlp_fc1, self.attn.to_qkv, ln=ln) if FluxAttentionAMD.grouped else None
+        q_mlp, q_qkv = both if both is not None else (None, None)  # one quantiser launch for the two projections
+        mlp = fused_gelu_mlp(hidden, self.mlp_fc1, self.mlp_fc2, ln=ln, quantized=q_mlp)
+        att = self.attn(hidden, rotary=rotary, ln=ln, quantized=q_qkv)
         # hidden + gate * (att + mlp), the next block's statistics and its three low-rank accumulators, one pass
         hidden, st, pool = residual_gate_stats(hidden, att, gate, b=mlp, zero_floats=_pad256(hidden.shape[1]) * (
             self.mlp_fc1.rank + self.mlp_fc2.rank + self.attn.to_qkv.rank))

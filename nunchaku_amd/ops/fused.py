@@ -8,14 +8,15 @@ from ..utils import ceil_divide
 from .gemm import svdq_gemm_w4a4_cuda
 
 
-def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256, ln=None) -> torch.Tensor:
+def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256, ln=None, quantized=None) -> torch.Tensor:
     """MLP ``fc2(gelu(fc1(x)))`` in three launches: quantise, fc1 GEMM whose epilogue applies GELU,
     re-quantises to unsigned 4-bit (shift 0.171875) and computes fc2's low-rank down projection,
     then the fc2 GEMM on those codes."""
     B, S, C_in = x.shape
     M = B * S
     x2 = x.reshape(M, C_in)
-    qx, ascales, lora_act = fc1.quantize(x2, ln=ln)  # ln: fused AdaLayerNormZero front end (extension)
+    # ln: fused AdaLayerNormZero front end (extension); quantized: (codes, scales, lora_act) made by quantize_two
+    qx, ascales, lora_act = fc1.quantize(x2, ln=ln) if quantized is None else quantized
     M_pad = ceil_divide(M, pad_size) * pad_size
     dev = x.device
     q_hidden = torch.empty(M_pad, fc1.out_features * 3 // 4, dtype=torch.uint8, device=dev)  # FP6 operand image
@@ -38,7 +39,7 @@ def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256, ln=None) -> t
 
 
 def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rotary_emb: torch.Tensor | None = None,
-                           output=None, attn_tokens: int = 0, out_vt: torch.Tensor | None = None, ln=None):
+                           output=None, attn_tokens: int = 0, out_vt: torch.Tensor | None = None, ln=None, quantized=None):
     """QKV projection with RMSNorm(q), RMSNorm(k) and rotary embedding applied in the GEMM epilogue.
     ``rotary_emb`` is the ``pack_rotemb`` tensor of the reference ([1, M_pad, 128] float32).
     ``out_vt`` ([out_features/3, tokens] view): V is written transposed there for ``ops.attention`` instead of
@@ -46,7 +47,7 @@ def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rota
     B, S, C_in = x.shape
     M = B * S
     x2 = x.reshape(M, C_in)
-    qx, ascales, lora_act = proj.quantize(x2, ln=ln)
+    qx, ascales, lora_act = proj.quantize(x2, ln=ln) if quantized is None else quantized
     if isinstance(output, tuple):
         raise NotImplementedError("the reference's packed (q, k, v) tuple is NVIDIA-fragment ordered; pass out_vt= instead")
     if output is None:
@@ -165,3 +166,27 @@ def fused_qkv_norm_rottary_pair(xa, proj_a, nq_a, nk_a, xb, proj_b, nq_b, nk_b, 
         out_vt=out_vt, lora_scales=getattr(proj_a, "lora_scales", None),
         second=_second(proj_b, norm_q=nq_b.weight, norm_k=nk_b.weight), split_rows=Ma)
     return True
+
+
+def quantize_two(x, lin_a, lin_b, ln=None):
+    """The SAME input quantised for two layers (different smoothing / low-rank factors) in one launch: the grouped
+    quantiser with both streams reading ``x``; returns ``((codes, scales, lora_act) for lin_a, ... for lin_b)`` as views
+    of one set of buffers, or None when the shapes do not allow it (rows not a multiple of 256, different ranks)."""
+    M, K = x.shape[-2], x.shape[-1]
+    if x.numel() != M * K or M % 256 or lin_a.in_features != lin_b.in_features or lin_a.rank != lin_b.rank:
+        return None
+    lin_a._ensure_layout()
+    lin_b._ensure_layout()
+    R, dev = lin_a.rank, x.device
+    pool = ln[3] if ln is not None and len(ln) > 3 else None
+    act = torch.empty(2 * M, K * 3 // 4, dtype=torch.uint8, device=dev)
+    asc = torch.empty(K // 64, 2 * M, dtype=x.dtype, device=dev)
+    lact, zeroed = _take(pool, 2 * M * R)
+    lact = lact.view(2 * M, R) if zeroed else torch.empty(2 * M, R, dtype=torch.float32, device=dev)
+    sec = dict(input=x, smooth=lin_b.smooth_factor, lora_down=lin_b.proj_down)
+    if ln is not None:
+        sec.update(ln_stats=ln[0], mod_scale=ln[1], mod_shift=ln[2])
+    svdq_quantize_w4a4_act_fuse_lora_cuda(x.reshape(M, K), output=act, oscales=asc, lora_down=lin_a.proj_down, lora_act_out=lact,
+                                          smooth=lin_a.smooth_factor, ln=None if ln is None else ln[:3], lora_act_zeroed=zeroed, second=sec)
+    ascf, n = asc.view(-1), M * (K // 64)
+    return ((act[:M], ascf[:n].view(K // 64, M), lact[:M]), (act[M:], ascf[n:].view(K // 64, M), lact[M:]))
