@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 9
+#define SVDQ_ABI_VERSION 10
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -268,6 +268,12 @@ typedef struct svdq_gemv_awq_args {
 } svdq_gemv_awq_args;
 
 int svdq_gemv_awq(const svdq_gemv_awq_args *args, void *stream);
+/* `count` (<= 80) independent GEMVs that share x, M, K, dtype and group_size in ONE launch (extension): all the
+ * modulation projections of a denoising step depend only on the timestep embedding, so they can be issued together
+ * before the first block instead of one launch per block.  Each entry brings its own qweight / scales / zeros / bias /
+ * out / N / out_chunks; x, M, K, ldx, group_size and dtype are taken from args[0]. */
+#define SVDQ_GEMV_BATCH_MAX 80
+int svdq_gemv_awq_batched(const svdq_gemv_awq_args *args, int32_t count, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Load-time re-layout of reference checkpoint tensors (NVIDIA fragment order -> CDNA4 order).

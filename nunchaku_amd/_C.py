@@ -284,6 +284,35 @@ class _Ops:
         return out
 
     @staticmethod
+    def gemv_awq_batched(in_feats, layers):
+        """Extension: the AWQ GEMVs of ``layers`` (``AWQW4A16Linear``-like objects: ``qweight, wscales, wzeros, bias,
+        out_features, in_features, group_size, out_chunks``) on the same single-row ``in_feats`` in ONE launch per 80
+        layers; returns the list of outputs (``[1, out_features]`` each, views of one buffer)."""
+        lib = _lib.load()
+        if in_feats.dtype not in _DT or in_feats.numel() != in_feats.shape[-1] or not in_feats.is_cuda:
+            raise ValueError("gemv_awq_batched: in_feats must be one row of a 16-bit GPU tensor")
+        x = in_feats.reshape(1, -1).contiguous()
+        k = x.shape[1]
+        total = sum(l.out_features for l in layers)
+        buf = torch.empty(total, dtype=x.dtype, device=x.device)
+        outs, off = [], 0
+        arr = (_lib.GemvAwqArgs * len(layers))()
+        for a, l in zip(arr, layers):
+            if l.in_features != k or l.wscales.dtype != x.dtype:
+                raise ValueError("gemv_awq_batched: every layer must take in_feats' width and dtype")
+            o = buf[off:off + l.out_features]
+            off += l.out_features
+            outs.append(o.view(1, -1))
+            a.x, a.qweight, a.scales, a.zeros = x.data_ptr(), _ptr(l.qweight), _ptr(l.wscales), _ptr(l.wzeros)
+            a.bias, a.out = _ptr(l.bias), o.data_ptr()
+            a.M, a.N, a.K, a.ldx = 1, l.out_features, k, k
+            a.group_size, a.dtype, a.out_chunks = l.group_size, _DT[x.dtype], int(getattr(l, "out_chunks", 1))
+        for s0 in range(0, len(layers), 80):
+            n = min(80, len(layers) - s0)
+            _lib.check(lib.svdq_gemv_awq_batched(C.cast(C.byref(arr[s0]), C.POINTER(_lib.GemvAwqArgs)), n, _stream()), "gemv_awq_batched")
+        return outs
+
+    @staticmethod
     def attention(q, k, vt, out, scale, zero=None):
         """Non-causal attention, head_dim 128 (role of the reference's ``ops.attention_fp16``, csrc/ops.h:114-121
         -> attention.cu:11-94).  Strided views, no copies: ``q``/``k``/``out`` are ``[L, H, 128]`` (any token and head

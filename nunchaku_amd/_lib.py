@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class QuantizeArgs(C.Structure):
@@ -79,6 +79,7 @@ EXPORTS = {
     "svdq_gemm_w4a4": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "svdq_attention": (C.c_int, [C.POINTER(AttentionArgs), C.c_void_p]),
     "svdq_gemv_awq": (C.c_int, [C.POINTER(GemvAwqArgs), C.c_void_p]),
+    "svdq_gemv_awq_batched": (C.c_int, [C.POINTER(GemvAwqArgs), C.c_int32, C.c_void_p]),
     "svdq_residual_gate_stats": (C.c_int, [C.POINTER(ResidualArgs), C.c_void_p]),
     "svdq_gemm_workspace_bytes": (C.c_int64, []),
     "svdq_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),

@@ -16,13 +16,12 @@ namespace svdq {
 constexpr int AWQ_GROUP = 64;
 
 template <int DT, int M>
-__global__ __launch_bounds__(256) void gemv_awq_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ qw,
-                                                        const uint16_t *__restrict__ scales, const uint16_t *__restrict__ zeros,
-                                                        const uint16_t *__restrict__ bias, uint16_t *__restrict__ out, int K, int N,
-                                                        int ldx, int ochunks) {
+__device__ __forceinline__ void gemv_awq_rowgroup(const uint16_t *__restrict__ x, const uint8_t *__restrict__ qw,
+                                                  const uint16_t *__restrict__ scales, const uint16_t *__restrict__ zeros,
+                                                  const uint16_t *__restrict__ bias, uint16_t *__restrict__ out, int K, int N,
+                                                  int ldx, int ochunks, int rg) {
     using T = typename Half<DT>::T;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rg = blockIdx.x * 4 + wave; // row group: output channels 4*rg .. 4*rg + 3
+    const int lane = threadIdx.x & 63;
     if (rg * 4 >= N) return;
     const int row = (lane >> 1) & 3, half = lane & 1, cl = lane >> 3; // this lane's channel, 32-channel half, chunk in the wave-load
     const int n = rg * 4 + row;
@@ -92,6 +91,27 @@ __global__ __launch_bounds__(256) void gemv_awq_kernel(const uint16_t *__restric
     }
 }
 
+template <int DT, int M>
+__global__ __launch_bounds__(256) void gemv_awq_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ qw,
+                                                        const uint16_t *__restrict__ scales, const uint16_t *__restrict__ zeros,
+                                                        const uint16_t *__restrict__ bias, uint16_t *__restrict__ out, int K, int N,
+                                                        int ldx, int ochunks) {
+    gemv_awq_rowgroup<DT, M>(x, qw, scales, zeros, bias, out, K, N, ldx, ochunks, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// batched form: the descriptors travel in the kernel arguments (80 x 48 B), a block finds its entry by a scalar scan
+struct GemvEntry { const uint8_t *qw; const uint16_t *scales, *zeros, *bias; uint16_t *out; int N, ochunks; };
+struct GemvBatch { GemvEntry e[SVDQ_GEMV_BATCH_MAX]; int count; }; // 80 x 48 B + 4: under the 4 KiB kernel-argument limit
+
+template <int DT>
+__global__ __launch_bounds__(256) void gemv_awq_batched_kernel(const uint16_t *__restrict__ x, const GemvBatch b, int K, int ldx) {
+    int i = 0, first = 0; // block-uniform scan: entry i owns blocks [first, first + ceil(N_i / 16))
+    while (i + 1 < b.count && (int)blockIdx.x >= first + (b.e[i].N / 4 + 3) / 4) { first += (b.e[i].N / 4 + 3) / 4; i++; }
+    const GemvEntry &e = b.e[i];
+    gemv_awq_rowgroup<DT, 1>(x, e.qw, e.scales, e.zeros, e.bias, e.out, K, e.N, ldx, e.ochunks,
+                             ((int)blockIdx.x - first) * 4 + (threadIdx.x >> 6));
+}
+
 template <int DT> static int launch_gemv(const svdq_gemv_awq_args *a, hipStream_t st) {
     dim3 grid((a->N / 4 + 3) / 4), block(256);
 #define SVDQ_GEMV_CASE(MM)                                                                                                          \
@@ -113,8 +133,7 @@ template <int DT> static int launch_gemv(const svdq_gemv_awq_args *a, hipStream_
 
 using namespace svdq;
 
-extern "C" int svdq_gemv_awq(const svdq_gemv_awq_args *a, void *stream) {
-    if (!a) { set_error("svdq_gemv_awq: args is NULL"); return SVDQ_E_INVALID; }
+static int validate_gemv(const svdq_gemv_awq_args *a) {
     if (!a->x || !a->qweight || !a->scales || !a->zeros || !a->out) { set_error("svdq_gemv_awq: x, qweight, scales, zeros and out are required"); return SVDQ_E_INVALID; }
     if (a->M < 1 || a->M > 8) { set_error("svdq_gemv_awq: M=%d must be in [1, 8] (gemv_awq.cu:280)", a->M); return SVDQ_E_INVALID; }
     if (a->group_size != AWQ_GROUP) { set_error("svdq_gemv_awq: group_size=%d (only 64 is implemented, gemv_awq.cu:281)", a->group_size); return SVDQ_E_UNSUPPORTED; }
@@ -123,10 +142,41 @@ extern "C" int svdq_gemv_awq(const svdq_gemv_awq_args *a, void *stream) {
     if (((uintptr_t)a->x | (uintptr_t)a->qweight) & 15) { set_error("svdq_gemv_awq: x and qweight must be 16-byte aligned"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemv_awq: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
     if (a->out_chunks < 0 || (a->out_chunks > 1 && a->N % a->out_chunks)) { set_error("svdq_gemv_awq: out_chunks=%d must divide N=%d", a->out_chunks, a->N); return SVDQ_E_INVALID; }
+    return SVDQ_OK;
+}
+
+extern "C" int svdq_gemv_awq(const svdq_gemv_awq_args *a, void *stream) {
+    if (!a) { set_error("svdq_gemv_awq: args is NULL"); return SVDQ_E_INVALID; }
+    if (int rc = validate_gemv(a)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(3, (double)a->N * a->K / 2 + 4.0 * (a->K / AWQ_GROUP) * a->N, st);
     if (a->dtype == SVDQ_BF16) launch_gemv<SVDQ_BF16>(a, st);
     else launch_gemv<SVDQ_FP16>(a, st);
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_gemv_awq launch");
+}
+
+extern "C" int svdq_gemv_awq_batched(const svdq_gemv_awq_args *a, int32_t count, void *stream) {
+    if (!a || count < 1 || count > SVDQ_GEMV_BATCH_MAX) { set_error("svdq_gemv_awq_batched: need 1 <= count=%d <= %d entries", count, SVDQ_GEMV_BATCH_MAX); return SVDQ_E_INVALID; }
+    GemvBatch b;
+    int blocks = 0;
+    double bytes = 0;
+    for (int i = 0; i < count; i++) {
+        if (int rc = validate_gemv(a + i)) return rc;
+        if (a[i].x != a[0].x || a[i].M != 1 || a[i].K != a[0].K || a[i].ldx != a[0].ldx || a[i].dtype != a[0].dtype) {
+            set_error("svdq_gemv_awq_batched: entry %d must share x, M = 1, K, ldx and dtype with entry 0", i);
+            return SVDQ_E_INVALID;
+        }
+        b.e[i] = GemvEntry{(const uint8_t *)a[i].qweight, (const uint16_t *)a[i].scales, (const uint16_t *)a[i].zeros,
+                           (const uint16_t *)a[i].bias, (uint16_t *)a[i].out, a[i].N, a[i].out_chunks};
+        blocks += (a[i].N / 4 + 3) / 4;
+        bytes += (double)a[i].N * a[i].K / 2 + 4.0 * (a[i].K / AWQ_GROUP) * a[i].N;
+    }
+    b.count = count;
+    hipStream_t st = (hipStream_t)stream;
+    const int prof = prof_begin(3, bytes, st);
+    if (a[0].dtype == SVDQ_BF16) hipLaunchKernelGGL((gemv_awq_batched_kernel<SVDQ_BF16>), dim3(blocks), dim3(256), 0, st, (const uint16_t *)a[0].x, b, a[0].K, a[0].ldx);
+    else hipLaunchKernelGGL((gemv_awq_batched_kernel<SVDQ_FP16>), dim3(blocks), dim3(256), 0, st, (const uint16_t *)a[0].x, b, a[0].K, a[0].ldx);
+    prof_end(prof, st);
+    return hip_check(hipGetLastError(), "svdq_gemv_awq_batched launch");
 }

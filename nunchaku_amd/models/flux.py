@@ -24,6 +24,7 @@ from torch import nn
 
 from ..ops.attention import attention_packed
 from ..ops.elementwise import residual_gate_stats
+from ..ops.gemv import awq_gemv_w4a16_batched
 from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair,
                          linear_pair, quantize_two)
 from ..utils import pad_tensor
@@ -157,8 +158,9 @@ class FluxJointBlockAMD(nn.Module):
         # already carries the +1 of the scale
         return F.layer_norm(x, (x.shape[-1],), eps=1e-6) * scale[:, None] + shift[:, None]
 
-    def forward(self, hidden, encoder_hidden, temb_act, rotary, stats=None):
-        """``stats`` = (image-stream, text-stream) LayerNorm statistics of the inputs: the fused path -- LayerNorm and
+    def forward(self, hidden, encoder_hidden, temb_act, rotary, stats=None, mods=None):
+        """``mods`` = (mod, mod_context) outputs computed ahead of the block (one batched GEMV launch per step).
+        ``stats`` = (image-stream, text-stream) LayerNorm statistics of the inputs: the fused path -- LayerNorm and
         modulation inside the quantisers, gated residual + next statistics in one element-wise pass (B == 1).
         Returns (encoder_hidden, hidden, stats)."""
         # normalization.py:85-98 -- emb.view(B, -1, 6).permute(2, 0, 1): interleaved chunks
@@ -178,8 +180,9 @@ class FluxJointBlockAMD(nn.Module):
             encoder_hidden = encoder_hidden + c_gate_mlp[:, None] * self.ff_context(n_e)
             return encoder_hidden, hidden, None
         (h_stats, h_pool), (e_stats, e_pool) = stats  # pools: fp32 zeros for the low-rank accumulators of the next calls
-        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.mod(temb_act).view(6, -1)
-        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.mod_context(temb_act).view(6, -1)
+        m_out, c_out = mods if mods is not None else (self.mod(temb_act), self.mod_context(temb_act))
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = m_out.view(6, -1)
+        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c_out.view(6, -1)
         a, ca = self.attn(hidden, encoder_hidden, rotary, ln=(h_stats, scale_msa, shift_msa, h_pool),
                           ln_ctx=(e_stats, c_scale_msa, c_shift_msa, e_pool))
         mp_h, mp_e = _pad256(hidden.shape[1]), _pad256(encoder_hidden.shape[1])
@@ -215,14 +218,14 @@ class FluxSingleBlockAMD(nn.Module):
         self.mlp_fc2 = SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})
         self.attn = FluxAttentionAMD(dim, heads, False, kw)
 
-    def forward(self, hidden, temb_act, rotary, stats=None):
+    def forward(self, hidden, temb_act, rotary, stats=None, mods=None):
         if stats is None:
             shift, scale, gate = self.mod(temb_act).view(temb_act.shape[0], 3, -1).permute(1, 0, 2)
             n = F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6) * scale[:, None] + shift[:, None]
             mlp = fused_gelu_mlp(n, self.mlp_fc1, self.mlp_fc2)
             att = self.attn(n, rotary=rotary)
             return hidden + gate[:, None] * (att + mlp), None  # transformer_flux_v2.py:332-335
-        shift, scale, gate = self.mod(temb_act).view(3, -1)
+        shift, scale, gate = (mods if mods is not None else self.mod(temb_act)).view(3, -1)
         st, pool = stats
         ln = (st, scale, shift, pool)  # one LayerNorm + modulation, consumed by both projections' quantisers
         both = quantize_two(hidden, self.mlp_fc1, self.attn.to_qkv, ln=ln) if FluxAttentionAMD.grouped else None
@@ -351,12 +354,17 @@ class FluxTransformerAMD(nn.Module):
 
         fused = self.fused_norm and hidden.shape[0] == 1
         stats = ((residual_gate_stats(hidden)[1], None), (residual_gate_stats(enc)[1], None)) if fused else None
-        for blk in self.blocks:
-            enc, hidden, stats = blk(hidden, enc, temb_act, (rot_img, rot_txt, rot_all), stats)
+        # every modulation projection depends on the timestep embedding only: one batched GEMV launch for the whole step
+        mods = awq_gemv_w4a16_batched(temb_act, [m for b in self.blocks for m in (b.mod, b.mod_context)] +
+                                      [b.mod for b in self.single_blocks]) if fused and not __import__("os").environ.get("SVDQ_NO_BATCHED_MODS") else None
+        nj = len(self.blocks)
+        for i, blk in enumerate(self.blocks):
+            enc, hidden, stats = blk(hidden, enc, temb_act, (rot_img, rot_txt, rot_all), stats,
+                                     mods=(mods[2 * i], mods[2 * i + 1]) if mods is not None else None)
         hidden = torch.cat([enc, hidden], dim=1)
         stats = (torch.cat([stats[1][0], stats[0][0]], dim=0), None) if fused else None  # [txt; img] row order
-        for blk in self.single_blocks:
-            hidden, stats = blk(hidden, temb_act, rot_all, stats)
+        for i, blk in enumerate(self.single_blocks):
+            hidden, stats = blk(hidden, temb_act, rot_all, stats, mods=mods[2 * nj + i] if mods is not None else None)
         hidden = hidden[:, t_txt:]
         scale, shift = self.norm_out_mod(temb_act).chunk(2, dim=-1)  # AdaLayerNormContinuous
         hidden = F.layer_norm(hidden, (self.dim,), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]

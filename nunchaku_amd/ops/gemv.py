@@ -22,3 +22,9 @@ def awq_gemv_w4a16_cuda(
     """``in_feats`` [m, k] 16-bit, ``kernel`` [n/4, k/2] int32 (checkpoint order), ``scaling_factors`` /
     ``zeros`` [k/group_size, n] -> [m, n].  ``bias`` (extension): fused 16-bit ``output.add_(bias)``."""
     return ops.gemv_awq(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size, bias, out_chunks)
+
+
+def awq_gemv_w4a16_batched(in_feats: torch.Tensor, layers) -> list[torch.Tensor]:
+    """All of ``layers`` (AWQW4A16Linear) applied to the same single row ``in_feats`` in one launch (extension): the
+    modulation projections of every block of a denoising step depend only on the timestep embedding."""
+    return ops.gemv_awq_batched(in_feats, list(layers))

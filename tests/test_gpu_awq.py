@@ -65,3 +65,23 @@ def test_gemv_awq_op_surface_and_errors():
         ops.gemv_awq(x, kern, t16(s, "bf16"), t16(z, "bf16"), 2, 64, 128, 128)
     with pytest.raises(ValueError):
         ops.gemv_awq(x.repeat(5, 1)[:9], kern, t16(s, "bf16"), t16(z, "bf16"), 9, 64, 128, 64)
+
+
+def test_gemv_awq_batched_matches_single_launches():
+    from nunchaku_amd.models.linear import AWQW4A16Linear
+    from nunchaku_amd.ops.gemv import awq_gemv_w4a16_batched
+
+    K = 256
+    layers = []
+    for i, (N, chunks) in enumerate([(768, 6), (384, 3), (64, 1), (1536, 6)] * 21):  # 84 layers: two launches
+        q, s, z, bias = _layer(N, K, "bf16", seed=100 + i % 4)
+        lin = AWQW4A16Linear(K, N, device="cuda")
+        lin.load_state_dict({"qweight": torch.from_numpy(O.pack_awq_w4_ref(q)), "wscales": t16(s, "bf16"), "wzeros": t16(z, "bf16"),
+                             "bias": t16(bias, "bf16")})
+        lin.out_chunks = chunks
+        layers.append(lin)
+    x = t16(np.random.default_rng(1).standard_normal((1, K)).astype(np.float32), "bf16")
+    outs = awq_gemv_w4a16_batched(x, layers)
+    assert len(outs) == len(layers)
+    for lin, o in list(zip(layers, outs))[::7]:
+        assert torch.equal(o, lin(x))
