@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 10
+#define SVDQ_ABI_VERSION 11
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -237,6 +237,14 @@ typedef struct svdq_residual_args {
      * quantiser / GELU_QUANT calls that follow: saves their memset launches).  zero_bytes must be a multiple of 16. */
     void *zero_ptr;
     int64_t zero_bytes;
+    /* Grouped launch (optional, res2 != NULL): a second, independent problem of the same width C and row stride
+     * (M2 rows; the text stream of a joint block beside the image stream) in the same launch.  a2 / b2 / gate2 /
+     * out2 / stats2 must mirror a / b / gate / out / stats in being given or NULL. */
+    const void *res2, *a2, *b2, *gate2;
+    void *out2;
+    float *stats2;
+    int32_t M2;
+    int32_t reserved2;
 } svdq_residual_args;
 
 int svdq_residual_gate_stats(const svdq_residual_args *args, void *stream);

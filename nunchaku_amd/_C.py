@@ -224,7 +224,7 @@ class _Ops:
         del keep, keep2
 
     @staticmethod
-    def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6, zero=None):
+    def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6, zero=None, second=None):
         """Extension: ``out = res + gate * (a [+ b])`` (16-bit torch-op rounding of a block's gated residual)
         and/or the LayerNorm statistics ``stats[m] = (mean, rstd)`` of the result, in one pass.  2-D row-major
         views with a common row stride; ``a`` None = statistics of ``res`` itself; ``out`` may be ``res``."""
@@ -250,6 +250,15 @@ class _Ops:
             if not zero.is_cuda or not zero.is_contiguous() or (zero.numel() * zero.element_size()) % 16:
                 raise ValueError("residual_gate_stats: zero must be a contiguous GPU tensor of a multiple of 16 bytes")
             args.zero_ptr, args.zero_bytes = zero.data_ptr(), zero.numel() * zero.element_size()
+        if second is not None:  # (res, a, b, gate, out, stats) of an independent second problem of the same width
+            r2, a2, b2, g2, o2, s2 = second
+            if r2.dim() != 2 or r2.shape[1] != Cc or r2.stride() != res.stride() or r2.dtype != res.dtype:
+                raise ValueError("residual_gate_stats: the second problem must have the width, row stride and dtype of the first")
+            for t in (a2, b2, o2):
+                if t is not None and (tuple(t.shape) != tuple(r2.shape) or t.stride() != r2.stride()):
+                    raise ValueError("residual_gate_stats: second problem: a, b, out must match res in shape and strides")
+            args.res2, args.a2, args.b2, args.gate2, args.out2, args.stats2 = dp(r2), dp(a2), dp(b2), dp(g2), dp(o2), dp(s2)
+            args.M2 = r2.shape[0]
         _lib.check(lib.svdq_residual_gate_stats(C.byref(args), _stream()), "residual_gate_stats")
 
     @staticmethod

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class QuantizeArgs(C.Structure):
@@ -33,6 +33,8 @@ class ResidualArgs(C.Structure):
         ("res", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("gate", C.c_void_p), ("out", C.c_void_p),
         ("stats", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("ld", C.c_int32), ("dtype", C.c_int32),
         ("eps", C.c_float), ("reserved", C.c_int32), ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_int64),
+        ("res2", C.c_void_p), ("a2", C.c_void_p), ("b2", C.c_void_p), ("gate2", C.c_void_p), ("out2", C.c_void_p),
+        ("stats2", C.c_void_p), ("M2", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 

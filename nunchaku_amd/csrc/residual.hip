@@ -17,13 +17,20 @@ template <int DT, int NV /* 16-byte pieces per lane */>
 __global__ __launch_bounds__(256) void residual_kernel(const uint16_t *__restrict__ res, const uint16_t *__restrict__ a,
                                                         const uint16_t *__restrict__ b, const uint16_t *__restrict__ gate,
                                                         uint16_t *__restrict__ out, float *__restrict__ stats, int M, int C, int ld,
-                                                        float eps, v4i *__restrict__ zero_ptr, long long zero_vec) {
+                                                        float eps, v4i *__restrict__ zero_ptr, long long zero_vec,
+                                                        const uint16_t *__restrict__ res2, const uint16_t *__restrict__ a2,
+                                                        const uint16_t *__restrict__ b2, const uint16_t *__restrict__ gate2,
+                                                        uint16_t *__restrict__ out2, float *__restrict__ stats2, int M2) {
     using T = typename Half<DT>::T;
     // side job: clear the scratch buffer, 16 bytes per thread, grid-strided (before any early return)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_vec; i += (long long)gridDim.x * 256) zero_ptr[i] = v4i{0, 0, 0, 0};
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) { // grouped launch: rows beyond the first problem belong to the second one (wave-uniform)
+        row -= M;
+        if (!res2 || row >= M2) return;
+        res = res2; a = a2; b = b2; gate = gate2; out = out2; stats = stats2;
+    }
     const size_t base = (size_t)row * ld;
     float y[NV][8];
     float sum = 0.f;
@@ -82,12 +89,14 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint16_t *__restric
 }
 
 template <int DT> static int launch_residual(const svdq_residual_args *p, hipStream_t st) {
-    dim3 grid((p->M + 3) / 4), block(256);
+    dim3 grid((p->M + (p->res2 ? p->M2 : 0) + 3) / 4), block(256);
 #define SVDQ_RES_CASE(NV)                                                                                                       \
     case NV:                                                                                                                    \
         hipLaunchKernelGGL((residual_kernel<DT, NV>), grid, block, 0, st, (const uint16_t *)p->res, (const uint16_t *)p->a,      \
                            (const uint16_t *)p->b, (const uint16_t *)p->gate, (uint16_t *)p->out, p->stats, p->M, p->C, p->ld,   \
-                           p->eps, (v4i *)p->zero_ptr, (long long)(p->zero_ptr ? p->zero_bytes / 16 : 0));                                                                                           \
+                           p->eps, (v4i *)p->zero_ptr, (long long)(p->zero_ptr ? p->zero_bytes / 16 : 0),                          \
+                           (const uint16_t *)p->res2, (const uint16_t *)p->a2, (const uint16_t *)p->b2, (const uint16_t *)p->gate2, \
+                           (uint16_t *)p->out2, p->stats2, p->M2);                                                                                           \
         return 0;
     switch ((p->C + 511) / 512) {
         SVDQ_RES_CASE(1) SVDQ_RES_CASE(2) SVDQ_RES_CASE(3) SVDQ_RES_CASE(4) SVDQ_RES_CASE(5) SVDQ_RES_CASE(6) SVDQ_RES_CASE(7) SVDQ_RES_CASE(8)
@@ -117,6 +126,18 @@ extern "C" int svdq_residual_gate_stats(const svdq_residual_args *a, void *strea
     if (a->zero_ptr && (a->zero_bytes < 0 || a->zero_bytes % 16 || ((uintptr_t)a->zero_ptr & 15))) {
         set_error("svdq_residual_gate_stats: zero_ptr must be 16-byte aligned and zero_bytes a non-negative multiple of 16");
         return SVDQ_E_INVALID;
+    }
+    if (a->res2) {
+        if (a->M2 <= 0 || (a->a != nullptr) != (a->a2 != nullptr) || (a->b != nullptr) != (a->b2 != nullptr) ||
+            (a->gate != nullptr) != (a->gate2 != nullptr) || (a->out != nullptr) != (a->out2 != nullptr) ||
+            (a->stats != nullptr) != (a->stats2 != nullptr)) {
+            set_error("svdq_residual_gate_stats: the second problem must mirror the first (and M2 > 0)");
+            return SVDQ_E_INVALID;
+        }
+        if (((uintptr_t)a->res2 | (uintptr_t)a->a2 | (uintptr_t)a->b2 | (uintptr_t)a->gate2 | (uintptr_t)a->out2) & 15 || ((uintptr_t)a->stats2 & 7)) {
+            set_error("svdq_residual_gate_stats: second problem: tensors must be 16-byte aligned (stats 8-byte)");
+            return SVDQ_E_INVALID;
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     const int rc = a->dtype == SVDQ_BF16 ? launch_residual<SVDQ_BF16>(a, st) : launch_residual<SVDQ_FP16>(a, st);

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..ops.attention import attention_packed
-from ..ops.elementwise import residual_gate_stats
+from ..ops.elementwise import residual_gate_stats, residual_gate_stats_pair
 from ..ops.gemv import awq_gemv_w4a16_batched
 from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair,
                          linear_pair, quantize_two)
@@ -190,13 +190,12 @@ class FluxJointBlockAMD(nn.Module):
         r_mlp_c = self.ff_context.fc1.rank + self.ff_context.fc2.rank
         if self.attn.grouped and encoder_hidden.shape[1] % 256 == 0:
             # grouped launches: the text stream's pool carries the scratch of BOTH streams (its rows come first)
-            hidden, h_stats = residual_gate_stats(hidden, a, gate_msa)
-            encoder_hidden, e_stats, e_pool = residual_gate_stats(encoder_hidden, ca, c_gate_msa, zero_floats=(mp_e + mp_h) * r_mlp)
+            encoder_hidden, e_stats, hidden, h_stats, e_pool = residual_gate_stats_pair(
+                encoder_hidden, ca, c_gate_msa, hidden, a, gate_msa, zero_floats=(mp_e + mp_h) * r_mlp)
             ffc, ff = fused_gelu_mlp_pair(encoder_hidden, self.ff_context.fc1, self.ff_context.fc2, hidden, self.ff.fc1, self.ff.fc2,
                                           ln_a=(e_stats, c_scale_mlp, c_shift_mlp, e_pool), ln_b=(h_stats, scale_mlp, shift_mlp))
-            hidden, h_stats = residual_gate_stats(hidden, ff, gate_mlp)
-            encoder_hidden, e_stats, e_pool = residual_gate_stats(encoder_hidden, ffc, c_gate_mlp,
-                                                                  zero_floats=(mp_e + mp_h) * self.attn.to_qkv.rank)
+            encoder_hidden, e_stats, hidden, h_stats, e_pool = residual_gate_stats_pair(
+                encoder_hidden, ffc, c_gate_mlp, hidden, ff, gate_mlp, zero_floats=(mp_e + mp_h) * self.attn.to_qkv.rank)
             return encoder_hidden, hidden, ((h_stats, None), (e_stats, e_pool))
         hidden, h_stats, h_pool = residual_gate_stats(hidden, a, gate_msa, zero_floats=mp_h * r_mlp)
         hidden, h_stats, h_pool = residual_gate_stats(hidden, self.ff(hidden, ln=(h_stats, scale_mlp, shift_mlp, h_pool)), gate_mlp,

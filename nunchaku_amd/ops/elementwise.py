@@ -50,3 +50,22 @@ def residual_gate_stats(res: torch.Tensor, a: torch.Tensor | None = None, gate: 
     if want_pool:
         return y, stats, ZeroPool(zero if zero is not None else torch.empty(0, dtype=torch.float32, device=res.device))
     return y, stats
+
+
+def residual_gate_stats_pair(res_a, a_a, gate_a, res_b, a_b, gate_b, zero_floats: int = 0, eps: float = 1e-6):
+    """Two independent gated residuals (the two streams of a joint block: same width, different row counts) and their
+    statistics in ONE launch, both in place.  Returns ``(y_a, stats_a, y_b, stats_b[, ZeroPool])``."""
+    C = res_a.shape[-1]
+    ra, rb = res_a.reshape(-1, C), res_b.reshape(-1, C)
+    sa = torch.empty(ra.shape[0], 2, dtype=torch.float32, device=res_a.device)
+    sb = torch.empty(rb.shape[0], 2, dtype=torch.float32, device=res_a.device)
+    if os.environ.get("SVDQ_NO_ZEROPOOL"):
+        zf = 0
+    else:
+        zf = zero_floats
+    zero = torch.empty((zf + 3) // 4 * 4, dtype=torch.float32, device=res_a.device) if zf > 0 else None
+    ops.residual_gate_stats(ra, a_a.reshape(-1, C), None, gate_a.reshape(-1), ra, sa, eps, zero,
+                            second=(rb, a_b.reshape(-1, C), None, gate_b.reshape(-1), rb, sb))
+    if zero_floats > 0:
+        return res_a, sa, res_b, sb, ZeroPool(zero if zero is not None else torch.empty(0, dtype=torch.float32, device=res_a.device))
+    return res_a, sa, res_b, sb

@@ -164,3 +164,18 @@ def test_flux_transformer_grouped_vs_separate_launches():
         FluxAttentionAMD.grouped = True
     rel = ((outs[True] - outs[False]).norm() / outs[False].norm()).item()
     assert torch.isfinite(outs[True]).all() and rel < 3e-2, f"grouped vs separate launches: relative L2 {rel:.3g}"
+
+
+def test_residual_gate_stats_pair_matches_two_calls():
+    from nunchaku_amd.ops.elementwise import residual_gate_stats, residual_gate_stats_pair
+
+    g = torch.Generator(device="cuda").manual_seed(9)
+    C = 3072
+    mk = lambda m: torch.randn(1, m, C, device="cuda", generator=g).bfloat16()
+    ra, aa, rb, ab = mk(512), mk(512), mk(301), mk(301)
+    ga, gb = torch.randn(C, device="cuda", generator=g).bfloat16(), torch.randn(C, device="cuda", generator=g).bfloat16()
+    ya, sa = residual_gate_stats(ra.clone(), aa, ga)
+    yb, sb = residual_gate_stats(rb.clone(), ab, gb)
+    pa, psa, pb, psb, pool = residual_gate_stats_pair(ra, aa, ga, rb, ab, gb, zero_floats=100)
+    assert torch.equal(pa, ya) and torch.equal(pb, yb) and torch.equal(psa, sa) and torch.equal(psb, sb)
+    assert not pool.take(100).any()
