@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 11
+#define SVDQ_ABI_VERSION 12
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -210,6 +210,19 @@ typedef struct svdq_attention_args {
      * projection's quantiser, see svdq_residual_args.zero_ptr).  zero_bytes must be a multiple of 16. */
     void *zero_ptr;
     int64_t zero_bytes;
+    /* Optional fused quantiser (extension): the output projection that follows reads the attention output only through
+     * svdq_quantize_w4a4_act_fuse_lora, and a wave's 32 query rows x 128 channels of one head ARE one F6 chunk in the
+     * register layout it already holds -- so the kernel can emit that projection's quantised activation directly
+     * (same arithmetic as the quantiser on the 16-bit rounded output: bit-identical codes and scales; lora_act summed
+     * over the H heads with fp32 atomics).  qact != NULL enables it; out may then be NULL.  Requires L % 256 == 0,
+     * K = H*128, R a multiple of 16 <= 32, and qlora_act zeroed by the caller on this stream.
+     * Rows >= qsplit_rows (a multiple of 256; 0 = off) use qsmooth2 / qlora_down2 (joint attention: text rows first). */
+    void *qact;               /* FP6 image, L * (H*128) * 3/4 bytes                                 */
+    void *qscales;            /* scale image, (H*128/64) * L 16-bit                                 */
+    float *qlora_act;         /* [L, R] fp32, pre-zeroed                                            */
+    const void *qsmooth, *qlora_down;   /* [H*128] natural; [R][H*128] rank-major (svdq_repack_lowrank(down=1)) */
+    const void *qsmooth2, *qlora_down2;
+    int32_t qR, qsplit_rows;
 } svdq_attention_args;
 
 int svdq_attention(const svdq_attention_args *args, void *stream);

@@ -322,27 +322,40 @@ class _Ops:
         return outs
 
     @staticmethod
-    def attention(q, k, vt, out, scale, zero=None):
+    def attention(q, k, vt, out, scale, zero=None, quant=None):
         """Non-causal attention, head_dim 128 (role of the reference's ``ops.attention_fp16``, csrc/ops.h:114-121
         -> attention.cu:11-94).  Strided views, no copies: ``q``/``k``/``out`` are ``[L, H, 128]`` (any token and head
         stride, unit channel stride), ``vt`` is ``[H, 128, L]`` with unit token stride (V transposed, as the QKV
         GEMM's ``out_vt`` writes it).  L must be a multiple of 128."""
         lib = _lib.load()
         for name, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
+            if name == "out" and t is None and quant is not None:
+                continue  # fused quantiser: the 16-bit output is not needed
             if t is None or t.dim() != 3 or t.stride(2) != 1:
                 raise ValueError(f"attention: {name} must be a 3-D view with unit innermost stride")
             if not t.is_cuda:
                 raise RuntimeError("nunchaku_amd ops need GPU tensors (there is no CPU path)")
-        if q.dtype not in _DT or k.dtype != q.dtype or vt.dtype != q.dtype or out.dtype != q.dtype:
+        if q.dtype not in _DT or k.dtype != q.dtype or vt.dtype != q.dtype or (out is not None and out.dtype != q.dtype):
             raise ValueError("attention: q, k, vt, out must share one 16-bit dtype")
         L, H, D = q.shape
-        if tuple(k.shape) != (L, H, D) or tuple(out.shape) != (L, H, D) or tuple(vt.shape) != (H, D, L):
+        if tuple(k.shape) != (L, H, D) or (out is not None and tuple(out.shape) != (L, H, D)) or tuple(vt.shape) != (H, D, L):
             raise ValueError("attention: expected q/k/out [L, H, D] and vt [H, D, L]")
         a = _lib.AttentionArgs()
-        a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+        a.q, a.k, a.vt = q.data_ptr(), k.data_ptr(), vt.data_ptr()
         a.ldq, a.q_hs = q.stride(0), q.stride(1)
         a.ldk, a.k_hs = k.stride(0), k.stride(1)
-        a.ldo, a.o_hs = out.stride(0), out.stride(1)
+        if out is not None:
+            a.out, a.ldo, a.o_hs = out.data_ptr(), out.stride(0), out.stride(1)
+        if quant is not None:
+            # extension: emit the following output projection's quantised activation directly (dict: act, ascales,
+            # lora_act (pre-zeroed), smooth, lora_down, R [, smooth2, lora_down2, split_rows])
+            Kq = H * D
+            if quant["act"].numel() != L * Kq * 3 // 4 or quant["ascales"].numel() != (Kq // 64) * L:
+                raise ValueError("attention: quant['act'] / quant['ascales'] must be the [L, 3K/4] / [K/64, L] operand images")
+            a.qact, a.qscales, a.qlora_act = _ptr(quant["act"]), _ptr(quant["ascales"]), _ptr(quant.get("lora_act"))
+            a.qsmooth, a.qlora_down, a.qR = _ptr(quant["smooth"]), _ptr(quant.get("lora_down")), int(quant.get("R", 0))
+            a.qsmooth2, a.qlora_down2 = _ptr(quant.get("smooth2")), _ptr(quant.get("lora_down2"))
+            a.qsplit_rows = int(quant.get("split_rows", 0))
         a.vt_hs, a.ldvt = vt.stride(0), vt.stride(1)
         a.L, a.H, a.head_dim, a.dtype = L, H, D, _DT[q.dtype]
         a.scale = float(scale)

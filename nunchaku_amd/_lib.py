@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class QuantizeArgs(C.Structure):
@@ -64,6 +64,9 @@ class AttentionArgs(C.Structure):
         ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldvt", C.c_int32), ("ldo", C.c_int32),
         ("L", C.c_int32), ("H", C.c_int32), ("head_dim", C.c_int32), ("dtype", C.c_int32),
         ("scale", C.c_float), ("reserved", C.c_int32), ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_int64),
+        ("qact", C.c_void_p), ("qscales", C.c_void_p), ("qlora_act", C.c_void_p), ("qsmooth", C.c_void_p),
+        ("qlora_down", C.c_void_p), ("qsmooth2", C.c_void_p), ("qlora_down2", C.c_void_p), ("qR", C.c_int32),
+        ("qsplit_rows", C.c_int32),
     ]
 
 

@@ -32,6 +32,12 @@ struct AttnParams {
     int debug;         // timing experiments (tools/bench_attention.py): results are WRONG when non-zero
     v4i *zero_ptr;     // optional scratch cleared by this launch (svdq_attention_args.zero_ptr)
     long long zero_vec; // its size in 16-byte units
+    // fused quantiser of the following output projection (svdq_attention_args.qact ...)
+    uint8_t *qact;
+    uint16_t *qscales;
+    float *qlora_act;
+    const uint16_t *qsmooth, *qlora_down, *qsmooth2, *qlora_down2;
+    int qR, qsplit_rows;
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -219,6 +225,87 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
     // ---- normalise and store: lane owns query row q0 + lr and channels 32*dt + 8c + 4h + e ------------------
     const float l_run = l2[0] + l2[1];
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    if (p.qact) {
+        // ---- fused quantiser of the output projection (quantize.hip, same arithmetic): this wave's 32 rows x 128
+        //      channels = F6 chunk (row tile q0/32, kp = head); lane (lr, h) holds exactly its lane record's channels
+        using T = typename Half<DT>::T;
+        const bool s2 = p.qsplit_rows > 0 && q0 >= p.qsplit_rows; // wave-uniform
+        const T *smooth = (const T *)(s2 ? p.qsmooth2 : p.qsmooth) + head * ATT_D;
+        const int K = p.H * ATT_D, KP = p.H;
+        if (p.qR > 0) { // lora_act[q][rank] += sum_d o16[q][d] * down[d][rank] over this head's 128 channels
+            const T *ld = (const T *)(s2 ? p.qlora_down2 : p.qlora_down) + head * ATT_D; // rank-major [R][K]
+            v16f dl;
+#pragma unroll
+            for (int i = 0; i < 16; i++) dl[i] = 0.f;
+            const bool live = lr < p.qR;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int qq = 0; qq < 2; qq++) {
+                    V8 wv, gv;
+                    if (live) {
+                        const T *src = ld + (size_t)lr * K + dt * 32 + qq * 16 + h * 4;
+                        const u16x4 w0 = *reinterpret_cast<const u16x4 *>(src);
+                        const u16x4 w1 = *reinterpret_cast<const u16x4 *>(src + 8);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { wv[j] = hfrom<T>(w0[j]); wv[4 + j] = hfrom<T>(w1[j]); }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) wv[j] = (T)0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) gv[j] = f2h<T>(o[dt][qq * 8 + j] * inv);
+                    dl = Half<DT>::mfma32(gv, wv, dl);
+                }
+            if (live) { // C layout: column (rank) = lane & 31, rows (i & 3) + 8 (i >> 2) + 4 h
+                float *dst = p.qlora_act + (size_t)(q0 + h * 4) * p.qR + lr;
+#pragma unroll
+                for (int i = 0; i < 16; i++) unsafeAtomicAdd(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.qR, dl[i]);
+            }
+        }
+        uint32_t rec[12];
+        T sc16[2];
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            float xh[32];
+            float amax = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int dt = 2 * g + t;
+                    const u16x4 sv = *reinterpret_cast<const u16x4 *>(smooth + dt * 32 + c * 8 + h * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float o16 = round16<T>(o[dt][c * 4 + e] * inv);
+                        const float sm = h2f(hfrom<T>(sv[e]));
+                        const float v = round16<T>(div_rn(o16, sm, __builtin_amdgcn_rcpf(sm)));
+                        xh[16 * t + c * 4 + e] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+                }
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            const float scale = amax * (1.0f / 7.0f);
+            const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
+            sc16[g] = f2h<T>(scale);
+            v16f ev, od;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                ev[i] = xh[2 * i] * rscale;
+                od[i] = xh[2 * i + 1] * rscale;
+            }
+            const v6i pk = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, 8.0f);
+#pragma unroll
+            for (int i = 0; i < 6; i++) rec[6 * g + i] = (uint32_t)pk[i];
+        }
+        const int rt = q0 >> 5;
+        uint8_t *dst = p.qact + ((size_t)rt * KP + head) * F6_CHUNK + (size_t)lane * 16;
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        *reinterpret_cast<uint4 *>(dst + F6_PLANE) = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+        *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[8], rec[9], rec[10], rec[11]);
+        p.qscales[(((size_t)rt * KP + head) * 2 + h) * 32 + lr] = hbits(sc16[h]);
+    }
+    if (!p.out) return;
     uint16_t *orow = p.out + (size_t)(q0 + lr) * p.ldo + (size_t)head * p.o_hs + 8 * h;
 #pragma unroll
     for (int dt = 0; dt < 4; dt++)
@@ -248,11 +335,25 @@ using namespace svdq;
 
 extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     if (!a) { set_error("svdq_attention: args is NULL"); return SVDQ_E_INVALID; }
-    if (!a->q || !a->k || !a->vt || !a->out) { set_error("svdq_attention: q, k, vt and out are required"); return SVDQ_E_INVALID; }
+    if (!a->q || !a->k || !a->vt || (!a->out && !a->qact)) { set_error("svdq_attention: q, k, vt and out (or qact) are required"); return SVDQ_E_INVALID; }
+    if (a->qact) {
+        if (!a->qscales || !a->qsmooth || a->L % 256 || a->qR < 0 || a->qR > 32 || a->qR % 16 || (a->qR > 0 && (!a->qlora_down || !a->qlora_act))) {
+            set_error("svdq_attention: fused quantiser needs qscales, qsmooth, L %% 256 == 0 and R=%d in {0, 16, 32} with qlora_down / qlora_act", a->qR);
+            return SVDQ_E_INVALID;
+        }
+        if (a->qsmooth2 && (a->qsplit_rows <= 0 || a->qsplit_rows % 256 || a->qsplit_rows >= a->L || (a->qR > 0 && !a->qlora_down2))) {
+            set_error("svdq_attention: fused quantiser: 0 < qsplit_rows < L must be a multiple of 256 (and qlora_down2 given)");
+            return SVDQ_E_INVALID;
+        }
+        if (((uintptr_t)a->qact & 15) || (((uintptr_t)a->qsmooth | (uintptr_t)a->qlora_down | (uintptr_t)a->qsmooth2 | (uintptr_t)a->qlora_down2) & 7)) {
+            set_error("svdq_attention: fused quantiser: qact must be 16-byte aligned, the vectors 8-byte");
+            return SVDQ_E_INVALID;
+        }
+    }
     if (a->head_dim != ATT_D) { set_error("svdq_attention: head_dim=%d (only 128 is implemented, as in the reference kernel)", a->head_dim); return SVDQ_E_UNSUPPORTED; }
     if (a->L <= 0 || a->L % 128 || a->H <= 0) { set_error("svdq_attention: L=%d must be a positive multiple of 128 and H=%d positive", a->L, a->H); return SVDQ_E_INVALID; }
     if (a->ldq % 8 || a->ldk % 8 || a->ldvt % 8 || a->ldo % 8 || a->q_hs % 8 || a->k_hs % 8 || a->vt_hs % 8 || a->o_hs % 8 ||
-        a->ldvt < a->L || a->ldq < ATT_D || a->ldk < ATT_D || a->ldo < ATT_D) {
+        a->ldvt < a->L || a->ldq < ATT_D || a->ldk < ATT_D || (a->out && a->ldo < ATT_D)) {
         set_error("svdq_attention: strides must be multiples of 8 elements, ldq/ldk/ldo >= 128 and ldvt >= L");
         return SVDQ_E_INVALID;
     }
@@ -267,6 +368,10 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.q_hs = a->q_hs; p.k_hs = a->k_hs; p.vt_hs = a->vt_hs; p.o_hs = a->o_hs;
     p.L = a->L; p.H = a->H; p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;
     p.scale_log2e = a->scale * 1.4426950408889634f;
+    p.qact = (uint8_t *)a->qact; p.qscales = (uint16_t *)a->qscales; p.qlora_act = a->qlora_act;
+    p.qsmooth = (const uint16_t *)a->qsmooth; p.qlora_down = (const uint16_t *)a->qlora_down;
+    p.qsmooth2 = (const uint16_t *)a->qsmooth2; p.qlora_down2 = (const uint16_t *)a->qlora_down2;
+    p.qR = a->qR; p.qsplit_rows = a->qsmooth2 ? a->qsplit_rows : 0;
     p.zero_ptr = (v4i *)a->zero_ptr;
     p.zero_vec = a->zero_ptr ? a->zero_bytes / 16 : 0;
     p.debug = a->reserved;

@@ -22,11 +22,11 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops.attention import attention_packed
+from ..ops.attention import attention_packed, attention_packed_quantized
 from ..ops.elementwise import residual_gate_stats, residual_gate_stats_pair
 from ..ops.gemv import awq_gemv_w4a16_batched
 from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair,
-                         linear_pair, quantize_two)
+                         linear_pair, linear_pair_quantized, quantize_two)
 from ..utils import pad_tensor
 from .embeddings import flux_pos_embed, pack_rotemb
 from .linear import AWQW4A16Linear, SVDQW4A4Linear
@@ -42,6 +42,11 @@ def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 1000
 
 def _pad256(n: int) -> int:
     return (n + 255) // 256 * 256
+
+
+def _pair_compatible(la, lb) -> bool:
+    return (la.in_features == lb.in_features and la.out_features == lb.out_features and la.rank == lb.rank
+            and (la.bias is None) == (lb.bias is None) and getattr(la, "lora_scales", None) == getattr(lb, "lora_scales", None))
 
 
 class _MLPEmbedder(nn.Module):
@@ -77,6 +82,8 @@ class FluxAttentionAMD(nn.Module):
     attention_impl = "svdq"
     # True: the text and image stream's projections of a joint block share one GEMM launch each (svdq_gemm_args.wgt2)
     grouped = not __import__("os").environ.get("SVDQ_NO_GROUPED")  # A/B knob
+    # True: the attention epilogue emits the output projection's quantised activation (svdq_attention_args.qact)
+    fused_out_quant = not __import__("os").environ.get("SVDQ_NO_ATTN_QUANT")  # A/B knob
 
     def _use_svdq(self, B, tokens):
         return self.attention_impl == "svdq" and B == 1 and self.head_dim == 128 and tokens % 128 == 0
@@ -108,6 +115,16 @@ class FluxAttentionAMD(nn.Module):
             fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary, output=qkv.view(B * tokens, -1),
                                    out_vt=vt, ln=ln, quantized=quantized)
         pool = None
+        if svdq and self.fused_out_quant and B == 1 and (not self.joint or (self.grouped and _pair_compatible(self.to_add_out, self.to_out))):
+            src = ln_ctx if self.joint else ln  # the pool of the stream whose rows come first carries the scratch
+            qpool = src[3] if src is not None and len(src) > 3 else None
+            qres = attention_packed_quantized(qkv[0], vt, self.heads, self.to_out, lin_first=self.to_add_out if self.joint else None,
+                                              split_rows=t_txt, pool=qpool)
+            if qres is not None:  # the 16-bit attention output never exists: straight into the output projection(s)
+                if self.joint:
+                    ca, a = linear_pair_quantized(*qres, self.to_add_out, self.to_out, t_txt)
+                    return a, ca
+                return self.to_out.forward_quant(*qres).view(B, tokens, -1)
         if svdq:  # the same launch clears the low-rank accumulators of the output projections' quantisers
             zf = _pad256(hidden.shape[1]) * self.to_out.rank + (_pad256(t_txt) * self.to_add_out.rank if self.joint else 0)
             o, pool = attention_packed(qkv[0], vt, self.heads, zero_floats=zf)
@@ -195,7 +212,7 @@ class FluxJointBlockAMD(nn.Module):
             ffc, ff = fused_gelu_mlp_pair(encoder_hidden, self.ff_context.fc1, self.ff_context.fc2, hidden, self.ff.fc1, self.ff.fc2,
                                           ln_a=(e_stats, c_scale_mlp, c_shift_mlp, e_pool), ln_b=(h_stats, scale_mlp, shift_mlp))
             encoder_hidden, e_stats, hidden, h_stats, e_pool = residual_gate_stats_pair(
-                encoder_hidden, ffc, c_gate_mlp, hidden, ff, gate_mlp, zero_floats=(mp_e + mp_h) * self.attn.to_qkv.rank)
+                encoder_hidden, ffc, c_gate_mlp, hidden, ff, gate_mlp, zero_floats=(mp_e + mp_h) * (self.attn.to_qkv.rank + self.attn.to_out.rank))
             return encoder_hidden, hidden, ((h_stats, None), (e_stats, e_pool))
         hidden, h_stats, h_pool = residual_gate_stats(hidden, a, gate_msa, zero_floats=mp_h * r_mlp)
         hidden, h_stats, h_pool = residual_gate_stats(hidden, self.ff(hidden, ln=(h_stats, scale_mlp, shift_mlp, h_pool)), gate_mlp,
@@ -233,7 +250,7 @@ class FluxSingleBlockAMD(nn.Module):
         att = self.attn(hidden, rotary=rotary, ln=ln, quantized=q_qkv)
         # hidden + gate * (att + mlp), the next block's statistics and its three low-rank accumulators, one pass
         hidden, st, pool = residual_gate_stats(hidden, att, gate, b=mlp, zero_floats=_pad256(hidden.shape[1]) * (
-            self.mlp_fc1.rank + self.mlp_fc2.rank + self.attn.to_qkv.rank))
+            self.mlp_fc1.rank + self.mlp_fc2.rank + self.attn.to_qkv.rank + self.attn.to_out.rank))
         return hidden, (st, pool)
 
 

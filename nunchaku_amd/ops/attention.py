@@ -39,3 +39,34 @@ def attention_packed(qkv: torch.Tensor, vt: torch.Tensor, heads: int, out: torch
 
         return out, ZeroPool(zero)
     return out
+
+
+def attention_packed_quantized(qkv: torch.Tensor, vt: torch.Tensor, heads: int, lin, lin_first=None, split_rows: int = 0,
+                               pool=None, scale: float | None = None):
+    """Attention whose epilogue emits the quantised input of the output projection ``lin`` directly (codes, scales and
+    low-rank down projection: what ``lin.quantize(attention_packed(...))`` would return, without the 16-bit round trip).
+    Joint attention: rows ``< split_rows`` belong to ``lin_first`` (text), the rest to ``lin``.  ``pool``: a ZeroPool for
+    the low-rank accumulator.  Returns ``(codes, scales, lora_act)`` or None when the shapes do not allow it."""
+    L, three_hd = qkv.shape
+    D = three_hd // (3 * heads)
+    K, R = heads * D, lin.rank
+    if D != 128 or L % 256 or K != lin.in_features or R > 32 or R % 16 or (lin_first is not None and (
+            lin_first.rank != R or lin_first.in_features != K or split_rows % 256 or not 0 < split_rows < L)):
+        return None
+    lin._ensure_layout()
+    dev = qkv.device
+    act = torch.empty(L, K * 3 // 4, dtype=torch.uint8, device=dev)
+    asc = torch.empty(K // 64, L, dtype=qkv.dtype, device=dev)
+    lact = pool.take(L * R) if pool is not None else None
+    lact = lact.view(L, R) if lact is not None else torch.zeros(L, R, dtype=torch.float32, device=dev)
+    quant = dict(act=act, ascales=asc, lora_act=lact, R=R)
+    if lin_first is not None:  # first parameter set = the rows that come first (text)
+        lin_first._ensure_layout()
+        quant.update(smooth=lin_first.smooth_factor, lora_down=lin_first.proj_down, smooth2=lin.smooth_factor,
+                     lora_down2=lin.proj_down, split_rows=split_rows)
+    else:
+        quant.update(smooth=lin.smooth_factor, lora_down=lin.proj_down)
+    q = qkv[:, : heads * D].unflatten(1, (heads, D))
+    k = qkv[:, heads * D : 2 * heads * D].unflatten(1, (heads, D))
+    ops.attention(q, k, vt.unflatten(0, (heads, D)), None, 1.0 / math.sqrt(D) if scale is None else scale, None, quant)
+    return act, asc, lact

@@ -125,6 +125,18 @@ def linear_pair(xa, la, xb, lb, pool=None):
     return out[:Ma].unsqueeze(0), out[Ma:].unsqueeze(0)
 
 
+def linear_pair_quantized(act, asc, lact, la, lb, Ma):
+    """The GEMM half of :func:`linear_pair` on an already quantised joint activation (rows < Ma: layer la)."""
+    la._ensure_layout()
+    lb._ensure_layout()
+    Mt = act.shape[0]
+    out = torch.empty(Mt, la.out_features, dtype=asc.dtype, device=act.device)
+    svdq_gemm_w4a4_cuda(act=act, wgt=la.qweight, out=out, ascales=asc, wscales=la.wscales, lora_act_in=lact, lora_up=la.proj_up,
+                        bias=la.bias, act_unsigned=la.act_unsigned, lora_scales=getattr(la, "lora_scales", None),
+                        second=_second(lb), split_rows=Ma)
+    return out[:Ma].unsqueeze(0), out[Ma:].unsqueeze(0)
+
+
 def fused_gelu_mlp_pair(xa, fc1a, fc2a, xb, fc1b, fc2b, ln_a=None, ln_b=None):
     """``(fc2a(gelu(fc1a(xa))), fc2b(gelu(fc1b(xb))))`` with two GEMM launches instead of four."""
     if not (_pair_ok(fc1a, fc1b, xa, xb) and _pair_ok(fc2a, fc2b, xa, xb)):

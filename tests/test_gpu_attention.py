@@ -166,3 +166,37 @@ def test_attention_full_size_properties():
     first = qkv[:half].contiguous()  # 2304 tokens: the 4-wave kernel, keys once instead of twice
     ref = attention_packed(first, first[:, 2 * H * 128:].t().contiguous(), H)
     assert (out3[:half].float() - ref.float()).abs().max() <= 2.0 ** -6 * ref.float().abs().max()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("joint", [False, True])
+def test_attention_fused_output_quantiser(dtype, joint):
+    """The attention epilogue emits the output projection's quantised input: identical codes and scales to quantising the
+    16-bit attention output with the stand-alone kernel; lora_act up to fp32 summation order."""
+    from nunchaku_amd import layout
+    from nunchaku_amd.ops.attention import attention_packed, attention_packed_quantized
+
+    H, L, R = 2, 512, 32
+    K = H * 128
+    td = TORCH_DT[dtype]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qkv = torch.randn(L, 3 * K, device="cuda", generator=g).to(td)
+    vt = qkv[:, 2 * K:].t().contiguous()
+    La = O.make_svdq_layer(K, 128, R, seed=1, dtype=dtype, cheap=True)
+    Lb = O.make_svdq_layer(K, 128, R, seed=2, dtype=dtype, cheap=True)
+    la, lb = make_module(La, dtype), make_module(Lb, dtype)
+    o = attention_packed(qkv, vt, H)
+    if joint:
+        got = attention_packed_quantized(qkv, vt, H, lb, lin_first=la, split_rows=256)
+        parts = [la.quantize(o[:256]), lb.quantize(o[256:])]
+        ref_codes = torch.cat([layout.unpack_act(p[0], K) for p in parts])
+        ref_scales = torch.cat([layout.unpack_scales(p[1], 256) for p in parts], dim=1)
+        ref_la = torch.cat([p[2] for p in parts])
+    else:
+        got = attention_packed_quantized(qkv, vt, H, lb)
+        p = lb.quantize(o)
+        ref_codes, ref_scales, ref_la = layout.unpack_act(p[0], K), layout.unpack_scales(p[1], L), p[2]
+    assert got is not None
+    assert torch.equal(layout.unpack_act(got[0], K), ref_codes)
+    assert torch.equal(layout.unpack_scales(got[1], L), ref_scales)
+    assert (got[2] - ref_la).abs().max() <= 2e-3 * ref_la.abs().max() + 1e-5
