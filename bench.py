@@ -42,7 +42,7 @@ FLUX_STEP_GOP = 59.5e3 + 0.83e3
 # command: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_profile_bench.sh ->
 # profiles/r1_bench_gemm_hbm_counters.json), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.
 # PMC counters cannot be read from inside the timed run, so this is the committed measurement, not a live one.
-GEMM_HBM_TRAFFIC_BYTES = (2 * 136091.39 + 83369.16) * 1024
+GEMM_HBM_TRAFFIC_BYTES = (2 * 136101.53 + 83388.60) * 1024
 
 
 def cpu_baseline(max_seconds: float = 30.0):
