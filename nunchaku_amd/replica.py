@@ -41,7 +41,23 @@ def broadcast_module_(module: torch.nn.Module, src: int = 0) -> int:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
     total = 0
-    for t in list(module.parameters()) + list(module.buffers()):
+    tensors = list(module.parameters()) + list(module.buffers())
+    dev = tensors[0].device
+    # shapes first: load-time repacks change them (SVDQW4A4Linear.repack_(): qweight [out, in/2] -> [out, 3*in/4]), and the
+    # source may already be in the kernel layout while the receivers still hold freshly constructed parameters
+    shapes = torch.zeros(len(tensors), 9, dtype=torch.int64, device=dev)
+    if dist.get_rank() == src:
+        for i, t in enumerate(tensors):
+            if t.dim() > 8:
+                raise ValueError("broadcast_module_: tensors of more than 8 dimensions are not supported")
+            shapes[i, 0] = t.dim()
+            shapes[i, 1:1 + t.dim()] = torch.tensor(list(t.shape), dtype=torch.int64)
+    dist.broadcast(shapes, src=src)
+    shapes = shapes.cpu().tolist()
+    for t, row in zip(tensors, shapes):
+        shape = tuple(int(v) for v in row[1:1 + int(row[0])])
+        if tuple(t.shape) != shape:
+            t.data = torch.empty(shape, dtype=t.dtype, device=t.device)
         flat = t.data.contiguous().view(-1).view(torch.uint8)
         dist.broadcast(flat, src=src)
         if not t.data.is_contiguous():

@@ -33,7 +33,10 @@ def _worker(rank, world, port, out):
         for p in (lin.wscales, lin.bias, lin.smooth_factor, lin.smooth_factor_orig, lin.proj_down, lin.proj_up):
             p.copy_(torch.randn(p.shape))
     lin._amd_layout = rank == 0
+    if rank == 0:  # the source has already been repacked: qweight is the [out, 3*in/4] FP6 image, the receivers' is [out, in/2]
+        lin.qweight.data = torch.randint(-128, 128, (256, 96), dtype=torch.int8)
     nbytes = replica.broadcast_module_(lin, src=0)
+    assert tuple(lin.qweight.shape) == (256, 96), "receivers must take the source's (repacked) shape"
     digest = torch.cat([p.detach().view(-1).view(torch.uint8).to(torch.int64) for p in lin.parameters()]).sum().item()
     slow = replica.max_over_ranks(1.0 + rank, "cpu")
     units = replica.shard_units(7, rank, world)
