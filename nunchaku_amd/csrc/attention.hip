@@ -6,9 +6,12 @@
 //   Q, K : token-major rows of the QKV GEMM output, element (l, h, d) at base + l*ld + h*128 + d
 //   V^T  : channel-major, element (h, d, l) at base + (h*128 + d)*ldvt + l   (written by the RMSNORM_ROPE
 //          epilogue of svdq_gemm_w4a4 when out_vt is given) -- the PV MFMA needs 8 consecutive KEYS per lane
-//   O    : token-major [L, H*128], directly the input of the output projection's quantiser
+//   O    : token-major [L, H*128], directly the input of the output projection's quantiser -- or no 16-bit output at
+//          all: with svdq_attention_args.qact the epilogue emits that quantiser's result itself (a wave's 32 rows x 128
+//          channels of one head are one F6 chunk in the register layout it holds)
 //
-// Kernel (DESIGN.md "Attention"): workgroup = 4 waves = 128 query rows of one head, wave = 32 query rows;
+// Kernel: workgroup = 8 waves = 256 query rows of one head (4 waves / 128 rows when L % 256 != 0), wave =
+// 32 query rows;
 // KV tiles of 64 keys, double-buffered in LDS with XOR-swizzled 16-byte pieces (conflict-free ds_read_b128);
 // the score MFMA is issued swapped (S^T = K Q^T) so a lane holds 32 of the 64 scores of ONE query row: the
 // online softmax is lane-local plus one lane^32 exchange; P is packed to 16-bit with v_cvt_pk + one
