@@ -70,3 +70,13 @@ def test_safetensors_round_trip(tmp_path):
     bad["x_embedder.weight"] = bad["x_embedder.weight"].float()
     with pytest.raises(TypeError):
         loader.load_flux_state_dict(_small(), bad)
+
+
+def test_zero_pool_hands_out_aligned_pieces_once():
+    from nunchaku_amd.ops.elementwise import ZeroPool
+
+    pool = ZeroPool(torch.zeros(100))
+    a, b = pool.take(10), pool.take(50)
+    assert a.numel() == 10 and b.numel() == 50
+    assert (b.data_ptr() - a.data_ptr()) == 12 * 4  # pieces start on 16-byte boundaries
+    assert pool.take(40) is None and pool.take(36) is not None
