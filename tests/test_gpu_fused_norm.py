@@ -179,3 +179,36 @@ def test_residual_gate_stats_pair_matches_two_calls():
     pa, psa, pb, psb, pool = residual_gate_stats_pair(ra, aa, ga, rb, ab, gb, zero_floats=100)
     assert torch.equal(pa, ya) and torch.equal(pb, yb) and torch.equal(psa, sa) and torch.equal(psb, sb)
     assert not pool.take(100).any()
+
+
+def test_flux_transformer_fp16_fused_vs_torch_ops():
+    """The whole fused / grouped / batched path in fp16 against the reference's torch-op sequence."""
+    from nunchaku_amd.models.flux import FluxAttentionAMD, FluxTransformerAMD
+
+    torch.manual_seed(7)
+    model = FluxTransformerAMD(num_layers=1, num_single_layers=1, dim=256, heads=2, in_channels=64, joint_attention_dim=128,
+                               pooled_projection_dim=64, torch_dtype=torch.float16, device="cuda")
+    model.init_synthetic_(seed=3)
+    model.eval()
+    side, t_txt = 16, 256
+    lat = torch.randn(1, side * side, 64, device="cuda").half()
+    enc = torch.randn(1, t_txt, 128, device="cuda").half()
+    pooled = torch.randn(1, 64, device="cuda").half()
+    img_ids = torch.zeros(side * side, 3, device="cuda")
+    img_ids[:, 1] = torch.arange(side, device="cuda").repeat_interleave(side)
+    img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
+    txt_ids = torch.zeros(t_txt, 3, device="cuda")
+    t, gd = torch.tensor([0.7], device="cuda"), torch.tensor([3.5], device="cuda")
+    outs = {}
+    try:
+        for fused in (True, False):
+            FluxTransformerAMD.fused_norm = fused
+            FluxAttentionAMD.grouped = fused
+            with torch.no_grad():
+                outs[fused] = model(lat, enc, pooled, t, img_ids, txt_ids, gd)[0].float()
+    finally:
+        FluxTransformerAMD.fused_norm = True
+        FluxAttentionAMD.grouped = True
+    assert outs[True].dtype == torch.float32 and torch.isfinite(outs[True]).all()
+    rel = ((outs[True] - outs[False]).norm() / outs[False].norm()).item()
+    assert rel < 3e-2, f"fp16 fused vs torch-op path: relative L2 {rel:.3g}"
