@@ -63,3 +63,44 @@ def test_captured_step_replays_like_eager(built_lib):
             ref = fn(lat, t)
         assert torch.isfinite(got).all()
         assert (got.float() - ref.float()).norm() / ref.float().norm() < 2e-2  # fp32-atomic noise through 4-bit layers
+
+
+def test_pipeline_facing_class_call_contract(built_lib, tmp_path):
+    """NunchakuFluxTransformer2DModelV2: from_pretrained on a safetensors file and the keyword call a FluxPipeline makes."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import json
+
+    from safetensors.torch import save_file
+
+    from nunchaku_amd.models.transformer_flux import NunchakuFluxTransformer2DModelV2, NunchakuFluxTransformer2dModel
+
+    assert NunchakuFluxTransformer2dModel is NunchakuFluxTransformer2DModelV2
+    cfg = dict(num_layers=1, num_single_layers=1, num_attention_heads=2, attention_head_dim=128, in_channels=64,
+               joint_attention_dim=128, pooled_projection_dim=64, guidance_embeds=True, axes_dims_rope=[16, 56, 56])
+    src = NunchakuFluxTransformer2DModelV2(cfg, device="cuda").init_synthetic_(seed=1, repack=False)
+    path = str(tmp_path / "svdq-int4_r32-tiny.safetensors")
+    save_file({k: v.contiguous().cpu() for k, v in loader.export_legacy_state_dict(src).items()}, path,
+              metadata={"config": json.dumps(cfg), "quantization_config": json.dumps({"rank": 32})})
+    model = NunchakuFluxTransformer2DModelV2.from_pretrained(path, device="cuda", torch_dtype=torch.bfloat16).eval()
+    assert model.config.in_channels == 64 and model.config.guidance_embeds and model.dtype == torch.bfloat16
+    side, t_txt = 16, 128
+    g = torch.Generator(device="cuda").manual_seed(2)
+    lat = torch.randn(1, side * side, 64, device="cuda", generator=g).bfloat16()
+    img_ids = torch.zeros(side * side, 3, device="cuda")
+    img_ids[:, 1] = torch.arange(side, device="cuda").repeat_interleave(side)
+    img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
+    kwargs = dict(hidden_states=lat, timestep=torch.tensor([0.5], device="cuda"), guidance=torch.tensor([3.5], device="cuda"),
+                  pooled_projections=torch.randn(1, 64, device="cuda", generator=g).bfloat16(),
+                  encoder_hidden_states=torch.randn(1, t_txt, 128, device="cuda", generator=g).bfloat16(),
+                  txt_ids=torch.zeros(t_txt, 3, device="cuda"), img_ids=img_ids, joint_attention_kwargs=None)
+    with torch.no_grad():
+        noise_pred = model(**kwargs, return_dict=False)[0]  # exactly how FluxPipeline.__call__ uses its transformer
+        out = model(**kwargs)
+        ref = src(lat, kwargs["encoder_hidden_states"], kwargs["pooled_projections"], kwargs["timestep"], img_ids,
+                  kwargs["txt_ids"], kwargs["guidance"]).sample
+    assert noise_pred.shape == lat.shape and torch.isfinite(noise_pred.float()).all()
+    assert (out.sample.float() - noise_pred.float()).norm() / noise_pred.float().norm() < 2e-2
+    assert (noise_pred.float() - ref.float()).norm() / ref.float().norm() < 2e-2
+    with pytest.raises(NotImplementedError):
+        model(**kwargs, controlnet_block_samples=[lat])
