@@ -1,4 +1,4 @@
-"""AWQ W4A16 GEMV wrapper (reference: nunchaku/ops/gemv.py:10-57).  Keyword names are the reference's."""
+"""AWQ W4A16 GEMV wrappers (reference: nunchaku/ops/gemv.py:10-57; keyword names are the reference's)."""
 
 from __future__ import annotations
 
@@ -7,20 +7,12 @@ import torch
 from .._C import ops
 
 
-def awq_gemv_w4a16_cuda(
-    in_feats: torch.Tensor,
-    kernel: torch.Tensor,
-    scaling_factors: torch.Tensor,
-    zeros: torch.Tensor,
-    m: int,
-    n: int,
-    k: int,
-    group_size: int = 64,
-    bias: torch.Tensor | None = None,
-    out_chunks: int = 1,
-) -> torch.Tensor:
-    """``in_feats`` [m, k] 16-bit, ``kernel`` [n/4, k/2] int32 (checkpoint order), ``scaling_factors`` /
-    ``zeros`` [k/group_size, n] -> [m, n].  ``bias`` (extension): fused 16-bit ``output.add_(bias)``."""
+def awq_gemv_w4a16_cuda(in_feats: torch.Tensor, kernel: torch.Tensor, scaling_factors: torch.Tensor, zeros: torch.Tensor,
+                        m: int, n: int, k: int, group_size: int = 64, bias: torch.Tensor | None = None,
+                        out_chunks: int = 1) -> torch.Tensor:
+    """``in_feats`` [m, k] 16-bit, ``kernel`` [n/4, k/2] int32 (checkpoint order), ``scaling_factors`` / ``zeros``
+    [k/group_size, n] -> a new [m, n] tensor.  Extensions: ``bias`` fuses the module's 16-bit ``output.add_(bias)``,
+    ``out_chunks`` = c writes the output de-interleaved into c contiguous [n/c] vectors."""
     return ops.gemv_awq(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size, bias, out_chunks)
 
 
