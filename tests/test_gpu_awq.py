@@ -29,7 +29,7 @@ def _layer(N, K, dtype, seed):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("m,N,K", [(1, 64, 128), (3, 256, 576), (8, 128, 1024), (1, 1536, 3072)])
+@pytest.mark.parametrize("m,N,K", [(1, 64, 128), (3, 256, 576), (8, 128, 1024), (1, 1536, 3072), (1, 18432, 3072)])  # last: FLUX.1 size
 def test_gemv_awq_matches_oracle(dtype, m, N, K):
     from nunchaku_amd.models.linear import AWQW4A16Linear
 
