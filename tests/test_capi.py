@@ -88,3 +88,25 @@ def test_python_wrappers_raise_without_gpu(built_lib):
         m(torch.zeros(1, 4, 128, dtype=torch.bfloat16))
     with pytest.raises(NotImplementedError):
         SVDQW4A4Linear(128, 128, precision="nvfp4")
+
+
+def test_ctypes_field_order_matches_header():
+    """Every struct of include/svdq_amd.h against its ctypes twin: same field NAMES in the same ORDER (sizes are checked
+    above) -- a transposed pair of pointers would otherwise go unnoticed until a kernel reads the wrong tensor."""
+    import re
+
+    src = open(os.path.join(ROOT, "include", "svdq_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)  # drop comments
+    twins = {"svdq_quantize_args": _lib.QuantizeArgs, "svdq_gemm_args": _lib.GemmArgs, "svdq_attention_args": _lib.AttentionArgs,
+             "svdq_gemv_awq_args": _lib.GemvAwqArgs, "svdq_residual_args": _lib.ResidualArgs}
+    for name, cls in twins.items():
+        body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", src, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            # "const void *a, *b" / "int32_t M, N" / "float *stats": names are the identifiers before ',' or the end
+            for part in decl.split(","):
+                fields.append(re.findall(r"[A-Za-z_][A-Za-z_0-9]*", part)[-1])
+        assert fields == [f[0] for f in cls._fields_], f"{name}: header {fields} != ctypes {[f[0] for f in cls._fields_]}"
