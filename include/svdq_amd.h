@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 12
+#define SVDQ_ABI_VERSION 13
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -151,10 +151,14 @@ typedef struct svdq_gemm_args {
     int32_t dtype;            /* SVDQ_BF16 | SVDQ_FP16                                          */
     int32_t act_unsigned;     /* informational: the FP6 image already encodes signedness        */
     int32_t fuse;             /* SVDQ_FUSE_*                                                    */
-    int32_t variant;          /* 0 = hand-scheduled main loop; 1 = compiler-scheduled (debug)   */
-    int32_t reserved;
+    int32_t variant;          /* 0 = hand-scheduled main loop; 1 = compiler-scheduled twin (same results; A/B debugging) */
+    int32_t reserved;         /* must be 0 */
     /* optional scratch for the stream-K tail (svdq_gemm_workspace_bytes() bytes, zero-filled ONCE by the
-     * caller, then reusable by every later call on the same stream; NULL = whole-tile schedule only)     */
+     * caller, then reusable by every later call ON THE SAME STREAM; NULL = whole-tile schedule only).
+     * One workspace must never be used by launches that can be in flight concurrently (two streams, two
+     * threads on different streams): keep one per (device, stream), as nunchaku_amd/_C.py does.  A violated
+     * contract cannot hang the GPU -- an owner's wait is bounded -- but it invalidates the results; it is
+     * reported by svdq_gemm_workspace_status(). */
     void *workspace;
     int64_t workspace_bytes;
     /* SVDQ_FUSE_RMSNORM_ROPE only, optional: the V third of the output (columns [2N/3, N)) is written
@@ -178,8 +182,11 @@ typedef struct svdq_gemm_args {
 } svdq_gemm_args;
 
 int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
-/* size of the stream-K workspace for the current device (256 arrival counters + 2 fp32 tiles per CU) */
+/* size of the stream-K workspace for the current device (255 arrival counters + 1 error word + 2 fp32 tiles per CU) */
 int64_t svdq_gemm_workspace_bytes(void);
+/* Synchronises `stream`, then returns SVDQ_E_HIP (and clears the flag) if a launch that used `workspace` timed out
+ * waiting for partial tiles -- see svdq_gemm_args.workspace; SVDQ_OK otherwise.  Test / debugging aid. */
+int svdq_gemm_workspace_status(void *workspace, void *stream);
 /* Host-side replay of the kernel's persistent / stream-K schedule (test helper; no GPU needed): writes up to
  * `cap` records of 6 int32 {position, tile, kp0, kp1, partial slot or -1, contributors the owner waits for}
  * and returns the number of segments, or -1 for invalid shapes. */

@@ -13,7 +13,6 @@ SURVEY.md section 5), unsupported reference features raise ``NotImplementedError
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 
@@ -36,22 +35,48 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-_workspaces: dict[int, torch.Tensor] = {}
+_workspaces: dict[tuple[int, int], torch.Tensor] = {}
 
 
 def _workspace(device: torch.device) -> torch.Tensor:
-    """Per-device scratch of the GEMM's stream-K tail (arrival counters + fp32 partial tiles).  Allocated
-    once from the torch caching allocator, zero-filled once; the kernel leaves the counters at zero."""
+    """Scratch of the GEMM's stream-K tail (arrival counters + fp32 partial tiles), one per (device, STREAM).
+
+    The C ABI allows a workspace to be reused only by launches that are ordered on one stream (include/svdq_amd.h,
+    ``svdq_gemm_args.workspace``): two GEMMs in flight on different streams of a device would share counters and
+    partial-tile slabs.  So the buffer is keyed by the current stream's handle: side streams (the offload manager's
+    schedule, a capturing stream, worker threads with their own streams) each get their own 64 MB buffer on first use,
+    allocated from the torch caching allocator, zero-filled once; the kernel leaves the counters at zero."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    ws = _workspaces.get(idx)
+    key = (idx, _stream())
+    ws = _workspaces.get(key)
     if ws is None:
         with torch.cuda.device(idx):
             ws = torch.zeros(int(_lib.load().svdq_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
-        _workspaces[idx] = ws
+        _workspaces[key] = ws
     return ws
 
 
+def release_workspaces() -> None:
+    """Drop every cached stream-K workspace (e.g. after a pool of temporary streams has been destroyed)."""
+    _workspaces.clear()
+
+
 class _Ops:
+    # 0 = hand-scheduled main loop, 1 = its compiler-scheduled twin (bit-identical results; A/B debugging and tests).
+    # A plain attribute, not an environment variable: nothing is read from os.environ on the launch path.
+    gemm_variant = 0
+    # False: launch without the stream-K workspace (whole-tile schedule only); tests compare the two schedules
+    gemm_use_workspace = True
+
+    @staticmethod
+    def gemm_workspace_status() -> None:
+        """Synchronise the current stream and raise ``RuntimeError`` if a stream-K GEMM on it timed out waiting for
+        partial tiles (a workspace shared across streams -- see ``_workspace``).  Test / debugging aid."""
+        key = (torch.cuda.current_device(), _stream())
+        ws = _workspaces.get(key)
+        if ws is not None:
+            _lib.check(_lib.load().svdq_gemm_workspace_status(ws.data_ptr(), _stream()), "gemm_workspace_status")
+
     @staticmethod
     def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False,
                                     ln_stats=None, mod_scale=None, mod_shift=None, lora_act_zeroed=False, second=None):
@@ -167,10 +192,10 @@ class _Ops:
         a.M = M_pad
         a.dtype = _DT[ascales.dtype]
         a.act_unsigned = int(bool(act_unsigned))
-        a.reserved = int(os.environ.get("SVDQ_GEMM_DEBUG", "0"))  # timing experiments only
-        ws = _workspace(act.device)
-        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        a.variant = int(os.environ.get("SVDQ_GEMM_VARIANT", "0"))  # 1 = compiler-scheduled loop (debug/A-B only)
+        if _Ops.gemm_use_workspace:
+            ws = _workspace(act.device)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.variant = _Ops.gemm_variant
 
         if qout is not None and oscales is not None:
             a.fuse = _lib.FUSE_GELU_QUANT
@@ -363,7 +388,6 @@ class _Ops:
             if not zero.is_cuda or not zero.is_contiguous() or (zero.numel() * zero.element_size()) % 16:
                 raise ValueError("attention: zero must be a contiguous GPU tensor of a multiple of 16 bytes")
             a.zero_ptr, a.zero_bytes = zero.data_ptr(), zero.numel() * zero.element_size()
-        a.reserved = int(os.environ.get("SVDQ_ATT_DEBUG", "0"))  # timing experiments only
         _lib.check(lib.svdq_attention(C.byref(a), _stream()), "attention")
 
 

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class QuantizeArgs(C.Structure):
@@ -87,6 +87,7 @@ EXPORTS = {
     "svdq_gemv_awq_batched": (C.c_int, [C.POINTER(GemvAwqArgs), C.c_int32, C.c_void_p]),
     "svdq_residual_gate_stats": (C.c_int, [C.POINTER(ResidualArgs), C.c_void_p]),
     "svdq_gemm_workspace_bytes": (C.c_int64, []),
+    "svdq_gemm_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "svdq_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_repack_qweight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_repack_wscales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -377,12 +377,13 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.qR = a->qR; p.qsplit_rows = a->qsmooth2 ? a->qsplit_rows : 0;
     p.zero_ptr = (v4i *)a->zero_ptr;
     p.zero_vec = a->zero_ptr ? a->zero_bytes / 16 : 0;
-    p.debug = a->reserved;
     hipStream_t st = (hipStream_t)stream;
-    const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
+#ifdef SVDQ_ABLATE
+    // tools-built ablation library only: reserved = wave-count override << 8 | ablation variant (results are garbage)
     const int nw = (a->reserved >> 8) & 0xf ? (a->reserved >> 8) & 0xf : (a->L % 256 == 0 ? 8 : 4);
     if ((nw != 4 && nw != 8) || a->L % (nw * 32)) { set_error("svdq_attention: bad wave-count override %d", nw); return SVDQ_E_INVALID; }
     p.debug = a->reserved & 0xff;
+    const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
     if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8, 0>(p, st); else launch_attention<SVDQ_FP16, 4, 0>(p, st); }
     else if (nw == 4) {
         switch (p.debug) { // non-zero: ablations (bf16 only), timing experiments, results are garbage
@@ -392,7 +393,7 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
         case 8: launch_attention<SVDQ_BF16, 4, 8>(p, st); break;
         case 16: launch_attention<SVDQ_BF16, 4, 16>(p, st); break;
         case 24: launch_attention<SVDQ_BF16, 4, 24>(p, st); break;
-        default: set_error("svdq_attention: unknown debug variant %d", p.debug); return SVDQ_E_INVALID;
+        default: prof_end(prof, st); set_error("svdq_attention: unknown debug variant %d", p.debug); return SVDQ_E_INVALID;
         }
     } else {
         switch (p.debug) {
@@ -409,9 +410,18 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
         case 98: launch_attention<SVDQ_BF16, 8, 98>(p, st); break;
         case 102: launch_attention<SVDQ_BF16, 8, 102>(p, st); break;
         case 103: launch_attention<SVDQ_BF16, 8, 103>(p, st); break;
-        default: set_error("svdq_attention: unknown debug variant %d", p.debug); return SVDQ_E_INVALID;
+        default: prof_end(prof, st); set_error("svdq_attention: unknown debug variant %d", p.debug); return SVDQ_E_INVALID;
         }
     }
+#else
+    if (a->reserved != 0) { set_error("svdq_attention: reserved must be 0 (timing ablations live in tools/ablate, not in this library)"); return SVDQ_E_INVALID; }
+    p.debug = 0;
+    const int nw = a->L % 256 == 0 ? 8 : 4;
+    const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
+    if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8, 0>(p, st); else launch_attention<SVDQ_FP16, 4, 0>(p, st); }
+    else if (nw == 8) launch_attention<SVDQ_BF16, 8, 0>(p, st);
+    else launch_attention<SVDQ_BF16, 4, 0>(p, st);
+#endif
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_attention launch");
 }

@@ -21,7 +21,7 @@
 //     64 x 64 = 2 x 2 MFMA tiles; two waves per SIMD so that one wave's fma stream overlaps the
 //     other's MFMAs (a single wave issues one VALU op per ~8 cycles on gfx950).
 //   * K-step = 128 channels (two groups).  Operands go HBM -> LDS by DMA (global_load_lds, 16 B per
-//     lane = one 1 KiB plane of an F6 chunk per wave instruction), 3-stage ring.
+//     lane = one 1 KiB plane of an F6 chunk per wave instruction), 4-stage ring (NSTAGE).
 //   * the MFMA is issued "transposed" (weights = A operand, activations = B) so that in the C layout
 //     a lane owns ONE output row m and 16 columns n = 32*tile + 8c + 4*(lane>>5) + e: 8-byte output
 //     stores, RoPE pairs and the next layer's FP6 lane record are lane-local.
@@ -42,6 +42,10 @@ constexpr int WS_BYTES = 1024;                 // 512 used; the DMA writes whole
 constexpr int STAGE_BYTES = A_BYTES + W_BYTES + AS_BYTES + WS_BYTES; // 38912 (tools/gen_gemm_loop.py: STAGE)
 constexpr int EPI_BYTES = 2048;                 // epilogue scratch behind the ring (the ring itself stays live)
 constexpr int MAX_LORA_TILES = 16;             // R <= 256
+// stream-K workspace header: 256 int32 words; words [0, 255) are per-remainder-tile arrival counters (at most CUs - 1
+// remainder tiles; the persistent grid never exceeds 256 workgroups), word 255 is the sticky error flag
+constexpr int SK_ERR_WORD = 255;
+constexpr int SK_SPIN_LIMIT = 1 << 22;         // x (s_sleep 8 + one L2 round trip) ~ 1 s
 
 struct GemmParams {
     const uint8_t *act;
@@ -70,9 +74,20 @@ struct GemmParams {
     uint8_t *workspace;      // stream-K: [256 int32 flags][2*G slabs of BM*BN fp32] or NULL
     long long workspace_bytes;
     int sk_gs;               // stream-K: workgroups sharing the remainder tiles (0 = whole tiles only); host heuristic
-    int debug; // timing experiments (tools/): bit0 skip output stores, bit1 skip bias + low-rank up
+#ifdef SVDQ_ABLATE
+    int debug;               // timing experiments (tools/ablate): bit0 skip output stores, bit1 skip bias + low-rank up, ...
+    long long *clk;          // per workgroup {shader cycles, 100 MHz ticks} of the whole kernel (effective clock probe)
+#endif
     float lora_scales[MAX_LORA_TILES];
 };
+
+// Timing-experiment switches exist only in the tools-built ablation library (-DSVDQ_ABLATE, tools/ablate/build.py);
+// in the product library DBG() is the constant 0 and every such branch folds away.
+#ifdef SVDQ_ABLATE
+#define DBG(bits) (p.debug & (bits))
+#else
+#define DBG(bits) (0)
+#endif
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     // reference: gemm_utils.cuh:305-312: x * (0.5 + 0.5 * tanh.approx(u)), u = 0.79788456 * (x + 0.044715 x^3).
@@ -94,13 +109,16 @@ typedef const __attribute__((address_space(1))) void gvoid;
 #define MXS_A 0x82828282
 #define MXS_B 0x81818181
 
-template <int DT, int FUSE, int LOOPV /* 0 asm, 1 C++, >= 2 ablations of the asm loop (tools only) */>
+template <int DT, int FUSE, int LOOPV /* 0 asm, 1 C++, >= 2 ablations of the asm loop (-DSVDQ_ABLATE builds only) */>
 __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES + EPI_BYTES];
 
     const int tid = threadIdx.x;
+#ifdef SVDQ_ABLATE
+    const long long clk_t0 = __builtin_readcyclecounter(), clk_r0 = wall_clock64();
+#endif
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, h = lane >> 5;
@@ -225,43 +243,13 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                   "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199",  \
                   "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220",  \
                   "v221", "v222", "v223", "v224"
-                if constexpr (LOOPV == 2) {
-                    asm volatile(
-#include "ablate/gemm_loop_bf16_dma.inc"
-                        SVDQ_LOOP_OPERANDS);
-                } else if constexpr (LOOPV == 3) {
-                    asm volatile(
-#include "ablate/gemm_loop_bf16_lds.inc"
-                        SVDQ_LOOP_OPERANDS);
-                } else if constexpr (LOOPV == 4) {
-                    asm volatile(
-#include "ablate/gemm_loop_bf16_fma.inc"
-                        SVDQ_LOOP_OPERANDS);
-                } else if constexpr (LOOPV == 5) {
-                    asm volatile(
-#include "ablate/gemm_loop_bf16_smfma.inc"
-                        SVDQ_LOOP_OPERANDS);
-                } else if constexpr (LOOPV == 6) {
-                    asm volatile(
-#include "ablate/gemm_loop_bf16_barrier.inc"
-                        SVDQ_LOOP_OPERANDS);
-                } else if constexpr (LOOPV == 7) {
-                    asm volatile(
-#include "ablate/gemm_loop_bf16_dma_lds.inc"
-                        SVDQ_LOOP_OPERANDS);
-                } else if constexpr (LOOPV == 8) {
-                    asm volatile(
-#include "ablate/gemm_loop_bf16_fma_smfma.inc"
-                        SVDQ_LOOP_OPERANDS);
-                } else if constexpr (LOOPV == 9) {
-                    asm volatile(
-#include "ablate/gemm_loop_bf16_dma_barrier.inc"
-                        SVDQ_LOOP_OPERANDS);
-                } else if constexpr (LOOPV == 10) {
-                    asm volatile(
-#include "ablate/gemm_loop_bf16_dma_lds_barrier.inc"
-                        SVDQ_LOOP_OPERANDS);
-                } else if constexpr (DT == SVDQ_BF16) {
+#ifdef SVDQ_ABLATE
+                // timing experiments: one wave per SIMD runs the (barrier-free, ablated) loop, its partner idles
+                if (DBG(512) && wv >= 4) { acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16; } else
+                if (DBG(1024) && wv < 4) { acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16; } else
+#include "gemm_ablate_loops.inc" /* generated by tools/ablate/build.py: `if constexpr (LOOPV == n) { asm volatile(...); } else` chain */
+#endif
+                if constexpr (DT == SVDQ_BF16) {
                     asm volatile(
 #include "gemm_loop_bf16.inc"
                         SVDQ_LOOP_OPERANDS);
@@ -275,7 +263,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             npre = min((unsigned)NSTAGE, ncnt);
             // the epilogue below waits on global loads (bias / low-rank operands) that are younger than the
             // prefetch DMAs of the next tile: vmcnt retires in order, so those DMAs have landed by then
-            landed = ((p.bias || p.R > 0) && !(p.debug & 2) && kp1 == KP) ? npre : 0;
+            landed = ((p.bias || p.R > 0) && !DBG(2) && kp1 == KP) ? npre : 0;
         } else {
             npre = 0;
             // ---- reference C++ main loop (variant 1: same arithmetic, compiler-scheduled, no cross-tile
@@ -399,8 +387,13 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 const int first = sched.first_contributor(cur);
                 const int needed = pos - first;
                 if (tid == 0) {
-                    while (__hip_atomic_load(flags + trel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < needed)
+                    // Bounded wait (~1 s): a missing arrival can only come from a broken contract (the workspace shared by
+                    // launches in flight on two streams, or not zero-filled).  Then give up instead of hanging the GPU:
+                    // raise the sticky error word svdq_gemm_workspace_status() reports; this tile's result is garbage.
+                    int spins = 0;
+                    while (__hip_atomic_load(flags + trel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < needed && ++spins < SK_SPIN_LIMIT)
                         __builtin_amdgcn_s_sleep(8);
+                    if (spins >= SK_SPIN_LIMIT) __hip_atomic_store(flags + SK_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(flags + trel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -424,7 +417,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         const int mw0 = m0 + wm * 64;
 
         // bias (reference EpilogueBias, gemm_base.cuh:710-781)
-        if (p.bias && !(p.debug & 2)) {
+        if (p.bias && !DBG(2)) {
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
@@ -440,7 +433,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         // low-rank up projection (reference EpilogueLoraUp, lora.cuh:110-241): fp32 activations are
         // scaled per 16 ranks and rounded to 16-bit (:145-158), multiplied on the matrix cores and
         // accumulated in fp32 -- here straight onto the GEMM accumulators.
-        if (p.R > 0 && !(p.debug & 2)) {
+        if (p.R > 0 && !DBG(2)) {
             for (int rc = 0; rc < p.R; rc += 16) {
                 const float sc = p.lora_scales[rc >> 4];
                 V8 la[2], lu[2];
@@ -541,7 +534,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = (p.debug & 128) ? acc[ni][mi][r] : round16<T>(gelu_tanh_f(acc[ni][mi][r]));
+                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = DBG(128) ? acc[ni][mi][r] : round16<T>(gelu_tanh_f(acc[ni][mi][r]));
 
             // EpilogueQuantize<false, unsigned> (gemm_w4a4.cuh:930-1043): 16-bit add of the shift,
             // fp32 divide by the next layer's smooth factor -> 16-bit, per (row, 64 columns) absmax,
@@ -570,7 +563,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         float sh = round16<T>(acc[ni][mi][r] + 0.171875f);
-                        float v = (p.debug & 256) ? sh : round16<T>(sh * smr[ni][r]);
+                        float v = DBG(256) ? sh : round16<T>(sh * smr[ni][r]);
                         xh[ni * 16 + r] = v;
                         amax = fmaxf(amax, fabsf(v));
                     }
@@ -610,7 +603,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.  With
             // the activations as the A operand the result tile has the RANK along the lanes, so every fp32
             // atomic instruction hits two 128-byte lines instead of 64 different ones.
-            if (p.R2 > 0 && !(p.debug & 64)) {
+            if (p.R2 > 0 && !DBG(64)) {
                 const T *ld = (const T *)(bm >= p.split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
                 for (int t2 = 0; t2 < p.R2; t2 += 32) {
                     v16f d[2];
@@ -643,8 +636,8 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) {
                         float *dst = p.lora_act_out + (size_t)(mw0 + mi * 32 + h * 4) * p.R2 + t2 + lr;
-                        if (live && !(p.debug & 16)) {
-                            if (p.debug & 32) {
+                        if (live && !DBG(16)) {
+                            if DBG(32) {
 #pragma unroll
                                 for (int i = 0; i < 16; i++) __hip_atomic_fetch_add(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.R2, d[mi][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             } else {
@@ -695,7 +688,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         for (int mi = 0; mi < 2; mi++) {
             const int m_abs = mw0 + mi * 32 + lr;
             T *orow = (T *)p.out + (size_t)m_abs * p.ldo + nw0 + h * 8;
-            const bool ok = m_abs < p.M && !(p.debug & 1);
+            const bool ok = m_abs < p.M && !DBG(1);
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
@@ -718,7 +711,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                     }
                     if (ok) {
                         v4i o = {(int)x[0], (int)x[1], (int)y[0], (int)y[1]};
-                        if (p.debug & 4) __builtin_nontemporal_store(o, reinterpret_cast<v4i *>(orow + ni * 32 + j * 16));
+                        if DBG(4) __builtin_nontemporal_store(o, reinterpret_cast<v4i *>(orow + ni * 32 + j * 16));
                         else *reinterpret_cast<v4i *>(orow + ni * 32 + j * 16) = o;
                     }
                 }
@@ -730,6 +723,12 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         bm = nbm;
         bn = nbn;
     }
+#ifdef SVDQ_ABLATE
+    if (p.clk && tid == 0) {
+        p.clk[2 * blockIdx.x] = __builtin_readcyclecounter() - clk_t0;
+        p.clk[2 * blockIdx.x + 1] = wall_clock64() - clk_r0;
+    }
+#endif
 }
 
 // number of workgroups of the persistent grid: one per CU (the kernel needs 114 KiB of LDS and 8 waves
@@ -740,6 +739,7 @@ static int device_cus() {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;
+        if (n > 256) n = 256; // the workspace header holds 255 arrival counters
         cus = n >= 8 ? (n / 8) * 8 : n;
     }
     return cus;
@@ -751,11 +751,15 @@ static long long workspace_bytes_needed() { return 1024 + 2LL * device_cus() * B
 // per tile, at least 8 K-steps per piece.  Returns the number of workgroups sharing the remainder (0 = off).
 static int streamk_groups(const GemmParams &p, int tiles, int KP) {
     const int cus = device_cus();
-    if (!p.workspace || p.workspace_bytes < workspace_bytes_needed() || (p.debug & 8)) return 0;
+    if (!p.workspace || p.workspace_bytes < workspace_bytes_needed() || DBG(8)) return 0;
     const int R = tiles % cus;
     if (R == 0) return 0;
+#ifdef SVDQ_ABLATE
     static const int max_pieces = getenv("SVDQ_SK_MAXPIECES") ? atoi(getenv("SVDQ_SK_MAXPIECES")) : 2; // experiment knobs
     static const int min_steps = getenv("SVDQ_SK_MINSTEPS") ? atoi(getenv("SVDQ_SK_MINSTEPS")) : 8;
+#else
+    constexpr int max_pieces = 2, min_steps = 8;
+#endif
     long long gs = (long long)R * max_pieces;
     if (gs > cus) gs = cus;
     while (gs > R && (long long)R * KP / gs < min_steps) gs--;
@@ -785,11 +789,41 @@ static void launch_fuse(const GemmParams &p, int fuse, hipStream_t st) {
     }
 }
 
+#ifdef SVDQ_ABLATE
+static long long *g_ablate_clk = nullptr;
+#include "gemm_ablate_launch.inc" /* generated: SVDQ_ABLATE_MAX_VARIANT, launch_ablation() */
+#endif
+
 } // namespace svdq
 
 using namespace svdq;
 
+#ifdef SVDQ_ABLATE
+// tools only: device buffer of 2 * grid int64 that every later gemm launch fills with {shader cycles, 100 MHz ticks} per workgroup
+extern "C" void svdq_ablate_set_clk(long long *dev_buf) { g_ablate_clk = dev_buf; }
+#endif
+
 extern "C" int64_t svdq_gemm_workspace_bytes(void) { return workspace_bytes_needed(); }
+
+// Reads the sticky error word of a stream-K workspace after the work queued on `stream` has drained (this call
+// SYNCHRONISES the stream: a test / debugging aid, not part of the hot path).  Non-zero means an owner workgroup gave up
+// waiting for partial tiles (gemm_w4a4_kernel, SK_SPIN_LIMIT): the workspace was shared by launches in flight on two
+// streams, or was not zero-filled.  The word is cleared by the call.
+extern "C" int svdq_gemm_workspace_status(void *workspace, void *stream) {
+    if (!workspace) { set_error("svdq_gemm_workspace_status: workspace is NULL"); return SVDQ_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    int word = 0;
+    int *dev = reinterpret_cast<int *>(workspace) + SK_ERR_WORD;
+    if (hip_check(hipMemcpyAsync(&word, dev, sizeof(int), hipMemcpyDeviceToHost, st), "svdq_gemm_workspace_status copy")) return SVDQ_E_HIP;
+    if (hip_check(hipStreamSynchronize(st), "svdq_gemm_workspace_status sync")) return SVDQ_E_HIP;
+    if (word != 0) {
+        (void)hipMemsetAsync(dev, 0, sizeof(int), st);
+        set_error("svdq_gemm_w4a4: a stream-K owner timed out waiting for partial tiles -- the workspace was used by launches in "
+                  "flight on more than one stream (or was not zero-filled); results of those launches are invalid");
+        return SVDQ_E_HIP;
+    }
+    return SVDQ_OK;
+}
 
 // Host-side replay of the persistent schedule (the same GemmSchedule code the kernel runs): for the problem
 // (M_pad, N, K) on `cus` compute units, with or without a stream-K workspace, write up to `cap` records
@@ -847,11 +881,18 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     }
     if (a->R > 0 && (!a->lora_act_in || !a->lora_up)) { set_error("svdq_gemm_w4a4: R > 0 needs lora_act_in and lora_up"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemm_w4a4: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
-    if (a->variant < 0 || a->variant > 18) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
+#ifdef SVDQ_ABLATE
+    if (a->variant < 0 || a->variant > SVDQ_ABLATE_MAX_VARIANT) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
     if (a->variant >= 2 && (a->dtype != SVDQ_BF16 || a->fuse != SVDQ_FUSE_NONE)) {
         set_error("svdq_gemm_w4a4: ablation variants (tools only, WRONG results) exist for bf16 / FUSE_NONE only");
         return SVDQ_E_INVALID;
     }
+#else
+    if (a->variant < 0 || a->variant > 1 || a->reserved != 0) {
+        set_error("svdq_gemm_w4a4: variant must be 0 or 1 and reserved must be 0 (timing ablations live in tools/ablate, not in this library)");
+        return SVDQ_E_INVALID;
+    }
+#endif
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
     case SVDQ_FUSE_SILU:
@@ -934,7 +975,10 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.split_bm = a->wgt2 ? a->split_rows / BM : 0x7fffffff;
     p.out_vt = a->fuse == SVDQ_FUSE_RMSNORM_ROPE ? a->out_vt : nullptr;
     p.ldvt = a->ldvt;
+#ifdef SVDQ_ABLATE
     p.debug = a->reserved;
+    p.clk = g_ablate_clk;
+#endif
     p.workspace = (uint8_t *)a->workspace;
     p.workspace_bytes = a->workspace_bytes;
     p.M = a->M; p.M_pad = a->M_pad; p.N = a->N; p.K = a->K; p.R = a->R; p.R2 = a->R2; p.ldo = a->ldo;
@@ -950,26 +994,10 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     } else if (a->variant == 1) {
         if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, 1>(p, a->fuse, st);
         else launch_fuse<SVDQ_FP16, 1>(p, a->fuse, st);
-    } else {
-        switch (a->variant) { // ablations of the asm loop: timing experiments only, results are garbage
-        case 2: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 2>(p, st); break;
-        case 3: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 3>(p, st); break;
-        case 4: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 4>(p, st); break;
-        case 5: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 5>(p, st); break;
-        case 6: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 6>(p, st); break;
-        case 7: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 7>(p, st); break;
-        case 8: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 8>(p, st); break;
-        case 9: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 9>(p, st); break;
-        case 10: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 10>(p, st); break;
-        case 11: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 11>(p, st); break;
-        case 12: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 12>(p, st); break;
-        case 13: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 13>(p, st); break;
-        case 15: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 15>(p, st); break;
-        case 16: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 16>(p, st); break;
-        case 17: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 17>(p, st); break;
-        default: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 18>(p, st); break;
-        }
     }
+#ifdef SVDQ_ABLATE
+    else launch_ablation(p, a->variant, st); // generated switch over the ablation loops (tools/ablate/build.py)
+#endif
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_gemm_w4a4 launch");
 }

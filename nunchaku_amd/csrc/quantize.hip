@@ -244,7 +244,11 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     using T = typename Half<DT>::T;
     const int KP = a->K / 128, tiles = a->M_pad / 32;
     // enough workgroups to fill 256 CUs several times over, but at least one chunk per wave
+#ifdef SVDQ_ABLATE
     static const int cpw_env = getenv("SVDQ_QUANT_CPW") ? atoi(getenv("SVDQ_QUANT_CPW")) : 0; // experiment knob
+#else
+    constexpr int cpw_env = 0;
+#endif
     int cpw = cpw_env > 0 ? cpw_env : 4; // chunks per workgroup = 4 waves x 1 chunk: many short waves hide the HBM round trip
     while ((long)tiles * ((KP + cpw - 1) / cpw) > 8192) cpw *= 2;
     if (cpw > KP) cpw = ((KP + 3) / 4) * 4;
@@ -258,7 +262,11 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     dim3 grid(tiles * slices), block(256);
     const int rt32 = (a->R + 31) / 32;
     QuantSecond s2{a->x2, a->smooth2, a->lora_down2, a->mod_scale2, a->mod_shift2, a->ln_stats2, a->M2, a->ldx2, a->split_rows};
+#ifdef SVDQ_ABLATE
     static const int occ_env = getenv("SVDQ_QUANT_OCC") ? atoi(getenv("SVDQ_QUANT_OCC")) : 0; // experiment knob
+#else
+    constexpr int occ_env = 0;
+#endif
 #define SVDQ_LAUNCH_Q(RT)                                                                                            \
     if (RT <= 2 && occ_env == 4)                                                                                     \
     hipLaunchKernelGGL((quantize_kernel<DT, RT, (RT <= 2 ? 4 : 1)>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth, \

@@ -27,7 +27,9 @@ class CapturedStep:
                 fn(*self.static_inputs)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # capture on the stream the warm-up ran on: the GEMM's stream-K workspace is per (device, stream) (_C._workspace),
+        # so it already exists and is not allocated (and re-zeroed on every replay) inside the graph
+        with torch.cuda.graph(self.graph, stream=side), torch.no_grad():
             self.output = fn(*self.static_inputs)
 
     def __call__(self, *inputs):

@@ -82,17 +82,18 @@ class Gen:
     def e(self, s):
         a = self.ablate
         if self.in_loop:
-            if "dma" in a and s.startswith("global_load_lds"):
+            if "dma" in a.split("+") and s.startswith("global_load_lds"):
                 return
-            if "lds" in a and s.startswith("ds_read"):
+            if "lds" in a.split("+") and s.startswith("ds_read"):
                 return
-            if "fma" in a and (s.startswith("v_pk_fma") or s.startswith("v_fmac")):
+            if "nofma" in a.split("+") or ("fma" in a.split("+")) or "pmfma+smfma+fma" in a:
+                if s.startswith("v_pk_fma") or s.startswith("v_fmac"):
+                    return
+            if ("smfma" in a.split("+") or "pmfma+smfma+fma" in a or "nos" in a.split("+")) and s.startswith(self.smfma):
                 return
-            if "smfma" in a and s.startswith(self.smfma):
+            if ("pmfma" in a.split("+") or "pmfma+smfma+fma" in a or "nop" in a.split("+")) and s.startswith("v_mfma_scale"):
                 return
-            if "pmfma" in a and s.startswith("v_mfma_scale"):
-                return
-            if "barrier" in a and s.startswith("s_barrier"):
+            if "barrier" in a.split("+") and s.startswith("s_barrier"):
                 return
             if "bare" in a:  # keep only the MFMAs, the fmas and the loop control
                 keep = s.startswith("v_mfma") or s.startswith("v_fmac") or s.startswith("v_pk_fma") or \
@@ -107,6 +108,10 @@ class Gen:
                     keep = True
                 if not keep:
                     return
+            if "fmov" in a and s.startswith("v_fmac"):      # same issue slots, no dependency on the MFMA results
+                s = "v_mov_b32 " + s.split()[1] + " 0"
+            if "findep" in a and s.startswith("v_fmac"):    # fma whose sources are not MFMA results
+                s = s.split(",")[0] + f", {vr(IN_LA)}, {vr(IN_LW)}"
         self.lines.append(s)
 
     def new_label(self):
@@ -304,7 +309,10 @@ class Gen:
                     f"s_add_u32 {sr(S_STEP)}, {sr(S_STEP)}, 1",
                 ] + [f"v_mov_b32 {vr(CUR[i])}, {vr(NXT[i])}" for i in range(4)]
             order = int(os.environ.get("SVDQ_GEN_ORDER", "0"))
-            split = {0: 8, 1: 0, 2: 4, 3: 12}[order]
+            for tok in self.ablate.split("+"):
+                if tok.startswith("ord"):
+                    order = int(tok[3:])
+            split = {0: 8, 1: 0, 2: 4, 3: 12, 4: 16}[order]
             if order == 1:
                 e(self.s_mfma(pb ^ 1, nbuf, nt))
             for ln in misc:
@@ -341,12 +349,18 @@ def emit(path, smfma, ablate=""):
     return len(lines)
 
 
+ABLATIONS = ("dma", "lds", "fma", "smfma", "barrier", "dma+lds", "fma+smfma", "dma+barrier", "dma+lds+barrier",
+             "bare", "bare+bare2", "bare+bare3", "bare+bare4", "pmfma+smfma+fma",
+             # compute side alone (variants 16..): what keeps P + S + 16 fma from the 64-cycle MFMA bound
+             "bare+nofma", "bare+nos", "bare+nop", "bare+fmov", "bare+findep", "bare+ord1", "bare+ord2", "bare+ord3", "bare+ord4",
+             # memory side alone (variants 25..): DMA / LDS reads / barrier without any arithmetic
+             "pmfma+smfma+fma+lds", "pmfma+smfma+fma+dma", "pmfma+smfma+fma+barrier", "pmfma+smfma+fma+lds+barrier",
+             "pmfma+smfma+fma+dma+barrier", "pmfma+smfma+fma+dma+lds")
+
+
 if __name__ == "__main__":
+    # product loops only; the timing ablations are generated by tools/ablate/build.py into tools/ablate/gen/ (untracked)
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nunchaku_amd", "csrc")
     n = emit(os.path.join(root, "gemm_loop_bf16.inc"), "v_mfma_f32_32x32x16_bf16")
     emit(os.path.join(root, "gemm_loop_fp16.inc"), "v_mfma_f32_32x32x16_f16")
-    for ab in ("dma", "lds", "fma", "smfma", "barrier", "dma+lds", "fma+smfma", "dma+barrier", "dma+lds+barrier",
-               "pmfma+smfma+fma", "pmfma+smfma+fma+lds", "pmfma+smfma+fma+lds+barrier",
-               "bare", "bare+bare2", "bare+bare3", "bare+bare4"):
-        emit(os.path.join(root, "ablate", f"gemm_loop_bf16_{ab.replace('+', '_')}.inc"), "v_mfma_f32_32x32x16_bf16", ab)
     print(f"wrote gemm_loop_{{bf16,fp16}}.inc ({n} lines each)")
