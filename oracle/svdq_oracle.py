@@ -121,13 +121,18 @@ def _qweight_index(N: int, K: int):
 
 
 def pack_qweight_ref(q: np.ndarray) -> np.ndarray:
-    """int values in [-8, 7], shape [N, K] -> reference packed int8 [N, K/2]."""
+    """int values in [-8, 7], shape [N, K] -> reference packed int8 [N, K/2].
+
+    Same map as :func:`_qweight_index` (which :func:`unpack_qweight_ref` and the tests use to cross-check it), written
+    as the packer's own view / permute so that FLUX-sized weights pack in a fraction of a second:
+    n = nt*128 + np*16 + n_pack*8 + n_lane, k = kt*64 + k_pack*32 + k_lane*8 + r  ->  word
+    ((((nt*KT + kt)*8 + np)*32 + n_lane*4 + k_lane)*4 + n_pack*2 + k_pack), nibble r."""
     N, K = q.shape
     assert N % 128 == 0 and K % 128 == 0, "packer.py:207-212"
-    word, nib = _qweight_index(N, K)
-    words = np.zeros(N * K // 8, dtype=np.uint32)
-    np.bitwise_or.at(words, word.ravel(), ((q.astype(np.int64) & 0xF) << (4 * nib)).astype(np.uint32).ravel())
-    return words.view(np.int8).reshape(N, K // 2)
+    v = (q.astype(np.uint32) & 0xF).reshape(N // 128, 8, 2, 8, K // 64, 2, 4, 8)  # nt np n_pack n_lane kt k_pack k_lane r
+    v = v.transpose(0, 4, 1, 3, 6, 2, 5, 7)                                        # nt kt np n_lane k_lane n_pack k_pack r
+    words = (v << (4 * np.arange(8, dtype=np.uint32))).sum(axis=-1, dtype=np.uint32)
+    return np.ascontiguousarray(words).reshape(-1).view(np.int8).reshape(N, K // 2)
 
 
 def unpack_qweight_ref(packed: np.ndarray) -> np.ndarray:
@@ -361,9 +366,10 @@ def int_group_dot(qa: np.ndarray, qw: np.ndarray) -> np.ndarray:
     M, K = qa.shape
     N = qw.shape[0]
     G = K // GROUP
-    a = qa.reshape(M, G, GROUP).astype(np.float64)
-    w = qw.reshape(N, G, GROUP).astype(np.float64)
-    # products are tiny integers: float64 matmul is exact and uses BLAS
+    a = qa.reshape(M, G, GROUP).astype(np.float32)
+    w = qw.reshape(N, G, GROUP).astype(np.float32)
+    # products and every partial sum are integers of magnitude <= 64 * 8 * 15 = 7680 < 2^24: a float32 matmul is exact
+    # in any summation order and uses BLAS (half the memory traffic of float64 at the FLUX shapes)
     return np.einsum("mgk,ngk->gmn", a, w, optimize=True).astype(np.int32)
 
 
@@ -589,6 +595,27 @@ def make_svdq_layer(K: int, N: int, R: int = 32, seed: int = 0, dtype: str = "bf
         "dense": W,
     }
     return layer
+
+
+def make_random_svdq_layer(K: int, N: int, R: int = 32, seed: int = 0, dtype: str = "bf16", bias: bool = True) -> dict:
+    """A layer with the tensor statistics of :func:`make_svdq_layer` drawn directly (no dense weight, no SVD): codes =
+    clip(rint(N(0, 2.6^2)), -8, 7), group scales ~ 0.02 * 2.7 / 7 * lognormal, smooth ~ exp(N(0, 0.5^2)), low-rank factors
+    ~ N(0, 0.02^2) / N(0, 0.05^2).  For the full-size (3072 x 12288) GPU parity tests, where building a layer must take
+    well under a second; the kernels' arithmetic does not depend on where the codes came from."""
+    rng = np.random.default_rng(seed)
+    qw = np.clip(np.rint(rng.standard_normal((N, K), dtype=F32) * F32(2.6)), -8, 7).astype(np.int8)
+    G = K // GROUP
+    ws = round16((0.0077 * np.exp(rng.standard_normal((G, N), dtype=F32) * F32(0.3))).astype(F32), dtype)
+    smooth = round16(np.exp(rng.standard_normal(K).astype(F32) * F32(0.5)).astype(F32), dtype)
+    L1 = (rng.standard_normal((K, R), dtype=F32) * F32(0.05)).astype(F32)
+    return {
+        "qweight": qw,
+        "wscales": ws,
+        "smooth": smooth,
+        "proj_down": round16((L1 / smooth[:, None]).astype(F32), dtype),
+        "proj_up": round16((rng.standard_normal((N, R), dtype=F32) * F32(0.02)).astype(F32), dtype),
+        "bias": round16((rng.standard_normal(N).astype(F32) * F32(0.1)).astype(F32), dtype) if bias else None,
+    }
 
 
 def make_activations(M: int, K: int, seed: int = 0, dtype: str = "bf16", positive: bool = False) -> np.ndarray:
