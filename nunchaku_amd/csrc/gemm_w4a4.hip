@@ -165,7 +165,8 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         dX2 = lds_base + A_BYTES + W_BYTES + AS_BYTES;
         iX2 = 128;
     } else {
-        nX = 1;
+        nX = 1;       // v1 loop: no second stream
+        dX2 = dX1;    // v2 loop: the W plane once more (same bytes to the same place) -- every wave issues 5 DMAs per K-step
     }
     const unsigned dA = lds_base + wv * F6_CHUNK;
     const unsigned in_la = lds_base + (wm * 2) * F6_CHUNK + lane * 16;
@@ -223,15 +224,11 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         }
 
         if constexpr (LOOPV != 1) {
-            // ---- hand-scheduled main loop (tools/gen_gemm_loop.py; DESIGN.md "Main loop") ---------
+            // ---- hand-scheduled main loop (generated inline asm, every operand pinned to a physical register;
+            //      DESIGN.md "Main loop").  v2 = tools/gen_gemm_loop2.py.
             const unsigned kp_s = kp1 - kp0;
-#define SVDQ_LOOP_OPERANDS                                                                                              \
-                : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
-                  "+{s[40:41]}"(pA), "+{s[42:43]}"(pX1), "+{s[44:45]}"(pX2), "+{s58}"(ring)                                      \
-                : "{v210}"(in_la), "{v211}"(in_lw), "{v212}"(in_lsa), "{v213}"(in_lsw), "{v214}"(offA), "{v215}"(offX1),         \
-                  "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX1), "{s51}"(iX2), "{s52}"(nX), \
-                  "{s59}"(npre), "{s60}"(ncnt), "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed)            \
-                : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", "v64", "v65", "v66", "v67", "v68", "v69", "v70",     \
+#define SVDQ_LOOP_CLOBBER_V                                                                                            \
+                  "v64", "v65", "v66", "v67", "v68", "v69", "v70",     \
                   "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", \
                   "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",       \
                   "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",  \
@@ -241,29 +238,68 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                   "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171",  \
                   "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185",  \
                   "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199",  \
-                  "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220",  \
-                  "v221", "v222", "v223", "v224"
+                  "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220"
 #ifdef SVDQ_ABLATE
-                // timing experiments: one wave per SIMD runs the (barrier-free, ablated) loop, its partner idles
+            if constexpr (LOOPV >= 2) {
+                // v1 loop (tools/gen_gemm_loop.py) and its instruction-class ablations: timing experiments only
+#define SVDQ_LOOP_OPERANDS                                                                                              \
+                : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
+                  "+{s[40:41]}"(pA), "+{s[42:43]}"(pX1), "+{s[44:45]}"(pX2), "+{s58}"(ring)                                      \
+                : "{v210}"(in_la), "{v211}"(in_lw), "{v212}"(in_lsa), "{v213}"(in_lsw), "{v214}"(offA), "{v215}"(offX1),         \
+                  "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX1), "{s51}"(iX2), "{s52}"(nX), \
+                  "{s59}"(npre), "{s60}"(ncnt), "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed)            \
+                : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", SVDQ_LOOP_CLOBBER_V, "v221", "v222", "v223", "v224"
+                // one wave per SIMD runs the (barrier-free, ablated) loop, its partner idles
                 if (DBG(512) && wv >= 4) { acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16; } else
                 if (DBG(1024) && wv < 4) { acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16; } else
 #include "gemm_ablate_loops.inc" /* generated by tools/ablate/build.py: `if constexpr (LOOPV == n) { asm volatile(...); } else` chain */
+                { asm volatile(
+#include "gemm_loop_bf16.inc"
+                        SVDQ_LOOP_OPERANDS); }
+#undef SVDQ_LOOP_OPERANDS
+                npre = min((unsigned)NSTAGE, ncnt);
+                landed = ((p.bias || p.R > 0) && !DBG(2) && kp1 == KP) ? npre : 0;
+            } else
 #endif
+            {
+                // buffer resources of the three operand streams (raw buffers, no range check: the loop never issues a
+                // DMA beyond the last K-step of the workgroup's last segment)
+                auto srd = [](unsigned long long ptr) {
+                    v4i r;
+                    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ptr);
+                    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ptr >> 32));
+                    r[2] = -1;
+                    r[3] = 0x00020000;
+                    return r;
+                };
+                v4i rA = srd(pA), rX1 = srd(pX1), rX2 = srd(pX2);
+                const unsigned iX2v = wv < 4 || wv >= 6 ? (unsigned)F6_CHUNK : 128u;
+#define SVDQ_LOOP2_OPERANDS                                                                                             \
+                : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
+                  "+{s[72:75]}"(rA), "+{s[76:79]}"(rX1), "+{s[80:83]}"(rX2)                                                      \
+                : "{v210}"(in_la), "{v211}"(in_lw), "{v212}"(in_lsa), "{v213}"(in_lsw), "{v214}"(offA), "{v215}"(offX1),         \
+                  "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX2v), "{s58}"(ring),           \
+                  "{s59}"(npre), "{s60}"(ncnt), "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed)            \
+                : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", "s84", "s85", "s86", "s87", SVDQ_LOOP_CLOBBER_V
                 if constexpr (DT == SVDQ_BF16) {
                     asm volatile(
-#include "gemm_loop_bf16.inc"
-                        SVDQ_LOOP_OPERANDS);
+#include "gemm_loop2_bf16.inc"
+                        SVDQ_LOOP2_OPERANDS);
                 } else {
                     asm volatile(
-#include "gemm_loop_fp16.inc"
-                        SVDQ_LOOP_OPERANDS);
+#include "gemm_loop2_fp16.inc"
+                        SVDQ_LOOP2_OPERANDS);
                 }
-#undef SVDQ_LOOP_OPERANDS
-
-            npre = min((unsigned)NSTAGE, ncnt);
-            // the epilogue below waits on global loads (bias / low-rank operands) that are younger than the
-            // prefetch DMAs of the next tile: vmcnt retires in order, so those DMAs have landed by then
-            landed = ((p.bias || p.R > 0) && !DBG(2) && kp1 == KP) ? npre : 0;
+#undef SVDQ_LOOP2_OPERANDS
+                ring = (ring + (kp_s % NSTAGE) * STAGE_BYTES) % (NSTAGE * STAGE_BYTES); // stage of the next segment's K-step 0
+                npre = min((unsigned)NSTAGE, ncnt);
+                // The loop returns with the next segment's first K-steps still in flight (no vmcnt drain: their latency
+                // overlaps the epilogue's own loads).  An epilogue that waits on a global load of its own -- younger than
+                // those DMAs, vmcnt retires in order -- proves them landed; otherwise the next prologue waits itself.
+                landed = ((p.bias || p.R > 0) && !DBG(2) && kp1 == KP) ? npre : 0;
+                pA = nA; pX1 = nX1; pX2 = nX2; // the next segment's bases (set by stream_ptrs above)
+            }
+#undef SVDQ_LOOP_CLOBBER_V
         } else {
             npre = 0;
             // ---- reference C++ main loop (variant 1: same arithmetic, compiler-scheduled, no cross-tile
@@ -416,46 +452,82 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         const int nw0 = n0 + wn * 64;
         const int mw0 = m0 + wm * 64;
 
-        // bias (reference EpilogueBias, gemm_base.cuh:710-781)
-        if (p.bias && !DBG(2)) {
+        // bias (reference EpilogueBias, gemm_base.cuh:710-781) and low-rank up projection (reference EpilogueLoraUp,
+        // lora.cuh:110-241): fp32 activations are scaled per 16 ranks and rounded to 16-bit (:145-158), multiplied on the
+        // matrix cores and accumulated in fp32 -- here straight onto the GEMM accumulators.
+        // Every operand of the tile is requested BEFORE the first one is consumed (one memory round trip per tile
+        // instead of one per dependent stage: ~3.8 us -> ~2 us of exposed epilogue at K = 3072).  The arithmetic and its
+        // order are unchanged: acc + bias, then one MFMA per 16 ranks in ascending rank order.
+        const bool use_bias = p.bias && !DBG(2);
+        const int Rr = DBG(2) ? 0 : p.R;
+        // uniform base pointer + ONE 32-bit per-lane byte offset per tensor: the loads below differ by immediates only
+        // (global_load saddr + voffset form), which keeps the address registers of 20 loads down to three.  The offsets
+        // are derived from a lane id that passes through an empty asm statement AFTER the main loop: otherwise the
+        // compiler hoists all the address arithmetic above the loop's asm block, where only ~30 VGPRs are free, and
+        // spills it to scratch.
+        unsigned lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const unsigned lr_e = lane_e & 31, h_e = lane_e >> 5;
+        u16x4 bv[2][4] = {}; // (zero-initialised: conditionally loaded values must not look loop-carried to the register allocator)
+        const char *b_base = (const char *)(bm >= p.split_bm ? p.bias2 : p.bias);
+        const unsigned b_off = (unsigned)(nw0 + h_e * 4) * 2u;
+        if (use_bias) {
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    u16x4 b = *reinterpret_cast<const u16x4 *>((const T *)(bm >= p.split_bm ? p.bias2 : p.bias) + nw0 + ni * 32 + c * 8 + h * 4);
+                for (int c = 0; c < 4; c++) bv[ni][c] = *reinterpret_cast<const u16x4 *>(b_base + b_off + (ni * 32 + c * 8) * 2);
+        }
+        const char *la_base = (const char *)p.lora_act_in;
+        const char *lu_base = (const char *)(bm >= p.split_bm ? p.lora_up2 : p.lora_up);
+        const unsigned la_off = ((unsigned)(mw0 + lr_e) * (unsigned)Rr + h_e * 8) * 4u;
+        const unsigned lu_off = ((unsigned)(nw0 + lr_e) * (unsigned)Rr + h_e * 8) * 2u;
+        const unsigned la_mi = 32u * Rr * 4u, lu_ni = 32u * Rr * 2u; // byte strides of the second row tile / column tile
+        auto load_la = [&](int rc, v4f (&x)[2][2]) {
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) {
+                x[mi][0] = *reinterpret_cast<const v4f *>(la_base + (la_off + mi * la_mi + rc * 4));
+                x[mi][1] = *reinterpret_cast<const v4f *>(la_base + (la_off + mi * la_mi + rc * 4 + 16));
+            }
+        };
+        auto load_lu = [&](int rc, V8 (&u)[2]) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) u[ni] = *reinterpret_cast<const V8 *>(lu_base + (lu_off + ni * lu_ni + rc * 2));
+        };
+        auto lora_mfma = [&](int rc, const v4f (&x)[2][2], const V8 (&u)[2]) {
+            const float sc = p.lora_scales[rc >> 4];
+            V8 la[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    la[mi][j] = f2h<T>(x[mi][0][j] * sc);
+                    la[mi][4 + j] = f2h<T>(x[mi][1][j] * sc);
+                }
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(u[ni], la[mi], acc[ni][mi]);
+        };
+        v4f x0[2][2] = {}, x1[2][2] = {};
+        V8 u0[2] = {}, u1[2] = {};
+        if (Rr > 0) { load_la(0, x0); load_lu(0, u0); }
+        if (Rr > 16) { load_la(16, x1); load_lu(16, u1); }
+        if (use_bias) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                        for (int e = 0; e < 4; e++) acc[ni][mi][c * 4 + e] += h2f(hfrom<T>(b[e]));
-                }
+                        for (int e = 0; e < 4; e++) acc[ni][mi][c * 4 + e] += h2f(hfrom<T>(bv[ni][c][e]));
         }
-
-        // low-rank up projection (reference EpilogueLoraUp, lora.cuh:110-241): fp32 activations are
-        // scaled per 16 ranks and rounded to 16-bit (:145-158), multiplied on the matrix cores and
-        // accumulated in fp32 -- here straight onto the GEMM accumulators.
-        if (p.R > 0 && !DBG(2)) {
-            for (int rc = 0; rc < p.R; rc += 16) {
-                const float sc = p.lora_scales[rc >> 4];
-                V8 la[2], lu[2];
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++) {
-                    const float *src = p.lora_act_in + (size_t)(mw0 + mi * 32 + lr) * p.R + rc + h * 8;
-                    v4f x0 = *reinterpret_cast<const v4f *>(src);
-                    v4f x1 = *reinterpret_cast<const v4f *>(src + 4);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        la[mi][j] = f2h<T>(x0[j] * sc);
-                        la[mi][4 + j] = f2h<T>(x1[j] * sc);
-                    }
-                }
-#pragma unroll
-                for (int ni = 0; ni < 2; ni++)
-                    lu[ni] = *reinterpret_cast<const V8 *>((const T *)(bm >= p.split_bm ? p.lora_up2 : p.lora_up) + (size_t)(nw0 + ni * 32 + lr) * p.R + rc + h * 8);
-#pragma unroll
-                for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                    for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(lu[ni], la[mi], acc[ni][mi]);
-            }
+        if (Rr > 0) lora_mfma(0, x0, u0);
+        if (Rr > 16) lora_mfma(16, x1, u1);
+        for (int rc = 32; rc < Rr; rc += 16) { // runtime LoRA beyond rank 32: one round trip per 16 ranks
+            load_la(rc, x0);
+            load_lu(rc, u0);
+            lora_mfma(rc, x0, u0);
         }
 
         // the single rounding to the 16-bit model dtype (the reference's tile is 16-bit from here on)

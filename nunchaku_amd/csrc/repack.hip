@@ -27,11 +27,11 @@ int prof_begin(int cls, double work, hipStream_t st) {
     int i = (int)g_prof_used++;
     g_prof_pool[i].cls = cls;
     g_prof_pool[i].work = work;
-    hipEventRecord(g_prof_pool[i].e0, st);
+    (void)hipEventRecord(g_prof_pool[i].e0, st);
     return i;
 }
 void prof_end(int i, hipStream_t st) {
-    if (i >= 0) hipEventRecord(g_prof_pool[i].e1, st);
+    if (i >= 0) (void)hipEventRecord(g_prof_pool[i].e1, st);
 }
 
 // ---- thread-local error string -----------------------------------------------------------
@@ -237,7 +237,7 @@ int svdq_unpack_scales(const void *simg, void *natural, int32_t ROWS, int32_t G,
 
 int svdq_prof_enable(int32_t max_launches) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto &r : g_prof_pool) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto &r : g_prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof_pool.clear();
     g_prof_used = 0;
     g_prof_on = false;

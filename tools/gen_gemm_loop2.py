@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate main loop v2 of svdq_gemm_w4a4 (gfx950): same arithmetic and register image as tools/gen_gemm_loop.py
+(bit-identical results), ~40 fewer instructions per K-step.
+
+    python tools/gen_gemm_loop2.py        # writes nunchaku_amd/csrc/gemm_loop2_{bf16,fp16}.inc
+
+Why (profiles/r2_gemm_ablation_cycles.txt): the loop is bound by instruction ISSUE, not by any pipe -- a SIMD with its
+two waves retires ~1 instruction per 4.5 cycles whatever the mix, MFMA and VALU barely overlap (P+S 64 cycles, P+S+16 fma
+86 per 32x32x64 tile-group, one wave or two), and every DMA / LDS / scalar instruction of the memory side adds its ~4.5
+cycles on top (compute alone 86, whole loop 129 cycles per tile-group).  v1 spends ~230 instructions per wave and K-step,
+144 of them arithmetic.  v2 removes bookkeeping, not work:
+  * the 4-stage LDS ring is unrolled: one copy of the K-step body per stage, every LDS address is base + immediate
+    (no per-step v_mov / v_add / s_cselect stage rotation);
+  * operand streams are MUBUF LDS-DMA (buffer_load_dwordx4 ... lds) with the K-step offset in ONE shared soffset SGPR per
+    stream class: 2 scalar adds per K-step instead of 6 add/addc, segment switch = 3 s_mov_b64 out of line;
+  * every wave issues exactly 5 DMA instructions per K-step (waves 6, 7 repeat their W plane), so the wait for "my DMAs of
+    K-step s+1 have landed" is the constant s_waitcnt vmcnt(10) -- no counting ladder, no taken branch on the hot path;
+    the DMA-less last K-steps of a workgroup's last segment take an out-of-line path with vmcnt(0);
+  * loop control: 3 + 4 scalar instructions per K-step, all branches not taken in steady state.
+
+Register plan (the C++ side pins its asm operands to the same registers, gemm_w4a4.hip):
+  v[0:63] acc   v[64:79] P0  v[80:95] S0  v[96:111] P1  v[112:127] S1   v[128:151] / v[152:175] fragment buffers 0 / 1
+  v[176:191] / v[192:207] scale tuples 0 / 1    v208 v209 MX exponents
+  v210..v213 in: per-lane LDS offsets of A frags, W frags, as, ws (stage-relative)   v214..v216 in: per-lane DMA offsets
+  v217..v220: the same four LDS offsets + 2*STAGE (stages 2, 3: ds offsets are 16-bit)
+  s46 K-steps of this segment   s47 s48 s49 LDS destinations of the A / X1 / X2 planes (stage-relative)
+  s50 per-K-step soffset increment of stream X2 (3072 for a W plane, 128 for a scale plane)
+  s[72:75] s[76:79] s[80:83] buffer resources of streams A, X1, X2 (in: this segment's bases; the loop moves them on)
+  s[62:63] s[64:65] s[66:67] bases of the NEXT segment's streams   s60 its K-step count (0 = none)
+  s58 in: LDS stage offset of this segment's K-step 0 (the caller advances it)   s59 this segment's K-steps already in flight
+  s68 leading K-steps known to have landed (0 or s59)   s53 s55 s56 s57 s61 s84 s85 s86 s87 scratch
+"""
+import os
+
+STAGE = 24576 + 12288 + 1024 + 1024
+NSTAGE = 4
+CHUNK, PLANE = 3072, 1024
+DMA_PER_STEP = 5
+
+ACC = 0
+PBUF = [64, 96]
+SBUF = [80, 112]
+FRAG = [128, 152]
+SCL = [176, 192]
+MXA, MXB = 208, 209
+IN_L = [210, 211, 212, 213]   # A, W, SA, SW (stages 0, 1)
+HI_L = [217, 218, 219, 220]   # + 2 * STAGE (stages 2, 3)
+OFF_A, OFF_X1, OFF_X2 = 214, 215, 216
+S_KP, S_DA, S_DX1, S_DX2, S_IX2 = 46, 47, 48, 49, 50
+S_STEP, S_TOT4, S_KP4, S_TMP, S_TOT = 53, 55, 56, 57, 61
+S_RING, S_NPRE, S_NCNT, S_LANDED = 58, 59, 60, 68
+S_NA, S_NX1, S_NX2 = 62, 64, 66
+SRD_A, SRD_X1, SRD_X2 = 72, 76, 80
+S_KOFF, S_KOFF2, S_DSTEP, S_STG = 84, 85, 86, 87
+
+
+def vr(a, n=1):
+    return f"v{a}" if n == 1 else f"v[{a}:{a + n - 1}]"
+
+
+def sr(a, n=1):
+    return f"s{a}" if n == 1 else f"s[{a}:{a + n - 1}]"
+
+
+class Gen:
+    def __init__(self, smfma, opts=""):
+        self.smfma = smfma
+        self.opts = set(o for o in opts.split("+") if o)
+        self.lines = []
+        self.label = 0
+
+    def e(self, s):
+        self.lines.append(s)
+
+    def new_label(self, tag=""):
+        self.label += 1
+        return f".Lsvdq2_{tag}{self.label}_%="
+
+    # ---- addressing -------------------------------------------------------------------
+    def lds(self, kind, stage):
+        """(address VGPR, immediate) of operand kind 0..3 in ring stage `stage`"""
+        if stage < 2:
+            return IN_L[kind], stage * STAGE
+        return HI_L[kind], (stage - 2) * STAGE
+
+    def frag_reads(self, buf, grp, stage):
+        out = []
+        for kind, roff in ((1, 0), (0, 12)):  # W fragments first (v1's order), then A
+            base, imm = self.lds(kind, stage)
+            for i in range(2):
+                f = FRAG[buf] + roff + 6 * i
+                o = imm + i * CHUNK
+                if grp == 0:
+                    out.append(f"ds_read_b128 {vr(f, 4)}, {vr(base)} offset:{o}")
+                    out.append(f"ds_read_b64 {vr(f + 4, 2)}, {vr(base)} offset:{o + PLANE}")
+                else:
+                    out.append(f"ds_read_b64 {vr(f, 2)}, {vr(base)} offset:{o + PLANE + 8}")
+                    out.append(f"ds_read_b128 {vr(f + 2, 4)}, {vr(base)} offset:{o + 2 * PLANE}")
+        for kind, roff in ((3, 0), (2, 8)):
+            base, imm = self.lds(kind, stage)
+            for i in range(2):
+                out.append(f"ds_read_u16 {vr(SCL[buf] + roff + 4 * i)}, {vr(base)} offset:{imm + i * 128 + grp * 64}")
+        return out
+
+    def p_mfma(self, dst_buf, buf, t):
+        ni, mi = t >> 1, t & 1
+        w = FRAG[buf] + 6 * ni
+        a = FRAG[buf] + 12 + 6 * mi
+        return (f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(PBUF[dst_buf], 16)}, {vr(w, 6)}, {vr(a, 6)}, 0, "
+                f"{vr(MXA)}, {vr(MXB)} op_sel_hi:[0,0,0] cbsz:2 blgp:2")
+
+    def s_mfma(self, dst_buf, buf, t):
+        ni, mi = t >> 1, t & 1
+        return f"{self.smfma} {vr(SBUF[dst_buf], 16)}, {vr(SCL[buf] + 4 * ni, 4)}, {vr(SCL[buf] + 8 + 4 * mi, 4)}, 0"
+
+    def fma(self, t, pb, lo, hi):
+        return [f"v_fmac_f32 {vr(ACC + 16 * t + r)}, {vr(PBUF[pb] + r)}, {vr(SBUF[pb] + r)}" for r in range(lo, hi)]
+
+    # ---- DMA --------------------------------------------------------------------------
+    def dma_issue(self, stage_imm=None):
+        """the 5 LDS-DMA wave loads of one K-step at the DMA cursor, into ring stage `stage_imm` (byte offset; None:
+        the stage offset is in S_STG), then advance the cursor by one K-step.  Scalar bookkeeping sits in the M0 -> DMA
+        wait-state slots."""
+        def m0(dst):
+            return f"s_add_u32 m0, {sr(dst)}, {stage_imm}" if stage_imm is not None else f"s_add_u32 m0, {sr(dst)}, {sr(S_STG)}"
+        ld = "buffer_load_dwordx4"
+        return [
+            m0(S_DA),
+            f"s_add_u32 {sr(S_DSTEP)}, {sr(S_DSTEP)}, 1",
+            f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen lds",
+            f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen offset:{PLANE} lds",
+            f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen offset:{2 * PLANE} lds",
+            m0(S_DX1),
+            "s_nop 0",
+            f"{ld} {vr(OFF_X1)}, {sr(SRD_X1, 4)}, {sr(S_KOFF)} offen lds",
+            m0(S_DX2),
+            f"s_add_u32 {sr(S_KOFF)}, {sr(S_KOFF)}, {CHUNK}",
+            f"{ld} {vr(OFF_X2)}, {sr(SRD_X2, 4)}, {sr(S_KOFF2)} offen lds",
+            f"s_add_u32 {sr(S_KOFF2)}, {sr(S_KOFF2)}, {sr(S_IX2)}",
+        ]
+
+    def switch_segment(self):
+        """DMA cursor moves to the first K-step of the next segment"""
+        return [
+            f"s_mov_b64 {sr(SRD_A, 2)}, {sr(S_NA, 2)}",
+            f"s_mov_b64 {sr(SRD_X1, 2)}, {sr(S_NX1, 2)}",
+            f"s_mov_b64 {sr(SRD_X2, 2)}, {sr(S_NX2, 2)}",
+            f"s_mov_b32 {sr(S_KOFF)}, 0",
+            f"s_mov_b32 {sr(S_KOFF2)}, 0",
+        ]
+
+    # ---- one K-step body for ring stage j --------------------------------------------------
+    def kstep(self, j, exit_label, ool):
+        e = self.e
+        nj = (j + 1) % NSTAGE
+        reads_g1 = self.frag_reads(1, 1, j)
+        reads_n0 = self.frag_reads(0, 0, nj)
+        for q in range(8):
+            t = q & 3
+            pb = q & 1
+            qn = q + 1
+            nbuf, nt = (qn >> 2) & 1, qn & 3
+            if q in (3, 7):
+                e("s_waitcnt lgkmcnt(0)")
+            e(self.p_mfma(pb ^ 1, nbuf, nt))
+            misc = []
+            if q < 3:
+                misc = reads_g1[4 * q:4 * q + 4]
+            elif q == 4:
+                Ltail, Lback, Lsw, Lbsw = (self.new_label(x) for x in ("tail", "back", "sw", "bsw"))
+                misc = [
+                    # this K-step issues the DMA of K-step step+4 iff it exists (this segment or the next one)
+                    f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_TOT4)}",
+                    f"s_cbranch_scc0 {Ltail}",
+                    # my 5 DMAs of K-step step+1 have landed: the 10 younger ones (step+2, step+3) may stay in flight
+                    f"s_waitcnt vmcnt({2 * DMA_PER_STEP})",
+                    "s_barrier",
+                    f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}",
+                    f"s_cbranch_scc1 {Lsw}",
+                    f"{Lbsw}:",
+                ] + self.dma_issue(j * STAGE) + [f"{Lback}:"] + reads_n0[0:4]
+                ool += [f"{Ltail}:", "s_waitcnt vmcnt(0)", "s_barrier", f"s_branch {Lback}",
+                        f"{Lsw}:"] + self.switch_segment() + [f"s_branch {Lbsw}"]
+            elif q in (5, 6):
+                misc = reads_n0[4 * (q - 4):4 * (q - 4) + 4]
+            elif q == 7:
+                misc = [f"s_add_u32 {sr(S_STEP)}, {sr(S_STEP)}, 1"]
+            for ln in misc:
+                e(ln)
+            for ln in self.fma(t, pb, 0, 8):
+                e(ln)
+            e(self.s_mfma(pb ^ 1, nbuf, nt))
+            for ln in self.fma(t, pb, 8, 16):
+                e(ln)
+        e(f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_KP)}")
+        e(f"s_cbranch_scc0 {exit_label}")
+
+    # ---- the whole asm block ---------------------------------------------------------------
+    def build(self):
+        e = self.e
+        e("; ---- svdq gemm main loop v2 (generated by tools/gen_gemm_loop2.py) ----")
+        for r in range(64):
+            e(f"v_mov_b32 {vr(ACC + r)}, 0")
+        for b in range(2):
+            for tpl in range(4):
+                for k in range(1, 4):
+                    e(f"v_mov_b32 {vr(SCL[b] + 4 * tpl + k)}, 0")
+        e(f"v_mov_b32 {vr(MXA)}, 0x82828282")
+        e(f"v_mov_b32 {vr(MXB)}, 0x81818181")
+        for k in range(4):
+            e(f"v_add_u32 {vr(HI_L[k])}, {2 * STAGE}, {vr(IN_L[k])}")
+        e(f"s_mov_b32 {sr(S_STEP)}, 0")
+        e(f"s_add_u32 {sr(S_TOT)}, {sr(S_KP)}, {sr(S_NCNT)}")
+        # thresholds on `step`: DMA of K-step step+4 exists iff step < tot-4; it is the next segment's first iff step == kp-4
+        e(f"s_sub_u32 {sr(S_TOT4)}, {sr(S_TOT)}, {NSTAGE}")
+        e(f"s_cselect_b32 {sr(S_TOT4)}, 0, {sr(S_TOT4)}")          # borrow (tot < 4): never
+        e(f"s_sub_u32 {sr(S_KP4)}, {sr(S_KP)}, {NSTAGE}")
+        e(f"s_cselect_b32 {sr(S_KP4)}, -1, {sr(S_KP4)}")            # kp < 4: the prologue below has switched already
+        # DMA cursor: K-step `npre` of this segment
+        e(f"s_mov_b32 {sr(S_DSTEP)}, {sr(S_NPRE)}")
+        e(f"s_mul_i32 {sr(S_KOFF)}, {sr(S_NPRE)}, {CHUNK}")
+        e(f"s_mul_i32 {sr(S_KOFF2)}, {sr(S_NPRE)}, {sr(S_IX2)}")
+        # prologue: top the stream up to NSTAGE K-steps in flight (all of them for a workgroup's first segment, normally
+        # none afterwards: the previous segment has fetched them).  Generic, branchy, rare.
+        e(f"s_mul_i32 {sr(S_TMP)}, {sr(S_NPRE)}, {STAGE}")
+        e(f"s_add_u32 {sr(S_STG)}, {sr(S_RING)}, {sr(S_TMP)}")
+        e(f"s_cmp_lt_u32 {sr(S_STG)}, {NSTAGE * STAGE}")
+        e(f"s_cselect_b32 {sr(S_TMP)}, 0, {NSTAGE * STAGE}")
+        e(f"s_sub_u32 {sr(S_STG)}, {sr(S_STG)}, {sr(S_TMP)}")     # ring + npre*STAGE mod ring size (npre <= NSTAGE)
+        Ltop, Ltopdone, Lnosw = self.new_label("top"), self.new_label("topdone"), self.new_label("nosw")
+        e(f"{Ltop}:")
+        e(f"s_cmp_lt_u32 {sr(S_DSTEP)}, {NSTAGE}")
+        e(f"s_cbranch_scc0 {Ltopdone}")
+        e(f"s_cmp_lt_u32 {sr(S_DSTEP)}, {sr(S_TOT)}")
+        e(f"s_cbranch_scc0 {Ltopdone}")
+        e(f"s_cmp_eq_u32 {sr(S_DSTEP)}, {sr(S_KP)}")
+        e(f"s_cbranch_scc0 {Lnosw}")
+        for ln in self.switch_segment():
+            e(ln)
+        e(f"{Lnosw}:")
+        for ln in self.dma_issue(None):
+            e(ln)
+        e(f"s_add_u32 {sr(S_STG)}, {sr(S_STG)}, {STAGE}")
+        e(f"s_cmp_lt_u32 {sr(S_STG)}, {NSTAGE * STAGE}")
+        e(f"s_cselect_b32 {sr(S_STG)}, {sr(S_STG)}, 0")
+        e(f"s_branch {Ltop}")
+        e(f"{Ltopdone}:")
+        Lpw = self.new_label("pw")
+        e(f"s_cmp_gt_u32 {sr(S_LANDED)}, 0")
+        e(f"s_cbranch_scc1 {Lpw}")
+        e("s_waitcnt vmcnt(0)")
+        e(f"{Lpw}:")
+        e("s_barrier")
+        # enter the unrolled ring at this segment's stage
+        entry = [self.new_label(f"in{j}_") for j in range(NSTAGE)]
+        for j in range(1, NSTAGE):
+            e(f"s_cmp_eq_u32 {sr(S_RING)}, {j * STAGE}")
+            e(f"s_cbranch_scc1 {entry[j]}")
+        body = [self.new_label(f"st{j}_") for j in range(NSTAGE)]
+        Lexit = self.new_label("exit")
+        ool = []
+        # per entry: first fragments + the first tile-group's MFMAs from that stage, then into the ring
+        for j in range(NSTAGE):
+            e(f"{entry[j]}:")
+            for ln in self.frag_reads(0, 0, j):
+                e(ln)
+            e("s_waitcnt lgkmcnt(0)")
+            e(self.p_mfma(0, 0, 0))
+            e(self.s_mfma(0, 0, 0))
+            e("s_nop 7")
+            e(f"s_branch {body[j]}")
+        return body, Lexit, ool
+
+    def finish(self, body, Lexit, ool):
+        e = self.e
+        for j in range(NSTAGE):
+            e(f"{body[j]}:")
+            self.kstep(j, Lexit, ool)
+        e(f"s_branch {body[0]}")
+        for ln in ool:
+            e(ln)
+        e(f"{Lexit}:")
+        # drain: the speculative fragment reads and MFMAs of the non-existent next step must not be in flight when the
+        # compiler's epilogue reuses their destination registers (XDL write -> VALU write needs <= 19 wait states; the
+        # compiler cannot see them).  The DMAs of the next segment stay in flight: no vmcnt wait here.
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_nop 15")
+        e("s_nop 7")
+        return self.lines
+
+
+def emit(path, smfma, opts=""):
+    g = Gen(smfma, opts)
+    body, Lexit, ool = g.build()
+    lines = g.finish(body, Lexit, ool)
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_loop2.py -- do not edit.\n")
+        for ln in lines:
+            f.write('"' + ln + '\\n"\n')
+    return len(lines)
+
+
+if __name__ == "__main__":
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nunchaku_amd", "csrc")
+    n = emit(os.path.join(root, "gemm_loop2_bf16.inc"), "v_mfma_f32_32x32x16_bf16")
+    emit(os.path.join(root, "gemm_loop2_fp16.inc"), "v_mfma_f32_32x32x16_f16")
+    print(f"wrote gemm_loop2_{{bf16,fp16}}.inc ({n} lines each)")
