@@ -77,6 +77,7 @@ struct GemmParams {
 #ifdef SVDQ_ABLATE
     int debug;               // timing experiments (tools/ablate): bit0 skip output stores, bit1 skip bias + low-rank up, ...
     long long *clk;          // per workgroup {shader cycles, 100 MHz ticks} of the whole kernel (effective clock probe)
+    long long *trace;        // workgroup 0: shader-cycle stamps {loop start, loop end, epilogue end} per segment (<= 32 segments)
 #endif
     float lora_scales[MAX_LORA_TILES];
 };
@@ -201,6 +202,9 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     auto next_seg = [&](Seg &sg) -> bool { return sched.next(sg); };
 
     unsigned ring = 0, npre = 0, landed = 0;
+#ifdef SVDQ_ABLATE
+    int seg_no = 0;
+#endif
     unsigned long long pA = 0, pX1 = 0, pX2 = 0;
     int bm = 0, bn = 0;
     Seg cur{0, 0, 0, 0}, nxt{0, 0, 0, 0};
@@ -223,6 +227,10 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             ncnt = nxt.kp1 - nxt.kp0;
         }
 
+#ifdef SVDQ_ABLATE
+        static_assert(true, "");
+        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[3 * seg_no] = __builtin_readcyclecounter() - clk_t0;
+#endif
         if constexpr (LOOPV != 1) {
             // ---- hand-scheduled main loop (generated inline asm, every operand pinned to a physical register;
             //      DESIGN.md "Main loop").  v2 = tools/gen_gemm_loop2.py.
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                   "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199",  \
                   "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220"
 #ifdef SVDQ_ABLATE
-            if constexpr (LOOPV >= 2) {
+            if constexpr (LOOPV >= 2 && LOOPV < 100) {
                 // v1 loop (tools/gen_gemm_loop.py) and its instruction-class ablations: timing experiments only
 #define SVDQ_LOOP_OPERANDS                                                                                              \
                 : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
@@ -274,13 +282,18 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 };
                 v4i rA = srd(pA), rX1 = srd(pX1), rX2 = srd(pX2);
                 const unsigned iX2v = wv < 4 || wv >= 6 ? (unsigned)F6_CHUNK : 128u;
+                const unsigned phaseB = wv >= 4 ? 1u : 0u; // "dph" loops only: waves 4..7 issue their DMAs half a K-step later
 #define SVDQ_LOOP2_OPERANDS                                                                                             \
                 : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
                   "+{s[72:75]}"(rA), "+{s[76:79]}"(rX1), "+{s[80:83]}"(rX2)                                                      \
                 : "{v210}"(in_la), "{v211}"(in_lw), "{v212}"(in_lsa), "{v213}"(in_lsw), "{v214}"(offA), "{v215}"(offX1),         \
-                  "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX2v), "{s58}"(ring),           \
+                  "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX2v), "{s52}"(phaseB),         \
+                  "{s58}"(ring),                                                                                                   \
                   "{s59}"(npre), "{s60}"(ncnt), "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed)            \
                 : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", "s84", "s85", "s86", "s87", SVDQ_LOOP_CLOBBER_V
+#ifdef SVDQ_ABLATE
+#include "gemm_ablate_loops2.inc" /* generated: option variants of the v2 loop, `if constexpr (LOOPV == n) { asm volatile(...); } else` chain */
+#endif
                 if constexpr (DT == SVDQ_BF16) {
                     asm volatile(
 #include "gemm_loop2_bf16.inc"
@@ -392,6 +405,9 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             }
         }
 
+#ifdef SVDQ_ABLATE
+        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[3 * seg_no + 1] = __builtin_readcyclecounter() - clk_t0;
+#endif
         // ---- stream-K: publish or collect partial tiles -----------------------------------------------
         bool run_epilogue = true;
         if (sk && (kp0 > 0 || kp1 < KP)) {
@@ -512,6 +528,27 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         V8 u0[2] = {}, u1[2] = {};
         if (Rr > 0) { load_la(0, x0); load_lu(0, u0); }
         if (Rr > 16) { load_la(16, x1); load_lu(16, u1); }
+        // GELU_QUANT: the next layer's smoothing factors and the first 32 ranks of its low-rank down projection ride on the
+        // same round trip (they are consumed ~2000 instructions later, behind the GELU and the requantisation)
+        u16x4 nsv[2][4] = {}, ldw[2][2][2] = {};
+        if constexpr (FUSE == SVDQ_FUSE_GELU_QUANT) {
+            const char *ns_base = (const char *)(bm >= p.split_bm ? p.next_smooth2 : p.next_smooth);
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) nsv[ni][c] = *reinterpret_cast<const u16x4 *>(ns_base + b_off + (ni * 32 + c * 8) * 2);
+            if (p.R2 > 0 && !DBG(64) && (int)lr_e < p.R2) {
+                const char *ld_base = (const char *)(bm >= p.split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
+                const unsigned ld_off = (lr_e * (unsigned)p.N + nw0 + h_e * 4) * 2u;
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        ldw[ni][q][0] = *reinterpret_cast<const u16x4 *>(ld_base + ld_off + (ni * 32 + q * 16) * 2);
+                        ldw[ni][q][1] = *reinterpret_cast<const u16x4 *>(ld_base + ld_off + (ni * 32 + q * 16 + 8) * 2);
+                    }
+            }
+        }
         if (use_bias) {
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
@@ -530,13 +567,17 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             lora_mfma(rc, x0, u0);
         }
 
-        // the single rounding to the 16-bit model dtype (the reference's tile is 16-bit from here on)
+        // the single rounding to the 16-bit model dtype (the reference's tile is 16-bit from here on).  With the default
+        // epilogue nothing but the store follows, and the store's own conversion IS this rounding (same RNE; the fp16
+        // clamp commutes with it): skipping the round trip through fp32 saves ~128 VALU instructions per tile.
+        if constexpr (FUSE != SVDQ_FUSE_NONE) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+            for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
+                for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(acc[ni][mi][r]);
+                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(acc[ni][mi][r]);
+        }
 
         if constexpr (FUSE == SVDQ_FUSE_SILU) {
 #pragma unroll
@@ -553,6 +594,30 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             const bool is_q = n0 < third;
             const bool is_k = !is_q && n0 < 2 * third;
             if (is_q || is_k) { // block-uniform
+                // the norm weights and the rotary table entries of this lane's 2 rows x 32 column pairs are requested
+                // BEFORE the row-sum exchange (two barriers): their memory round trip overlaps it instead of following it
+                const T *nw = (const T *)(bm >= p.split_bm ? (is_q ? p.norm_q2 : p.norm_k2) : (is_q ? p.norm_q : p.norm_k));
+                u16x4 wvv[2][4] = {};
+                float2 rot[2][2][4][2] = {};
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) wvv[ni][c] = *reinterpret_cast<const u16x4 *>(nw + wn * 64 + ni * 32 + c * 8 + h * 4);
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++) {
+                    const int m_abs = m0 + wm * 64 + mi * 32 + lr;
+                    // packed rotary order (models/embeddings.py:100-138): [m/16][d/8][r8*4+p][rh][sin,cos]; the first pair
+                    // of the lane's 4 columns (wn*64 + ni*32 + c*8 + h*4) is pair wn*32 + ni*16 + c*4 + 2h
+                    const float *rrow = p.rotary_emb + ((size_t)(m_abs >> 4) * 16) * 128 + (size_t)((m_abs & 7) * 4) * 4 + ((m_abs >> 3) & 1) * 2 + h * 8;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const float *rp = rrow + (wn * 8 + ni * 4 + c) * 128;
+                            rot[mi][ni][c][0] = *reinterpret_cast<const float2 *>(rp);
+                            rot[mi][ni][c][1] = *reinterpret_cast<const float2 *>(rp + 4);
+                        }
+                }
                 __syncthreads(); // the previous tile's readers of the epilogue scratch are done
                 // LDS-address-space pointer (no flat cast: the aperture compare it needs trips an LLVM verifier bug here)
                 __attribute__((address_space(3))) float *sq = (__attribute__((address_space(3))) float *)(lds + NSTAGE * STAGE_BYTES); // [2 (wn)][256 rows]
@@ -567,25 +632,17 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                     if (h == 0) sq[wn * 256 + wm * 64 + mi * 32 + lr] = s;
                 }
                 __syncthreads();
-                const T *nw = (const T *)(bm >= p.split_bm ? (is_q ? p.norm_q2 : p.norm_k2) : (is_q ? p.norm_q : p.norm_k));
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++) {
                     const int row = wm * 64 + mi * 32 + lr;
                     const float tot = sq[row] + sq[256 + row];
                     const float coef = 1.0f / sqrtf(tot / 128.0f + 1e-6f);
-                    const int m_abs = m0 + row;
-                    // packed rotary order (models/embeddings.py:100-138): [m/16][d/8][r8*4+p][rh][sin,cos]
-                    const size_t rbase = ((size_t)(m_abs >> 4) * 16) * 128 + (size_t)((m_abs & 7) * 4) * 4 + ((m_abs >> 3) & 1) * 2;
 #pragma unroll
                     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
-                            const int col = wn * 64 + ni * 32 + c * 8 + h * 4; // column inside the head
-                            u16x4 wv = *reinterpret_cast<const u16x4 *>(nw + col);
-                            const int pi = col >> 1; // first pair index
-                            const float *rp = p.rotary_emb + rbase + (size_t)(pi >> 2) * 128 + (size_t)(pi & 3) * 4;
-                            float2 sc0 = *reinterpret_cast<const float2 *>(rp);
-                            float2 sc1 = *reinterpret_cast<const float2 *>(rp + 4);
+                            const u16x4 wv = wvv[ni][c];
+                            const float2 sc0 = rot[mi][ni][c][0], sc1 = rot[mi][ni][c][1];
                             float v0 = acc[ni][mi][c * 4 + 0] * (coef * h2f(hfrom<T>(wv[0])));
                             float v1 = acc[ni][mi][c * 4 + 1] * (coef * h2f(hfrom<T>(wv[1])));
                             float v2 = acc[ni][mi][c * 4 + 2] * (coef * h2f(hfrom<T>(wv[2])));
@@ -622,7 +679,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    u16x4 sv = *reinterpret_cast<const u16x4 *>((const T *)(bm >= p.split_bm ? p.next_smooth2 : p.next_smooth) + nw0 + ni * 32 + c * 8 + h * 4);
+                    const u16x4 sv = nsv[ni][c];
 #pragma unroll
                     for (int e = 0; e < 4; e++) smr[ni][c * 4 + e] = __builtin_amdgcn_rcpf(h2f(hfrom<T>(sv[e])));
                 }
@@ -688,9 +745,12 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                         for (int q = 0; q < 2; q++) {
                             V8 wv;
                             if (live) {
-                                const T *src = ld + (size_t)(t2 + lr) * p.N + nw0 + ni * 32 + q * 16 + h * 4;
-                                u16x4 w0 = *reinterpret_cast<const u16x4 *>(src);
-                                u16x4 w1 = *reinterpret_cast<const u16x4 *>(src + 8);
+                                u16x4 w0 = ldw[ni][q][0], w1 = ldw[ni][q][1]; // ranks 0..31: requested at the top of the epilogue
+                                if (t2 > 0) {
+                                    const T *src = ld + (size_t)(t2 + lr) * p.N + nw0 + ni * 32 + q * 16 + h * 4;
+                                    w0 = *reinterpret_cast<const u16x4 *>(src);
+                                    w1 = *reinterpret_cast<const u16x4 *>(src + 8);
+                                }
 #pragma unroll
                                 for (int j = 0; j < 4; j++) { wv[j] = hfrom<T>(w0[j]); wv[4 + j] = hfrom<T>(w1[j]); }
                             } else {
@@ -790,6 +850,10 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         }
         } // FUSE != GELU_QUANT
         } // run_epilogue
+#ifdef SVDQ_ABLATE
+        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[3 * seg_no + 2] = __builtin_readcyclecounter() - clk_t0;
+        seg_no++;
+#endif
         have = have_next;
         cur = nxt;
         bm = nbm;
@@ -863,6 +927,7 @@ static void launch_fuse(const GemmParams &p, int fuse, hipStream_t st) {
 
 #ifdef SVDQ_ABLATE
 static long long *g_ablate_clk = nullptr;
+static long long *g_ablate_trace = nullptr;
 #include "gemm_ablate_launch.inc" /* generated: SVDQ_ABLATE_MAX_VARIANT, launch_ablation() */
 #endif
 
@@ -873,6 +938,8 @@ using namespace svdq;
 #ifdef SVDQ_ABLATE
 // tools only: device buffer of 2 * grid int64 that every later gemm launch fills with {shader cycles, 100 MHz ticks} per workgroup
 extern "C" void svdq_ablate_set_clk(long long *dev_buf) { g_ablate_clk = dev_buf; }
+// tools only: device buffer of 96 int64: workgroup 0 stamps {loop start, loop end, epilogue end} (shader cycles) per segment
+extern "C" void svdq_ablate_set_trace(long long *dev_buf) { g_ablate_trace = dev_buf; }
 #endif
 
 extern "C" int64_t svdq_gemm_workspace_bytes(void) { return workspace_bytes_needed(); }
@@ -1050,6 +1117,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
 #ifdef SVDQ_ABLATE
     p.debug = a->reserved;
     p.clk = g_ablate_clk;
+    p.trace = g_ablate_trace;
 #endif
     p.workspace = (uint8_t *)a->workspace;
     p.workspace_bytes = a->workspace_bytes;

@@ -67,7 +67,7 @@ typedef const char *(*err_fn)(void);
 int main(int argc, char **argv) {
     std::string lib = "nunchaku_amd/csrc/libsvdq_amd.so";
     int M = 4096, K = 12288, N = 3072, R = 32, fuse = 0, iters = 20, warm = 1500, dtype = SVDQ_BF16, reserved = 0, use_ws = 1, split = 0;
-    bool zero = false;
+    bool zero = false, do_trace = false;
     double sustain = 0;
     std::vector<int> variants = {0};
     for (int i = 1; i < argc; i++) {
@@ -82,6 +82,7 @@ int main(int argc, char **argv) {
         else if (a == "--reserved") reserved = atoi(argv[++i]);
         else if (a == "--no-ws") use_ws = 0;
         else if (a == "--zero") zero = true;
+        else if (a == "--trace") do_trace = true;
         else if (a == "--split") split = atoi(argv[++i]);
         else if (a == "--sustain") sustain = atof(argv[++i]);
         else if (a == "--variants") { variants.clear(); char *s = argv[++i]; for (char *t = strtok(s, ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
@@ -92,6 +93,7 @@ int main(int argc, char **argv) {
     gemm_fn gemm = (gemm_fn)dlsym(h, "svdq_gemm_w4a4");
     wsb_fn wsb = (wsb_fn)dlsym(h, "svdq_gemm_workspace_bytes");
     clk_fn set_clk = (clk_fn)dlsym(h, "svdq_ablate_set_clk");
+    clk_fn set_trace = (clk_fn)dlsym(h, "svdq_ablate_set_trace");
     err_fn last_error = (err_fn)dlsym(h, "svdq_last_error");
     if (!gemm || !wsb || !last_error) { fprintf(stderr, "missing symbols in %s\n", lib.c_str()); return 1; }
 
@@ -161,6 +163,20 @@ int main(int argc, char **argv) {
                 double sc = 0, st_ = 0; int n = 0;
                 for (int i = 0; i < 512; i++) if (hc[2 * i + 1] > 0) { sc += hc[2 * i]; st_ += hc[2 * i + 1]; n++; }
                 if (n) { cyc = sc / n; eff_ghz = sc / (st_ * 10.0); } // ticks are 10 ns
+            }
+            if (set_trace && do_trace) { // per-segment phase stamps of workgroup 0
+                long long *tr; CK(hipMalloc((void **)&tr, 96 * sizeof(long long))); CK(hipMemset(tr, 0, 96 * sizeof(long long)));
+                set_trace(tr);
+                gemm(&a, st);
+                CK(hipStreamSynchronize(st));
+                set_trace(nullptr);
+                long long ht[96];
+                CK(hipMemcpy(ht, tr, sizeof(ht), hipMemcpyDeviceToHost));
+                printf("{\"trace_variant\":%d,\"segments\":[", v);
+                for (int i = 0; i < 32 && ht[3 * i + 2] > 0; i++)
+                    printf("%s[%lld,%lld,%lld]", i ? "," : "", ht[3 * i], ht[3 * i + 1], ht[3 * i + 2]);
+                printf("]}\n");
+                CK(hipFree(tr));
             }
             printf("{\"M\":%d,\"K\":%d,\"N\":%d,\"R\":%d,\"fuse\":%d,\"variant\":%d,\"reserved\":%d,\"zero\":%d,\"ws\":%d,\"split\":%d,\"us\":%.2f,\"TOPS\":%.1f,"
                    "\"wg_cycles\":%.0f,\"eff_GHz\":%.3f}\n", M, K, N, R, fuse, v, reserved, (int)zero, use_ws, split, us, ops / us * 1e-6, cyc, eff_ghz);

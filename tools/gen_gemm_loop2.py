@@ -52,6 +52,7 @@ S_RING, S_NPRE, S_NCNT, S_LANDED = 58, 59, 60, 68
 S_NA, S_NX1, S_NX2 = 62, 64, 66
 SRD_A, SRD_X1, SRD_X2 = 72, 76, 80
 S_KOFF, S_KOFF2, S_DSTEP, S_STG = 84, 85, 86, 87
+S_PHASE = 52  # in ("dph" builds): 1 for waves 4..7
 
 
 def vr(a, n=1):
@@ -150,18 +151,43 @@ class Gen:
         ]
 
     # ---- one K-step body for ring stage j --------------------------------------------------
-    def kstep(self, j, exit_label, ool):
+    def kstep(self, j, exit_label, ool, phase=0):
+        """K-step body for ring stage j.  phase 0: the wave issues its DMAs right behind the K-step barrier (tile-group 4).
+        phase 1 ("dph" option, waves 4..7): it issues them four tile-groups later, at the top of the NEXT K-step body, so
+        that the two waves of a SIMD are never both busy with their DMA bursts; returns the label to enter this body at
+        (phase 1: behind the deferred-issue block, which the first K-step of a segment must skip)."""
         e = self.e
         nj = (j + 1) % NSTAGE
+        pj = (j - 1) % NSTAGE
         reads_g1 = self.frag_reads(1, 1, j)
         reads_n0 = self.frag_reads(0, 0, nj)
+        if phase == 1:
+            # DMA of K-step step+3 (deferred from the previous body) into the stage K-step step-1 just vacated
+            Lskip, Lsw, Lbsw = (self.new_label(x) for x in ("dskip", "dsw", "dbsw"))
+            e(f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_TOT4)}")
+            e(f"s_cbranch_scc0 {Lskip}")
+            e(f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}")
+            e(f"s_cbranch_scc1 {Lsw}")
+            e(f"{Lbsw}:")
+            for ln in self.dma_issue(pj * STAGE):
+                e(ln)
+            e(f"{Lskip}:")
+            ool += [f"{Lsw}:"] + self.switch_segment() + [f"s_branch {Lbsw}"]
+        Lin = self.new_label(f"in{phase}st{j}_")
+        e(f"{Lin}:")
         for q in range(8):
             t = q & 3
             pb = q & 1
             qn = q + 1
             nbuf, nt = (qn >> 2) & 1, qn & 3
+            # LDS returns in order.  The 12 fragment / scale reads of a group are W0 W0 W1 W1 | A0 A0 A1 A1 | sw0 sw1 sa0 sa1;
+            # each MFMA waits only for the reads it consumes (lgkmcnt = reads allowed to remain outstanding):
+            #   P(tile 0) needs reads 1..6, S(tile 0) 1..11, P(tile 1) 1..8, S(tile 1) all 12 (+4 newer ones issued since)
+            fine = "lgkf" in self.opts  # opt-in: measured 1.4 % SLOWER than the two plain lgkmcnt(0) waits (same box A/B)
             if q in (3, 7):
-                e("s_waitcnt lgkmcnt(0)")
+                e("s_waitcnt lgkmcnt(6)" if fine else "s_waitcnt lgkmcnt(0)")
+            elif q in (0, 4) and fine:
+                e("s_waitcnt lgkmcnt(4)")
             e(self.p_mfma(pb ^ 1, nbuf, nt))
             misc = []
             if q < 3:
@@ -169,18 +195,19 @@ class Gen:
             elif q == 4:
                 Ltail, Lback, Lsw, Lbsw = (self.new_label(x) for x in ("tail", "back", "sw", "bsw"))
                 misc = [
-                    # this K-step issues the DMA of K-step step+4 iff it exists (this segment or the next one)
+                    # in-line path iff the wave's youngest 10 DMAs are exactly those of K-steps step+2, step+3
+                    # (phase 0: iff it issues K-step step+4 now; phase 1: iff K-step step+3 has been issued)
                     f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_TOT4)}",
                     f"s_cbranch_scc0 {Ltail}",
                     # my 5 DMAs of K-step step+1 have landed: the 10 younger ones (step+2, step+3) may stay in flight
                     f"s_waitcnt vmcnt({2 * DMA_PER_STEP})",
                     "s_barrier",
-                    f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}",
-                    f"s_cbranch_scc1 {Lsw}",
-                    f"{Lbsw}:",
-                ] + self.dma_issue(j * STAGE) + [f"{Lback}:"] + reads_n0[0:4]
-                ool += [f"{Ltail}:", "s_waitcnt vmcnt(0)", "s_barrier", f"s_branch {Lback}",
-                        f"{Lsw}:"] + self.switch_segment() + [f"s_branch {Lbsw}"]
+                ]
+                if phase == 0:
+                    misc += [f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}", f"s_cbranch_scc1 {Lsw}", f"{Lbsw}:"] + self.dma_issue(j * STAGE)
+                    ool += [f"{Lsw}:"] + self.switch_segment() + [f"s_branch {Lbsw}"]
+                misc += [f"{Lback}:"] + reads_n0[0:4]
+                ool += [f"{Ltail}:", "s_waitcnt vmcnt(0)", "s_barrier", f"s_branch {Lback}"]
             elif q in (5, 6):
                 misc = reads_n0[4 * (q - 4):4 * (q - 4) + 4]
             elif q == 7:
@@ -189,11 +216,23 @@ class Gen:
                 e(ln)
             for ln in self.fma(t, pb, 0, 8):
                 e(ln)
+            if fine and q in (3, 7):
+                e("s_waitcnt lgkmcnt(1)")
+            elif fine and q in (0, 4):
+                e("s_waitcnt lgkmcnt(4)")
             e(self.s_mfma(pb ^ 1, nbuf, nt))
             for ln in self.fma(t, pb, 8, 16):
                 e(ln)
         e(f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_KP)}")
-        e(f"s_cbranch_scc0 {exit_label}")
+        if phase == 0:
+            e(f"s_cbranch_scc0 {exit_label}")
+        else:
+            # leaving the segment: the deferred DMA (K-step step+3, the next segment's) is issued here, into this stage
+            Lstub = self.new_label("xstub")
+            e(f"s_cbranch_scc0 {Lstub}")
+            ool += [f"{Lstub}:", f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_TOT4)}", f"s_cbranch_scc0 {exit_label}"] + \
+                self.dma_issue(j * STAGE) + [f"s_branch {exit_label}"]
+        return Lin
 
     # ---- the whole asm block ---------------------------------------------------------------
     def build(self):
@@ -212,9 +251,13 @@ class Gen:
         e(f"s_mov_b32 {sr(S_STEP)}, 0")
         e(f"s_add_u32 {sr(S_TOT)}, {sr(S_KP)}, {sr(S_NCNT)}")
         # thresholds on `step`: DMA of K-step step+4 exists iff step < tot-4; it is the next segment's first iff step == kp-4
-        e(f"s_sub_u32 {sr(S_TOT4)}, {sr(S_TOT)}, {NSTAGE}")
+        if "dph" in self.opts:  # phase-1 waves run their DMA stream one K-step later: thresholds tot-3 / kp-3
+            e(f"s_sub_u32 {sr(S_TMP)}, {NSTAGE}, {sr(S_PHASE)}")
+        else:
+            e(f"s_mov_b32 {sr(S_TMP)}, {NSTAGE}")
+        e(f"s_sub_u32 {sr(S_TOT4)}, {sr(S_TOT)}, {sr(S_TMP)}")
         e(f"s_cselect_b32 {sr(S_TOT4)}, 0, {sr(S_TOT4)}")          # borrow (tot < 4): never
-        e(f"s_sub_u32 {sr(S_KP4)}, {sr(S_KP)}, {NSTAGE}")
+        e(f"s_sub_u32 {sr(S_KP4)}, {sr(S_KP)}, {sr(S_TMP)}")
         e(f"s_cselect_b32 {sr(S_KP4)}, -1, {sr(S_KP4)}")            # kp < 4: the prologue below has switched already
         # DMA cursor: K-step `npre` of this segment
         e(f"s_mov_b32 {sr(S_DSTEP)}, {sr(S_NPRE)}")
@@ -256,9 +299,9 @@ class Gen:
         for j in range(1, NSTAGE):
             e(f"s_cmp_eq_u32 {sr(S_RING)}, {j * STAGE}")
             e(f"s_cbranch_scc1 {entry[j]}")
-        body = [self.new_label(f"st{j}_") for j in range(NSTAGE)]
+        nph = 2 if "dph" in self.opts else 1
+        body_in = [[self.new_label(f"b{ph}in{j}_") for j in range(NSTAGE)] for ph in range(nph)]
         Lexit = self.new_label("exit")
-        ool = []
         # per entry: first fragments + the first tile-group's MFMAs from that stage, then into the ring
         for j in range(NSTAGE):
             e(f"{entry[j]}:")
@@ -268,15 +311,21 @@ class Gen:
             e(self.p_mfma(0, 0, 0))
             e(self.s_mfma(0, 0, 0))
             e("s_nop 7")
-            e(f"s_branch {body[j]}")
-        return body, Lexit, ool
-
-    def finish(self, body, Lexit, ool):
-        e = self.e
-        for j in range(NSTAGE):
-            e(f"{body[j]}:")
-            self.kstep(j, Lexit, ool)
-        e(f"s_branch {body[0]}")
+            if nph == 2:
+                e(f"s_cmp_eq_u32 {sr(S_PHASE)}, 1")
+                e(f"s_cbranch_scc1 {body_in[1][j]}")
+            e(f"s_branch {body_in[0][j]}")
+        ool = []
+        for ph in range(nph):
+            top = self.new_label(f"top{ph}_")
+            e(f"{top}:")
+            for j in range(NSTAGE):
+                # the body's own entry label sits behind a phase-1 body's deferred-issue block: alias it
+                start = len(self.lines)
+                lin = self.kstep(j, Lexit, ool, ph)
+                self.lines = [ln.replace(lin, body_in[ph][j]) for ln in self.lines[:start]] + \
+                             [ln.replace(lin, body_in[ph][j]) for ln in self.lines[start:]]
+            e(f"s_branch {top}")
         for ln in ool:
             e(ln)
         e(f"{Lexit}:")
@@ -291,8 +340,7 @@ class Gen:
 
 def emit(path, smfma, opts=""):
     g = Gen(smfma, opts)
-    body, Lexit, ool = g.build()
-    lines = g.finish(body, Lexit, ool)
+    lines = g.build()
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_loop2.py -- do not edit.\n")
         for ln in lines:
@@ -302,6 +350,7 @@ def emit(path, smfma, opts=""):
 
 if __name__ == "__main__":
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nunchaku_amd", "csrc")
-    n = emit(os.path.join(root, "gemm_loop2_bf16.inc"), "v_mfma_f32_32x32x16_bf16")
-    emit(os.path.join(root, "gemm_loop2_fp16.inc"), "v_mfma_f32_32x32x16_f16")
+    opts = os.environ.get("SVDQ_GEN2_OPTS", "")
+    n = emit(os.path.join(root, "gemm_loop2_bf16.inc"), "v_mfma_f32_32x32x16_bf16", opts)
+    emit(os.path.join(root, "gemm_loop2_fp16.inc"), "v_mfma_f32_32x32x16_f16", opts)
     print(f"wrote gemm_loop2_{{bf16,fp16}}.inc ({n} lines each)")
