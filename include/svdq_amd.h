@@ -237,7 +237,7 @@ int svdq_attention(const svdq_attention_args *args, void *stream);
 /* ------------------------------------------------------------------------------------------
  * Gated residual + LayerNorm statistics (extension; the element-wise glue between the operators of a block,
  * transformer_flux_v2.py:118-342):
- *   t = b ? round16(a + b) : a;      if (gate) t = round16(gate[c] * t);      y = a ? round16(res + t) : res;
+ *   t = b ? round16(a + b) : a;      if (gate) t = round16(gate[c] * t);      y = a ? round16(res + t) : res;   [fp16: optional clip]
  *   out[m, :] = y (if out);          stats[m] = (mean(y), 1/sqrt(var(y) + eps)) over the 16-bit values (if stats)
  * i.e. the reference's 16-bit torch ops `residual + gate.unsqueeze(1) * (attn [+ mlp])`
  * (transformer_flux_v2.py:230-251,332-335) with the statistics the next LayerNorm needs produced in the same pass.  out may alias res.  C must be a multiple of 8 with ceil(C/512) in {1..8, 12, 16, 24, 32}.
@@ -252,7 +252,9 @@ typedef struct svdq_residual_args {
     int32_t M, C, ld;  /* ld: common row stride of res / a / b / out in elements */
     int32_t dtype;
     float eps;
-    int32_t reserved;
+    int32_t clamp_fp16; /* SVDQ_FP16 only: bit 0 (first problem) / bit 1 (second problem) set: y is clipped to +-65504 before
+                           the store and the statistics -- the reference's fp16 blocks clip the text stream after a joint
+                           block and the hidden state after a single block (transformer_flux_v2.py:254-255, 339-340) */
     /* optional: zero-fill an unrelated scratch buffer in the same pass (the fp32 low-rank accumulators of the
      * quantiser / GELU_QUANT calls that follow: saves their memset launches).  zero_bytes must be a multiple of 16. */
     void *zero_ptr;

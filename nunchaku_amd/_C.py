@@ -61,6 +61,80 @@ def release_workspaces() -> None:
     _workspaces.clear()
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Reference-shaped buffers and reference-layout parameters (drop-in for the reference's UNCHANGED Python callers)
+#
+# The reference's ops/quantize.py, ops/fused.py and models/linear.py allocate the opaque activation-code buffers as
+# [M_pad, K/2] bytes and hand over parameters in the checkpoint (NVIDIA fragment) layout.  This library's images are
+# [M_pad, 3K/4] (FP6) and its parameters are re-laid out once.  So that those callers run UNCHANGED against this module:
+#   * a code buffer of the reference size gets the real FP6 image ATTACHED to the tensor object (`_svdq_fp6`): callers
+#     only ever pass the buffer on to gemm_w4a4, which finds the image there; the bytes of the small buffer stay unused;
+#   * a weight-side tensor that does not carry the `_svdq_amd` mark (set by SVDQW4A4Linear.repack_() on its Parameters) is
+#     taken to be in the checkpoint layout and converted on first use; the converted copy is cached on the tensor object
+#     and reused until the tensor is modified in place or reallocated.
+# The fast path of this package (nunchaku_amd.models / nunchaku_amd.ops) allocates FP6-sized buffers and repacks its
+# parameters in place: neither mechanism is touched there.
+# ----------------------------------------------------------------------------------------------------------------------
+def _fp6_image(buf: torch.Tensor, rows: int, K: int, create: bool, what: str) -> torch.Tensor:
+    """The FP6 operand image behind the opaque code buffer ``buf`` ([rows, 3K/4]: itself; [rows, K/2]: attached)."""
+    if buf.shape[-1] * 4 == K * 3:
+        return buf
+    if buf.shape[-1] * 2 != K:
+        raise ValueError(f"{what}: the code buffer must be [M_pad, 3K/4] bytes (this library's FP6 image) or the reference's [M_pad, K/2]")
+    img = getattr(buf, "_svdq_fp6", None)
+    if img is None or tuple(img.shape) != (rows, K * 3 // 4) or img.device != buf.device:
+        if not create:
+            raise ValueError(f"{what}: this reference-sized code buffer was not produced by quantize_w4a4_act_fuse_lora / "
+                             "gemm_w4a4 of this library (its FP6 image is attached to the tensor OBJECT: pass the same object on)")
+        img = torch.empty(rows, K * 3 // 4, dtype=torch.uint8, device=buf.device)
+        buf._svdq_fp6 = img
+    return img
+
+
+def mark_amd(t: torch.Tensor | None) -> torch.Tensor | None:
+    """Declare ``t`` to hold this library's kernel layout (no conversion on use)."""
+    if t is not None:
+        t._svdq_amd = True
+    return t
+
+
+def _param(t: torch.Tensor | None, kind: str):
+    """A weight-side tensor in the kernel layout: ``t`` itself when marked, else its cached conversion from the checkpoint
+    layout (kind: "vec" bias / smooth, "wscales", "up" / "down" low-rank factors)."""
+    if t is None or getattr(t, "_svdq_amd", False):
+        return t
+    key = (t._version, t.data_ptr(), tuple(t.shape))
+    cache = getattr(t, "_svdq_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    from . import layout
+
+    src = t.detach()
+    if kind == "vec":
+        conv = layout.repack_vec(src)
+    elif kind == "wscales":
+        conv = layout.repack_wscales(src)
+    else:
+        conv = layout.repack_lowrank(src, down=(kind == "down"))
+    t._svdq_cache = (key, conv)
+    return conv
+
+
+def _weight(wgt: torch.Tensor, K: int) -> torch.Tensor:
+    """qweight: [N, 3K/4] FP6 image (kernel layout) or the checkpoint's [N, K/2] int8 (converted once, cached on the tensor)."""
+    if wgt.shape[-1] * 4 == K * 3:
+        return wgt
+    key = (wgt._version, wgt.data_ptr(), tuple(wgt.shape))
+    cache = getattr(wgt, "_svdq_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    from . import layout
+
+    conv = layout.repack_qweight(wgt.detach().view(torch.int8))
+    wgt._svdq_cache = (key, conv)
+    return conv
+
+
 class _Ops:
     # 0 = hand-scheduled main loop, 1 = its compiler-scheduled twin (bit-identical results; A/B debugging and tests).
     # A plain attribute, not an environment variable: nothing is read from os.environ on the launch path.
@@ -99,11 +173,13 @@ class _Ops:
         M, K = input.shape
         M_pad = output.numel() // output.shape[-1]
         R = 0 if lora_down is None else lora_down.shape[-1]
+        image = _fp6_image(output, M_pad, K, True, "quantize_w4a4_act_fuse_lora")
+        smooth, lora_down = _param(smooth, "vec"), _param(lora_down, "down")
         a = _lib.QuantizeArgs()
         a.x = input.data_ptr()
         a.smooth = _ptr(smooth)
         a.lora_down = _ptr(lora_down)
-        a.act = _ptr(output)
+        a.act = _ptr(image)
         a.ascales = _ptr(oscales)
         a.lora_act = _ptr(lora_act_out)
         a.M, a.M_pad, a.K, a.R = M, M_pad, K, R
@@ -125,14 +201,12 @@ class _Ops:
             if x2.stride(-1) != 1:
                 x2 = x2.contiguous()
             a.x2, a.M2, a.ldx2, a.split_rows = x2.data_ptr(), x2.shape[0], x2.stride(0), M
-            a.smooth2, a.lora_down2 = _ptr(second.get("smooth")), _ptr(second.get("lora_down"))
+            sm2, ld2 = _param(second.get("smooth"), "vec"), _param(second.get("lora_down"), "down")
+            a.smooth2, a.lora_down2 = _ptr(sm2), _ptr(ld2)
             a.ln_stats2, a.mod_scale2, a.mod_shift2 = _ptr(second.get("ln_stats")), _ptr(second.get("mod_scale")), _ptr(second.get("mod_shift"))
-            keep2 = (x2, second)
-        if output.shape[-1] * 4 != K * 3 or oscales.numel() != (K // 64) * M_pad:
-            raise ValueError(
-                "quantize_w4a4_act_fuse_lora: output must be the [M_pad, 3K/4] byte FP6 operand image of this "
-                "library (nunchaku_amd.layout.act_image_shape) and oscales must hold (K/64)*M_pad scales"
-            )
+            keep2 = (x2, second, sm2, ld2)
+        if oscales.numel() != (K // 64) * M_pad:
+            raise ValueError("quantize_w4a4_act_fuse_lora: oscales must hold (K/64)*M_pad scales")
         if R and lora_act_out.numel() != M_pad * R:
             raise ValueError("quantize_w4a4_act_fuse_lora: lora_act_out must hold M_pad*R floats")
         _lib.check(lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), _stream()), "quantize_w4a4_act_fuse_lora")
@@ -162,11 +236,18 @@ class _Ops:
             raise ValueError("gemm_w4a4: alpha must be 1.0 for int4 (launch_impl.cuh:107)")
         if out_linearattn is not None or out_vk is not None:
             raise NotImplementedError("gemm_w4a4: the SANA LiteLA epilogue is out of scope")
+        packed_qkv = None
         if out_q is not None or out_k is not None or out_v is not None:
-            raise NotImplementedError(
-                "gemm_w4a4: the reference's packed out_q/out_k/out_v tile order is NVIDIA-fragment specific; "
-                "pass out_vt= and use ops.attention on the [tokens, 3*H*128] output instead"
-            )
+            # the reference's "nunchaku-fp16" attention path (attention_processors/flux.py:114-237): Q / K / V go to three
+            # opaque [B, H, T_pad, 128] buffers that only ops.attention_fp16 reads.  Adapter: the GEMM runs into a scratch
+            # [M, N] tensor and the thirds are scattered head-major into the caller's (strided) views below.
+            if out_q is None or out_k is None or out_v is None or out is not None:
+                raise ValueError("gemm_w4a4: out_q, out_k and out_v go together (and without out)")
+            for t in (out_q, out_k, out_v):
+                if t.dim() != 4 or t.shape[0] != 1 or t.shape[-1] != 128 or t.stride(-1) != 1 or t.shape != out_q.shape:
+                    raise NotImplementedError("gemm_w4a4: out_q / out_k / out_v must be [1, H, T_pad, 128] views (batch 1, head_dim 128)")
+            packed_qkv = (out_q, out_k, out_v, int(attn_tokens))
+            out = torch.empty(int(attn_tokens) if attn_tokens else out_q.shape[2], 3 * out_q.shape[1] * 128, dtype=out_q.dtype, device=out_q.device)
         if act is None or wgt is None or ascales is None or wscales is None:
             raise ValueError("gemm_w4a4: act, wgt, ascales and wscales are required")
         if ascales.dtype not in _DT:
@@ -174,15 +255,19 @@ class _Ops:
 
         a = _lib.GemmArgs()
         M_pad = act.numel() // act.shape[-1]
-        K = act.shape[-1] * 4 // 3  # FP6 operand image: 6 bits per code
+        K = ascales.numel() // M_pad * 64  # (the code buffer may be reference-sized: K comes from the scale image)
         N = wgt.shape[0]
-        if wgt.shape[-1] * 4 != K * 3 or act.shape[-1] * 4 != K * 3:
-            raise ValueError("gemm_w4a4: act and wgt must be [rows, 3K/4]-byte FP6 operand images with the same K")
-        a.act, a.wgt, a.ascales, a.wscales = _ptr(act), _ptr(wgt), _ptr(ascales), _ptr(wscales)
+        if wgt.shape[-1] * 4 != K * 3 and wgt.shape[-1] * 2 != K:
+            raise ValueError("gemm_w4a4: wgt must be the [N, 3K/4]-byte FP6 operand image or the checkpoint's [N, K/2] with the K of act")
+        act_img = _fp6_image(act, M_pad, K, False, "gemm_w4a4 (act)")
+        wgt_img = _weight(wgt, K)
+        wscales, bias = _param(wscales, "wscales"), _param(bias, "vec")
+        a.act, a.wgt, a.ascales, a.wscales = _ptr(act_img), _ptr(wgt_img), _ptr(ascales), _ptr(wscales)
         a.bias = _ptr(bias)
         R = 0
         if lora_up is not None and lora_up.numel() > 0:
             R = lora_up.shape[-1]
+            lora_up = _param(lora_up, "up")
             a.lora_up, a.lora_act_in = _ptr(lora_up), _ptr(lora_act_in)
         keep = None
         if lora_scales is not None and R:
@@ -199,9 +284,12 @@ class _Ops:
 
         if qout is not None and oscales is not None:
             a.fuse = _lib.FUSE_GELU_QUANT
-            a.qout, a.oscales, a.next_smooth = _ptr(qout), _ptr(oscales), _ptr(smooth_factor)
+            qout_img = _fp6_image(qout, M_pad, N, True, "gemm_w4a4 (qout)")
+            smooth_factor = _param(smooth_factor, "vec")
+            a.qout, a.oscales, a.next_smooth = _ptr(qout_img), _ptr(oscales), _ptr(smooth_factor)
             if lora_down is not None and lora_down.numel() > 0:
                 a.R2 = lora_down.shape[-1]
+                lora_down = _param(lora_down, "down")
                 a.next_lora_down, a.lora_act_out = _ptr(lora_down), _ptr(lora_act_out)
                 if not lora_act_zeroed:  # extension: the caller cleared it already (residual_gate_stats(..., zero=))
                     lora_act_out.zero_()  # launch_impl.cuh:252
@@ -232,24 +320,38 @@ class _Ops:
                 raise ValueError("gemm_w4a4: out rows must satisfy M <= M_pad < M + 256 (launch_impl.cuh:55)")
         keep2 = None
         if second is not None:
-            g = lambda k: _ptr(second.get(k))
             if second.get("wgt") is None or tuple(second["wgt"].shape) != tuple(wgt.shape):
                 raise ValueError("gemm_w4a4: second['wgt'] must have the shape of wgt")
+            conv = {"wgt": _weight(second["wgt"], K), "wscales": _param(second.get("wscales"), "wscales"),
+                    "bias": _param(second.get("bias"), "vec"), "lora_up": _param(second.get("lora_up"), "up"),
+                    "smooth_factor": _param(second.get("smooth_factor"), "vec"), "lora_down": _param(second.get("lora_down"), "down"),
+                    "norm_q": second.get("norm_q"), "norm_k": second.get("norm_k")}
+            g = lambda k: _ptr(conv.get(k))
             a.wgt2, a.wscales2, a.bias2 = g("wgt"), g("wscales"), g("bias")
             a.lora_up2 = g("lora_up") if R else None
             a.next_smooth2, a.norm_q2, a.norm_k2 = g("smooth_factor"), g("norm_q"), g("norm_k")
             a.next_lora_down2 = g("lora_down") if a.R2 else None
             a.split_rows = int(split_rows)
-            keep2 = second  # keeps the tensors alive until the launch has been issued
+            keep2 = (second, conv)  # keeps the tensors alive until the launch has been issued
         if out_vt is not None and a.fuse != _lib.FUSE_RMSNORM_ROPE:
             raise ValueError("gemm_w4a4: out_vt needs the RMSNorm+RoPE epilogue (rotary_emb, norm_q, norm_k)")
         if out_vt is not None and out_vt.shape[1] < a.M:
             raise ValueError("gemm_w4a4: out_vt has fewer columns than out has rows")
         _lib.check(lib.svdq_gemm_w4a4(C.byref(a), _stream()), "gemm_w4a4")
         del keep, keep2
+        if packed_qkv is not None:
+            oq, ok, ov, tokens = packed_qkv
+            H, M = oq.shape[1], out.shape[0]
+            if tokens and tokens != M:
+                raise ValueError("gemm_w4a4: attn_tokens must equal the number of rows of the projection")
+            if M != oq.shape[2]:
+                # the reference masks the padded key rows inside its attention kernel; this library's kernel has no mask
+                raise NotImplementedError("gemm_w4a4: packed Q/K/V need a token count that is a multiple of the pad size (no padded rows)")
+            for dst, third in zip((oq, ok, ov), out.view(M, 3, H, 128).unbind(1)):
+                dst[0].copy_(third.transpose(0, 1))  # [H, T, 128] head-major, the layout ops.attention_fp16 reads
 
     @staticmethod
-    def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6, zero=None, second=None):
+    def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6, zero=None, second=None, clamp_fp16=0):
         """Extension: ``out = res + gate * (a [+ b])`` (16-bit torch-op rounding of a block's gated residual)
         and/or the LayerNorm statistics ``stats[m] = (mean, rstd)`` of the result, in one pass.  2-D row-major
         views with a common row stride; ``a`` None = statistics of ``res`` itself; ``out`` may be ``res``."""
@@ -271,6 +373,7 @@ class _Ops:
         dp = lambda t: None if t is None else t.data_ptr()
         args.res, args.a, args.b, args.gate, args.out, args.stats = dp(res), dp(a), dp(b), dp(gate), dp(out), dp(stats)
         args.M, args.C, args.ld, args.dtype, args.eps = M, Cc, res.stride(0), _DT[res.dtype], float(eps)
+        args.clamp_fp16 = int(clamp_fp16)  # bit 0 / bit 1: clip the first / second problem's result to +-65504 (fp16 only)
         if zero is not None:  # scratch cleared in the same pass (fp32 low-rank accumulators of the calls that follow)
             if not zero.is_cuda or not zero.is_contiguous() or (zero.numel() * zero.element_size()) % 16:
                 raise ValueError("residual_gate_stats: zero must be a contiguous GPU tensor of a multiple of 16 bytes")
@@ -345,6 +448,21 @@ class _Ops:
             n = min(80, len(layers) - s0)
             _lib.check(lib.svdq_gemv_awq_batched(C.cast(C.byref(arr[s0]), C.POINTER(_lib.GemvAwqArgs)), n, _stream()), "gemv_awq_batched")
         return outs
+
+    @staticmethod
+    def attention_fp16(q, k, v, o, scale):
+        """reference: csrc/ops.h:114-121 -> kernels::attention_fp16 (attention.cu:11-94): ``q`` / ``k`` / ``v`` are the opaque
+        [1, H, T_pad, 128] buffers a ``gemm_w4a4(..., out_q, out_k, out_v, attn_tokens)`` call filled, ``o`` is the linear
+        [1, T_pad, H*128] output.  Non-causal, no mask.  (The reference kernel is fp16-only; this one takes bf16 too.)
+        V is needed key-contiguous by this library's kernel: one transposing copy (the fused path, ``out_vt``, has none)."""
+        for name, t in (("q", q), ("k", k), ("v", v)):
+            if t.dim() != 4 or t.shape[0] != 1 or t.shape[-1] != 128 or t.stride(-1) != 1:
+                raise NotImplementedError(f"attention_fp16: {name} must be [1, H, T_pad, 128] (batch 1, head_dim 128)")
+        H, T = q.shape[1], q.shape[2]
+        if tuple(o.shape) != (1, T, H * 128) or not o.is_contiguous():
+            raise ValueError("attention_fp16: o must be a contiguous [1, T_pad, H*128] tensor")
+        vt = v[0].transpose(1, 2).contiguous()  # [H, 128, T]
+        _Ops.attention(q[0].transpose(0, 1), k[0].transpose(0, 1), vt, o[0].view(T, H, 128), scale)
 
     @staticmethod
     def attention(q, k, vt, out, scale, zero=None, quant=None):

@@ -32,7 +32,7 @@ class ResidualArgs(C.Structure):
     _fields_ = [
         ("res", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p), ("gate", C.c_void_p), ("out", C.c_void_p),
         ("stats", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("ld", C.c_int32), ("dtype", C.c_int32),
-        ("eps", C.c_float), ("reserved", C.c_int32), ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_int64),
+        ("eps", C.c_float), ("clamp_fp16", C.c_int32), ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_int64),
         ("res2", C.c_void_p), ("a2", C.c_void_p), ("b2", C.c_void_p), ("gate2", C.c_void_p), ("out2", C.c_void_p),
         ("stats2", C.c_void_p), ("M2", C.c_int32), ("reserved2", C.c_int32),
     ]

@@ -267,12 +267,19 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
 #else
     constexpr int occ_env = 0;
 #endif
-#define SVDQ_LAUNCH_Q(RT)                                                                                            \
+#ifdef SVDQ_ABLATE
+#define SVDQ_LAUNCH_Q_OCC4(RT)                                                                                       \
     if (RT <= 2 && occ_env == 4)                                                                                     \
     hipLaunchKernelGGL((quantize_kernel<DT, RT, (RT <= 2 ? 4 : 1)>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth, \
                        (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
                        a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift, s2);          \
-    else                                                                                                             \
+    else
+#else
+#define SVDQ_LAUNCH_Q_OCC4(RT)
+    (void)occ_env;
+#endif
+#define SVDQ_LAUNCH_Q(RT)                                                                                            \
+    SVDQ_LAUNCH_Q_OCC4(RT)                                                                                           \
     hipLaunchKernelGGL((quantize_kernel<DT, RT, 1>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,          \
                        (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
                        a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift, s2)
@@ -282,6 +289,7 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     else if (rt32 <= 4) SVDQ_LAUNCH_Q(4);
     else SVDQ_LAUNCH_Q(8);
 #undef SVDQ_LAUNCH_Q
+#undef SVDQ_LAUNCH_Q_OCC4
     return hip_check(hipGetLastError(), "svdq_quantize_w4a4_act_fuse_lora launch");
 }
 

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint16_t *__restric
                                                         float eps, v4i *__restrict__ zero_ptr, long long zero_vec,
                                                         const uint16_t *__restrict__ res2, const uint16_t *__restrict__ a2,
                                                         const uint16_t *__restrict__ b2, const uint16_t *__restrict__ gate2,
-                                                        uint16_t *__restrict__ out2, float *__restrict__ stats2, int M2) {
+                                                        uint16_t *__restrict__ out2, float *__restrict__ stats2, int M2, int clamp) {
     using T = typename Half<DT>::T;
     // side job: clear the scratch buffer, 16 bytes per thread, grid-strided (before any early return)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_vec; i += (long long)gridDim.x * 256) zero_ptr[i] = v4i{0, 0, 0, 0};
@@ -30,7 +30,11 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint16_t *__restric
         row -= M;
         if (!res2 || row >= M2) return;
         res = res2; a = a2; b = b2; gate = gate2; out = out2; stats = stats2;
+        clamp >>= 1;
     }
+    // fp16 only: y = clip(y, +-65504) like the reference's blocks (transformer_flux_v2.py:254-255, 339-340): an overflowed
+    // sum is stored as the largest finite value and the statistics see that value, not inf
+    const bool clip = DT == SVDQ_FP16 && (clamp & 1);
     const size_t base = (size_t)row * ld;
     float y[NV][8];
     float sum = 0.f;
@@ -54,6 +58,7 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint16_t *__restric
                 if (b) t = round16<T>(t + h2f(hfrom<T>(bv[e])));
                 if (gate) t = round16<T>(h2f(hfrom<T>(gv[e])) * t);
                 y[v][e] = round16<T>(h2f(hfrom<T>(rv[e])) + t);
+                if (clip) y[v][e] = fminf(fmaxf(y[v][e], -65504.f), 65504.f);
             }
         } else {
 #pragma unroll
@@ -96,7 +101,7 @@ template <int DT> static int launch_residual(const svdq_residual_args *p, hipStr
                            (const uint16_t *)p->b, (const uint16_t *)p->gate, (uint16_t *)p->out, p->stats, p->M, p->C, p->ld,   \
                            p->eps, (v4i *)p->zero_ptr, (long long)(p->zero_ptr ? p->zero_bytes / 16 : 0),                          \
                            (const uint16_t *)p->res2, (const uint16_t *)p->a2, (const uint16_t *)p->b2, (const uint16_t *)p->gate2, \
-                           (uint16_t *)p->out2, p->stats2, p->M2);                                                                                           \
+                           (uint16_t *)p->out2, p->stats2, p->M2, p->clamp_fp16);                                                                                           \
         return 0;
     switch ((p->C + 511) / 512) {
         SVDQ_RES_CASE(1) SVDQ_RES_CASE(2) SVDQ_RES_CASE(3) SVDQ_RES_CASE(4) SVDQ_RES_CASE(5) SVDQ_RES_CASE(6) SVDQ_RES_CASE(7) SVDQ_RES_CASE(8)

@@ -70,6 +70,7 @@ class FluxAttentionAMD(nn.Module):
         self.norm_k = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=kw["torch_dtype"], device=kw["device"])
         self.to_out = SVDQW4A4Linear(dim, dim, **kw)
         self.joint = joint
+        self.added_kv_proj_dim = dim if joint else None  # the attribute the reference's processors test (flux.py:84,177)
         if joint:
             self.add_qkv_proj = SVDQW4A4Linear(dim, 3 * dim, **kw)
             self.norm_added_q = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=kw["torch_dtype"], device=kw["device"])
@@ -81,9 +82,9 @@ class FluxAttentionAMD(nn.Module):
     # models/attention_processors/flux.py:24-59).  "svdq" needs B == 1, head_dim 128, tokens % 128 == 0.
     attention_impl = "svdq"
     # True: the text and image stream's projections of a joint block share one GEMM launch each (svdq_gemm_args.wgt2)
-    grouped = not __import__("os").environ.get("SVDQ_NO_GROUPED")  # A/B knob
+    grouped = True  # plain class attribute (set False for A/B runs); nothing is read from the environment
     # True: the attention epilogue emits the output projection's quantised activation (svdq_attention_args.qact)
-    fused_out_quant = not __import__("os").environ.get("SVDQ_NO_ATTN_QUANT")  # A/B knob
+    fused_out_quant = True
 
     def _use_svdq(self, B, tokens):
         return self.attention_impl == "svdq" and B == 1 and self.head_dim == 128 and tokens % 128 == 0
@@ -195,6 +196,8 @@ class FluxJointBlockAMD(nn.Module):
             encoder_hidden = encoder_hidden + c_gate_msa[:, None] * ca
             n_e = self._ln_mod(encoder_hidden, c_scale_mlp, c_shift_mlp)
             encoder_hidden = encoder_hidden + c_gate_mlp[:, None] * self.ff_context(n_e)
+            if encoder_hidden.dtype == torch.float16:  # transformer_flux_v2.py: the fp16 joint block clips its text stream
+                encoder_hidden = encoder_hidden.clip(-65504, 65504)
             return encoder_hidden, hidden, None
         (h_stats, h_pool), (e_stats, e_pool) = stats  # pools: fp32 zeros for the low-rank accumulators of the next calls
         m_out, c_out = mods if mods is not None else (self.mod(temb_act), self.mod_context(temb_act))
@@ -212,7 +215,8 @@ class FluxJointBlockAMD(nn.Module):
             ffc, ff = fused_gelu_mlp_pair(encoder_hidden, self.ff_context.fc1, self.ff_context.fc2, hidden, self.ff.fc1, self.ff.fc2,
                                           ln_a=(e_stats, c_scale_mlp, c_shift_mlp, e_pool), ln_b=(h_stats, scale_mlp, shift_mlp))
             encoder_hidden, e_stats, hidden, h_stats, e_pool = residual_gate_stats_pair(
-                encoder_hidden, ffc, c_gate_mlp, hidden, ff, gate_mlp, zero_floats=(mp_e + mp_h) * (self.attn.to_qkv.rank + self.attn.to_out.rank))
+                encoder_hidden, ffc, c_gate_mlp, hidden, ff, gate_mlp, zero_floats=(mp_e + mp_h) * (self.attn.to_qkv.rank + self.attn.to_out.rank),
+                clamp_fp16_a=True)  # the reference clips the text stream at the end of an fp16 joint block
             return encoder_hidden, hidden, ((h_stats, None), (e_stats, e_pool))
         hidden, h_stats, h_pool = residual_gate_stats(hidden, a, gate_msa, zero_floats=mp_h * r_mlp)
         hidden, h_stats, h_pool = residual_gate_stats(hidden, self.ff(hidden, ln=(h_stats, scale_mlp, shift_mlp, h_pool)), gate_mlp,
@@ -220,7 +224,7 @@ class FluxJointBlockAMD(nn.Module):
         encoder_hidden, e_stats, e_pool = residual_gate_stats(encoder_hidden, ca, c_gate_msa, zero_floats=mp_e * r_mlp_c)
         encoder_hidden, e_stats, e_pool = residual_gate_stats(
             encoder_hidden, self.ff_context(encoder_hidden, ln=(e_stats, c_scale_mlp, c_shift_mlp, e_pool)), c_gate_mlp,
-            zero_floats=mp_e * self.attn.add_qkv_proj.rank)
+            zero_floats=mp_e * self.attn.add_qkv_proj.rank, clamp_fp16=True)
         return encoder_hidden, hidden, ((h_stats, h_pool), (e_stats, e_pool))
 
 
@@ -240,7 +244,10 @@ class FluxSingleBlockAMD(nn.Module):
             n = F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6) * scale[:, None] + shift[:, None]
             mlp = fused_gelu_mlp(n, self.mlp_fc1, self.mlp_fc2)
             att = self.attn(n, rotary=rotary)
-            return hidden + gate[:, None] * (att + mlp), None  # transformer_flux_v2.py:332-335
+            out = hidden + gate[:, None] * (att + mlp)  # transformer_flux_v2.py:332-335
+            if out.dtype == torch.float16:
+                out = out.clip(-65504, 65504)
+            return out, None
         shift, scale, gate = (mods if mods is not None else self.mod(temb_act)).view(3, -1)
         st, pool = stats
         ln = (st, scale, shift, pool)  # one LayerNorm + modulation, consumed by both projections' quantisers
@@ -250,7 +257,7 @@ class FluxSingleBlockAMD(nn.Module):
         att = self.attn(hidden, rotary=rotary, ln=ln, quantized=q_qkv)
         # hidden + gate * (att + mlp), the next block's statistics and its three low-rank accumulators, one pass
         hidden, st, pool = residual_gate_stats(hidden, att, gate, b=mlp, zero_floats=_pad256(hidden.shape[1]) * (
-            self.mlp_fc1.rank + self.mlp_fc2.rank + self.attn.to_qkv.rank + self.attn.to_out.rank))
+            self.mlp_fc1.rank + self.mlp_fc2.rank + self.attn.to_qkv.rank + self.attn.to_out.rank), clamp_fp16=True)
         return hidden, (st, pool)
 
 
@@ -260,6 +267,8 @@ class FluxTransformerAMD(nn.Module):
     # True: AdaLayerNormZero runs inside the quantisers and the gated residuals are one fused pass each
     # (svdq_quantize_args.ln_stats, svdq_residual_gate_stats); False: the reference's torch-op sequence.
     fused_norm = True
+    # True: all modulation GEMVs of a step in one batched launch before the first block
+    batched_mods = True
 
     def __init__(self, num_layers=19, num_single_layers=38, dim=3072, heads=24, in_channels=64,
                  joint_attention_dim=4096, pooled_projection_dim=768, rank=32, guidance_embeds=True,
@@ -280,6 +289,19 @@ class FluxTransformerAMD(nn.Module):
 
     def svdq_layers(self):
         return [m for m in self.modules() if isinstance(m, SVDQW4A4Linear)]
+
+    def set_attention_impl(self, impl: str, attn_func=None):
+        """reference: NunchakuFluxTransformer2dModel.set_attention_impl (transformer_flux.py:648-667).  ``"nunchaku-fp16"``:
+        the attention kernel of this library fed by the QKV epilogue (its role on MI355X; bf16 and fp16);
+        ``"flashattn2"``: ``torch.nn.functional.scaled_dot_product_attention``."""
+        table = {"nunchaku-fp16": "svdq", "svdq": "svdq", "flashattn2": "sdpa", "sdpa": "sdpa"}
+        if impl == "custom" or attn_func is not None:
+            raise NotImplementedError("set_attention_impl: custom attention functions are not supported")
+        if impl not in table:
+            raise ValueError(f"set_attention_impl: unknown implementation {impl!r}")
+        for m in self.modules():
+            if isinstance(m, FluxAttentionAMD):
+                m.attention_impl = table[impl]
 
     # runtime LoRA (reference: NunchakuFluxTransformer2dModel.update_lora_params / set_lora_strength,
     # transformer_flux.py:783-855): per-layer factors in logical layout widen the low-rank branch of that layer
@@ -354,10 +376,20 @@ class FluxTransformerAMD(nn.Module):
         timestep/guidance [1]; img_ids [T_img, 3]; txt_ids [T_txt, 3]  ->  [1, T_img, 64]
         (transformer_flux_v2.py:430-561; batch 1 -- the fused QKV epilogue takes one rotary table)."""
         dt = self.dtype_
+        if hidden_states.shape[0] > 1:
+            # The fused QKV epilogue takes ONE rotary table and the operand buffers of a launch belong to one sample
+            # (reference: rotary_emb.shape[0] * shape[1] == M assert, launch_impl.cuh:353; SURVEY.md section 8e): a batch
+            # is a loop over samples here -- the data-parallel unit of this library is the replica, not the batch axis.
+            def per(t, i):
+                return t[i:i + 1] if t is not None and t.dim() > 0 and t.shape[0] == hidden_states.shape[0] else t
+            return torch.cat([self.forward(hidden_states[i:i + 1], encoder_hidden_states[i:i + 1], pooled_projections[i:i + 1],
+                                           per(timestep, i), img_ids, txt_ids, per(guidance, i))
+                              for i in range(hidden_states.shape[0])], dim=0)
         hidden = self.x_embedder(hidden_states)
-        temb = self.time_embed(timestep_embedding(timestep * 1000).to(dt))
+        # diffusers casts timestep / guidance to the model dtype BEFORE the x1000 (transformer_flux.py: timestep.to(dtype) * 1000)
+        temb = self.time_embed(timestep_embedding(timestep.to(dt) * 1000).to(dt))
         if self.guidance_embed is not None:
-            temb = temb + self.guidance_embed(timestep_embedding(guidance * 1000).to(dt))
+            temb = temb + self.guidance_embed(timestep_embedding(guidance.to(dt) * 1000).to(dt))
         temb = temb + self.text_embed(pooled_projections)
         temb_act = F.silu(temb)
         enc = self.context_embedder(encoder_hidden_states)
@@ -372,7 +404,7 @@ class FluxTransformerAMD(nn.Module):
         stats = ((residual_gate_stats(hidden)[1], None), (residual_gate_stats(enc)[1], None)) if fused else None
         # every modulation projection depends on the timestep embedding only: one batched GEMV launch for the whole step
         mods = awq_gemv_w4a16_batched(temb_act, [m for b in self.blocks for m in (b.mod, b.mod_context)] +
-                                      [b.mod for b in self.single_blocks]) if fused and not __import__("os").environ.get("SVDQ_NO_BATCHED_MODS") else None
+                                      [b.mod for b in self.single_blocks]) if fused and self.batched_mods else None
         nj = len(self.blocks)
         for i, blk in enumerate(self.blocks):
             enc, hidden, stats = blk(hidden, enc, temb_act, (rot_img, rot_txt, rot_all), stats,

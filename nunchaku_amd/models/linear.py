@@ -6,7 +6,8 @@ fragment order; ``repack_()`` converts them ONCE (same ``nn.Parameter`` objects)
 operand images the HIP kernels read: ``qweight`` becomes the [out, 3*in/4]-byte FP6 (e2m3) register
 image of v_mfma_scale_f32_32x32x64_f8f6f4 (a 4-bit code is exactly an FP6 value), the other tensors
 are permuted in place.  It runs lazily before the first kernel call and again after every
-``load_state_dict`` (a pre-hook restores the checkpoint shape of ``qweight`` first).
+``load_state_dict``, PER TENSOR: only the tensors a (possibly partial) state dict actually brought are
+converted again; ``state_dict()`` of a repacked layer raises (it would not be a checkpoint).
 """
 
 from __future__ import annotations
@@ -70,40 +71,86 @@ class SVDQW4A4Linear(nn.Module):
         self.lora_scales: list[float] | None = None
         self._base_lowrank = None
 
-        # False while the parameters hold the reference (checkpoint) layout
-        self._amd_layout = False
-        self._register_load_state_dict_pre_hook(self._restore_checkpoint_shapes, with_module=True)
-        self.register_load_state_dict_post_hook(self._mark_reference_layout)
+        # names of the parameters that currently hold the MI355X kernel layout (empty: everything is in the reference /
+        # checkpoint layout).  Tracked per tensor: a partial load_state_dict (strict=False, only the 16-bit tensors, ...)
+        # brings SOME tensors back in checkpoint layout and must not touch the others.
+        self._amd_names: set[str] = set()
+        self._incoming: tuple[str, ...] = ()
+        self._register_load_state_dict_pre_hook(self._before_load, with_module=True)
+        self.register_load_state_dict_post_hook(self._after_load)
+        self._register_state_dict_hook(self._refuse_repacked_state_dict)
 
     # ------------------------------------------------------------------ layout
-    @staticmethod
-    def _mark_reference_layout(module, incompatible_keys):
-        module._amd_layout = False
+    _LAYOUT_PARAMS = ("qweight", "wscales", "smooth_factor", "bias", "proj_down", "proj_up")
+
+    def _layout_params(self):
+        return [n for n in self._LAYOUT_PARAMS if getattr(self, n, None) is not None and not (n.startswith("proj_") and self.rank == 0)]
+
+    @property
+    def _amd_layout(self) -> bool:
+        """True when every parameter is in the kernel layout (nothing left for repack_() to do)."""
+        return all(n in self._amd_names for n in self._layout_params())
+
+    @_amd_layout.setter
+    def _amd_layout(self, value: bool):
+        self._amd_names = set(self._layout_params()) if value else set()
+        for n in self._layout_params():
+            getattr(self, n)._svdq_amd = bool(value)
+
+    def _set_amd_names(self, names):
+        """Adopt a layout state decided elsewhere (replica broadcast): which parameters hold the kernel layout."""
+        self._amd_names = set(names)
+        for n in self._layout_params():
+            getattr(self, n)._svdq_amd = n in self._amd_names
 
     @staticmethod
-    def _restore_checkpoint_shapes(module, state_dict, prefix, local_metadata, strict, missing, unexpected, errors):
-        # a checkpoint brings the base rank and [out, in/2] int8 again: drop a runtime LoRA, undo the FP6 image shape
-        module.reset_lora()
-        qw = module.qweight
-        if qw.shape[-1] != module.in_features // 2:
-            qw.data = torch.empty(module.out_features, module.in_features // 2, dtype=torch.int8, device=qw.device)
+    def _before_load(module, state_dict, prefix, local_metadata, strict, missing, unexpected, errors):
+        # only the tensors actually present under `prefix` come back in checkpoint layout
+        incoming = tuple(n for n in module._LAYOUT_PARAMS if prefix + n in state_dict)
+        module._incoming = incoming
+        if "proj_down" in incoming or "proj_up" in incoming:
+            module.reset_lora()  # a checkpoint brings the base rank again: drop a runtime LoRA first
+        if "qweight" in incoming:
+            qw = module.qweight
+            if qw.shape[-1] != module.in_features // 2:  # undo the FP6 image shape so that the [out, in/2] int8 tensor copies in
+                qw.data = torch.empty(module.out_features, module.in_features // 2, dtype=torch.int8, device=qw.device)
+                module._amd_names.discard("qweight")
+
+    @staticmethod
+    def _after_load(module, incompatible_keys):
+        module._amd_names.difference_update(module._incoming)
+        for n in module._incoming:
+            getattr(module, n)._svdq_amd = False
+        module._incoming = ()
+
+    @staticmethod
+    def _refuse_repacked_state_dict(module, state_dict, prefix, local_metadata):
+        if module._amd_names:
+            raise RuntimeError(
+                f"{prefix or 'SVDQW4A4Linear'}: {sorted(module._amd_names)} hold the MI355X operand layout (repack_() ran): "
+                "state_dict() of a repacked layer is not a checkpoint.  Save the model before its first forward / repack_(), "
+                "or keep the original checkpoint file.")
 
     @torch.no_grad()
     def repack_(self) -> "SVDQW4A4Linear":
-        """Permute the checkpoint-layout parameters into the kernel layout, in place (idempotent)."""
+        """Permute the checkpoint-layout parameters into the kernel layout, in place (idempotent, per tensor)."""
         if self._amd_layout:
             return self
         if not self.qweight.is_cuda:
             raise RuntimeError("SVDQW4A4Linear.repack_(): move the layer to the GPU first (no CPU path)")
-        self.qweight.data = layout.repack_qweight(self.qweight.data)
-        self.wscales.data.copy_(layout.repack_wscales(self.wscales.data))
-        self.smooth_factor.data.copy_(layout.repack_vec(self.smooth_factor.data))
-        if self.bias is not None:
-            self.bias.data.copy_(layout.repack_vec(self.bias.data))
-        if self.rank > 0:
-            self.proj_down.data.copy_(layout.repack_lowrank(self.proj_down.data, down=True))
-            self.proj_up.data.copy_(layout.repack_lowrank(self.proj_up.data, down=False))
-        self._amd_layout = True
+        todo = [n for n in self._layout_params() if n not in self._amd_names]
+        for n in todo:
+            t = getattr(self, n)
+            if n == "qweight":
+                t.data = layout.repack_qweight(t.data)
+            elif n == "wscales":
+                t.data.copy_(layout.repack_wscales(t.data))
+            elif n in ("smooth_factor", "bias"):
+                t.data.copy_(layout.repack_vec(t.data))
+            else:
+                t.data.copy_(layout.repack_lowrank(t.data, down=(n == "proj_down")))
+            t._svdq_amd = True  # nunchaku_amd._C: this Parameter holds the kernel layout, pass it through unconverted
+            self._amd_names.add(n)
         return self
 
     def _ensure_layout(self):

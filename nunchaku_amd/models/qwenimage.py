@@ -1,0 +1,370 @@
+"""Qwen-Image transformer block and model on the SVDQuant hot path (BASELINE config 5).
+
+Reference: ``NunchakuQwenImageTransformerBlock`` / ``NunchakuQwenImageTransformer2DModel``
+(nunchaku/models/transformers/transformer_qwenimage.py:159-307, 309-560), ``NunchakuQwenAttention`` (:37-157) with
+``NunchakuQwenImageNaiveFA2Processor`` (models/attention_processors/qwenimage.py), ``NunchakuFeedForward``
+(models/attention.py:76-123) and ``CPUOffloadManager`` (models/utils.py:52-262).  Module and parameter NAMES follow the
+reference (``img_mod.1``, ``attn.to_qkv``, ``attn.to_out.0``, ``attn.add_qkv_proj``, ``attn.to_add_out``, ``img_mlp.net.0.proj``,
+``img_mlp.net.2``, ...), so a reference checkpoint's state dict loads key for key.
+
+Dual-stream block, hidden 3072 = 24 heads x 128, MLP x4, every projection an ``SVDQW4A4Linear``, the two modulation
+projections ``AWQW4A16Linear`` (W4A16 GEMV).  What differs from the reference's op sequence is WHERE the attention glue runs:
+the reference projects QKV with a plain quantised linear and applies RMSNorm(q, k), the complex rotary multiplication and
+SDPA as separate torch / diffusers ops; Qwen's rotary (``apply_rotary_emb_qwen(use_real=False)``: consecutive channel pairs
+times a unit complex number) is exactly the adjacent-pair rotation of the FLUX QKV epilogue, so here the projection runs
+with the fused RMSNorm + RoPE epilogue (V written transposed) and attention is this library's kernel on the QKV buffer in
+place -- both streams in ONE launch each when the text length is a multiple of 256 (grouped launches).  ``fused_qkv = False``
+on the attention module selects the reference's op-for-op sequence (plain projection, torch RMSNorm / rotary, SDPA).
+"""
+
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..ops.attention import attention_packed
+from ..ops.fused import fused_gelu_mlp, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair, linear_pair
+from ..utils import pad_tensor
+from .embeddings import pack_rotemb
+from .linear import AWQW4A16Linear, SVDQW4A4Linear
+from .offload import CPUOffloadManager
+
+
+def _pad256(n: int) -> int:
+    return (n + 255) // 256 * 256
+
+
+class _GELUProj(nn.Module):
+    """``net.0`` of a diffusers FeedForward with ``activation_fn="gelu-approximate"``: holds ``proj`` (the activation itself
+    is fused into the projection's GEMM epilogue)."""
+
+    def __init__(self, dim, hidden, kw):
+        super().__init__()
+        self.proj = SVDQW4A4Linear(dim, hidden, **kw)
+
+
+class NunchakuFeedForward(nn.Module):
+    """reference: models/attention.py:76-123 -- ``net = [GELU(proj), Dropout, Linear]``; fc1 -> GELU -> fc2 with the
+    requantisation fused into fc1's epilogue."""
+
+    def __init__(self, dim, kw, mult: int = 4):
+        super().__init__()
+        self.net = nn.ModuleList([_GELUProj(dim, mult * dim, kw), nn.Identity(),
+                                  SVDQW4A4Linear(mult * dim, dim, **{**kw, "act_unsigned": True})])
+
+    def forward(self, x):
+        return fused_gelu_mlp(x, self.net[0].proj, self.net[2])
+
+
+class NunchakuQwenAttention(nn.Module):
+    """Joint attention of a Qwen-Image block (reference :37-157): fused QKV projections per stream, QK RMSNorm, rotary,
+    joint softmax attention over [text; image], output projections per stream."""
+
+    fused_qkv = True  # False: the reference's op-for-op sequence (processor NunchakuQwenImageNaiveFA2Processor)
+
+    def __init__(self, dim, heads, kw):
+        super().__init__()
+        self.heads, self.head_dim = heads, dim // heads
+        dt, dev = kw["torch_dtype"], kw["device"]
+        self.to_qkv = SVDQW4A4Linear(dim, 3 * dim, **kw)
+        self.add_qkv_proj = SVDQW4A4Linear(dim, 3 * dim, **kw)
+        self.to_out = nn.ModuleList([SVDQW4A4Linear(dim, dim, **kw), nn.Identity()])  # diffusers: [Linear, Dropout]
+        self.to_add_out = SVDQW4A4Linear(dim, dim, **kw)
+        self.norm_q = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=dt, device=dev)
+        self.norm_k = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=dt, device=dev)
+        self.norm_added_q = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=dt, device=dev)
+        self.norm_added_k = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=dt, device=dev)
+        self.added_kv_proj_dim = dim
+
+    def forward(self, hidden_states, encoder_hidden_states, encoder_hidden_states_mask=None, attention_mask=None,
+                image_rotary_emb=None, **kwargs):
+        """-> (image stream output, text stream output), as the reference's processor returns them.
+        ``image_rotary_emb`` = (img_freqs, txt_freqs) complex ``[T, 64]`` (diffusers ``QwenEmbedRope``) or, precomputed
+        once per forward by the model, the packed real tables of :func:`pack_qwen_rotary`."""
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is not supported")
+        B, t_img, _ = hidden_states.shape
+        t_txt = encoder_hidden_states.shape[1]
+        tokens, hd = t_txt + t_img, self.heads * self.head_dim
+        packed = image_rotary_emb if isinstance(image_rotary_emb, dict) else pack_qwen_rotary(*image_rotary_emb)
+        if self.fused_qkv and B == 1 and self.head_dim == 128 and tokens % 128 == 0:
+            qkv = torch.empty(tokens, 3 * hd, dtype=hidden_states.dtype, device=hidden_states.device)
+            vt = torch.empty(hd, tokens, dtype=hidden_states.dtype, device=hidden_states.device)
+            done = False
+            if t_txt % 256 == 0 and t_img % 256 == 0:  # both streams in one launch (rows: text first)
+                done = fused_qkv_norm_rottary_pair(encoder_hidden_states, self.add_qkv_proj, self.norm_added_q, self.norm_added_k,
+                                                   hidden_states, self.to_qkv, self.norm_q, self.norm_k, packed["all"], qkv, out_vt=vt)
+            if not done:
+                fused_qkv_norm_rottary(encoder_hidden_states, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, packed["txt"],
+                                       output=qkv[:t_txt], out_vt=vt[:, :t_txt])
+                fused_qkv_norm_rottary(hidden_states, self.to_qkv, self.norm_q, self.norm_k, packed["img"], output=qkv[t_txt:],
+                                       out_vt=vt[:, t_txt:])
+            o = attention_packed(qkv, vt, self.heads).unsqueeze(0)
+        else:
+            o = self._reference_ops(hidden_states, encoder_hidden_states, packed)
+        if t_txt % 256 == 0 and B == 1:
+            txt, img = linear_pair(o[:, :t_txt], self.to_add_out, o[:, t_txt:], self.to_out[0])
+            return img, txt
+        return self.to_out[0](o[:, t_txt:]), self.to_add_out(o[:, :t_txt])
+
+    def _reference_ops(self, hidden_states, encoder_hidden_states, packed):
+        """NunchakuQwenImageNaiveFA2Processor, op for op: plain quantised projections, torch RMSNorm, rotary as the complex
+        product in fp32 with one rounding, ``scaled_dot_product_attention`` over [text; image]."""
+        B = hidden_states.shape[0]
+        shp = (B, -1, self.heads, self.head_dim)
+
+        def stream(x, proj, nq, nk, cs):
+            q, k, v = (t.view(shp) for t in proj(x).chunk(3, dim=-1))
+            return _rotate(nq(q), cs), _rotate(nk(k), cs), v
+
+        tq, tk, tv = stream(encoder_hidden_states, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, packed["txt_cs"])
+        iq, ik, iv = stream(hidden_states, self.to_qkv, self.norm_q, self.norm_k, packed["img_cs"])
+        q, k, v = (torch.cat(p, dim=1).transpose(1, 2) for p in ((tq, iq), (tk, ik), (tv, iv)))
+        o = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
+        return o.transpose(1, 2).flatten(2, 3).to(hidden_states.dtype)
+
+
+def _rotate(x: torch.Tensor, cs: torch.Tensor) -> torch.Tensor:
+    """``apply_rotary_emb_qwen(x, freqs, use_real=False)``: consecutive channel pairs times cos + i sin, fp32, one rounding.
+    x [B, T, H, D]; cs [T, D/2, 2] = (cos, sin)."""
+    xf = x.float().unflatten(-1, (-1, 2))
+    c, s = cs[None, :, None, :, 0], cs[None, :, None, :, 1]
+    out = torch.stack([xf[..., 0] * c - xf[..., 1] * s, xf[..., 0] * s + xf[..., 1] * c], dim=-1)
+    return out.flatten(-2).to(x.dtype)
+
+
+def pack_qwen_rotary(img_freqs: torch.Tensor, txt_freqs: torch.Tensor) -> dict:
+    """Complex rotary tables ``[T, 64]`` of the image and the text stream (diffusers ``QwenEmbedRope`` output) -> what the
+    kernels read: the fused QKV epilogue's packed (sin, cos) tables (models/embeddings.py:pack_rotemb, 256-row padding)
+    per stream and for the concatenated [text; image] sequence, plus plain (cos, sin) tables for the torch-op path."""
+    def cs(f):
+        return torch.stack([f.real.float(), f.imag.float()], dim=-1)  # [T, 64, (cos, sin)]
+
+    def packed(c):
+        sin_cos = torch.stack([c[..., 1], c[..., 0]], dim=-1)[None, :, :, None, :]  # [1, T, 64, 1, (sin, cos)]
+        return pack_rotemb(pad_tensor(sin_cos, 256, 1))
+
+    ic, tc = cs(img_freqs), cs(txt_freqs)
+    return {"img": packed(ic), "txt": packed(tc), "all": packed(torch.cat([tc, ic], dim=0)), "img_cs": ic, "txt_cs": tc}
+
+
+def qwen_rope_freqs(img_shape: tuple[int, int, int], txt_len: int, axes_dim=(16, 56, 56), theta: float = 10000.0,
+                    scale_rope: bool = True, device="cpu"):
+    """Rotary frequencies of one (frames, height, width) latent grid and ``txt_len`` text tokens, restated from diffusers'
+    ``QwenEmbedRope`` (transformer_qwenimage.py; diffusers is not installed here): per axis ``exp(i * pos * theta^(-2j/d))``,
+    image positions centred per axis when ``scale_rope``, text positions continuing after ``max(height, width) / 2``.
+    -> (img_freqs [F*H*W, 64] complex64, txt_freqs [txt_len, 64] complex64)."""
+    def axis(pos, d):
+        inv = 1.0 / theta ** (torch.arange(0, d, 2, dtype=torch.float32, device=device) / d)
+        return torch.polar(torch.ones(len(pos), d // 2, device=device), pos.float()[:, None] * inv[None])
+
+    frame, height, width = img_shape
+
+    def centred(n):
+        return torch.cat([torch.arange(-(n - n // 2), 0, device=device), torch.arange(0, n // 2, device=device)]) if scale_rope \
+            else torch.arange(n, device=device)
+
+    ff = axis(torch.arange(frame, device=device), axes_dim[0])[:, None, None, :].expand(frame, height, width, -1)
+    fh = axis(centred(height), axes_dim[1])[None, :, None, :].expand(frame, height, width, -1)
+    fw = axis(centred(width), axes_dim[2])[None, None, :, :].expand(frame, height, width, -1)
+    img = torch.cat([ff, fh, fw], dim=-1).reshape(frame * height * width, -1)
+    start = max(height // 2, width // 2) if scale_rope else max(height, width)
+    tpos = torch.arange(start, start + txt_len, device=device)
+    txt = torch.cat([axis(tpos, d) for d in axes_dim], dim=-1)
+    return img, txt
+
+
+class NunchakuQwenImageTransformerBlock(nn.Module):
+    """reference :159-307.  ``scale_shift`` = 1.0: the checkpoint's modulation does NOT carry the +1 of the scale (unlike
+    nunchaku's FLUX checkpoints), it is added here (:203-205)."""
+
+    def __init__(self, dim: int = 3072, num_attention_heads: int = 24, attention_head_dim: int = 128, rank: int = 32,
+                 scale_shift: float = 1.0, torch_dtype: torch.dtype = torch.bfloat16, device="cuda"):
+        super().__init__()
+        assert dim == num_attention_heads * attention_head_dim
+        kw = dict(rank=rank, torch_dtype=torch_dtype, device=device)
+        self.dim = dim
+        self.img_mod = nn.Sequential(nn.SiLU(), AWQW4A16Linear(dim, 6 * dim, torch_dtype=torch_dtype, device=device))
+        self.img_norm1 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.attn = NunchakuQwenAttention(dim, num_attention_heads, kw)
+        self.img_norm2 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.img_mlp = NunchakuFeedForward(dim, kw)
+        self.txt_mod = nn.Sequential(nn.SiLU(), AWQW4A16Linear(dim, 6 * dim, torch_dtype=torch_dtype, device=device))
+        self.txt_norm1 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.txt_norm2 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.txt_mlp = NunchakuFeedForward(dim, kw)
+        self.scale_shift = scale_shift
+
+    def _modulate(self, x, mod_params):
+        shift, scale, gate = mod_params.chunk(3, dim=-1)
+        if self.scale_shift != 0:
+            scale = scale + self.scale_shift
+        return x * scale.unsqueeze(1) + shift.unsqueeze(1), gate.unsqueeze(1)
+
+    def forward(self, hidden_states, encoder_hidden_states, encoder_hidden_states_mask=None, temb=None, image_rotary_emb=None,
+                joint_attention_kwargs=None):
+        B = temb.shape[0]
+        # nunchaku's modulation weights are stored channel-interleaved: [B, dim * 6] -> [B, 6 * dim] (:236-243)
+        img_mod = self.img_mod(temb).view(B, -1, 6).transpose(1, 2).reshape(B, -1)
+        txt_mod = self.txt_mod(temb).view(B, -1, 6).transpose(1, 2).reshape(B, -1)
+        img_mod1, img_mod2 = img_mod.chunk(2, dim=-1)
+        txt_mod1, txt_mod2 = txt_mod.chunk(2, dim=-1)
+        img_x, img_gate1 = self._modulate(self.img_norm1(hidden_states), img_mod1)
+        txt_x, txt_gate1 = self._modulate(self.txt_norm1(encoder_hidden_states), txt_mod1)
+        img_attn, txt_attn = self.attn(hidden_states=img_x, encoder_hidden_states=txt_x, encoder_hidden_states_mask=encoder_hidden_states_mask,
+                                       image_rotary_emb=image_rotary_emb, **(joint_attention_kwargs or {}))
+        hidden_states = hidden_states + img_gate1 * img_attn
+        encoder_hidden_states = encoder_hidden_states + txt_gate1 * txt_attn
+        img_x2, img_gate2 = self._modulate(self.img_norm2(hidden_states), img_mod2)
+        hidden_states = hidden_states + img_gate2 * self.img_mlp(img_x2)
+        txt_x2, txt_gate2 = self._modulate(self.txt_norm2(encoder_hidden_states), txt_mod2)
+        encoder_hidden_states = encoder_hidden_states + txt_gate2 * self.txt_mlp(txt_x2)
+        if encoder_hidden_states.dtype == torch.float16:  # :300-303
+            encoder_hidden_states = encoder_hidden_states.clip(-65504, 65504)
+        if hidden_states.dtype == torch.float16:
+            hidden_states = hidden_states.clip(-65504, 65504)
+        return encoder_hidden_states, hidden_states
+
+
+class _TimestepEmbed(nn.Module):
+    """diffusers ``QwenTimestepProjEmbeddings``: sinusoidal(256, flip_sin_to_cos, scale 1000) -> Linear -> SiLU -> Linear."""
+
+    def __init__(self, dim, dtype, device):
+        super().__init__()
+        self.timestep_embedder = nn.ModuleDict({"linear_1": nn.Linear(256, dim, dtype=dtype, device=device),
+                                                "linear_2": nn.Linear(dim, dim, dtype=dtype, device=device)})
+
+    def forward(self, timestep, dtype):
+        half = 128
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=timestep.device) / half)
+        args = timestep.float()[:, None] * 1000.0 * freqs[None]
+        emb = torch.cat([args.cos(), args.sin()], dim=-1).to(dtype)
+        return self.timestep_embedder["linear_2"](F.silu(self.timestep_embedder["linear_1"](emb)))
+
+
+class NunchakuQwenImageTransformer2DModel(nn.Module):
+    """reference :309-560 (``diffusers.QwenImageTransformer2DModel`` subclass there; diffusers is not a dependency here,
+    the pipeline duck-types its transformer): 60 dual-stream blocks, ``set_offload`` for layer-wise host offload."""
+
+    def __init__(self, num_layers: int = 60, num_attention_heads: int = 24, attention_head_dim: int = 128, in_channels: int = 64,
+                 out_channels: int = 16, joint_attention_dim: int = 3584, patch_size: int = 2, axes_dims_rope=(16, 56, 56),
+                 rank: int = 32, torch_dtype: torch.dtype = torch.bfloat16, device="cuda"):
+        super().__init__()
+        dim = num_attention_heads * attention_head_dim
+        self.inner_dim, self.axes = dim, tuple(axes_dims_rope)
+        self.config = SimpleNamespace(num_layers=num_layers, num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+                                      in_channels=in_channels, out_channels=out_channels, joint_attention_dim=joint_attention_dim,
+                                      patch_size=patch_size, axes_dims_rope=self.axes, guidance_embeds=False)
+        self.time_text_embed = _TimestepEmbed(dim, torch_dtype, device)
+        self.txt_norm = nn.RMSNorm(joint_attention_dim, eps=1e-6, dtype=torch_dtype, device=device)
+        self.img_in = nn.Linear(in_channels, dim, dtype=torch_dtype, device=device)
+        self.txt_in = nn.Linear(joint_attention_dim, dim, dtype=torch_dtype, device=device)
+        self.transformer_blocks = nn.ModuleList([
+            NunchakuQwenImageTransformerBlock(dim, num_attention_heads, attention_head_dim, rank=rank, torch_dtype=torch_dtype, device=device)
+            for _ in range(num_layers)])
+        self.norm_out = nn.ModuleDict({"linear": nn.Linear(dim, 2 * dim, dtype=torch_dtype, device=device)})  # AdaLayerNormContinuous
+        self.proj_out = nn.Linear(dim, patch_size * patch_size * out_channels, dtype=torch_dtype, device=device)
+        self.dtype_ = torch_dtype
+        self.offload = False
+        self.offload_manager: CPUOffloadManager | None = None
+
+    @property
+    def dtype(self):
+        return self.dtype_
+
+    @property
+    def device(self):
+        return self.proj_out.weight.device
+
+    def svdq_layers(self):
+        return [m for m in self.modules() if isinstance(m, SVDQW4A4Linear)]
+
+    def set_offload(self, offload: bool, **kwargs):
+        """reference :415-451 -- layer-wise host offload of the transformer blocks (models/offload.py)."""
+        if offload == self.offload:
+            return
+        self.offload = offload
+        if offload:
+            self.offload_manager = CPUOffloadManager(
+                list(self.transformer_blocks), device=kwargs.get("device", self.device), use_pin_memory=kwargs.get("use_pin_memory", True),
+                on_gpu_modules=[self.img_in, self.txt_in, self.txt_norm, self.time_text_embed, self.norm_out, self.proj_out],
+                num_blocks_on_gpu=kwargs.get("num_blocks_on_gpu", 1))
+        else:
+            self.offload_manager = None
+            torch.cuda.empty_cache()
+
+    def to(self, *args, **kwargs):
+        """reference :560-612: no dtype casts of a quantised model; with offload on, the blocks stay where the manager put them."""
+        if any(isinstance(a, torch.dtype) for a in args) or "dtype" in kwargs:
+            raise ValueError("Casting a quantized model to a new `dtype` is unsupported")
+        if self.offload:
+            return self
+        return super().to(*args, **kwargs)
+
+    @torch.no_grad()
+    def init_synthetic_(self, seed: int = 0):
+        """Random-init weights of the Qwen-Image shape (no checkpoints in this environment), written in the checkpoint layout."""
+        dev = self.proj_out.weight.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        for m in self.modules():
+            if isinstance(m, SVDQW4A4Linear):
+                K = m.in_features
+                m.qweight.copy_(torch.randint(-128, 128, m.qweight.shape, generator=g, device=dev, dtype=torch.int16))
+                m.wscales.copy_((torch.rand(m.wscales.shape, generator=g, device=dev) * 0.5 + 0.75) * (1.0 / (4.6 * math.sqrt(K))))
+                if m.bias is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g, device=dev) * 0.02)
+                m.smooth_factor.copy_(torch.rand((K,), generator=g, device=dev) + 0.5)
+                m.smooth_factor_orig.copy_(m.smooth_factor)
+                m.proj_down.copy_(torch.randn(m.proj_down.shape, generator=g, device=dev) * (0.5 / math.sqrt(K)))
+                m.proj_up.copy_(torch.randn(m.proj_up.shape, generator=g, device=dev) * (0.5 / math.sqrt(m.rank)))
+                m._amd_layout = False
+            elif isinstance(m, AWQW4A16Linear):
+                sc = 1.0 / (4.6 * math.sqrt(m.in_features))
+                m.qweight.copy_(torch.randint(-2 ** 31, 2 ** 31, m.qweight.shape, generator=g, device=dev, dtype=torch.int64))
+                m.wscales.copy_((torch.rand(m.wscales.shape, generator=g, device=dev) * 0.5 + 0.75) * sc)
+                m.wzeros.copy_(m.wscales.float() * -7.5)
+                m.bias.zero_()
+            elif isinstance(m, nn.Linear):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g, device=dev) / math.sqrt(m.in_features))
+                m.bias.zero_()
+            elif isinstance(m, nn.RMSNorm):
+                m.weight.fill_(1.0)
+        return self
+
+    def forward(self, hidden_states, encoder_hidden_states=None, encoder_hidden_states_mask=None, timestep=None, img_shapes=None,
+                txt_seq_lens=None, guidance=None, attention_kwargs=None, controlnet_block_samples=None, return_dict: bool = True):
+        """hidden_states [1, T_img, 64] (packed 2x2 latent patches); encoder_hidden_states [1, T_txt, 3584]; timestep [1] (already
+        divided by 1000 by the pipeline); img_shapes [(frames, H/2, W/2)] of the latent grid.  -> [1, T_img, 64]."""
+        if controlnet_block_samples is not None:
+            raise NotImplementedError("ControlNet residuals are out of scope (SURVEY.md section 8)")
+        dt = self.dtype_
+        hidden = self.img_in(hidden_states)
+        enc = self.txt_in(self.txt_norm(encoder_hidden_states))
+        temb = self.time_text_embed(timestep.to(dt), dt)
+        t_txt = enc.shape[1]
+        shape = img_shapes[0] if img_shapes else (1, int(math.isqrt(hidden.shape[1])), int(math.isqrt(hidden.shape[1])))
+        if isinstance(shape, (list, tuple)) and isinstance(shape[0], (list, tuple)):
+            shape = shape[0]
+        rot = pack_qwen_rotary(*qwen_rope_freqs(tuple(shape), t_txt, self.axes, device=hidden.device))
+        compute_stream = torch.cuda.current_stream()
+        if self.offload:
+            self.offload_manager.initialize(compute_stream)
+        for i, block in enumerate(self.transformer_blocks):
+            if self.offload:
+                block = self.offload_manager.get_block(i)
+            enc, hidden = block(hidden_states=hidden, encoder_hidden_states=enc, encoder_hidden_states_mask=encoder_hidden_states_mask,
+                                temb=temb, image_rotary_emb=rot, joint_attention_kwargs=attention_kwargs)
+            if self.offload:
+                self.offload_manager.step(compute_stream)
+        scale, shift = self.norm_out["linear"](F.silu(temb)).chunk(2, dim=-1)  # AdaLayerNormContinuous
+        hidden = F.layer_norm(hidden, (self.inner_dim,), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]
+        out = self.proj_out(hidden)
+        if not return_dict:
+            return (out,)
+        from .transformer_flux import Transformer2DModelOutput
+
+        return Transformer2DModelOutput(sample=out)

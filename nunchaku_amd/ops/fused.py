@@ -49,7 +49,18 @@ def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rota
     x2 = x.reshape(M, C_in)
     qx, ascales, lora_act = proj.quantize(x2, ln=ln) if quantized is None else quantized
     if isinstance(output, tuple):
-        raise NotImplementedError("the reference's packed (q, k, v) tuple is NVIDIA-fragment ordered; pass out_vt= instead")
+        # the reference's "nunchaku-fp16" attention hand-off (ops/fused.py:140-160): three opaque [B, H, T_pad, 128] buffers
+        # that only _C.ops.attention_fp16 reads.  Adapter path (one scatter copy); out_vt= is the copy-free form.
+        assert len(output) == 3
+        proj._ensure_layout()
+        svdq_gemm_w4a4_cuda(
+            act=qx, wgt=proj.qweight, ascales=ascales, wscales=proj.wscales, lora_act_in=lora_act, lora_up=proj.proj_up,
+            bias=proj.bias, fp4=False, alpha=proj.wtscale, wcscales=proj.wcscales,
+            norm_q=None if norm_q is None else norm_q.weight, norm_k=None if norm_k is None else norm_k.weight,
+            rotary_emb=None if rotary_emb is None else rotary_emb.reshape(-1, rotary_emb.shape[-1]),
+            out_q=output[0], out_k=output[1], out_v=output[2], attn_tokens=attn_tokens or M,
+            lora_scales=getattr(proj, "lora_scales", None))
+        return output
     if output is None:
         output = torch.empty(M, proj.out_features, dtype=x.dtype, device=x.device)
     proj._ensure_layout()

@@ -560,18 +560,38 @@ def fused_gelu_mlp(x, fc1: dict, fc2: dict, dtype="bf16", accum="fp32"):
 # Synthetic SVDQuant layers (SURVEY.md §8d "synthetic inputs")
 # --------------------------------------------------------------------------
 def make_svdq_layer(K: int, N: int, R: int = 32, seed: int = 0, dtype: str = "bf16", bias: bool = True,
-                    cheap: bool = False) -> dict:
+                    cheap: bool = False, svd: str = "full", lowrank_energy: float = 0.0) -> dict:
     """W ~ N(0, 0.02^2) [N, K]; smooth ~ exp(N(0, 0.5^2)); W_hat = W*diag(smooth); rank-R
     truncated SVD -> L1 [K, R], L2 [R, N]; residual -> symmetric s4, group 64, scale = amax/7.
     proj_down = L1 / smooth (it is applied to the raw x), proj_up = L2^T.  ``cheap`` replaces
     the SVD by a random rank-R factor pair (for big shapes in benches)."""
     rng = np.random.default_rng(seed)
     W = (rng.standard_normal((N, K)) * 0.02).astype(F32)
+    if lowrank_energy > 0.0:
+        # a weight whose energy sits mostly in a rank-R component (fraction `lowrank_energy` of the Frobenius norm^2), the
+        # situation SVDQuant is designed for: the 16-bit low-rank branch carries the bulk, the 4-bit branch a small
+        # residual -- a forward pass is then well conditioned with respect to +-1 code flips
+        A = rng.standard_normal((N, R)).astype(F32)
+        B = rng.standard_normal((R, K)).astype(F32)
+        low0 = (A @ B) * F32(0.02 / np.sqrt(R))
+        W = (np.sqrt(lowrank_energy) * low0 + np.sqrt(1.0 - lowrank_energy) * W).astype(F32)
     smooth = round16(np.exp(rng.standard_normal(K) * 0.5).astype(F32), dtype)
     What = W * smooth[None, :]
     if cheap:
         L2t = (rng.standard_normal((N, R)) * 0.02).astype(F32)
         L1 = (rng.standard_normal((K, R)) * 0.05).astype(F32)
+        low = L2t @ L1.T
+    elif svd == "randomized":
+        # rank-R range finder with two power iterations (Halko et al.): the top-R subspace of a 12288 x 3072 matrix in a
+        # few seconds instead of a full SVD; only used to build test layers with checkpoint-like statistics
+        A = What.astype(np.float64)
+        Q = np.linalg.qr(A @ rng.standard_normal((K, R + 16)))[0]
+        for _ in range(2):
+            Q = np.linalg.qr(A @ (A.T @ Q))[0]
+        Ub, S, Vt = np.linalg.svd(Q.T @ A, full_matrices=False)
+        U = Q @ Ub
+        L2t = (U[:, :R] * np.sqrt(S[:R])).astype(F32)
+        L1 = (Vt[:R].T * np.sqrt(S[:R])).astype(F32)
         low = L2t @ L1.T
     else:
         U, S, Vt = np.linalg.svd(What.astype(np.float64), full_matrices=False)

@@ -200,3 +200,36 @@ def test_attention_fused_output_quantiser(dtype, joint):
     assert torch.equal(layout.unpack_act(got[0], K), ref_codes)
     assert torch.equal(layout.unpack_scales(got[1], L), ref_scales)
     assert (got[2] - ref_la).abs().max() <= 2e-3 * ref_la.abs().max() + 1e-5
+
+
+def test_reference_fp16_attention_operators():
+    """The reference's "nunchaku-fp16" attention surface (attention_processors/flux.py:114-237, csrc/ops.h:114-121):
+    fused_qkv_norm_rottary(..., output=(q, k, v), attn_tokens=) + _C.ops.attention_fp16, through the nunchaku shim,
+    against the SDPA processor on the same module."""
+    from nunchaku.models.attention_processors.flux import NunchakuFluxFA2Processor, NunchakuFluxFP16AttnProcessor
+    from nunchaku_amd.models.flux import FluxAttentionAMD
+    from nunchaku_amd.models.embeddings import flux_pos_embed, pack_rotemb
+    from nunchaku_amd.models.flux import FluxTransformerAMD
+
+    model = FluxTransformerAMD(num_layers=1, num_single_layers=1, dim=256, heads=2, in_channels=64, joint_attention_dim=128,
+                               pooled_projection_dim=64, torch_dtype=torch.float16, device="cuda").init_synthetic_(seed=2).eval()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    t_txt, t_img = 256, 256
+    x = torch.randn(1, t_img, 256, device="cuda", generator=g).half()
+    e = torch.randn(1, t_txt, 256, device="cuda", generator=g).half()
+    ids = torch.zeros(t_txt + t_img, 3, device="cuda")
+    ids[t_txt:, 1] = torch.arange(16, device="cuda").repeat_interleave(16)
+    ids[t_txt:, 2] = torch.arange(16, device="cuda").repeat(16)
+    rot = flux_pos_embed(ids, (16, 56, 56))
+    rot_txt, rot_img, rot_all = pack_rotemb(rot[:, :t_txt]), pack_rotemb(rot[:, t_txt:]), pack_rotemb(rot)
+    joint, single = model.blocks[0].attn, model.single_blocks[0].attn
+    assert isinstance(joint, FluxAttentionAMD) and joint.added_kv_proj_dim is not None and single.added_kv_proj_dim is None
+    with torch.no_grad():
+        for proc_ref, proc in ((NunchakuFluxFA2Processor(), NunchakuFluxFP16AttnProcessor()),):
+            a0, c0 = proc_ref(joint, x, e, image_rotary_emb=(rot_img, rot_txt))
+            a1, c1 = proc(joint, x, e, image_rotary_emb=(rot_img, rot_txt))
+            s0 = proc_ref(single, torch.cat([e, x], 1), image_rotary_emb=rot_all)
+            s1 = proc(single, torch.cat([e, x], 1), image_rotary_emb=rot_all)
+    for got, ref in ((a1, a0), (c1, c0), (s1, s0)):
+        err = (got.float() - ref.float()).abs().max().item()
+        assert torch.isfinite(got.float()).all() and err <= 2e-2 * ref.float().abs().max().item() + 1e-3, err

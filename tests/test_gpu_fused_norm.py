@@ -212,3 +212,26 @@ def test_flux_transformer_fp16_fused_vs_torch_ops():
     assert outs[True].dtype == torch.float32 and torch.isfinite(outs[True]).all()
     rel = ((outs[True] - outs[False]).norm() / outs[False].norm()).item()
     assert rel < 3e-2, f"fp16 fused vs torch-op path: relative L2 {rel:.3g}"
+
+
+def test_residual_fp16_clip_follows_the_reference_blocks():
+    """fp16: res + gate * a overflows -> the reference clips the stream to +-65504 (transformer_flux_v2.py:254-255,
+    339-340); the fused pass does the same before the store AND the statistics, per problem of a grouped launch."""
+    from nunchaku_amd.ops.elementwise import residual_gate_stats, residual_gate_stats_pair
+
+    M, C = 8, 512
+    res = torch.full((M, C), 60000.0, dtype=torch.float16, device="cuda")
+    res[:, ::2] = -60000.0
+    a = res.clone()
+    gate = torch.ones(C, dtype=torch.float16, device="cuda")
+    y, st = residual_gate_stats(res.clone(), a, gate, clamp_fp16=True)
+    assert torch.isfinite(y.float()).all() and float(y.abs().max()) == 65504.0 and torch.isfinite(st).all()
+    y2, st2 = residual_gate_stats(res.clone(), a, gate)  # the flag off: plain fp16 arithmetic, inf like torch
+    assert torch.isinf(y2.float()).all()
+    assert torch.equal(y2, res + gate[None] * a)
+    # grouped: only the first problem (the text stream of a joint block) is clipped
+    ya, sa, yb, sb = residual_gate_stats_pair(res.clone(), a, gate, res.clone(), a, gate, clamp_fp16_a=True)
+    assert torch.isfinite(ya.float()).all() and torch.isinf(yb.float()).all()
+    # bf16 is never clipped
+    yb16, _ = residual_gate_stats(res.bfloat16(), a.bfloat16(), gate.bfloat16(), clamp_fp16=True)
+    assert float(yb16.float().abs().max()) > 1e5

@@ -299,3 +299,76 @@ def test_runtime_lora_widens_the_low_rank_branch():
     mod.reset_lora()
     assert mod.rank == 32 and mod.lora_scales is None
     assert_close_16(f32(mod(tx))[0], base, dtype, "reset", max_bad_frac=2e-3)
+
+
+def test_partial_state_dict_update_of_a_repacked_layer():
+    """load only the bias into a layer that has already run (its tensors are in the kernel layout): the weights
+    stay intact, the new bias is repacked alone, the output follows the oracle with the new bias."""
+    dtype, M, K, N = "bf16", 256, 256, 128
+    L, x = _gemm_inputs(M, K, N, 32, dtype, seed=77)
+    mod = make_module(L, dtype)
+    tx = t16(x, dtype).view(1, M, K)
+    y0 = f32(mod(tx))[0]
+    assert mod._amd_layout
+    new_bias = O.round16(np.random.default_rng(5).standard_normal(N).astype(np.float32), dtype)
+    mod.load_state_dict({"bias": torch.from_numpy(O.pack_vec_ref(new_bias)).to(TORCH_DT[dtype])}, strict=False)
+    assert mod._amd_names == {"qweight", "wscales", "smooth_factor", "proj_down", "proj_up"}
+    y1 = f32(mod(tx))[0]
+    assert mod._amd_layout
+    L2 = dict(L)
+    L2["bias"] = new_bias
+    qx, asc, la = mod.quantize(t16(x, dtype))
+    q, a, _ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"], dtype)
+    ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=new_bias, lora_act_in=la.cpu().numpy(), lora_up=L["proj_up"])["out"][:M]
+    assert_close_16(f32(mod.forward_quant(qx, asc, la))[:M], ref, dtype, "after the bias-only update")
+    assert np.abs(y1 - y0).max() > 0.1  # the bias really changed
+    with pytest.raises(RuntimeError, match="not a checkpoint"):
+        mod.state_dict()
+
+
+def test_reference_style_calls_with_reference_sized_buffers_and_checkpoint_layout():
+    """Drop-in boundary: ``nunchaku._C.ops`` called exactly as the reference's own
+    ops/quantize.py + ops/fused.py do -- positional arguments, opaque code buffers of the REFERENCE size [M_pad, K/2],
+    parameters straight from a checkpoint (NVIDIA fragment layout, never repacked by the caller) -- gives the oracle's result."""
+    from nunchaku._C import ops
+
+    dtype, M, C, Hd, R = "bf16", 300, 256, 512, 32
+    td = TORCH_DT[dtype]
+    fc1 = O.make_svdq_layer(C, Hd, R, seed=51, dtype=dtype, cheap=True)
+    fc2 = O.make_svdq_layer(Hd, C, R, seed=52, dtype=dtype, cheap=True)
+    x = O.make_activations(M, C, seed=53, dtype=dtype)
+    from tests.helpers import reference_state_dict
+
+    p1 = {k: v.cuda() for k, v in reference_state_dict(fc1, dtype).items()}
+    p2 = {k: v.cuda() for k, v in reference_state_dict(fc2, dtype).items()}
+    xt = t16(x, dtype)
+    M_pad = 512
+    # --- nunchaku/ops/quantize.py:60-80
+    qx = torch.empty(M_pad, C // 2, dtype=torch.uint8, device="cuda")
+    asc = torch.empty(C // 64, M_pad, dtype=td, device="cuda")
+    la = torch.empty(M_pad, R, dtype=torch.float32, device="cuda")
+    ops.quantize_w4a4_act_fuse_lora(xt, qx, asc, p1["proj_down"], la, p1["smooth_factor"], False, False)
+    # --- plain linear, nunchaku/ops/gemm.py:130-160 (29 positional arguments)
+    out = torch.empty(M, Hd, dtype=td, device="cuda")
+    ops.gemm_w4a4(qx, p1["qweight"], out, None, asc, p1["wscales"], None, None, la, p1["proj_up"], None, None, None, None, None,
+                  p1["bias"], None, None, None, False, [1.0, 1.0], False, False, 1.0, None, None, None, None, 0)
+    q, a, _ = O.quantize_w4a4_act_fuse_lora(x, fc1["smooth"], fc1["proj_down"], dtype)
+    ref = O.gemm_w4a4(q, a, fc1["qweight"], fc1["wscales"], dtype=dtype, bias=fc1["bias"], lora_act_in=la.cpu().numpy(),
+                      lora_up=fc1["proj_up"])["out"][:M]
+    assert_close_16(f32(out), ref, dtype, "reference-style linear")
+    # --- fused MLP, nunchaku/ops/fused.py:52-77: reference-sized qout between the two GEMMs
+    qh = torch.empty(M_pad, Hd // 2, dtype=torch.uint8, device="cuda")
+    sh = torch.empty(Hd // 64, M_pad, dtype=td, device="cuda")
+    lh = torch.empty(M_pad, R, dtype=torch.float32, device="cuda")
+    ops.gemm_w4a4(qx, p1["qweight"], None, qh, asc, p1["wscales"], sh, None, la, p1["proj_up"], p2["proj_down"], lh, None, None, None,
+                  p1["bias"], p2["smooth_factor"], None, None, False, [1.0, 1.0], False, False, 1.0, None, None, None, None, 0)
+    y = torch.empty(M, C, dtype=td, device="cuda")
+    ops.gemm_w4a4(qh, p2["qweight"], y, None, sh, p2["wscales"], None, None, lh, p2["proj_up"], None, None, None, None, None,
+                  p2["bias"], None, None, None, True, [1.0, 1.0], False, False, 1.0, None, None, None, None, 0)
+    ref_mlp = O.fused_gelu_mlp(x, fc1, fc2, dtype)
+    got = f32(y)
+    assert np.linalg.norm(got - ref_mlp) / np.linalg.norm(ref_mlp) < 2e-2
+    # a code buffer this library did not fill is refused, not read
+    with pytest.raises(ValueError, match="not produced"):
+        ops.gemm_w4a4(torch.empty_like(qx), p1["qweight"], out, None, asc, p1["wscales"], None, None, la, p1["proj_up"], None, None, None,
+                      None, None, p1["bias"], None, None, None, False, [1.0, 1.0], False, False, 1.0, None, None, None, None, 0)

@@ -1,0 +1,198 @@
+"""Qwen-Image block (BASELINE config 5) on the GPU: parity against a CPU twin that follows
+the reference's op sequence (NunchakuQwenImageTransformerBlock + NunchakuQwenImageNaiveFA2Processor) with the numpy oracle
+for every quantised operator; the fused path (RMSNorm + RoPE in the QKV epilogue, this library's attention kernel, grouped
+launches) against the reference-op path on the GPU; and the layer-wise host offload against the resident model, bit for bit."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import svdq_oracle as O
+from tests.flux_ref import DT, psnr_rel, r16
+from tests.helpers import reference_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _fill(model, seed=0, lowrank_energy=0.9):
+    from nunchaku_amd.models.linear import AWQW4A16Linear, SVDQW4A4Linear
+
+    torch.manual_seed(seed)
+    layers = {}
+    with torch.no_grad():
+        for name, mod in model.named_modules():
+            if isinstance(mod, SVDQW4A4Linear):
+                L = O.make_svdq_layer(mod.in_features, mod.out_features, 32, seed=seed * 1000 + len(layers), dtype=DT, cheap=False,
+                                      svd="randomized", lowrank_energy=lowrank_energy)
+                layers[name] = L
+                mod.load_state_dict({k: v.cuda() for k, v in reference_state_dict(L, DT).items()})
+            elif isinstance(mod, AWQW4A16Linear):
+                rng = np.random.default_rng(seed * 1000 + 500 + len(layers))
+                w = O.round16(rng.standard_normal((mod.out_features, mod.in_features)).astype(np.float32) / mod.in_features ** 0.5, DT)
+                q, s_, z_ = O.awq_quantize_ref(w, DT)
+                bias = O.round16(rng.standard_normal(mod.out_features).astype(np.float32) * 0.02, DT)
+                layers[name] = {"q": q, "s": s_, "z": z_, "bias": bias}
+                mod.load_state_dict({"qweight": torch.from_numpy(O.pack_awq_w4_ref(q)).cuda(), "wscales": torch.from_numpy(s_).cuda().bfloat16(),
+                                     "wzeros": torch.from_numpy(z_).cuda().bfloat16(), "bias": torch.from_numpy(bias).cuda().bfloat16()})
+            elif isinstance(mod, torch.nn.Linear):
+                mod.weight.copy_(torch.randn_like(mod.weight, dtype=torch.float32) / mod.in_features ** 0.5)
+                mod.bias.copy_(torch.randn_like(mod.bias, dtype=torch.float32) * 0.02)
+            elif isinstance(mod, torch.nn.RMSNorm):
+                mod.weight.copy_(1 + 0.1 * torch.randn_like(mod.weight, dtype=torch.float32))
+    return layers
+
+
+class BlockTwin:
+    """CPU forward of one Qwen-Image block, the reference's op sequence with one 16-bit rounding per torch op."""
+
+    def __init__(self, block, layers, prefix=""):
+        self.b, self.L, self.p = block, layers, prefix
+
+    def svdq(self, name, x):
+        return torch.from_numpy(O.svdq_linear(x.numpy(), self.L[self.p + name], DT, "fp32")["out"])
+
+    def awq(self, name, x):
+        L = self.L[self.p + name]
+        return torch.from_numpy(O.awq_gemv_w4a16(x.numpy(), L["q"], L["s"], L["z"], DT, bias=L["bias"]))
+
+    def mlp(self, name, x):
+        return torch.from_numpy(O.fused_gelu_mlp(x.numpy(), self.L[self.p + name + ".net.0.proj"], self.L[self.p + name + ".net.2"], DT))
+
+    @staticmethod
+    def modulate(x, shift, scale, gate):
+        n = r16(F.layer_norm(x, (x.shape[-1],), eps=1e-6))
+        return r16(r16(n * r16(scale + 1.0)[None]) + shift[None]), gate
+
+    @staticmethod
+    def rms(x, w):  # nn.RMSNorm on a 16-bit tensor: fp32 inside, 16-bit out
+        return r16(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float().cpu())
+
+    @staticmethod
+    def rot(x, cs):  # x [T, H, 128], cs [T, 64, (cos, sin)]
+        xf = x.unflatten(-1, (-1, 2))
+        c, s = cs[:, None, :, 0], cs[:, None, :, 1]
+        return r16(torch.stack([xf[..., 0] * c - xf[..., 1] * s, xf[..., 0] * s + xf[..., 1] * c], dim=-1).flatten(-2))
+
+    def forward(self, hidden, enc, temb, img_cs, txt_cs):
+        b = self.b
+        H = b.attn.heads
+        ta = r16(F.silu(temb))
+        im = self.awq("img_mod.1", ta).view(-1, 6).T  # rows: shift1 scale1 gate1 shift2 scale2 gate2
+        tm = self.awq("txt_mod.1", ta).view(-1, 6).T
+        ix, ig1 = self.modulate(hidden, im[0], im[1], im[2])
+        tx, tg1 = self.modulate(enc, tm[0], tm[1], tm[2])
+
+        def stream(x, proj, nq, nk, cs):
+            q, k, v = (t.reshape(-1, H, 128) for t in self.svdq(proj, x).chunk(3, dim=-1))
+            return self.rot(self.rms(q, nq.weight), cs), self.rot(self.rms(k, nk.weight), cs), v
+
+        tq, tk, tv = stream(tx, "attn.add_qkv_proj", b.attn.norm_added_q, b.attn.norm_added_k, txt_cs)
+        iq, ik, iv = stream(ix, "attn.to_qkv", b.attn.norm_q, b.attn.norm_k, img_cs)
+        q, k, v = (torch.cat(p, 0).transpose(0, 1) for p in ((tq, iq), (tk, ik), (tv, iv)))
+        o = r16((torch.softmax(q @ k.transpose(1, 2) / 128 ** 0.5, dim=-1) @ v).transpose(0, 1).reshape(-1, H * 128))
+        tt = enc.shape[0]
+        hidden = r16(hidden + r16(ig1[None] * self.svdq("attn.to_out.0", o[tt:])))
+        enc = r16(enc + r16(tg1[None] * self.svdq("attn.to_add_out", o[:tt])))
+        ix2, ig2 = self.modulate(hidden, im[3], im[4], im[5])
+        hidden = r16(hidden + r16(ig2[None] * self.mlp("img_mlp", ix2)))
+        tx2, tg2 = self.modulate(enc, tm[3], tm[4], tm[5])
+        enc = r16(enc + r16(tg2[None] * self.mlp("txt_mlp", tx2)))
+        return enc, hidden
+
+
+def _block_inputs(dim, t_img, t_txt, seed=1):
+    from nunchaku_amd.models.qwenimage import qwen_rope_freqs
+
+    g = torch.Generator().manual_seed(seed)
+    side = int(t_img ** 0.5)
+    hidden = r16(torch.randn(t_img, dim, generator=g))
+    enc = r16(torch.randn(t_txt, dim, generator=g))
+    temb = r16(torch.randn(1, dim, generator=g))
+    img_f, txt_f = qwen_rope_freqs((1, side, side), t_txt)
+    return hidden, enc, temb, img_f, txt_f
+
+
+@pytest.mark.parametrize("t_txt", [256, 128], ids=["grouped", "separate"])
+def test_qwen_block_matches_the_reference_op_sequence(t_txt):
+    from nunchaku_amd.models.qwenimage import NunchakuQwenAttention, NunchakuQwenImageTransformerBlock
+
+    dim, t_img = 256, 256
+    block = NunchakuQwenImageTransformerBlock(dim, 2, 128, device="cuda").eval()
+    layers = _fill(block, seed=3)
+    hidden, enc, temb, img_f, txt_f = _block_inputs(dim, t_img, t_txt)
+    cs = lambda f: torch.stack([f.real.float(), f.imag.float()], dim=-1)
+    with torch.no_grad():
+        e_ref, h_ref = BlockTwin(block, layers).forward(hidden, enc, temb, cs(img_f), cs(txt_f))
+        outs = {}
+        for fused in (True, False):
+            NunchakuQwenAttention.fused_qkv = fused
+            try:
+                e, h = block(hidden.cuda().bfloat16()[None], enc.cuda().bfloat16()[None], None, temb.cuda().bfloat16(),
+                             (img_f.cuda(), txt_f.cuda()))
+            finally:
+                NunchakuQwenAttention.fused_qkv = True
+            outs[fused] = (e[0].float().cpu(), h[0].float().cpu())
+    for fused, (e, h) in outs.items():
+        for name, got, ref in (("text", e, e_ref), ("image", h, h_ref)):
+            psnr, rel = psnr_rel(got, ref)
+            print(f"qwen block fused={fused} {name}: PSNR {psnr:.1f} dB rel {rel:.2e}")
+            assert torch.isfinite(got).all() and psnr > 45.0 and rel < 2e-2, (fused, name, psnr, rel)
+    # the fused path (QKV epilogue + svdq attention, grouped when t_txt % 256 == 0) against the reference-op path on the GPU
+    for i in range(2):
+        psnr, _ = psnr_rel(outs[True][i], outs[False][i])
+        assert psnr > 45.0
+
+
+def _small_model(layers=4):
+    from nunchaku_amd.models.qwenimage import NunchakuQwenImageTransformer2DModel
+
+    return NunchakuQwenImageTransformer2DModel(num_layers=layers, num_attention_heads=2, attention_head_dim=128, in_channels=64,
+                                               out_channels=16, joint_attention_dim=128, device="cuda").init_synthetic_(seed=5).eval()
+
+
+def test_qwen_model_offload_equals_resident():
+    """set_offload(True): blocks live in pinned host memory, two buffer slots on the GPU, copies on a side stream one block
+    ahead.  Two forwards (the ring wraps) must reproduce the resident model (up to the run-to-run noise of the fp32-atomic
+    low-rank reductions, which two resident runs show as well) -- both when offload is switched on BEFORE
+    the first forward (the host copies keep qweight as 4-bit nibbles, expanded to the FP6 image on the GPU after the copy) and
+    when it is switched on later (the layers are already repacked: the FP6 image itself travels)."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    lat = torch.randn(1, 256, 64, device="cuda", generator=g).bfloat16()
+    enc = torch.randn(1, 256, 128, device="cuda", generator=g).bfloat16()
+    t = torch.tensor([0.6], device="cuda")
+    resident = _small_model(5)
+    with torch.no_grad():
+        ref = [resident(lat, enc, None, t, [(1, 16, 16)]).sample.clone() for _ in range(2)]
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    noise = rel(ref[0], ref[1])  # fp32 atomics (K-sliced low-rank sums) + 4-bit code flips downstream: not bit-reproducible
+    assert noise < 3e-2
+    for late in (False, True):
+        model = resident if late else _small_model(5)  # same seed: same weights
+        with torch.no_grad():
+            model.set_offload(True, num_blocks_on_gpu=2, use_pin_memory=True)
+            mgr = model.offload_manager
+            assert all(not next(b.parameters()).is_cuda for b in mgr.blocks[2:]) and all(next(b.parameters()).is_cuda for b in mgr.blocks[:2])
+            assert all(p.is_pinned() for b in mgr.blocks[2:] for p in b.parameters() if p.numel())
+            fp6 = sum(m.qweight.numel() for m in mgr.buffer_blocks[0].modules() if hasattr(m, "qweight") and m.qweight.dtype == torch.int8)
+            nib = sum(t_.numel() for t_ in mgr._host_nibbles[2].values())
+            # the link carries nibbles (2/3 of the FP6 image bytes) unless the layers had been repacked before
+            assert nib == (0 if late else fp6 * 2 // 3)
+            got = [model(lat, enc, None, t, [(1, 16, 16)]).sample.clone() for _ in range(2)]
+            torch.cuda.synchronize()
+            assert mgr.forward_counter == 2 and mgr.current_block_idx == 0
+        for a, b in zip(got, ref):
+            assert torch.isfinite(a.float()).all() and rel(a, b) <= 3 * noise + 5e-3, f"offloaded forward (late={late}): rel {rel(a, b):.3e} vs noise {noise:.3e}"
+        model.set_offload(False)
+        assert model.offload_manager is None
+
+
+def test_qwen_rope_tables():
+    from nunchaku_amd.models.qwenimage import pack_qwen_rotary, qwen_rope_freqs
+
+    img, txt = qwen_rope_freqs((1, 16, 16), 40)
+    assert img.shape == (256, 64) and txt.shape == (40, 64) and img.dtype == torch.complex64
+    assert torch.allclose(img.abs(), torch.ones(256, 64)) and torch.allclose(txt.abs(), torch.ones(40, 64))
+    # centred positions: row h of the grid carries position h - 8 on the height axis (56 dims = 28 complex, after the 8 of the frame axis)
+    assert torch.allclose(img[8 * 16, 8:36], torch.ones(28, dtype=torch.complex64), atol=1e-6)  # height position 0
+    p = pack_qwen_rotary(img, txt)
+    assert p["img"].shape == (1, 256, 128) and p["txt"].shape == (1, 256, 128) and p["all"].shape == (1, 512, 128)

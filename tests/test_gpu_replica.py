@@ -40,7 +40,7 @@ def _worker(rank, world, port, out):
         y = model(lat, enc, pooled, torch.tensor([0.5], device="cuda"), img_ids, torch.zeros(t_txt, 3, device="cuda"),
                   torch.tensor([3.5], device="cuda")).float()
     torch.cuda.synchronize()
-    out.put((rank, nbytes, y.cpu()))
+    out.put((rank, nbytes, y.cpu().numpy()))  # by value: a torch tensor travels as a shared-memory handle that dies with this process
     replica.barrier()
     dist.destroy_process_group()
 
@@ -61,5 +61,6 @@ def test_two_replicas_agree_after_the_weight_broadcast(built_lib):
         p.join(timeout=120)
         assert p.exitcode == 0
     (_, n0, y0), (_, n1, y1) = res
+    y0, y1 = torch.from_numpy(y0), torch.from_numpy(y1)
     assert n0 == n1 > 0 and torch.isfinite(y0).all()
     assert (y0 - y1).norm() / y0.norm() < 2e-2  # same weights, same inputs; fp32-atomic noise only

@@ -35,7 +35,7 @@ def _worker(rank, world, port, out):
     lin._amd_layout = rank == 0
     if rank == 0:  # the source has already been repacked: qweight is the [out, 3*in/4] FP6 image, the receivers' is [out, in/2]
         lin.qweight.data = torch.randint(-128, 128, (256, 96), dtype=torch.int8)
-    nbytes = replica.broadcast_module_(lin, src=0)
+    nbytes = replica.broadcast_module_(lin, src=0, bucket_bytes=20000)  # several buckets: 24 KB image, 2 KB vectors
     assert tuple(lin.qweight.shape) == (256, 96), "receivers must take the source's (repacked) shape"
     digest = torch.cat([p.detach().view(-1).view(torch.uint8).to(torch.int64) for p in lin.parameters()]).sum().item()
     slow = replica.max_over_ranks(1.0 + rank, "cpu")
