@@ -77,7 +77,7 @@ struct GemmParams {
 #ifdef SVDQ_ABLATE
     int debug;               // timing experiments (tools/ablate): bit0 skip output stores, bit1 skip bias + low-rank up, ...
     long long *clk;          // per workgroup {shader cycles, 100 MHz ticks} of the whole kernel (effective clock probe)
-    long long *trace;        // workgroup 0: shader-cycle stamps {loop start, loop end, epilogue end} per segment (<= 32 segments)
+    long long *trace;        // workgroup 0: shader-cycle stamps {loop start, loop end, after bias+low-rank, after GELU+requant (GELU_QUANT), before the stores, end} per segment (<= 32)
 #endif
     float lora_scales[MAX_LORA_TILES];
 };
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 
 #ifdef SVDQ_ABLATE
         static_assert(true, "");
-        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[3 * seg_no] = __builtin_readcyclecounter() - clk_t0;
+        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no] = __builtin_readcyclecounter() - clk_t0;
 #endif
         if constexpr (LOOPV != 1) {
             // ---- hand-scheduled main loop (generated inline asm, every operand pinned to a physical register;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         }
 
 #ifdef SVDQ_ABLATE
-        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[3 * seg_no + 1] = __builtin_readcyclecounter() - clk_t0;
+        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 1] = __builtin_readcyclecounter() - clk_t0;
 #endif
         // ---- stream-K: publish or collect partial tiles -----------------------------------------------
         bool run_epilogue = true;
@@ -567,6 +567,11 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             lora_mfma(rc, x0, u0);
         }
 
+#ifdef SVDQ_ABLATE
+        asm volatile("" ::: "memory");
+        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 2] = __builtin_readcyclecounter() - clk_t0;
+        asm volatile("" ::: "memory");
+#endif
         // the single rounding to the 16-bit model dtype (the reference's tile is 16-bit from here on).  With the default
         // epilogue nothing but the store follows, and the store's own conversion IS this rounding (same RNE; the fp16
         // clamp commutes with it): skipping the round trip through fp32 saves ~128 VALU instructions per tile.
@@ -724,6 +729,11 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 }
                 if (h == 0) ((T *)p.oscales)[simg_index(m_abs, g2, KP2)] = f2h<T>(scale);
             }
+#ifdef SVDQ_ABLATE
+            asm volatile("" ::: "memory");
+            if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 3] = __builtin_readcyclecounter() - clk_t0;
+            asm volatile("" ::: "memory");
+#endif
             // EpilogueLoraDown for the NEXT layer on the GELU output, before shift/smooth
             // (issued AFTER the requantisation below in program order: vmcnt retires in order on CDNA, so any load
             //  that followed these fp32 atomics would wait for their memory-side round trip)
@@ -783,6 +793,11 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 
         }
 
+#ifdef SVDQ_ABLATE
+        asm volatile("" ::: "memory");
+        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 4] = __builtin_readcyclecounter() - clk_t0;
+        asm volatile("" ::: "memory");
+#endif
         // EpilogueDefault (gemm_base.cuh:667-698): store rows < M; fp16 clamps to +-65504.
         // A lane holds 4 consecutive columns per (tile, c); the partner lane (lane ^ 32) holds the next 4.
         // One v_permlane32_swap per dword turns two 8-byte pieces per lane into one 16-byte piece, so a
@@ -851,7 +866,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         } // FUSE != GELU_QUANT
         } // run_epilogue
 #ifdef SVDQ_ABLATE
-        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[3 * seg_no + 2] = __builtin_readcyclecounter() - clk_t0;
+        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 5] = __builtin_readcyclecounter() - clk_t0;
         seg_no++;
 #endif
         have = have_next;
@@ -938,7 +953,7 @@ using namespace svdq;
 #ifdef SVDQ_ABLATE
 // tools only: device buffer of 2 * grid int64 that every later gemm launch fills with {shader cycles, 100 MHz ticks} per workgroup
 extern "C" void svdq_ablate_set_clk(long long *dev_buf) { g_ablate_clk = dev_buf; }
-// tools only: device buffer of 96 int64: workgroup 0 stamps {loop start, loop end, epilogue end} (shader cycles) per segment
+// tools only: device buffer of 192 int64: workgroup 0 stamps 6 phase boundaries (shader cycles) per segment
 extern "C" void svdq_ablate_set_trace(long long *dev_buf) { g_ablate_trace = dev_buf; }
 #endif
 

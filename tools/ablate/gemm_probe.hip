@@ -165,16 +165,16 @@ int main(int argc, char **argv) {
                 if (n) { cyc = sc / n; eff_ghz = sc / (st_ * 10.0); } // ticks are 10 ns
             }
             if (set_trace && do_trace) { // per-segment phase stamps of workgroup 0
-                long long *tr; CK(hipMalloc((void **)&tr, 96 * sizeof(long long))); CK(hipMemset(tr, 0, 96 * sizeof(long long)));
+                long long *tr; CK(hipMalloc((void **)&tr, 192 * sizeof(long long))); CK(hipMemset(tr, 0, 192 * sizeof(long long)));
                 set_trace(tr);
                 gemm(&a, st);
                 CK(hipStreamSynchronize(st));
                 set_trace(nullptr);
-                long long ht[96];
+                long long ht[192];
                 CK(hipMemcpy(ht, tr, sizeof(ht), hipMemcpyDeviceToHost));
                 printf("{\"trace_variant\":%d,\"segments\":[", v);
-                for (int i = 0; i < 32 && ht[3 * i + 2] > 0; i++)
-                    printf("%s[%lld,%lld,%lld]", i ? "," : "", ht[3 * i], ht[3 * i + 1], ht[3 * i + 2]);
+                for (int i = 0; i < 32 && ht[6 * i + 5] > 0; i++)
+                    printf("%s[%lld,%lld,%lld,%lld,%lld,%lld]", i ? "," : "", ht[6 * i], ht[6 * i + 1], ht[6 * i + 2], ht[6 * i + 3], ht[6 * i + 4], ht[6 * i + 5]);
                 printf("]}\n");
                 CK(hipFree(tr));
             }
