@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 13
+#define SVDQ_ABI_VERSION 14
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -230,9 +230,28 @@ typedef struct svdq_attention_args {
     const void *qsmooth, *qlora_down;   /* [H*128] natural; [R][H*128] rank-major (svdq_repack_lowrank(down=1)) */
     const void *qsmooth2, *qlora_down2;
     int32_t qR, qsplit_rows;
+    /* optional scratch of the persistent schedule (svdq_attention_workspace_bytes() bytes, zero-filled ONCE by the caller;
+     * the kernel leaves its counters at zero).  A task = (head, 256 query rows) x all KV tiles; when the tasks do not fill
+     * whole rounds of compute units (FLUX.1 at 1024^2: 432 tasks on 256 CUs) the launch becomes one workgroup per CU, the
+     * KV tiles of all tasks dealt evenly, partial (O, m, l) exchanged through this buffer.  Same contract as
+     * svdq_gemm_args.workspace: never shared by launches that can be in flight concurrently; a waiting workgroup gives up
+     * after ~1 s and raises the error word svdq_attention_workspace_status() reports.  NULL (or too small): plain grid.
+     * Results of the two schedules differ by fp32 summation order only. */
+    void *workspace;
+    int64_t workspace_bytes;
 } svdq_attention_args;
 
 int svdq_attention(const svdq_attention_args *args, void *stream);
+/* size of the persistent-schedule workspace for the current device (1023 arrival counters + 1 error word + one fp32 slab per CU) */
+int64_t svdq_attention_workspace_bytes(void);
+/* Synchronises `stream`, then returns SVDQ_E_HIP (and clears the flag) if a launch that used `workspace` timed out waiting
+ * for partial results; SVDQ_OK otherwise.  Test / debugging aid. */
+int svdq_attention_workspace_status(void *workspace, void *stream);
+/* Host-side replay of the persistent schedule for (L, H) on `cus` compute units: up to `cap` records of 6 int32
+ * {workgroup, task = head * (L/256) + query tile, first KV tile, end KV tile, owner workgroup or -1 (this segment owns its
+ * task), last contributing workgroup or -1 (no other contributor)}; returns the number of segments, 0 when the problem runs
+ * on the plain grid (L % 256 != 0 or whole rounds of tasks), -1 on bad arguments.  No GPU needed. */
+int svdq_attention_schedule(int32_t L, int32_t H, int32_t cus, int32_t *out, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * Gated residual + LayerNorm statistics (extension; the element-wise glue between the operators of a block,

@@ -35,23 +35,27 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-_workspaces: dict[tuple[int, int], torch.Tensor] = {}
+_workspaces: dict[tuple[int, int, str], torch.Tensor] = {}
 
 
-def _workspace(device: torch.device) -> torch.Tensor:
-    """Scratch of the GEMM's stream-K tail (arrival counters + fp32 partial tiles), one per (device, STREAM).
+def _workspace(device: torch.device, kind: str = "gemm") -> torch.Tensor:
+    """Scratch of the GEMM's stream-K tail (arrival counters + fp32 partial tiles) or, ``kind="attention"``, of the
+    attention kernel's persistent schedule (counters + fp32 partial (O, m, l)); one per (device, STREAM, kind).
 
     The C ABI allows a workspace to be reused only by launches that are ordered on one stream (include/svdq_amd.h,
     ``svdq_gemm_args.workspace``): two GEMMs in flight on different streams of a device would share counters and
     partial-tile slabs.  So the buffer is keyed by the current stream's handle: side streams (the offload manager's
-    schedule, a capturing stream, worker threads with their own streams) each get their own 64 MB buffer on first use,
-    allocated from the torch caching allocator, zero-filled once; the kernel leaves the counters at zero."""
+    schedule, a capturing stream, worker threads with their own streams) each get their own 64 MB (GEMM) / 33 MB
+    (attention) buffer on first use, allocated from the torch caching allocator, zero-filled once; the kernels leave the
+    counters at zero."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, _stream())
+    key = (idx, _stream(), kind)
     ws = _workspaces.get(key)
     if ws is None:
+        lib = _lib.load()
+        size = lib.svdq_attention_workspace_bytes() if kind == "attention" else lib.svdq_gemm_workspace_bytes()
         with torch.cuda.device(idx):
-            ws = torch.zeros(int(_lib.load().svdq_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
+            ws = torch.zeros(int(size), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 
@@ -146,10 +150,20 @@ class _Ops:
     def gemm_workspace_status() -> None:
         """Synchronise the current stream and raise ``RuntimeError`` if a stream-K GEMM on it timed out waiting for
         partial tiles (a workspace shared across streams -- see ``_workspace``).  Test / debugging aid."""
-        key = (torch.cuda.current_device(), _stream())
+        key = (torch.cuda.current_device(), _stream(), "gemm")
         ws = _workspaces.get(key)
         if ws is not None:
             _lib.check(_lib.load().svdq_gemm_workspace_status(ws.data_ptr(), _stream()), "gemm_workspace_status")
+
+    # False: plain grid (one workgroup per task) instead of the persistent schedule; tests compare the two
+    attention_use_workspace = True
+
+    @staticmethod
+    def attention_workspace_status() -> None:
+        """Raises if an attention launch on the current stream gave up waiting for partial results.  Test / debugging aid."""
+        ws = _workspaces.get((torch.cuda.current_device(), _stream(), "attention"))
+        if ws is not None:
+            _lib.check(_lib.load().svdq_attention_workspace_status(ws.data_ptr(), _stream()), "attention_workspace_status")
 
     @staticmethod
     def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False,
@@ -506,6 +520,9 @@ class _Ops:
             if not zero.is_cuda or not zero.is_contiguous() or (zero.numel() * zero.element_size()) % 16:
                 raise ValueError("attention: zero must be a contiguous GPU tensor of a multiple of 16 bytes")
             a.zero_ptr, a.zero_bytes = zero.data_ptr(), zero.numel() * zero.element_size()
+        if _Ops.attention_use_workspace and L % 256 == 0:
+            ws = _workspace(q.device, "attention")
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(lib.svdq_attention(C.byref(a), _stream()), "attention")
 
 

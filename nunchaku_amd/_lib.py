@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class QuantizeArgs(C.Structure):
@@ -66,7 +66,7 @@ class AttentionArgs(C.Structure):
         ("scale", C.c_float), ("reserved", C.c_int32), ("zero_ptr", C.c_void_p), ("zero_bytes", C.c_int64),
         ("qact", C.c_void_p), ("qscales", C.c_void_p), ("qlora_act", C.c_void_p), ("qsmooth", C.c_void_p),
         ("qlora_down", C.c_void_p), ("qsmooth2", C.c_void_p), ("qlora_down2", C.c_void_p), ("qR", C.c_int32),
-        ("qsplit_rows", C.c_int32),
+        ("qsplit_rows", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -88,6 +88,9 @@ EXPORTS = {
     "svdq_residual_gate_stats": (C.c_int, [C.POINTER(ResidualArgs), C.c_void_p]),
     "svdq_gemm_workspace_bytes": (C.c_int64, []),
     "svdq_gemm_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "svdq_attention_workspace_bytes": (C.c_int64, []),
+    "svdq_attention_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "svdq_attention_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_repack_qweight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_repack_wscales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -17,6 +17,14 @@
 // online softmax is lane-local plus one lane^32 exchange; P is packed to 16-bit with v_cvt_pk + one
 // v_permlane32_swap per dword into exactly the B-operand fragments of the PV MFMA (O^T = V^T P^T), whose
 // accumulator again has the query along the lanes -- the running rescale is a per-lane scalar.
+//
+// Schedule.  A task = (head, 256 query rows) x all L/64 KV tiles.  FLUX.1 at 1024^2: 24 heads x 18 = 432 tasks on 256 CUs =
+// 1.69 rounds of workgroups, the second round 69 % full.  With a workspace the launch is PERSISTENT instead: one workgroup
+// per CU, the linear (task, KV tile) space is dealt evenly (121.5 tiles each, cut at even tile indices), a workgroup's run
+// is cut at task boundaries into segments.  The workgroup holding a task's FIRST tiles owns it: the others publish their
+// un-normalised (O, m, l) -- a lane-for-lane image of the registers, fp32 -- through the workspace, the owner folds them in
+// (ascending workgroup order: deterministic) and runs the epilogue.  Logical workgroup g = (blockIdx % 8) * G/8 + blockIdx / 8:
+// the workgroups of one XCD take neighbouring runs, i.e. the same few heads, so K / V^T stream through that XCD's L2 once.
 #include "svdq_common.h"
 #include <type_traits>
 
@@ -41,6 +49,42 @@ struct AttnParams {
     float *qlora_act;
     const uint16_t *qsmooth, *qlora_down, *qsmooth2, *qlora_down2;
     int qR, qsplit_rows;
+    // persistent schedule (svdq_attention_args.workspace): arrival counters + error word, then one slab per workgroup
+    int *ws_flags;
+    float *ws_slabs;
+};
+
+constexpr int ATT_SLAB_O = 8 * 16 * 64 * 4;            // floats: [wave][j][lane][4] image of o
+constexpr int ATT_SLAB_FLOATS = ATT_SLAB_O + 8 * 64 * 2; // + [wave][lane]{m, l}
+constexpr int ATT_WS_HEADER = 4096;                    // bytes: 1023 arrival counters + error word
+constexpr int ATT_ERR_WORD = 1023;
+constexpr int ATT_SPIN_LIMIT = 1 << 22;                // x s_sleep(8) ~ 1 s: a broken workspace contract, not a slow peer
+// rescale the running output only when some row's maximum grew by more than this (in log2 units, i.e. after the
+// scale*log2(e) factor): until then P = exp2(s - m_stale) <= 2^8, exact in fp32 and with the same RELATIVE rounding
+// in the 16-bit P fragments; later tiles almost never rescale (64 multiplies + exp per wave-tile saved)
+#ifndef SVDQ_ATT_THR
+#define SVDQ_ATT_THR 8.0f
+#endif
+constexpr float ATT_DEFER_LOG2 = SVDQ_ATT_THR;
+
+// The persistent schedule's arithmetic, shared by the kernel and its host replay (svdq_attention_schedule).
+// Linear position = task * ntiles + KV tile; workgroup i runs [bound(i), bound(i + 1)), cut at even tiles.
+struct AttnSchedule {
+    int ntiles, G;
+    long long half_total; // tasks * ntiles / 2
+    __host__ __device__ int bound(int i) const { return (int)(half_total * i / G) * 2; }
+    // the workgroup < g whose run holds the FIRST tile of `task` (g's own first segment starts inside that task)
+    __host__ __device__ int owner_of(int g, int task) const {
+        int o = g - 1;
+        while (bound(o) > task * ntiles) o--;
+        return o;
+    }
+    // the workgroup > g whose run holds the LAST tile of `task` (g's last segment starts the task but does not finish it)
+    __host__ __device__ int last_contributor(int g, int task) const {
+        int last = g + 1;
+        while (bound(last + 1) < (task + 1) * ntiles) last++;
+        return last;
+    }
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -52,9 +96,18 @@ template <int DT> __device__ __forceinline__ unsigned pack2(float a, float b) {
     else return __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a, b}, f16x2));
 }
 
+// l += the two 16-bit values of `packed` (v_dot2c_f32_bf16 / v_dot2c_f32_f16 against (1, 1)): the row sum is taken over the
+// ROUNDED probabilities, the same numbers the PV MFMA multiplies -- their rounding error cancels in O / l (a row dominated
+// by one key returns that key's value exactly, whatever reference point the exponentials use)
+template <int DT> __device__ __forceinline__ float sum2(unsigned packed, float l) {
+    if constexpr (DT == SVDQ_BF16) return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), __builtin_bit_cast(bf16x2, 0x3f803f80u), l, false);
+    else return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, packed), __builtin_bit_cast(f16x2, 0x3c003c00u), l, false);
+}
+
 // NW waves = NW * 32 query rows of one head per workgroup.  DBG: ablation bits (bench only).
-template <int DT, int NW, int DBG>
+template <int DT, int NW, int DBG, bool PERSIST>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnParams p) {
+    static_assert(!PERSIST || NW == 8, "the persistent schedule is built for the 8-wave workgroup");
     using V8 = typename Half<DT>::V8;
     constexpr int NT = NW * 64;          // threads
     constexpr int PIECES = 1024 / NT;    // 16-byte pieces of each of K and V^T a thread stages per tile
@@ -65,20 +118,17 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y;
-    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
     for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * NT + tid; i < p.zero_vec; i += (long long)gridDim.x * gridDim.y * NT)
         p.zero_ptr[i] = v4i{0, 0, 0, 0}; // side job: clear the next quantiser's low-rank accumulators
-    const uint8_t *kbase = (const uint8_t *)(p.k + (size_t)head * p.k_hs);
-    const uint8_t *vtbase = (const uint8_t *)(p.vt + (size_t)head * p.vt_hs);
 
-    // ---- Q fragments: B operand of S^T = K Q^T, lane (q = lr, d = 16*ds + 8h .. +7) -----------------------
-    V8 qf[8];
-    {
-        const uint16_t *qrow = p.q + (size_t)(q0 + lr) * p.ldq + (size_t)head * p.q_hs + 8 * h;
-#pragma unroll
-        for (int ds = 0; ds < 8; ds++) qf[ds] = *reinterpret_cast<const V8 *>(qrow + 16 * ds);
-    }
+    // ---- this workgroup's run of the linear (task, KV tile) space ---------------------------------------------
+    const int ntiles = p.L / ATT_KB; // even: L is a multiple of 128
+    const int QT = p.L / (NW * 32);  // tasks per head
+    const int G = PERSIST ? (int)gridDim.x : 1;
+    const int g = !PERSIST ? 0 : (G % 8 == 0 ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x);
+    const AttnSchedule sched{ntiles, G, (long long)p.H * QT * ntiles / 2}; // runs start at even tiles (the loop is unrolled by 2)
+    const int run_lo = PERSIST ? sched.bound(g) : ((int)blockIdx.y * QT + (int)blockIdx.x) * ntiles;
+    const int run_hi = PERSIST ? sched.bound(g + 1) : run_lo + ntiles;
 
     // ---- tile staging: 1024 16-byte pieces per matrix per tile, PIECES per thread; XOR-swizzled so that the
     //      16 lanes a ds_read_b128 serves per LDS cycle hit 16 different 16-byte columns.  All per-thread
@@ -101,6 +151,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) va[ks] = ATT_TILE + lr * 128 + (((2 * ks + h) ^ ((lr >> 1) & 7)) << 4);
 
+    const uint8_t *kbase = nullptr, *vtbase = nullptr; // K / V^T of the current segment's head
     v4i kreg[PIECES], vreg[PIECES];
     auto load_tile = [&](int kv0) {
         const uint8_t *kt = kbase + (size_t)kv0 * p.ldk * 2; // wave-uniform
@@ -119,19 +170,12 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
         }
     };
 
+    V8 qf[8];
     v16f o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; dt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) o[dt][r] = 0.f;
     float m_run = -INFINITY; // running row max, raw score units (shared by the two lanes of a query row)
-    v2f l2 = {0.f, 0.f};     // this lane's share of the row sum, as two partial sums (v_pk_add_f32)
+    v2f l2 = {0.f, 0.f};     // this lane's share of the row sum, as two partial sums (two independent v_dot2c chains)
     const float c = p.scale_log2e;
-
-    const int ntiles = p.L / ATT_KB; // even: L is a multiple of 128
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    int j_end = 0;           // end of the current segment's KV tiles
 
     auto step = [&](auto bufc, int j) {
         constexpr int BUF = (DBG & 2) ? 0 : decltype(bufc)::value;
@@ -153,7 +197,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             }
         }
 
-        if (j + 1 < ntiles && !(DBG & 2)) load_tile((j + 1) * ATT_KB); // in flight under the softmax and the PV MFMAs
+        if (j + 1 < j_end && !(DBG & 2)) load_tile((j + 1) * ATT_KB); // in flight under the softmax and the PV MFMAs
 
         // ---- online softmax: lane holds 32 of the 64 scores of query row lr (the partner lane the others) --
         float mloc = fmaxf(s[0][0], s[1][0]);
@@ -162,10 +206,18 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             mloc = fmaxf(fmaxf(mloc, s[0][r]), r + 1 < 16 ? s[0][r + 1] : s[0][r]);
             mloc = fmaxf(fmaxf(mloc, s[1][r]), r + 1 < 16 ? s[1][r + 1] : s[1][r]);
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        // rescale only when some row of this wave has a new maximum (exactly equivalent to rescaling always:
-        // alpha = 1 otherwise); later tiles mostly skip the 64 multiplies
-        if (__builtin_amdgcn_ballot_w64(mloc > m_run) != 0) {
+        {   // the partner lane (lane ^ 32) holds the other 32 scores of the row: one v_permlane32_swap, no LDS round trip
+            // (the second result goes through an empty asm statement: this LLVM folds a floating-point max / compare of the
+            //  swap's two results to the first one -- integer uses, as in the P packing below, are fine)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
+            unsigned other = sw[1];
+            asm volatile("" : "+v"(other));
+            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, other));
+        }
+        // rescale only when some row of this wave outgrew its running maximum by more than ATT_DEFER_LOG2 (m_run = -inf on
+        // the first tile: always).  A stale maximum is still a valid reference point of the online softmax: O and l carry
+        // the same factor and it cancels in the final division.
+        if (__builtin_amdgcn_ballot_w64((mloc - m_run) * c > ATT_DEFER_LOG2) != 0) {
             const float m_new = fmaxf(m_run, mloc);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c); // 0 on the first tile (m_run = -inf)
             m_run = m_new;
@@ -181,7 +233,6 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             for (int r = 0; r < 16; r += 2) {
                 v2f t = __builtin_elementwise_fma((v2f){s[kt][r], s[kt][r + 1]}, c2, mc2);
                 if constexpr (!(DBG & 1)) { t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]); }
-                l2 += t;
                 s[kt][r] = t[0];
                 s[kt][r + 1] = t[1];
             }
@@ -197,6 +248,13 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             for (int d2 = 0; d2 < 2; d2++) {
                 x[d2] = pack2<DT>(s[kt][r0 + 2 * d2], s[kt][r0 + 2 * d2 + 1]);
                 y[d2] = pack2<DT>(s[kt][r0 + 4 + 2 * d2], s[kt][r0 + 4 + 2 * d2 + 1]);
+#ifdef SVDQ_ATT_OLD_LSUM
+                l2[0] += (s[kt][r0 + 2 * d2] + s[kt][r0 + 2 * d2 + 1]);
+                l2[1] += (s[kt][r0 + 4 + 2 * d2] + s[kt][r0 + 4 + 2 * d2 + 1]);
+#else
+                l2[0] = sum2<DT>(x[d2], l2[0]); // this lane's own 4 probabilities, before the exchange
+                l2[1] = sum2<DT>(y[d2], l2[1]);
+#endif
                 auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
                 x[d2] = sw[0];
                 y[d2] = sw[1];
@@ -217,16 +275,97 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             }
         }
 
-        if (j + 1 < ntiles && !(DBG & 2)) store_tile((BUF ^ 1) * 2 * ATT_TILE); // that buffer was last read in iteration j-1
+        if (j + 1 < j_end && !(DBG & 2)) store_tile((BUF ^ 1) * 2 * ATT_TILE); // that buffer was last read in iteration j-1
         if constexpr (!(DBG & 4)) __syncthreads();
     };
-    for (int j = 0; j < ntiles; j += 2) {
-        step(std::integral_constant<int, 0>{}, j);
-        step(std::integral_constant<int, 1>{}, j + 1);
-    }
+    for (int pos = run_lo; pos < run_hi;) {
+        // ---- one segment: KV tiles [j0, j1) of one task ------------------------------------------------------
+        const int task = pos / ntiles, j0 = pos - task * ntiles;
+        const int j1 = min(ntiles, j0 + (run_hi - pos));
+        pos += j1 - j0;
+        const int head = task / QT;
+        const int q0 = (task - head * QT) * (NW * 32) + wave * 32;
+        kbase = (const uint8_t *)(p.k + (size_t)head * p.k_hs);
+        vtbase = (const uint8_t *)(p.vt + (size_t)head * p.vt_hs);
+        {   // Q fragments: B operand of S^T = K Q^T, lane (q = lr, d = 16*ds + 8h .. +7)
+            const uint16_t *qrow = p.q + (size_t)(q0 + lr) * p.ldq + (size_t)head * p.q_hs + 8 * h;
+#pragma unroll
+            for (int ds = 0; ds < 8; ds++) qf[ds] = *reinterpret_cast<const V8 *>(qrow + 16 * ds);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[dt][r] = 0.f;
+        m_run = -INFINITY;
+        l2 = v2f{0.f, 0.f};
+        j_end = j1;
+        load_tile(j0 * ATT_KB);
+        store_tile(0); // every wave passed the barrier that ends the previous segment's last step: both buffers are free
+        __syncthreads();
+        for (int j = j0; j < j1; j += 2) { // j1 - j0 is even
+            step(std::integral_constant<int, 0>{}, j);
+            step(std::integral_constant<int, 1>{}, j + 1);
+        }
+        float l_run = l2[0] + l2[1];
+
+        if constexpr (PERSIST) {
+            typedef __attribute__((address_space(1))) int gint; // explicit global address space: no flat aperture checks
+            typedef __attribute__((address_space(1))) v4f gv4f;
+            typedef __attribute__((address_space(1))) v2f gv2f;
+            gint *flags = (gint *)p.ws_flags;
+            if (j0 > 0) {
+                // ---- not the owner: publish the raw state (16 coalesced 1 KiB stores per wave + {m, l}), make it visible
+                //      at agent scope, bump the owner's arrival counter.  At most one such segment per workgroup (its first).
+                float *slab = p.ws_slabs + (size_t)g * ATT_SLAB_FLOATS;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const v4f v = {o[j >> 2][(j & 3) * 4 + 0], o[j >> 2][(j & 3) * 4 + 1], o[j >> 2][(j & 3) * 4 + 2], o[j >> 2][(j & 3) * 4 + 3]};
+                    *(gv4f *)(slab + ((size_t)(wave * 16 + j) * 64 + lane) * 4) = v;
+                }
+                *(gv2f *)(slab + ATT_SLAB_O + (size_t)(wave * 64 + lane) * 2) = v2f{m_run, l_run};
+                const int owner = sched.owner_of(g, task);
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(flags + owner, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                continue;
+            }
+            if (j1 < ntiles) {
+                // ---- owner of a split task: fold in the segments of the workgroups g+1 .. last (they hold the rest of
+                //      the task: the last one at the START of its run, any in between as their WHOLE run)
+                const int last = sched.last_contributor(g, task);
+                if (tid == 0) {
+                    // Bounded wait (~1 s): a missing arrival can only come from a broken contract (the workspace shared by
+                    // launches in flight on two streams, or not zero-filled).  Then give up instead of hanging the GPU:
+                    // raise the sticky error word svdq_attention_workspace_status() reports; this task's rows are garbage.
+                    int spins = 0;
+                    while (__hip_atomic_load(flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < last - g && ++spins < ATT_SPIN_LIMIT)
+                        __builtin_amdgcn_s_sleep(8);
+                    if (spins >= ATT_SPIN_LIMIT) __hip_atomic_store(flags + ATT_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(flags + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                for (int q = g + 1; q <= last; q++) {
+                    const float *slab = p.ws_slabs + (size_t)q * ATT_SLAB_FLOATS;
+                    const v2f ml = __builtin_nontemporal_load((const gv2f *)(slab + ATT_SLAB_O + (size_t)(wave * 64 + lane) * 2));
+                    const float m_new = fmaxf(m_run, ml[0]);
+                    const float fa = __builtin_amdgcn_exp2f((m_run - m_new) * c), fb = __builtin_amdgcn_exp2f((ml[0] - m_new) * c);
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)(wave * 16 + j) * 64 + lane) * 4));
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o[j >> 2][(j & 3) * 4 + e] = o[j >> 2][(j & 3) * 4 + e] * fa + v[e] * fb;
+                    }
+                    l_run = l_run * fa + ml[1] * fb;
+                    m_run = m_new;
+                }
+            }
+        }
 
     // ---- normalise and store: lane owns query row q0 + lr and channels 32*dt + 8c + 4h + e ------------------
-    const float l_run = l2[0] + l2[1];
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
     if (p.qact) {
         // ---- fused quantiser of the output projection (quantize.hip, same arithmetic): this wave's 32 rows x 128
@@ -308,7 +447,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
         *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[8], rec[9], rec[10], rec[11]);
         p.qscales[(((size_t)rt * KP + head) * 2 + h) * 32 + lr] = hbits(sc16[h]);
     }
-    if (!p.out) return;
+    if (p.out) {
     uint16_t *orow = p.out + (size_t)(q0 + lr) * p.ldo + (size_t)head * p.o_hs + 8 * h;
 #pragma unroll
     for (int dt = 0; dt < 4; dt++)
@@ -325,16 +464,90 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             }
             *reinterpret_cast<v4i *>(orow + 32 * dt + 16 * j2) = v4i{(int)x[0], (int)x[1], (int)y[0], (int)y[1]};
         }
+    } // p.out
+    } // segments
 }
 
 template <int DT, int NW, int DBG> static void launch_attention(const AttnParams &p, hipStream_t st) {
     dim3 grid(p.L / (NW * 32), p.H), block(NW * 64);
-    hipLaunchKernelGGL((attention_kernel<DT, NW, DBG>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((attention_kernel<DT, NW, DBG, false>), grid, block, 0, st, p);
+}
+template <int DT> static void launch_attention_persistent(const AttnParams &p, int groups, hipStream_t st) {
+    hipLaunchKernelGGL((attention_kernel<DT, 8, 0, true>), dim3(groups), dim3(512), 0, st, p);
+}
+
+// workgroups of the persistent schedule: one per CU (64 KiB of LDS and 8 waves of ~230 VGPRs: exactly one is resident per CU)
+static int attention_cus() {
+    static int cus = 0; // benign race: every thread computes the same value
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        if (n > 1016) n = 1016; // the workspace header holds 1023 arrival counters
+        cus = n >= 8 ? (n / 8) * 8 : n;
+    }
+    return cus;
+}
+static int attention_groups_for(int L, int H, int cus);
+// Persistent or plain grid?  Whole rounds of tasks need no split (and no partial traffic); otherwise deal the KV tiles of
+// all tasks evenly to min(CUs, tiles/2) workgroups, a multiple of 8 (XCD-aware numbering).  0 = plain grid.
+static int attention_groups(const AttnParams &p) { return p.ws_flags ? attention_groups_for(p.L, p.H, attention_cus()) : 0; }
+static int attention_groups_for(int L, int H, int cus) {
+    if (L % 256) return 0;
+    const long long tasks = (long long)H * (L / 256), half = tasks * (L / ATT_KB) / 2;
+    if (tasks % cus == 0) return 0;
+    long long gs = half < cus ? half : cus;
+    if (gs >= 8) gs = gs / 8 * 8;
+    return gs >= 2 ? (int)gs : 0;
 }
 
 } // namespace svdq
 
 using namespace svdq;
+
+extern "C" int64_t svdq_attention_workspace_bytes(void) { return ATT_WS_HEADER + (int64_t)attention_cus() * ATT_SLAB_FLOATS * 4; }
+
+extern "C" int svdq_attention_workspace_status(void *workspace, void *stream) {
+    if (!workspace) { set_error("svdq_attention_workspace_status: workspace is NULL"); return SVDQ_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    int word = 0;
+    int *dev = reinterpret_cast<int *>(workspace) + ATT_ERR_WORD;
+    if (hip_check(hipMemcpyAsync(&word, dev, sizeof(int), hipMemcpyDeviceToHost, st), "svdq_attention_workspace_status copy")) return SVDQ_E_HIP;
+    if (hip_check(hipStreamSynchronize(st), "svdq_attention_workspace_status sync")) return SVDQ_E_HIP;
+    if (word != 0) {
+        (void)hipMemsetAsync(dev, 0, sizeof(int), st);
+        set_error("svdq_attention: a task owner timed out waiting for partial results -- the workspace was used by launches in "
+                  "flight on more than one stream (or was not zero-filled); results of those launches are invalid");
+        return SVDQ_E_HIP;
+    }
+    return SVDQ_OK;
+}
+
+// Host-side replay of the persistent schedule (the same AttnSchedule code the kernel runs): for (L, H) on `cus` compute units
+// write up to `cap` records {workgroup, task, j0, j1, owner-or-minus-one, last-contributor-or-minus-one} and return the
+// number of segments; 0 = this problem runs on the plain grid; -1 = bad arguments.
+extern "C" int svdq_attention_schedule(int32_t L, int32_t H, int32_t cus, int32_t *out, int32_t cap) {
+    if (L <= 0 || L % 128 || H <= 0 || cus <= 0 || cus > 1016) return -1;
+    const int G = attention_groups_for(L, H, cus >= 8 ? cus / 8 * 8 : cus);
+    if (G == 0) return 0;
+    const int ntiles = L / ATT_KB, QT = L / 256;
+    const AttnSchedule sched{ntiles, G, (long long)H * QT * ntiles / 2};
+    int n = 0;
+    for (int g = 0; g < G; g++)
+        for (int pos = sched.bound(g), hi = sched.bound(g + 1); pos < hi;) {
+            const int task = pos / ntiles, j0 = pos - task * ntiles;
+            const int j1 = ntiles < j0 + (hi - pos) ? ntiles : j0 + (hi - pos);
+            pos += j1 - j0;
+            if (out && n < cap) {
+                int32_t *r = out + 6 * n;
+                r[0] = g; r[1] = task; r[2] = j0; r[3] = j1;
+                r[4] = j0 > 0 ? sched.owner_of(g, task) : -1;
+                r[5] = j0 == 0 && j1 < ntiles ? sched.last_contributor(g, task) : -1;
+            }
+            n++;
+        }
+    return n;
+}
 
 extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     if (!a) { set_error("svdq_attention: args is NULL"); return SVDQ_E_INVALID; }
@@ -377,6 +590,15 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.qR = a->qR; p.qsplit_rows = a->qsmooth2 ? a->qsplit_rows : 0;
     p.zero_ptr = (v4i *)a->zero_ptr;
     p.zero_vec = a->zero_ptr ? a->zero_bytes / 16 : 0;
+    p.ws_flags = nullptr;
+    p.ws_slabs = nullptr;
+    if (a->workspace) {
+        if (((uintptr_t)a->workspace & 15) || a->workspace_bytes < 0) { set_error("svdq_attention: workspace must be 16-byte aligned"); return SVDQ_E_INVALID; }
+        if (a->workspace_bytes >= svdq_attention_workspace_bytes()) { // a smaller one is ignored (plain grid), as in svdq_gemm_w4a4
+            p.ws_flags = (int *)a->workspace;
+            p.ws_slabs = (float *)((uint8_t *)a->workspace + ATT_WS_HEADER);
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
 #ifdef SVDQ_ABLATE
     // tools-built ablation library only: reserved = wave-count override << 8 | ablation variant (results are garbage)
@@ -384,6 +606,9 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     if ((nw != 4 && nw != 8) || a->L % (nw * 32)) { set_error("svdq_attention: bad wave-count override %d", nw); return SVDQ_E_INVALID; }
     p.debug = a->reserved & 0xff;
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
+    if (a->reserved == 0 && attention_groups(p) > 0) {
+        if (a->dtype == SVDQ_FP16) launch_attention_persistent<SVDQ_FP16>(p, attention_groups(p), st); else launch_attention_persistent<SVDQ_BF16>(p, attention_groups(p), st);
+    } else
     if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8, 0>(p, st); else launch_attention<SVDQ_FP16, 4, 0>(p, st); }
     else if (nw == 4) {
         switch (p.debug) { // non-zero: ablations (bf16 only), timing experiments, results are garbage
@@ -417,8 +642,10 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     if (a->reserved != 0) { set_error("svdq_attention: reserved must be 0 (timing ablations live in tools/ablate, not in this library)"); return SVDQ_E_INVALID; }
     p.debug = 0;
     const int nw = a->L % 256 == 0 ? 8 : 4;
+    const int groups = attention_groups(p);
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
-    if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8, 0>(p, st); else launch_attention<SVDQ_FP16, 4, 0>(p, st); }
+    if (groups > 0) { if (a->dtype == SVDQ_FP16) launch_attention_persistent<SVDQ_FP16>(p, groups, st); else launch_attention_persistent<SVDQ_BF16>(p, groups, st); }
+    else if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8, 0>(p, st); else launch_attention<SVDQ_FP16, 4, 0>(p, st); }
     else if (nw == 8) launch_attention<SVDQ_BF16, 8, 0>(p, st);
     else launch_attention<SVDQ_BF16, 4, 0>(p, st);
 #endif

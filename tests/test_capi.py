@@ -37,7 +37,7 @@ def test_struct_sizes_match_header(built_lib):
     assert C.sizeof(_lib.QuantizeArgs) == 6 * 8 + 8 * 4 + 3 * 8 + 6 * 8 + 4 * 4  # + LN front end, second set, M2/ldx2/split_rows/lora_act_zeroed
     assert C.sizeof(_lib.ResidualArgs) == 6 * 8 + 6 * 4 + 8 + 8 + 6 * 8 + 2 * 4  # + zero_ptr, zero_bytes, second problem
     assert C.sizeof(_lib.GemmArgs) == 17 * 8 + 12 * 4 + 2 * 8 + 8 + 2 * 4 + 8 * 8 + 2 * 4  # + workspace(+bytes), out_vt, ldvt, second weight set, split_rows
-    assert C.sizeof(_lib.AttentionArgs) == 4 * 8 + 4 * 8 + 8 * 4 + 4 + 4 + 8 + 8 + 7 * 8 + 2 * 4  # + zero_ptr/bytes, fused quantiser
+    assert C.sizeof(_lib.AttentionArgs) == 4 * 8 + 4 * 8 + 8 * 4 + 4 + 4 + 8 + 8 + 7 * 8 + 2 * 4 + 2 * 8  # + zero_ptr/bytes, fused quantiser, workspace(+bytes)
     assert C.sizeof(_lib.GemvAwqArgs) == 6 * 8 + 6 * 4 + 2 * 4  # + out_chunks, reserved
 
 

@@ -53,6 +53,39 @@ def test_attention_matches_fp32_reference(dtype, L, H):
     assert err <= 1.5 * err_sdpa + 1e-6, f"attention error {err:.3g} vs torch 16-bit SDPA {err_sdpa:.3g}"
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("L,H", [(256, 3), (1024, 3), (512, 130), (4608, 24)])
+def test_attention_persistent_schedule_matches_plain_grid(dtype, L, H):
+    """With a workspace the launch is persistent (one workgroup per CU, tasks split along the keys, partial (O, m, l) merged
+    by the task's owner: 2 workgroups per task at (256, 3), 8 at (1024, 3), the FLUX.1 case last).  Same result as the
+    plain grid up to fp32 summation order, bit-reproducible from launch to launch, counters left at zero."""
+    from nunchaku_amd import _lib
+    from nunchaku_amd._C import ops
+    from nunchaku_amd.ops.attention import attention_packed
+
+    assert _lib.load().svdq_attention_schedule(L, H, 256, None, 0) > 0  # this shape does take the persistent path
+    td = TORCH_DT[dtype]
+    g = torch.Generator(device="cuda").manual_seed(L * 7 + H)
+    qkv = torch.randn(L, 3 * H * 128, device="cuda", generator=g).to(td)
+    qkv[: L // 2, : H * 128] *= 4.0
+    vt = qkv[:, 2 * H * 128:].t().contiguous()
+    try:
+        ops.attention_use_workspace = False
+        plain = attention_packed(qkv, vt, H)
+    finally:
+        ops.attention_use_workspace = True
+    runs = [attention_packed(qkv, vt, H) for _ in range(3)]
+    ops.attention_workspace_status()
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11
+    diff = (runs[0].float() - plain.float()).abs().max().item()
+    assert diff <= 2 * ulp * plain.float().abs().max().item(), f"persistent vs plain grid: {diff:.3g}"
+    if L * H <= 70000:
+        q, k, v = (qkv[:, i * H * 128:(i + 1) * H * 128].unflatten(1, (H, 128)) for i in range(3))
+        ref = _ref_attention(q, k, v).reshape(L, H * 128)
+        assert (runs[0].float() - ref).abs().max().item() <= 3 * ulp * ref.abs().max().item()
+
+
 def test_attention_strided_heads_and_errors():
     from nunchaku_amd._C import ops
 
@@ -230,6 +263,9 @@ def test_reference_fp16_attention_operators():
             a1, c1 = proc(joint, x, e, image_rotary_emb=(rot_img, rot_txt))
             s0 = proc_ref(single, torch.cat([e, x], 1), image_rotary_emb=rot_all)
             s1 = proc(single, torch.cat([e, x], 1), image_rotary_emb=rot_all)
+    # The outputs pass through the W4A4 output projection: attention results that differ in the last bit (different kernels'
+    # summation order) flip a few 4-bit codes, so single elements move by a few per cent of the maximum while the bulk agrees.
     for got, ref in ((a1, a0), (c1, c0), (s1, s0)):
         err = (got.float() - ref.float()).abs().max().item()
-        assert torch.isfinite(got.float()).all() and err <= 2e-2 * ref.float().abs().max().item() + 1e-3, err
+        rel = ((got.float() - ref.float()).norm() / ref.float().norm()).item()
+        assert torch.isfinite(got.float()).all() and rel <= 1e-2 and err <= 4e-2 * ref.float().abs().max().item() + 1e-3, (err, rel)

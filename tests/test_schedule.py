@@ -64,3 +64,63 @@ def test_invalid_shapes_are_rejected():
     lib = _lib.load()
     assert lib.svdq_gemm_schedule(100, 128, 128, 256, 0, None, 0) == -1
     assert lib.svdq_gemm_schedule(256, 128, 64, 256, 0, None, 0) == -1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# svdq_attention's persistent schedule (attention.hip: AttnSchedule), replayed on the host by the same code
+# ---------------------------------------------------------------------------------------------------------------------
+def _attn_schedule(L, H, cus):
+    lib = _lib.load()
+    n = lib.svdq_attention_schedule(L, H, cus, None, 0)
+    if n <= 0:
+        return n, None
+    buf = (C.c_int32 * (6 * n))()
+    assert lib.svdq_attention_schedule(L, H, cus, buf, n) == n
+    return n, np.ctypeslib.as_array(buf).reshape(n, 6).copy()
+
+
+@pytest.mark.parametrize("L,H,cus", [(4608, 24, 256), (256, 3, 256), (1024, 3, 256), (512, 130, 256), (4096, 24, 256),
+                                     (4608, 24, 304), (2048, 5, 64), (256, 1, 256), (32768, 25, 256), (768, 7, 8)])
+def test_attention_schedule_covers_every_tile_once_and_owners_agree(built_lib, L, H, cus):
+    n, seg = _attn_schedule(L, H, cus)
+    ntiles, tasks = L // 64, H * (L // 256)
+    assert n > 0
+    G = int(seg[:, 0].max()) + 1
+    assert G <= cus and (G % 8 == 0 or G < 8) and G <= tasks * ntiles // 2
+    cover = np.zeros((tasks, ntiles), dtype=np.int32)
+    for g, task, j0, j1, owner, last in seg:
+        assert 0 <= j0 < j1 <= ntiles and j0 % 2 == 0 and j1 % 2 == 0  # even cuts: the tile loop is unrolled by two
+        cover[task, j0:j1] += 1
+    assert (cover == 1).all()
+    per_wg = np.bincount(seg[:, 0], weights=seg[:, 3] - seg[:, 2], minlength=G)
+    assert per_wg.max() - per_wg.min() <= 2  # balanced to one tile pair
+    first_seg = {}  # workgroup -> index of its first segment
+    for i, g in enumerate(seg[:, 0]):
+        first_seg.setdefault(int(g), i)
+    owners = {int(task): int(g) for g, task, j0, j1, owner, last in seg if j0 == 0}
+    assert len(owners) == tasks
+    contributors = {}
+    for i, (g, task, j0, j1, owner, last) in enumerate(seg):
+        if j0 > 0:
+            assert first_seg[int(g)] == i, "a workgroup publishes at most once: its FIRST segment"
+            assert owner == owners[int(task)] and owner < g
+            contributors.setdefault(int(task), []).append(int(g))
+        else:
+            assert owner == -1
+            if j1 < ntiles:
+                assert i + 1 == len(seg) or seg[i + 1][0] != g, "a split task's owner segment is its workgroup's LAST"
+    for g, task, j0, j1, owner, last in seg:
+        if j0 == 0:
+            cs = contributors.get(int(task), [])
+            if j1 < ntiles:
+                assert cs == list(range(g + 1, last + 1))  # exactly the workgroups g+1 .. last, each once
+            else:
+                assert last == -1 and cs == []
+
+
+def test_attention_schedule_plain_grid_cases_and_errors(built_lib):
+    lib = _lib.load()
+    assert lib.svdq_attention_schedule(8192, 8, 256, None, 0) == 0   # 256 tasks on 256 CUs: whole rounds
+    assert lib.svdq_attention_schedule(384, 4, 256, None, 0) == 0    # L % 256 != 0: the 4-wave kernel
+    assert lib.svdq_attention_schedule(200, 4, 256, None, 0) == -1
+    assert lib.svdq_attention_schedule(256, 0, 256, None, 0) == -1

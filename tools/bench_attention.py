@@ -17,7 +17,13 @@ def t(fn, it=20):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it * 1e3
 
 fl = 4 * H * L * L * 128
-us = t(lambda: attention_packed(qkv, vt, H, out=out)); print(f"svdq_attention {us:.1f} us  {fl/us/1e6:.0f} TFLOP/s")
+from nunchaku_amd._C import ops
+for rep in range(2):  # same box, interleaved: persistent schedule (workspace) vs plain grid
+    ops.attention_use_workspace = False
+    us0 = t(lambda: attention_packed(qkv, vt, H, out=out)); print(f"svdq_attention plain grid  {us0:.1f} us  {fl/us0/1e6:.0f} TFLOP/s")
+    ops.attention_use_workspace = True
+    us = t(lambda: attention_packed(qkv, vt, H, out=out)); print(f"svdq_attention persistent  {us:.1f} us  {fl/us/1e6:.0f} TFLOP/s")
+ops.attention_workspace_status()
 q, k, v = (qkv[:, i * H * 128:(i + 1) * H * 128].unflatten(1, (H, 128)).permute(1, 0, 2)[None] for i in range(3))
 us2 = t(lambda: F.scaled_dot_product_attention(q, k, v)); print(f"torch sdpa (strided views) {us2:.1f} us  {fl/us2/1e6:.0f} TFLOP/s")
 ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float())[0].permute(1, 0, 2).reshape(L, H * 128)
