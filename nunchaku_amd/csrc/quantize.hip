@@ -20,6 +20,10 @@
 
 namespace svdq {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 // grouped launch: rows >= split_rows read a second input and use a second parameter set (svdq_quantize_args.x2 ...)
 struct QuantSecond {
     const void *x, *smooth, *lora_down, *mod_scale, *mod_shift;
@@ -239,6 +243,290 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
     }
 }
 
+
+// --------------------------------------------------------------------------------------------------------------------
+// Fast path (R <= 32, i.e. every SVDQuant checkpoint's own low-rank branch): same arithmetic, same outputs, built for
+// latency instead of registers.  Counters of the general kernel above at the FLUX.1 shape (profiles/r2_quantize_pmc.txt): a
+// wave lives ~21 us for ONE chunk, its VALU is busy 14 % of that; 43 % is s_waitcnt on 80 narrow loads (64 of them re-read
+// per-channel parameters every row tile needs alike), 38 % issue stalls; 236 VGPRs hold two workgroups per CU.  Here:
+//   * whatever does not depend on the row goes through LDS, converted ONCE per wave: the smoothing factors with their
+//     reciprocals, the modulation vectors (fp32, in the element order the packed arithmetic wants) and the chunk's slice of
+//     lora_down (the MFMA B operand, XOR-swizzled 16-byte pieces, global -> LDS by LDS-DMA) -- 11 wide coalesced loads
+//     instead of 64 broadcast ones, ~100 VGPRs less, 4 workgroups per CU;
+//   * the element-wise chain runs on float pairs (v_pk_add / v_pk_mul / v_pk_fma_f32: two values per instruction) and is
+//     laid out so that the pairs ARE the operand tuples of the FP6 pack instruction (elements 0,2 | 1,3 of a 4-channel
+//     piece): no moves.  The 16-bit rounding points are unchanged (bit-identical codes and scales);
+//   * with the LayerNorm front end the recomputed 16-bit activations are put back into channel order (two v_perm_b32 per piece)
+//     for the low-rank MFMA, so the chunk's partial sums are bit-identical to the general kernel's.
+// --------------------------------------------------------------------------------------------------------------------
+struct QuantParams {
+    const void *x, *smooth, *lora_down, *mod_scale, *mod_shift;
+    const float *ln_stats;
+    uint8_t *act;
+    void *ascales;
+    float *lora_act;
+    int M, K, R, ldx, use_atomics;
+    QuantSecond s2;
+};
+
+constexpr int QV2_PARAM_BYTES = 4 * 128 * 4;     // per wave: smooth, 1/smooth, mod_scale, mod_shift as fp32
+constexpr int QV2_WAVE_BYTES = QV2_PARAM_BYTES + 32 * 256; // + lora_down slice [32 ranks][128 channels] 16-bit
+
+template <int DT> struct Pair16;
+template <> struct Pair16<SVDQ_BF16> {
+    static __device__ __forceinline__ v2f lo(unsigned d0, unsigned d1) { return v2f{__builtin_bit_cast(float, d0 << 16), __builtin_bit_cast(float, d1 << 16)}; }
+    static __device__ __forceinline__ v2f hi(unsigned d0, unsigned d1) { return v2f{__builtin_bit_cast(float, d0 & 0xffff0000u), __builtin_bit_cast(float, d1 & 0xffff0000u)}; }
+    static __device__ __forceinline__ unsigned pack(v2f v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+    static __device__ __forceinline__ v2f unpack(unsigned u) { return v2f{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)}; }
+};
+template <> struct Pair16<SVDQ_FP16> {
+    static __device__ __forceinline__ v2f lo(unsigned d0, unsigned d1) { return v2f{(float)__builtin_bit_cast(f16x2, d0)[0], (float)__builtin_bit_cast(f16x2, d1)[0]}; }
+    static __device__ __forceinline__ v2f hi(unsigned d0, unsigned d1) { return v2f{(float)__builtin_bit_cast(f16x2, d0)[1], (float)__builtin_bit_cast(f16x2, d1)[1]}; }
+    static __device__ __forceinline__ unsigned pack(v2f v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2)); }
+    static __device__ __forceinline__ v2f unpack(unsigned u) { return __builtin_convertvector(__builtin_bit_cast(f16x2, u), v2f); }
+};
+// div_rn on pairs (same operations, same order)
+__device__ __forceinline__ v2f div_rn2(v2f a, v2f b, v2f rb) {
+    v2f q = a * rb;
+    v2f e = __builtin_elementwise_fma(-q, b, a);
+    q = __builtin_elementwise_fma(e, rb, q);
+    e = __builtin_elementwise_fma(-q, b, a);
+    return __builtin_elementwise_fma(e, rb, q);
+}
+
+
+// One 4-channel piece (e0 e1 | e2 e3 in the dwords d0 | d1) of a lane's record through the LayerNorm front end and the
+// smoothing division.  Parameters arrive in pair order (e0 e2 | e1 e3).  Out: the 16-bit activations the low-rank MFMA
+// sees (a0 = e0 e1, a1 = e2 e3: natural order, as in the input), and x_hat as float pairs (e0 e2), (e1 e3).
+//   bf16: float pairs, two values per instruction; the 16-bit rounding is its own instruction either way.
+//   fp16: element by element, in the expression shapes of the general kernel -- the backend folds an fp32 operation and the
+//         conversion that follows into ONE v_fma_mix*_f16 (a single rounding; oracle: _round16_fma), which a packed
+//         multiply followed by a packed conversion would round twice (1 value in ~10^6 differs in the last bit).
+template <int DT, bool LN, bool SMOOTH>
+__device__ __forceinline__ void quant_piece(unsigned d0, unsigned d1, v2f mean2, v2f rstd2, bool valid, v4f ms, v4f mh, v4f sm, v4f rs,
+                                            unsigned &a0, unsigned &a1, v2f &xe, v2f &xo) {
+    using T = typename Half<DT>::T;
+    using P16 = Pair16<DT>;
+    a0 = d0; a1 = d1; // (without the front end the MFMA takes the input dwords as they are)
+    if constexpr (DT == SVDQ_BF16) {
+        xe = P16::lo(d0, d1); xo = P16::hi(d0, d1);
+        if constexpr (LN) { // x <- round16(round16(round16((x - mean) * rstd) * scale) + shift); padded rows stay 0
+            xe = P16::unpack(P16::pack((xe - mean2) * rstd2));
+            xo = P16::unpack(P16::pack((xo - mean2) * rstd2));
+            xe = P16::unpack(P16::pack(xe * v2f{ms[0], ms[1]})) + v2f{mh[0], mh[1]};
+            xo = P16::unpack(P16::pack(xo * v2f{ms[2], ms[3]})) + v2f{mh[2], mh[3]};
+            const unsigned he = valid ? P16::pack(xe) : 0u, ho = valid ? P16::pack(xo) : 0u; // (e0 e2), (e1 e3)
+            xe = P16::unpack(he); xo = P16::unpack(ho);
+            a0 = __builtin_amdgcn_perm(ho, he, 0x05040100u); // (e0 e1)
+            a1 = __builtin_amdgcn_perm(ho, he, 0x07060302u); // (e2 e3)
+        }
+        if constexpr (SMOOTH) {
+            xe = P16::unpack(P16::pack(div_rn2(xe, v2f{sm[0], sm[1]}, v2f{rs[0], rs[1]})));
+            xo = P16::unpack(P16::pack(div_rn2(xo, v2f{sm[2], sm[3]}, v2f{rs[2], rs[3]})));
+        }
+    } else {
+        const f16x2 h0 = __builtin_bit_cast(f16x2, d0), h1 = __builtin_bit_cast(f16x2, d1);
+        T x16[4] = {h0[0], h1[0], h0[1], h1[1]}; // pair order: e0 e2 e1 e3
+        float xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if constexpr (LN) {
+                const float lnv = round16<T>((h2f(x16[i]) - mean2[0]) * rstd2[0]);
+                const float y = round16<T>(lnv * ms[i]) + mh[i];
+                x16[i] = valid ? f2h<T>(y) : (T)0.f;
+            }
+            xf[i] = h2f(x16[i]);
+            if constexpr (SMOOTH) xf[i] = round16<T>(div_rn(xf[i], sm[i], rs[i]));
+        }
+        if constexpr (LN) {
+            a0 = __builtin_bit_cast(unsigned, f16x2{x16[0], x16[2]});
+            a1 = __builtin_bit_cast(unsigned, f16x2{x16[1], x16[3]});
+        }
+        xe = v2f{xf[0], xf[1]}; xo = v2f{xf[2], xf[3]};
+    }
+}
+
+template <int DT, bool LORA, bool LN, bool SMOOTH>
+__global__ __launch_bounds__(256, 4) void quantize_kernel_v2(QuantParams p) {
+    using T = typename Half<DT>::T;
+    using V8 = typename Half<DT>::V8;
+    using P16 = Pair16<DT>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * QV2_WAVE_BYTES];
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef __attribute__((address_space(3))) v4f lds_v4f;
+    typedef __attribute__((address_space(3))) v2f lds_v2f;
+    typedef __attribute__((address_space(3))) v4i lds_v4i;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) u32x2 lds_u2;
+    typedef __attribute__((address_space(3))) v16f lds_v16f;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int K = p.K, KP = K / 128;
+    const int slices = (KP + 3) / 4;
+    const int rt = blockIdx.x / slices, kp = (blockIdx.x % slices) * 4 + wave;
+    const bool active = kp < KP; // wave-uniform
+    lds_u8 *const W = (lds_u8 *)lds + wave * QV2_WAVE_BYTES; // this wave's private region: no workgroup barrier before the final sum
+
+    // grouped launch: this row tile's stream (block-uniform); outputs stay addressed by the joint row tile index rt
+    const bool second = p.s2.x != nullptr && rt * 32 >= p.s2.split_rows;
+    const T *x = (const T *)(second ? p.s2.x : p.x);
+    const T *smooth = (const T *)(second ? p.s2.smooth : p.smooth);
+    const T *lora_down = (const T *)(second ? p.s2.lora_down : p.lora_down);
+    const float *ln_stats = second ? p.s2.ln_stats : p.ln_stats;
+    const T *mod_scale = (const T *)(second ? p.s2.mod_scale : p.mod_scale);
+    const T *mod_shift = (const T *)(second ? p.s2.mod_shift : p.mod_shift);
+    const int ldx = second ? p.s2.ldx : p.ldx, M = second ? p.s2.M : p.M;
+    const int row = rt * 32 + r - (second ? p.s2.split_rows : 0); // row inside this stream's input
+    const bool valid = row < M;
+    constexpr bool ln = LN; // (the launcher checks that both streams of a grouped launch agree)
+
+    v16f accL;
+#pragma unroll
+    for (int j = 0; j < 16; j++) accL[j] = 0.f;
+
+    if (active) {
+        // ---- 1. every global access of the chunk goes out back to back: 16 activation loads (this lane's record: row r,
+        //         channels 64 grp + 8 tc + 4 h + e, 8 bytes per piece), the lora_down slice as LDS-DMA (no registers:
+        //         instruction i = ranks 4i .. 4i+3, whole 256-byte rows, a lane fetches the piece whose swizzled slot it
+        //         fills), the per-channel parameters (lane l: channels 2l, 2l+1).  Buffer loads: a row >= M / a rank >= R
+        //         lies beyond the descriptor's range and reads as zero -- no exec-mask branch around any of them (ranks >= R:
+        //         whatever their LDS rows hold only reaches accumulator columns that are never stored).
+        // (the launcher sends inputs whose padded extent exceeds the descriptor's 2 GiB reach to the general kernel)
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)(((long long)(M - 1) * ldx + K) * 2), 0x00020000);
+        unsigned xoff = ((unsigned)row * (unsigned)ldx + kp * 128 + 4 * h) * 2u; // row >= M: out of range by construction
+        unsigned ldo[4]; // slice offsets of instructions i = j, j + 4 (rank 4j + lane/16 [+ 16]; its swizzle only depends on j)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned rank = 4 * j + (lane >> 4);
+            ldo[j] = (rank * (unsigned)K + kp * 128 + (((lane & 15) ^ (rank & 15)) * 8)) * 2u;
+        }
+        // all address arithmetic happens BEFORE the first load is issued (the backend otherwise interleaves it with the loads
+        // and, reusing a load's destination as the undefined half of a 64-bit multiply-add operand, waits for that load)
+        asm volatile("" : "+v"(xoff), "+v"(ldo[0]), "+v"(ldo[1]), "+v"(ldo[2]), "+v"(ldo[3]));
+        uint2 xv[2][8];
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++)
+#pragma unroll
+            for (int tc = 0; tc < 8; tc++) {
+                const auto w = __builtin_amdgcn_raw_buffer_load_b64(rx, xoff + (grp * 64 + 8 * tc) * 2, 0, 0);
+                xv[grp][tc] = make_uint2((unsigned)w[0], (unsigned)w[1]);
+            }
+        if constexpr (LORA) {
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)lora_down, 0, (int)((size_t)p.R * K * 2), 0x00020000);
+            typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void *)(W + QV2_PARAM_BYTES + i * 1024), 16, ldo[i & 3], (i >> 2) * 16 * K * 2, 0, 0);
+        }
+        const int ch = kp * 128 + 2 * lane;
+        unsigned sm2 = 0, ms2 = 0, mh2 = 0;
+        if constexpr (SMOOTH) sm2 = *reinterpret_cast<const unsigned *>(smooth + ch);
+        if constexpr (LN) {
+            ms2 = *reinterpret_cast<const unsigned *>(mod_scale + ch);
+            mh2 = *reinterpret_cast<const unsigned *>(mod_shift + ch);
+        }
+        v2f mean2 = {0.f, 0.f}, rstd2 = {0.f, 0.f};
+        if constexpr (LN) { // (a padded row borrows the last row's statistics: its result is forced to zero below)
+            const float2 st = *reinterpret_cast<const float2 *>(ln_stats + 2 * (size_t)(valid ? row : M - 1));
+            mean2 = v2f{st.x, st.x};
+            rstd2 = v2f{st.y, st.y};
+        }
+        // ---- 3. parameters -> LDS as fp32 in pair order: a 4-channel piece (e0 e1 e2 e3) is stored (e0 e2 | e1 e3).  Lane l
+        //         owns channels 2l, 2l+1 = elements (0,1) or (2,3) of piece l/2: slots {0,2} or {1,3} of that piece
+        {
+            const int slot = (lane >> 1) * 4 + (lane & 1);
+            __attribute__((address_space(3))) float *P = (__attribute__((address_space(3))) float *)W;
+            if constexpr (SMOOTH) {
+                const v2f sm = P16::unpack(sm2);
+                P[slot] = sm[0]; P[slot + 2] = sm[1];
+                P[128 + slot] = __builtin_amdgcn_rcpf(sm[0]); P[128 + slot + 2] = __builtin_amdgcn_rcpf(sm[1]);
+            }
+            if constexpr (LN) {
+                const v2f ms = P16::unpack(ms2), mh = P16::unpack(mh2);
+                P[256 + slot] = ms[0]; P[256 + slot + 2] = ms[1];
+                P[384 + slot] = mh[0]; P[384 + slot + 2] = mh[1];
+            }
+        }
+        // (one wave, in-order LDS: its own reads below see its own writes; no barrier)
+
+        // ---- 4. the two groups of the chunk
+        uint8_t *dst = p.act + ((size_t)rt * KP + kp) * F6_CHUNK + (size_t)lane * 16;
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+            v16f ev, od; // elements 0,2 / 1,3 of the lane's eight 4-channel pieces = the two sources of the FP6 pack
+            float amax = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { // pieces 2q, 2q+1, then the low-rank MFMA that consumes exactly those two
+                unsigned ae[2], ao[2]; // 16-bit activations as the MFMA sees them: (e0 e1), (e2 e3) of the two pieces
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int tc = 2 * q + t;
+                    const int pofs = (grp * 64 + 8 * tc + 4 * h) * 4; // byte offset of this piece in a parameter array
+                    v4f ms = {}, mh = {}, sm = {}, rs = {};
+                    if constexpr (LN) { ms = *(const lds_v4f *)(W + 2 * 512 + pofs); mh = *(const lds_v4f *)(W + 3 * 512 + pofs); }
+                    if constexpr (SMOOTH) { sm = *(const lds_v4f *)(W + pofs); rs = *(const lds_v4f *)(W + 512 + pofs); }
+                    v2f xe, xo;
+                    quant_piece<DT, LN, SMOOTH>(xv[grp][tc].x, xv[grp][tc].y, mean2, rstd2, valid, ms, mh, sm, rs, ae[t], ao[t], xe, xo);
+                    ev[2 * tc] = xe[0]; ev[2 * tc + 1] = xe[1];
+                    od[2 * tc] = xo[0]; od[2 * tc + 1] = xo[1];
+                    amax = fmaxf(fmaxf(amax, fabsf(xe[0])), fabsf(xe[1]));
+                    amax = fmaxf(fmaxf(amax, fabsf(xo[0])), fabsf(xo[1]));
+                }
+                if constexpr (LORA) {
+                    // D[m][rank] += x[m][k] * lora_down[k][rank]: pieces 2q, 2q+1 of every lane are k-slots 8h .. 8h+7
+                    const V8 a = __builtin_bit_cast(V8, v4i{(int)ae[0], (int)ao[0], (int)ae[1], (int)ao[1]});
+                    const int piece = grp * 8 + 2 * q; // 16-byte pieces of rank r's row: this lane's half (8 h) of pieces `piece`, `piece + 1`
+                    if (grp == 0 && q == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the LDS-DMA of the slice has landed
+                    const u32x2 b0 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + ((piece ^ (r & 15)) << 4) + 8 * h);
+                    const u32x2 b1 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + (((piece + 1) ^ (r & 15)) << 4) + 8 * h);
+                    const V8 b = __builtin_bit_cast(V8, v4i{(int)b0[0], (int)b0[1], (int)b1[0], (int)b1[1]});
+                    accL = Half<DT>::mfma32(a, b, accL);
+                }
+                // scheduling fence: keeps the backend from hoisting all 64 parameter reads of the chunk to the top (it then needs
+                // > 128 VGPRs and spills); the other three waves of the SIMD cover the LDS latency
+                asm volatile("" ::: "memory");
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            const float scale = amax * (1.0f / 7.0f);
+            const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
+            // q = rne(x_hat / scale) as FP6 e2m3 = q/8, 32 x 6 bits in ONE v_cvt_scalef32_2xpk16_fp6_f32 (see the general kernel)
+            ev = ev * rscale;
+            od = od * rscale;
+            const v6i pk = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, 8.0f);
+            if (grp == 0) {
+                *reinterpret_cast<uint4 *>(dst) = make_uint4((unsigned)pk[0], (unsigned)pk[1], (unsigned)pk[2], (unsigned)pk[3]);
+                *reinterpret_cast<uint2 *>(dst + F6_PLANE) = make_uint2((unsigned)pk[4], (unsigned)pk[5]);
+            } else {
+                *reinterpret_cast<uint2 *>(dst + F6_PLANE + 8) = make_uint2((unsigned)pk[0], (unsigned)pk[1]);
+                *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4((unsigned)pk[2], (unsigned)pk[3], (unsigned)pk[4], (unsigned)pk[5]);
+            }
+            // S image: [rt][kp][grp][32]; lane (r, h) writes group h
+            if (h == grp) ((T *)p.ascales)[(((size_t)rt * KP + kp) * 2 + grp) * 32 + r] = f2h<T>(scale);
+        }
+    }
+
+    if constexpr (LORA) {
+        // combine the four waves' partial sums in a fixed order (each wave parks its tile in its own region)
+        *(lds_v16f *)(W + QV2_PARAM_BYTES + lane * 64) = accL;
+        __syncthreads();
+        if (wave == 0) {
+            const lds_u8 *B = (const lds_u8 *)lds + QV2_PARAM_BYTES + lane * 64;
+            const v16f s = ((*(const lds_v16f *)(B) + *(const lds_v16f *)(B + QV2_WAVE_BYTES)) + *(const lds_v16f *)(B + 2 * QV2_WAVE_BYTES)) +
+                           *(const lds_v16f *)(B + 3 * QV2_WAVE_BYTES);
+            if (r < p.R) { // C layout: col (rank) = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int m = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    float *dstl = p.lora_act + (size_t)m * p.R + r;
+                    if (p.use_atomics) unsafeAtomicAdd(dstl, s[i]);
+                    else *dstl = s[i];
+                }
+            }
+        }
+    }
+}
+
 template <int DT>
 static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     using T = typename Half<DT>::T;
@@ -248,6 +536,11 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     static const int cpw_env = getenv("SVDQ_QUANT_CPW") ? atoi(getenv("SVDQ_QUANT_CPW")) : 0; // experiment knob
 #else
     constexpr int cpw_env = 0;
+#endif
+#ifdef SVDQ_ABLATE
+    static const bool force_general = getenv("SVDQ_QUANT_GENERAL") != nullptr; // A/B against the general kernel
+#else
+    constexpr bool force_general = false;
 #endif
     int cpw = cpw_env > 0 ? cpw_env : 4; // chunks per workgroup = 4 waves x 1 chunk: many short waves hide the HBM round trip
     while ((long)tiles * ((KP + cpw - 1) / cpw) > 8192) cpw *= 2;
@@ -262,6 +555,19 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     dim3 grid(tiles * slices), block(256);
     const int rt32 = (a->R + 31) / 32;
     QuantSecond s2{a->x2, a->smooth2, a->lora_down2, a->mod_scale2, a->mod_shift2, a->ln_stats2, a->M2, a->ldx2, a->split_rows};
+    if (rt32 <= 1 && cpw == 4 && !force_general && (long long)a->M_pad * (a->ldx > a->ldx2 ? a->ldx : a->ldx2) * 2 < 0x7fffffffLL) {
+        // fast path: one chunk per wave, 4 waves = 4 neighbouring chunks of one row tile (same grid as the general kernel at cpw = 4)
+        QuantParams qp{a->x, a->smooth, a->lora_down, a->mod_scale, a->mod_shift, a->ln_stats, (uint8_t *)a->act, a->ascales, a->lora_act,
+                       a->M, a->K, a->R, a->ldx, atomics, s2};
+        const int sel = (a->R > 0 ? 4 : 0) | (a->ln_stats ? 2 : 0) | (a->smooth ? 1 : 0);
+        switch (sel) {
+#define SVDQ_QV2(n, LORA, LN, SM) case n: hipLaunchKernelGGL((quantize_kernel_v2<DT, LORA, LN, SM>), grid, block, 0, st, qp); break;
+            SVDQ_QV2(0, false, false, false) SVDQ_QV2(1, false, false, true) SVDQ_QV2(2, false, true, false) SVDQ_QV2(3, false, true, true)
+            SVDQ_QV2(4, true, false, false) SVDQ_QV2(5, true, false, true) SVDQ_QV2(6, true, true, false) SVDQ_QV2(7, true, true, true)
+#undef SVDQ_QV2
+        }
+        return hip_check(hipGetLastError(), "svdq_quantize_w4a4_act_fuse_lora launch");
+    }
 #ifdef SVDQ_ABLATE
     static const int occ_env = getenv("SVDQ_QUANT_OCC") ? atoi(getenv("SVDQ_QUANT_OCC")) : 0; // experiment knob
 #else
