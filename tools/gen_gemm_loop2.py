@@ -115,6 +115,12 @@ class Gen:
         return f"{self.smfma} {vr(SBUF[dst_buf], 16)}, {vr(SCL[buf] + 4 * ni, 4)}, {vr(SCL[buf] + 8 + 4 * mi, 4)}, 0"
 
     def fma(self, t, pb, lo, hi):
+        """acc += P * S for registers lo .. hi-1 of tile t.  "pkf": packed fp32 FMAs (v_pk_fma_f32: two accumulators per
+        instruction at the same issue cost; same fp32 fused multiply-add per element, bit-identical) -- half the VALU
+        instructions of the loop, which is bound by instruction issue."""
+        if "pkf" in self.opts:
+            return [f"v_pk_fma_f32 {vr(ACC + 16 * t + r, 2)}, {vr(PBUF[pb] + r, 2)}, {vr(SBUF[pb] + r, 2)}, {vr(ACC + 16 * t + r, 2)}"
+                    for r in range(lo, hi, 2)]
         return [f"v_fmac_f32 {vr(ACC + 16 * t + r)}, {vr(PBUF[pb] + r)}, {vr(SBUF[pb] + r)}" for r in range(lo, hi)]
 
     # ---- DMA --------------------------------------------------------------------------
