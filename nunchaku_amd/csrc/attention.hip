@@ -207,12 +207,11 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             mloc = fmaxf(fmaxf(mloc, s[1][r]), r + 1 < 16 ? s[1][r + 1] : s[1][r]);
         }
         {   // the partner lane (lane ^ 32) holds the other 32 scores of the row: one v_permlane32_swap, no LDS round trip
-            // (the second result goes through an empty asm statement: this LLVM folds a floating-point max / compare of the
-            //  swap's two results to the first one -- integer uses, as in the P packing below, are fine)
+            // (scalar copies first: this clang's __builtin_bit_cast applied to a vector ELEMENT reads element 0 -- max(sw[0], sw[1])
+            //  became sw[0]: half a row's maximum, still a valid reference point in bf16, an overflow to inf in fp16)
             const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
-            unsigned other = sw[1];
-            asm volatile("" : "+v"(other));
-            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, other));
+            const unsigned mine = sw[0], other = sw[1];
+            mloc = fmaxf(__builtin_bit_cast(float, mine), __builtin_bit_cast(float, other));
         }
         // rescale only when some row of this wave outgrew its running maximum by more than ATT_DEFER_LOG2 (m_run = -inf on
         // the first tile: always).  A stale maximum is still a valid reference point of the online softmax: O and l carry
