@@ -207,7 +207,7 @@ class Gen:
                     f"s_cbranch_scc0 {Ltail}",
                     # my 5 DMAs of K-step step+1 have landed: the 10 younger ones (step+2, step+3) may stay in flight
                     f"s_waitcnt vmcnt({2 * DMA_PER_STEP})",
-                    "s_barrier",
+                    "s_nop 0" if "nobar" in self.opts else "s_barrier",  # "nobar": timing ablation only (waves race: wrong results)
                 ]
                 if phase == 0:
                     misc += [f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}", f"s_cbranch_scc1 {Lsw}", f"{Lbsw}:"] + self.dma_issue(j * STAGE)
@@ -244,6 +244,14 @@ class Gen:
     def build(self):
         e = self.e
         e("; ---- svdq gemm main loop v2 (generated by tools/gen_gemm_loop2.py) ----")
+        # "prio1": static priority 1 for waves 4..7 (the younger wave of every SIMD, the arbitration loser) for the whole loop;
+        # "prio0": the same for waves 0..3 (control experiment)
+        if "prio1" in self.opts or "prio0" in self.opts:
+            Lp = self.new_label("prio")
+            e(f"s_cmp_eq_u32 {sr(S_PHASE)}, {1 if 'prio1' in self.opts else 0}")
+            e(f"s_cbranch_scc0 {Lp}")
+            e("s_setprio 1")
+            e(f"{Lp}:")
         for r in range(64):
             e(f"v_mov_b32 {vr(ACC + r)}, 0")
         for b in range(2):
@@ -341,6 +349,8 @@ class Gen:
         e("s_waitcnt lgkmcnt(0)")
         e("s_nop 15")
         e("s_nop 7")
+        if "prio1" in self.opts or "prio0" in self.opts:
+            e("s_setprio 0")
         return self.lines
 
 
