@@ -62,10 +62,7 @@ constexpr int ATT_SPIN_LIMIT = 1 << 22;                // x s_sleep(8) ~ 1 s: a 
 // rescale the running output only when some row's maximum grew by more than this (in log2 units, i.e. after the
 // scale*log2(e) factor): until then P = exp2(s - m_stale) <= 2^8, exact in fp32 and with the same RELATIVE rounding
 // in the 16-bit P fragments; later tiles almost never rescale (64 multiplies + exp per wave-tile saved)
-#ifndef SVDQ_ATT_THR
-#define SVDQ_ATT_THR 8.0f
-#endif
-constexpr float ATT_DEFER_LOG2 = SVDQ_ATT_THR;
+constexpr float ATT_DEFER_LOG2 = 8.0f;
 
 // The persistent schedule's arithmetic, shared by the kernel and its host replay (svdq_attention_schedule).
 // Linear position = task * ntiles + KV tile; workgroup i runs [bound(i), bound(i + 1)), cut at even tiles.
@@ -247,13 +244,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             for (int d2 = 0; d2 < 2; d2++) {
                 x[d2] = pack2<DT>(s[kt][r0 + 2 * d2], s[kt][r0 + 2 * d2 + 1]);
                 y[d2] = pack2<DT>(s[kt][r0 + 4 + 2 * d2], s[kt][r0 + 4 + 2 * d2 + 1]);
-#ifdef SVDQ_ATT_OLD_LSUM
-                l2[0] += (s[kt][r0 + 2 * d2] + s[kt][r0 + 2 * d2 + 1]);
-                l2[1] += (s[kt][r0 + 4 + 2 * d2] + s[kt][r0 + 4 + 2 * d2 + 1]);
-#else
                 l2[0] = sum2<DT>(x[d2], l2[0]); // this lane's own 4 probabilities, before the exchange
                 l2[1] = sum2<DT>(y[d2], l2[1]);
-#endif
                 auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
                 x[d2] = sw[0];
                 y[d2] = sw[1];
