@@ -137,6 +137,39 @@ def test_grouped_launches_match_separate_calls(dtype):
     assert rel < 2e-2, f"grouped MLP (second weight set) vs oracle: {rel:.3g}"
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("with_ln", [False, True])
+@pytest.mark.parametrize("M,K", [(256, 384), (512, 3072)])
+def test_one_input_two_parameter_sets_matches_two_quantiser_calls(dtype, with_ln, M, K):
+    """FLUX single blocks quantise ONE hidden state for two layers (QKV projection and fc1: different smoothing factors and
+    low-rank factors, same LayerNorm front end) in one grouped launch whose two streams read the same x: bit-identical codes
+    and scales to two separate calls, lora_act up to fp32 order (K = 3072 is sliced over 6 workgroups: atomics).
+    (A variant that ran the second parameter set over the first pass's 16-bit activations -- one read of x, one LayerNorm --
+    was measured at the step level and brought nothing: 64.3-64.6 vs 64.6-64.9 ms; the launch's two rounds of single-pass
+    workgroups already overlap the second round's loads with the first round's arithmetic.)"""
+    from nunchaku_amd import layout
+    from nunchaku_amd.ops.fused import quantize_two
+
+    La = O.make_svdq_layer(K, 128, 32, seed=31, dtype=dtype, cheap=True)
+    Lb = O.make_svdq_layer(K, 256, 32, seed=32, dtype=dtype, cheap=True)
+    la, lb = make_module(La, dtype), make_module(Lb, dtype)
+    rng = np.random.default_rng(M + K)
+    x = O.round16(O.make_activations(M, K, seed=33, dtype=dtype) * 2 + 0.5, dtype)
+    xt = t16(x, dtype)
+    ln = None
+    if with_ln:
+        scale = t16(O.round16(1 + rng.standard_normal(K).astype(np.float32) * 0.3, dtype), dtype)
+        shift = t16(O.round16(rng.standard_normal(K).astype(np.float32) * 0.2, dtype), dtype)
+        ln = (torch.from_numpy(O.ln_stats_ref(x)).cuda(), scale, shift)
+    both = quantize_two(xt, la, lb, ln=ln)
+    assert both is not None
+    for (codes, scales, lact), lin in zip(both, (la, lb)):
+        q, a, l_ = lin.quantize(xt, ln=ln)
+        assert torch.equal(layout.unpack_act(codes, K), layout.unpack_act(q, K))
+        assert torch.equal(layout.unpack_scales(scales, M), layout.unpack_scales(a, q.shape[0]))
+        assert (lact - l_[:M]).abs().max() <= 2e-3 * l_.abs().max() + 1e-5
+
+
 def test_flux_transformer_grouped_vs_separate_launches():
     from nunchaku_amd.models.flux import FluxAttentionAMD, FluxTransformerAMD
 
