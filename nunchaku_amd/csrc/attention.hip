@@ -20,11 +20,12 @@
 //
 // Schedule.  A task = (head, 256 query rows) x all L/64 KV tiles.  FLUX.1 at 1024^2: 24 heads x 18 = 432 tasks on 256 CUs =
 // 1.69 rounds of workgroups, the second round 69 % full.  With a workspace the launch is PERSISTENT instead: one workgroup
-// per CU, the linear (task, KV tile) space is dealt evenly (121.5 tiles each, cut at even tile indices), a workgroup's run
-// is cut at task boundaries into segments.  The workgroup holding a task's FIRST tiles owns it: the others publish their
-// un-normalised (O, m, l) -- a lane-for-lane image of the registers, fp32 -- through the workspace, the owner folds them in
-// (ascending workgroup order: deterministic) and runs the epilogue.  Logical workgroup g = (blockIdx % 8) * G/8 + blockIdx / 8:
-// the workgroups of one XCD take neighbouring runs, i.e. the same few heads, so K / V^T stream through that XCD's L2 once.
+// per CU takes its whole tasks first (432 / 256 = 1 each), then the remaining 176 tasks are split along the keys: their
+// (task, KV tile) space is dealt evenly (49.5 tiles each, cut at even tile indices), a workgroup's run is cut at task
+// boundaries into segments.  The workgroup holding a task's FIRST tiles owns it: the others publish their un-normalised
+// (O, m, l) -- a lane-for-lane image of the registers, fp32 -- through the workspace, the owner folds them in (ascending
+// workgroup order: deterministic) and runs the epilogue.  Logical workgroup g = (blockIdx % 8) * G/8 + blockIdx / 8: the
+// workgroups of one XCD take neighbouring tasks, i.e. the same few heads, and walk their keys together.
 #include "svdq_common.h"
 #include <type_traits>
 
@@ -65,21 +66,30 @@ constexpr int ATT_SPIN_LIMIT = 1 << 22;                // x s_sleep(8) ~ 1 s: a 
 constexpr float ATT_DEFER_LOG2 = 8.0f;
 
 // The persistent schedule's arithmetic, shared by the kernel and its host replay (svdq_attention_schedule).
-// Linear position = task * ntiles + KV tile; workgroup i runs [bound(i), bound(i + 1)), cut at even tiles.
+// Workgroup g first takes F = tasks / G WHOLE tasks (task f*G + g: the workgroups of an XCD, numbered contiguously, walk the keys
+// of the same few heads in lockstep -- K / V^T tiles are fetched once per XCD and hit in its L2 for the others, as in a plain
+// grid).  The R = tasks - F*G remainder tasks are split along the keys: linear position = local task * ntiles + KV tile,
+// workgroup i < Gs runs [bound(i), bound(i + 1)), cut at even tiles.
 struct AttnSchedule {
-    int ntiles, G;
-    long long half_total; // tasks * ntiles / 2
-    __host__ __device__ int bound(int i) const { return (int)(half_total * i / G) * 2; }
-    // the workgroup < g whose run holds the FIRST tile of `task` (g's own first segment starts inside that task)
-    __host__ __device__ int owner_of(int g, int task) const {
+    int ntiles, G, F, Gs;
+    long long half_rem; // R * ntiles / 2
+    __host__ __device__ void init(int tasks, int ntiles_, int G_) {
+        ntiles = ntiles_; G = G_;
+        F = tasks / G;
+        half_rem = (long long)(tasks - F * G) * ntiles / 2;
+        Gs = half_rem < G ? (int)half_rem : G; // workgroups sharing the remainder (every one of them gets at least two tiles)
+    }
+    __host__ __device__ int bound(int i) const { return Gs ? (int)(half_rem * i / Gs) * 2 : 0; }
+    // the workgroup < g whose run holds the FIRST tile of local task `tl` (g's own first run segment starts inside that task)
+    __host__ __device__ int owner_of(int g, int tl) const {
         int o = g - 1;
-        while (bound(o) > task * ntiles) o--;
+        while (bound(o) > tl * ntiles) o--;
         return o;
     }
-    // the workgroup > g whose run holds the LAST tile of `task` (g's last segment starts the task but does not finish it)
-    __host__ __device__ int last_contributor(int g, int task) const {
+    // the workgroup > g whose run holds the LAST tile of local task `tl` (g's last segment starts the task but does not finish it)
+    __host__ __device__ int last_contributor(int g, int tl) const {
         int last = g + 1;
-        while (bound(last + 1) < (task + 1) * ntiles) last++;
+        while (bound(last + 1) < (tl + 1) * ntiles) last++;
         return last;
     }
 };
@@ -123,9 +133,11 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
     const int QT = p.L / (NW * 32);  // tasks per head
     const int G = PERSIST ? (int)gridDim.x : 1;
     const int g = !PERSIST ? 0 : (G % 8 == 0 ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x);
-    const AttnSchedule sched{ntiles, G, (long long)p.H * QT * ntiles / 2}; // runs start at even tiles (the loop is unrolled by 2)
-    const int run_lo = PERSIST ? sched.bound(g) : ((int)blockIdx.y * QT + (int)blockIdx.x) * ntiles;
-    const int run_hi = PERSIST ? sched.bound(g + 1) : run_lo + ntiles;
+    AttnSchedule sched;
+    sched.init(p.H * QT, ntiles, G);
+    int whole_left = PERSIST ? sched.F : 1;                       // whole tasks still to do (plain grid: exactly one)
+    int pos = PERSIST && g < sched.Gs ? sched.bound(g) : 0;        // remainder run [pos, run_hi), runs start at even tiles
+    const int run_hi = PERSIST && g < sched.Gs ? sched.bound(g + 1) : 0;
 
     // ---- tile staging: 1024 16-byte pieces per matrix per tile, PIECES per thread; XOR-swizzled so that the
     //      16 lanes a ds_read_b128 serves per LDS cycle hit 16 different 16-byte columns.  All per-thread
@@ -269,11 +281,20 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
         if (j + 1 < j_end && !(DBG & 2)) store_tile((BUF ^ 1) * 2 * ATT_TILE); // that buffer was last read in iteration j-1
         if constexpr (!(DBG & 4)) __syncthreads();
     };
-    for (int pos = run_lo; pos < run_hi;) {
-        // ---- one segment: KV tiles [j0, j1) of one task ------------------------------------------------------
-        const int task = pos / ntiles, j0 = pos - task * ntiles;
-        const int j1 = min(ntiles, j0 + (run_hi - pos));
-        pos += j1 - j0;
+    while (true) {
+        // ---- one segment: KV tiles [j0, j1) of one task.  tl: the task's index among the remainder tasks (-1: a whole task)
+        int task, j0, j1, tl = -1;
+        if (whole_left > 0) {
+            task = PERSIST ? (sched.F - whole_left) * G + g : (int)blockIdx.y * QT + (int)blockIdx.x;
+            j0 = 0; j1 = ntiles;
+            whole_left--;
+        } else if (pos < run_hi) {
+            tl = pos / ntiles;
+            j0 = pos - tl * ntiles;
+            j1 = min(ntiles, j0 + (run_hi - pos));
+            pos += j1 - j0;
+            task = sched.F * G + tl;
+        } else break;
         const int head = task / QT;
         const int q0 = (task - head * QT) * (NW * 32) + wave * 32;
         kbase = (const uint8_t *)(p.k + (size_t)head * p.k_hs);
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
                     *(gv4f *)(slab + ((size_t)(wave * 16 + j) * 64 + lane) * 4) = v;
                 }
                 *(gv2f *)(slab + ATT_SLAB_O + (size_t)(wave * 64 + lane) * 2) = v2f{m_run, l_run};
-                const int owner = sched.owner_of(g, task);
+                const int owner = sched.owner_of(g, tl);
                 __syncthreads();
                 if (tid == 0) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             if (j1 < ntiles) {
                 // ---- owner of a split task: fold in the segments of the workgroups g+1 .. last (they hold the rest of
                 //      the task: the last one at the START of its run, any in between as their WHOLE run)
-                const int last = sched.last_contributor(g, task);
+                const int last = sched.last_contributor(g, tl);
                 if (tid == 0) {
                     // Bounded wait (~1 s): a missing arrival can only come from a broken contract (the workspace shared by
                     // launches in flight on two streams, or not zero-filled).  Then give up instead of hanging the GPU:
@@ -522,21 +543,26 @@ extern "C" int svdq_attention_schedule(int32_t L, int32_t H, int32_t cus, int32_
     const int G = attention_groups_for(L, H, cus >= 8 ? cus / 8 * 8 : cus);
     if (G == 0) return 0;
     const int ntiles = L / ATT_KB, QT = L / 256;
-    const AttnSchedule sched{ntiles, G, (long long)H * QT * ntiles / 2};
+    AttnSchedule sched;
+    sched.init(H * QT, ntiles, G);
     int n = 0;
-    for (int g = 0; g < G; g++)
+    auto emit = [&](int g, int task, int j0, int j1, int owner, int last) {
+        if (out && n < cap) {
+            int32_t *r = out + 6 * n;
+            r[0] = g; r[1] = task; r[2] = j0; r[3] = j1; r[4] = owner; r[5] = last;
+        }
+        n++;
+    };
+    for (int g = 0; g < G; g++) {
+        for (int f = 0; f < sched.F; f++) emit(g, f * G + g, 0, ntiles, -1, -1); // whole tasks first
+        if (g >= sched.Gs) continue;
         for (int pos = sched.bound(g), hi = sched.bound(g + 1); pos < hi;) {
-            const int task = pos / ntiles, j0 = pos - task * ntiles;
+            const int tl = pos / ntiles, j0 = pos - tl * ntiles;
             const int j1 = ntiles < j0 + (hi - pos) ? ntiles : j0 + (hi - pos);
             pos += j1 - j0;
-            if (out && n < cap) {
-                int32_t *r = out + 6 * n;
-                r[0] = g; r[1] = task; r[2] = j0; r[3] = j1;
-                r[4] = j0 > 0 ? sched.owner_of(g, task) : -1;
-                r[5] = j0 == 0 && j1 < ntiles ? sched.last_contributor(g, task) : -1;
-            }
-            n++;
+            emit(g, sched.F * G + tl, j0, j1, j0 > 0 ? sched.owner_of(g, tl) : -1, j0 == 0 && j1 < ntiles ? sched.last_contributor(g, tl) : -1);
         }
+    }
     return n;
 }
 

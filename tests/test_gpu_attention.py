@@ -60,7 +60,7 @@ def test_attention_persistent_schedule_matches_plain_grid(dtype, L, H):
     by the task's owner: 2 workgroups per task at (256, 3), 8 at (1024, 3), the FLUX.1 case last).  Same result as the
     plain grid up to fp32 summation order, bit-reproducible from launch to launch, counters left at zero."""
     from nunchaku_amd import _lib
-    from nunchaku_amd._C import ops
+    from nunchaku_amd._C import _Ops, ops
     from nunchaku_amd.ops.attention import attention_packed
 
     assert _lib.load().svdq_attention_schedule(L, H, 256, None, 0) > 0  # this shape does take the persistent path
@@ -70,10 +70,10 @@ def test_attention_persistent_schedule_matches_plain_grid(dtype, L, H):
     qkv[: L // 2, : H * 128] *= 4.0
     vt = qkv[:, 2 * H * 128:].t().contiguous()
     try:
-        ops.attention_use_workspace = False
+        _Ops.attention_use_workspace = False
         plain = attention_packed(qkv, vt, H)
     finally:
-        ops.attention_use_workspace = True
+        _Ops.attention_use_workspace = True
     runs = [attention_packed(qkv, vt, H) for _ in range(3)]
     ops.attention_workspace_status()
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
@@ -87,7 +87,7 @@ def test_attention_persistent_schedule_matches_plain_grid(dtype, L, H):
 
 
 def test_attention_strided_heads_and_errors():
-    from nunchaku_amd._C import ops
+    from nunchaku_amd._C import _Ops, ops
 
     L, H = 256, 2
     g = torch.Generator(device="cuda").manual_seed(5)

@@ -94,15 +94,22 @@ def test_attention_schedule_covers_every_tile_once_and_owners_agree(built_lib, L
     assert (cover == 1).all()
     per_wg = np.bincount(seg[:, 0], weights=seg[:, 3] - seg[:, 2], minlength=G)
     assert per_wg.max() - per_wg.min() <= 2  # balanced to one tile pair
-    first_seg = {}  # workgroup -> index of its first segment
-    for i, g in enumerate(seg[:, 0]):
-        first_seg.setdefault(int(g), i)
+    whole = tasks // G  # every workgroup first takes `whole` complete tasks (task f * G + g), then its share of the split remainder
+    first_seg = {}  # workgroup -> index of the first segment of its remainder run
+    count = {}
+    for i, (g, task, j0, j1, owner, last) in enumerate(seg):
+        k = count.get(int(g), 0)
+        count[int(g)] = k + 1
+        if k < whole:
+            assert task == k * G + g and j0 == 0 and j1 == ntiles and owner == -1 and last == -1
+        elif k == whole:
+            first_seg[int(g)] = i
     owners = {int(task): int(g) for g, task, j0, j1, owner, last in seg if j0 == 0}
     assert len(owners) == tasks
     contributors = {}
     for i, (g, task, j0, j1, owner, last) in enumerate(seg):
         if j0 > 0:
-            assert first_seg[int(g)] == i, "a workgroup publishes at most once: its FIRST segment"
+            assert first_seg[int(g)] == i, "a workgroup publishes at most once: the FIRST segment of its remainder run"
             assert owner == owners[int(task)] and owner < g
             contributors.setdefault(int(task), []).append(int(g))
         else:

@@ -17,11 +17,11 @@ def t(fn, it=20):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it * 1e3
 
 fl = 4 * H * L * L * 128
-from nunchaku_amd._C import ops
+from nunchaku_amd._C import _Ops, ops
 for rep in range(2):  # same box, interleaved: persistent schedule (workspace) vs plain grid
-    ops.attention_use_workspace = False
+    _Ops.attention_use_workspace = False
     us0 = t(lambda: attention_packed(qkv, vt, H, out=out)); print(f"svdq_attention plain grid  {us0:.1f} us  {fl/us0/1e6:.0f} TFLOP/s")
-    ops.attention_use_workspace = True
+    _Ops.attention_use_workspace = True
     us = t(lambda: attention_packed(qkv, vt, H, out=out)); print(f"svdq_attention persistent  {us:.1f} us  {fl/us/1e6:.0f} TFLOP/s")
 ops.attention_workspace_status()
 q, k, v = (qkv[:, i * H * 128:(i + 1) * H * 128].unflatten(1, (H, 128)).permute(1, 0, 2)[None] for i in range(3))
