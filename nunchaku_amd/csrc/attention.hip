@@ -285,7 +285,13 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
         // ---- one segment: KV tiles [j0, j1) of one task.  tl: the task's index among the remainder tasks (-1: a whole task)
         int task, j0, j1, tl = -1;
         if (whole_left > 0) {
-            task = PERSIST ? (sched.F - whole_left) * G + g : (int)blockIdx.y * QT + (int)blockIdx.x;
+            if constexpr (PERSIST) task = (sched.F - whole_left) * G + g;
+            else {
+                // plain grid: workgroups are dealt round-robin to the 8 XCDs in launch order; give XCD x the tasks
+                // [x * N/8, (x+1) * N/8) in that order, so the workgroups resident on it share heads (K / V^T tiles in its L2)
+                const int b = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, N = (int)(gridDim.x * gridDim.y);
+                task = N % 8 == 0 ? (b % 8) * (N / 8) + b / 8 : b;
+            }
             j0 = 0; j1 = ntiles;
             whole_left--;
         } else if (pos < run_hi) {
