@@ -770,3 +770,50 @@ def ln_mod_ref(x: np.ndarray, stats: np.ndarray, scale: np.ndarray, shift: np.nd
     ln = _round16_fma((x.astype(F32) - stats[:, 0:1]).astype(np.float64) * stats[:, 1:2].astype(np.float64), dtype)
     m = round16((ln.astype(np.float64) * scale.astype(np.float64)[None, :]).astype(F32), dtype)  # exact in fp32
     return _round16_fma(m.astype(np.float64) + shift.astype(np.float64)[None, :], dtype)
+
+
+# --------------------------------------------------------------------------
+# Attention over the packed QKV.  The reference computes it with its own fp16 flash
+# kernel (src/kernels/zgemm/attention.cu:11-94, attention.cuh) or torch SDPA (attention_processors/flux.py:62-110): any
+# correct softmax(QK^T/sqrt(d))V in 16-bit I/O.  This restatement follows the ARITHMETIC of nunchaku_amd/csrc/attention.hip
+# tile by tile, so the GPU test can hold the kernel (plain grid and persistent schedule alike) to ~1 ulp of the 16-bit
+# output instead of the loose "as good as SDPA" bar: it pins the kernel against its own specification, not against the
+# reference's different-but-equivalent algorithm.
+# --------------------------------------------------------------------------
+def attention_tiled(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: float, dtype: str, kb: int = 64, wave_rows: int = 32,
+                    defer_log2: float = 8.0) -> np.ndarray:
+    """One head.  q [Lq, d], k / v [L, d]: 16-bit values carried as float32.  Per tile of ``kb`` keys:
+    S = Q K^T in fp32; row maximum of the tile; the running (O, l) are rescaled only when some row of the 32-row wave
+    block outgrew its running maximum by more than ``defer_log2`` (in log2 units, after scale * log2(e)) -- then EVERY
+    row of the block takes max(m, m_tile); P = exp2(S c - m c) in fp32, ROUNDED to the 16-bit type; O += P16 V (fp32
+    accumulate) and l += sum(P16) -- the row sum is over the rounded probabilities; out = round16(O / l)."""
+    Lq, d = q.shape
+    L = k.shape[0]
+    assert L % kb == 0 and Lq % wave_rows == 0
+    c = F32(scale * 1.4426950408889634)
+    q, k, v = q.astype(F32), k.astype(F32), v.astype(F32)
+    out = np.empty((Lq, d), dtype=F32)
+    for w0 in range(0, Lq, wave_rows):
+        qb = q[w0:w0 + wave_rows]
+        o = np.zeros((wave_rows, d), dtype=F32)
+        m = np.full(wave_rows, -np.inf, dtype=F32)
+        l = np.zeros(wave_rows, dtype=F32)
+        for t0 in range(0, L, kb):
+            s = (qb @ k[t0:t0 + kb].T).astype(F32)
+            mloc = s.max(axis=1)
+            with np.errstate(invalid="ignore"):
+                grow = (mloc - m) * c
+            if (grow > F32(defer_log2)).any():
+                m_new = np.maximum(m, mloc)
+                with np.errstate(invalid="ignore"):
+                    alpha = np.exp2(((m - m_new) * c).astype(F32)).astype(F32)
+                alpha = np.where(np.isneginf(m), F32(0), alpha)
+                o *= alpha[:, None]
+                l *= alpha
+                m = m_new
+            p = np.exp2((s * c - (m * c)[:, None]).astype(F32)).astype(F32)
+            p16 = round16(p, dtype)
+            o += (p16 @ v[t0:t0 + kb]).astype(F32)
+            l += p16.sum(axis=1, dtype=F32)
+        out[w0:w0 + wave_rows] = o / l[:, None]
+    return round16(out, dtype)

@@ -86,6 +86,37 @@ def test_attention_persistent_schedule_matches_plain_grid(dtype, L, H):
         assert (runs[0].float() - ref).abs().max().item() <= 3 * ulp * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("L,H", [(256, 2), (1024, 3), (1152, 2)])
+def test_attention_matches_its_tile_by_tile_restatement(dtype, L, H):
+    """oracle.attention_tiled follows the kernel's arithmetic tile by tile (deferred rescale per 32-row wave block, probabilities
+    rounded to 16 bits, row sums over the ROUNDED probabilities): the kernel -- plain grid (L = 1152: the 4-wave kernel) and
+    persistent schedule with its split tasks (the others) -- must agree to about one unit in the last place of the 16-bit output.
+    What remains is the hardware exp2 (1 ulp of fp32, which can move a probability across a 16-bit rounding boundary) and the
+    fp32 summation order inside the MFMA and across merged partial results."""
+    from nunchaku_amd.ops.attention import attention_packed
+
+    td = TORCH_DT[dtype]
+    g = torch.Generator(device="cuda").manual_seed(17 * L + H)
+    qkv = torch.randn(L, 3 * H * 128, device="cuda", generator=g).to(td)
+    qkv[: L // 2, : H * 128] *= 4.0  # peaky rows: the deferred rescale and the dominated-row case both occur
+    vt = qkv[:, 2 * H * 128:].t().contiguous()
+    out = f32(attention_packed(qkv, vt, H)).reshape(L, H, 128)
+    x = f32(qkv).reshape(L, 3, H, 128)
+    ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11
+    worst, off = 0.0, 0.0
+    for h in range(H):
+        ref = O.attention_tiled(x[:, 0, h], x[:, 1, h], x[:, 2, h], 1.0 / math.sqrt(128), dtype)
+        # the error scale of a sum of rounded terms is ulp * sum p |v| (the same weights applied to |V|), not ulp * |result|:
+        # an output near zero is a sum of cancelling terms
+        cond = O.attention_tiled(x[:, 0, h], x[:, 1, h], np.abs(x[:, 2, h]), 1.0 / math.sqrt(128), dtype)
+        err = np.abs(out[:, h] - ref) / cond
+        worst = max(worst, float(err.max()))
+        off = max(off, float((err > 1.0 * ulp).mean()))
+    # (the final 16-bit rounding alone moves an output by up to one of its own ulps when o * (1 / l) and o / l differ in the last fp32 bit)
+    assert worst <= 2.5 * ulp and off <= 1e-2, f"vs the tiled restatement: worst {worst / ulp:.2f} ulp of sum p|v|, {off:.2e} of the outputs beyond 1 ulp"
+
+
 def test_attention_strided_heads_and_errors():
     from nunchaku_amd._C import _Ops, ops
 
