@@ -162,10 +162,16 @@ def test_qwen_model_offload_equals_resident():
     t = torch.tensor([0.6], device="cuda")
     resident = _small_model(5)
     with torch.no_grad():
-        ref = [resident(lat, enc, None, t, [(1, 16, 16)]).sample.clone() for _ in range(2)]
+        ref = [resident(lat, enc, None, t, [(1, 16, 16)]).sample.clone() for _ in range(4)]
     rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
-    noise = rel(ref[0], ref[1])  # fp32 atomics (K-sliced low-rank sums) + 4-bit code flips downstream: not bit-reproducible
-    assert noise < 3e-2
+    # Not bit-reproducible, and bimodal: 30 forwards of the SAME resident model land at relative distances 0, 8e-5, 1.5e-2, 1.8e-2
+    # or 2.0e-2 from the first one (measured) -- the order of the fp32 atomics of a K-sliced low-rank sum decides a 16-bit
+    # rounding, that flips a 4-bit activation code, and one flipped code in this tiny model is a 2 % event.  Offloaded forwards
+    # show the same set of values.  So the bar is the flip level, not the distance between two particular resident runs;
+    # stale or half-copied weights (what this test is for) would be an O(1) error.
+    noise = max(rel(ref[i], ref[k]) for i in range(4) for k in range(i))
+    assert noise < 5e-2
+    tol = 5e-2
     for late in (False, True):
         model = resident if late else _small_model(5)  # same seed: same weights
         with torch.no_grad():
@@ -180,8 +186,9 @@ def test_qwen_model_offload_equals_resident():
             got = [model(lat, enc, None, t, [(1, 16, 16)]).sample.clone() for _ in range(2)]
             torch.cuda.synchronize()
             assert mgr.forward_counter == 2 and mgr.current_block_idx == 0
-        for a, b in zip(got, ref):
-            assert torch.isfinite(a.float()).all() and rel(a, b) <= 3 * noise + 5e-3, f"offloaded forward (late={late}): rel {rel(a, b):.3e} vs noise {noise:.3e}"
+        for a in got:
+            d = min(rel(a, b) for b in ref)
+            assert torch.isfinite(a.float()).all() and d <= tol, f"offloaded forward (late={late}): rel {d:.3e} (resident runs among themselves: {noise:.3e})"
         model.set_offload(False)
         assert model.offload_manager is None
 
