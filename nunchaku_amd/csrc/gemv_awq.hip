@@ -15,6 +15,112 @@ namespace svdq {
 
 constexpr int AWQ_GROUP = 64;
 
+typedef float gv2f __attribute__((ext_vector_type(2)));
+typedef __bf16 gbf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 gf16x2 __attribute__((ext_vector_type(2)));
+// acc + round16(a) + round16(b): one v_cvt_pk (the two roundings) and one v_dot2c_f32_* against (1, 1)
+template <int DT> __device__ __forceinline__ float add2_rounded(float a, float b, float acc) {
+    if constexpr (DT == SVDQ_BF16) {
+        const gbf16x2 pk = __builtin_convertvector((gv2f){a, b}, gbf16x2);
+        return __builtin_amdgcn_fdot2_f32_bf16(pk, __builtin_bit_cast(gbf16x2, 0x3f803f80u), acc, false);
+    } else {
+        const gf16x2 pk = __builtin_convertvector((gv2f){a, b}, gf16x2);
+        return __builtin_amdgcn_fdot2(pk, __builtin_bit_cast(gf16x2, 0x3c003c00u), acc, false);
+    }
+}
+
+constexpr int AWQ_XLDS_MAX_K = 8192; // M = 1: the activation vector lives in LDS as fp32 (32 KiB at most)
+
+// M = 1 (the modulation projections of a denoise step: 1.6 GB of codes, one activation vector).  At 1.7-1.9 TB/s the kernel
+// is nowhere near HBM: it pays ~10 VALU instructions per weight for the reference's two 16-bit roundings per product.  This
+// path trims them: x is converted ONCE per workgroup (fp32 in LDS, broadcast ds_read_b128 instead of an unpack per weight and
+// lane), nibbles become floats through v_cvt_f32_ubyteN on two masked copies of the word, and the accumulation takes two
+// rounded products per v_cvt_pk + v_dot2c.  Same rounding points; the fp32 sum is formed in a different order (as between any
+// two launches of the reference).  Measured in the FLUX step (all 57 blocks' projections in one batched launch): 919 -> 826 us.
+template <int DT>
+__device__ __forceinline__ void gemv_awq_rowgroup_x1(const float *xs /* LDS */, const uint8_t *__restrict__ qw,
+                                                     const uint16_t *__restrict__ scales, const uint16_t *__restrict__ zeros,
+                                                     const uint16_t *__restrict__ bias, uint16_t *__restrict__ out, int K, int N,
+                                                     int ochunks, int rg) {
+    using T = typename Half<DT>::T;
+    typedef __attribute__((address_space(3))) v4f lds_v4f;
+    const int lane = threadIdx.x & 63;
+    if (rg * 4 >= N) return;
+    const int row = (lane >> 1) & 3, half = lane & 1, cl = lane >> 3;
+    const int n = rg * 4 + row;
+    const int chunks = K / AWQ_GROUP;
+    const uint8_t *wbase = qw + (size_t)rg * K * 2;
+    float acc = 0.f, acc2 = 0.f; // two chains
+    constexpr int U = 4;
+    for (int c0 = 0; c0 < chunks; c0 += 8 * U) {
+        v4i w[U];
+        float s[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int c = c0 + 8 * u + cl;
+            const bool live = c < chunks;
+            w[u] = live ? __builtin_nontemporal_load(reinterpret_cast<const v4i *>(wbase + (size_t)(c0 + 8 * u) * 128 + lane * 16)) : v4i{0, 0, 0, 0};
+            s[u] = live ? h2f(hfrom<T>(scales[(size_t)c * N + n])) : 0.f;
+            z[u] = live ? h2f(hfrom<T>(zeros[(size_t)c * N + n])) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int c = c0 + 8 * u + cl;
+            if (c0 + 8 * u >= chunks) break; // wave-uniform
+            const int k0 = (c < chunks ? c : 0) * AWQ_GROUP + half * 32; // dead lanes read chunk 0 and add w = 0
+            const __attribute__((address_space(3))) float *xk = (const __attribute__((address_space(3))) float *)xs + k0;
+            // 8 int16 = 32 channels: int16 j, nibble e <-> channel 8*e + j of this half (tinychat_utils.py:97-105); dword i holds
+            // int16 2i (low half) and 2i+1: byte b of (word & 0x0f0f0f0f) is nibble e = 2*(b&1) of int16 2i + (b>>1), byte b of
+            // ((word >> 4) & 0x0f0f0f0f) nibble e = 2*(b&1) + 1
+            float xv[32];
+#pragma unroll
+            for (int v = 0; v < 8; v++) {
+                const v4f t = *(const lds_v4f *)(xk + 4 * v);
+                xv[4 * v] = t[0]; xv[4 * v + 1] = t[1]; xv[4 * v + 2] = t[2]; xv[4 * v + 3] = t[3];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned word = (unsigned)w[u][i];
+                const unsigned ev = word & 0x0f0f0f0fu, od = (word >> 4) & 0x0f0f0f0fu;
+                float p[8];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int j = 2 * i + (b >> 1);
+                    const float qe = (float)((ev >> (8 * b)) & 0xffu), qo = (float)((od >> (8 * b)) & 0xffu);
+                    const float we = round16<T>(__builtin_fmaf(qe, s[u], z[u])), wo = round16<T>(__builtin_fmaf(qo, s[u], z[u]));
+                    p[2 * b] = we * xv[8 * (2 * (b & 1)) + j];
+                    p[2 * b + 1] = wo * xv[8 * (2 * (b & 1) + 1) + j];
+                }
+                acc = add2_rounded<DT>(p[0], p[1], acc);
+                acc2 = add2_rounded<DT>(p[2], p[3], acc2);
+                acc = add2_rounded<DT>(p[4], p[5], acc);
+                acc2 = add2_rounded<DT>(p[6], p[7], acc2);
+            }
+        }
+    }
+    float a = acc + acc2;
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 8);
+    a += __shfl_xor(a, 16);
+    a += __shfl_xor(a, 32);
+    if (half == 0 && cl == 0) {
+        float y = round16<T>(a);
+        if (bias) y = round16<T>(y + h2f(hfrom<T>(bias[n])));
+        const int no = ochunks > 1 ? (n % ochunks) * (N / ochunks) + n / ochunks : n;
+        out[no] = hbits(f2h<T>(y));
+    }
+}
+
+// x [K] 16-bit -> fp32 in LDS, cooperatively (every thread of the 256-thread workgroup; ends with a barrier)
+template <int DT> __device__ __forceinline__ void gemv_stage_x(float *xs /* LDS */, const uint16_t *__restrict__ x, int K) {
+    using T = typename Half<DT>::T;
+    for (int k = threadIdx.x * 4; k < K; k += 256 * 4) {
+        const u16x4 v = *reinterpret_cast<const u16x4 *>(x + k);
+        *reinterpret_cast<v4f *>(xs + k) = v4f{h2f(hfrom<T>(v[0])), h2f(hfrom<T>(v[1])), h2f(hfrom<T>(v[2])), h2f(hfrom<T>(v[3]))};
+    }
+    __syncthreads();
+}
+
 template <int DT, int M>
 __device__ __forceinline__ void gemv_awq_rowgroup(const uint16_t *__restrict__ x, const uint8_t *__restrict__ qw,
                                                   const uint16_t *__restrict__ scales, const uint16_t *__restrict__ zeros,
@@ -96,6 +202,14 @@ __global__ __launch_bounds__(256) void gemv_awq_kernel(const uint16_t *__restric
                                                         const uint16_t *__restrict__ scales, const uint16_t *__restrict__ zeros,
                                                         const uint16_t *__restrict__ bias, uint16_t *__restrict__ out, int K, int N,
                                                         int ldx, int ochunks) {
+    if constexpr (M == 1) {
+        __shared__ __attribute__((aligned(16))) float xs[AWQ_XLDS_MAX_K];
+        if (K <= AWQ_XLDS_MAX_K) { // block-uniform
+            gemv_stage_x<DT>(xs, x, K);
+            gemv_awq_rowgroup_x1<DT>(xs, qw, scales, zeros, bias, out, K, N, ochunks, blockIdx.x * 4 + (threadIdx.x >> 6));
+            return;
+        }
+    }
     gemv_awq_rowgroup<DT, M>(x, qw, scales, zeros, bias, out, K, N, ldx, ochunks, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
@@ -108,6 +222,12 @@ __global__ __launch_bounds__(256) void gemv_awq_batched_kernel(const uint16_t *_
     int i = 0, first = 0; // block-uniform scan: entry i owns blocks [first, first + ceil(N_i / 16))
     while (i + 1 < b.count && (int)blockIdx.x >= first + (b.e[i].N / 4 + 3) / 4) { first += (b.e[i].N / 4 + 3) / 4; i++; }
     const GemvEntry &e = b.e[i];
+    __shared__ __attribute__((aligned(16))) float xs[AWQ_XLDS_MAX_K];
+    if (K <= AWQ_XLDS_MAX_K) { // block-uniform
+        gemv_stage_x<DT>(xs, x, K);
+        gemv_awq_rowgroup_x1<DT>(xs, e.qw, e.scales, e.zeros, e.bias, e.out, K, e.N, e.ochunks, ((int)blockIdx.x - first) * 4 + (threadIdx.x >> 6));
+        return;
+    }
     gemv_awq_rowgroup<DT, 1>(x, e.qw, e.scales, e.zeros, e.bias, e.out, K, e.N, ldx, e.ochunks,
                              ((int)blockIdx.x - first) * 4 + (threadIdx.x >> 6));
 }
