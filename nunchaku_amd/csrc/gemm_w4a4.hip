@@ -918,10 +918,21 @@ static int streamk_groups(const GemmParams &p, int tiles, int KP) {
     const double with_sk = (double)R * KP / gs + 10.0, without = (double)KP;
     return with_sk < 0.85 * without ? (int)gs : 0;
 }
+// Grid of a launch WITHOUT stream-K.  Whole rounds on fewer workgroups: 1296 tiles are 6 rounds on 256 CUs (the last one 6 % full)
+// and 6 rounds on 216 -- the same number of tile times, but no CU sits through a nearly empty round and the chip is
+// power-limited: the 40 idle CUs lend their budget to the busy ones (QKV+RoPE 192 -> 185 us, fc1+GELU_QUANT 278 -> 270 us,
+// out-projection 60.7 -> 59.4 us; profiles/r2_gemm_loop_variants_ab.txt).  A multiple of 8 (XCD-aware numbering).
+static int whole_rounds_grid(int tiles, int cus) {
+    if (tiles <= cus) return tiles;
+    const int rounds = (tiles + cus - 1) / cus;
+    const int g = ((tiles + rounds - 1) / rounds + 7) / 8 * 8;
+    return g <= cus ? g : cus;
+}
 static int persistent_grid(const GemmParams &p, int tiles) {
     const int cus = device_cus();
     if (p.sk_gs > 0) return tiles < cus ? max(tiles, p.sk_gs) : cus;
-    return tiles < cus ? tiles : cus;
+    if (DBG(8192)) return tiles < cus ? tiles : cus; // (ablation build: one workgroup per CU as before)
+    return whole_rounds_grid(tiles, cus);
 }
 
 template <int DT, int FUSE, int LOOPV>
@@ -995,7 +1006,7 @@ extern "C" int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t c
             if (g > R && (double)R * KP / g + 10.0 < 0.85 * KP) gs = (int)g;
         }
     }
-    const int G = gs > 0 ? (tiles < cus ? (tiles > gs ? tiles : gs) : cus) : (tiles < cus ? tiles : cus);
+    const int G = gs > 0 ? (tiles < cus ? (tiles > gs ? tiles : gs) : cus) : whole_rounds_grid(tiles, cus);
     int n = 0;
     for (int pos = 0; pos < G; pos++) {
         GemmSchedule sc;
