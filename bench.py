@@ -107,6 +107,11 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events in the timed region (their cost: ~0.5 %%)")
     ap.add_argument("--layers", type=int, nargs=2, default=(19, 38), help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--geometry", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="workgroup geometry of the W4A4 GEMM (svdq_gemm_args.geometry): 0 = the library's choice, 1 = 256x128 "
+                         "tiles / one workgroup per CU, 2 = 128x128 tiles / two per CU out of phase, 3 = 2 without the phase offset")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="fixed-point low-rank accumulation (nunchaku_amd.mode): bit-reproducible steps")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured HIP graph (no per-launch events: the roofline object is then "
                          "measured on one extra eager step after the timed region)")
@@ -120,6 +125,11 @@ def main():
     from nunchaku_amd import _lib, replica
     from nunchaku_amd.models.flux import FluxTransformerAMD
 
+    from nunchaku_amd import mode
+    from nunchaku_amd._C import _Ops
+
+    _Ops.gemm_geometry = args.geometry
+    mode.set_deterministic(args.deterministic)
     rank, local_rank, world = replica.init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 14
+#define SVDQ_ABI_VERSION 15
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -63,6 +63,17 @@ enum {
     SVDQ_FUSE_RMSNORM_ROPE = 3 /* QKV: RMSNorm(q,k)+RoPE then store              (launch_impl.cuh:347-405) */
 };
 
+/* lora_act formats.  The low-rank activations lora_act[M_pad, R] are an OPAQUE hand-off between the kernel that produces
+ * them (the quantiser, a GELU_QUANT epilogue, the attention kernel's fused quantiser) and the GEMM that consumes them
+ * (the reference's order is NVIDIA-fragment specific, lora.cuh:61-80; only the size M_pad*R*4 bytes is visible to callers).
+ *   SVDQ_LORA_ACT_F32: natural [m][r] fp32; partial sums (K slices, column tiles, heads) are combined with fp32 atomics,
+ *                      so the last bits depend on their arrival order -- the reference's own behaviour (lora.cuh:82-94,323).
+ *   SVDQ_LORA_ACT_Q32: natural [m][r] int64 holding value * 2^32 (Q31.32 fixed point), M_pad*R*8 bytes; partial sums are
+ *                      combined with 64-bit INTEGER atomics, which are associative: the result is bit-reproducible from
+ *                      run to run ("deterministic mode").  Producer and consumer must agree; the buffer must be zeroed
+ *                      (all-zero bytes are 0.0 in both formats). */
+enum { SVDQ_LORA_ACT_F32 = 0, SVDQ_LORA_ACT_Q32 = 1 };
+
 /* ------------------------------------------------------------------------------------------
  * svdq_quantize_w4a4_act_fuse_lora
  * replaces kernels::quantize_w4a4_act_fuse_lora (zgemm.h:39-46, gemm_w4a4.cuh:1097-1184).
@@ -81,7 +92,7 @@ typedef struct svdq_quantize_args {
     const void *lora_down; /* [K*R] 16-bit in svdq_repack_lowrank(down=1) order; NULL if R==0 */
     void *act;             /* out: FP6 image of the int4 codes, M_pad*K*3/4 bytes            */
     void *ascales;         /* out: (K/64)*M_pad 16-bit                                        */
-    float *lora_act;       /* out: M_pad*R fp32 (zeroed + accumulated inside the call)        */
+    void *lora_act;        /* out: M_pad*R fp32 -- or int64, see lora_act_format -- (zeroed + accumulated inside the call) */
     int32_t M;             /* actual rows                                                     */
     int32_t M_pad;         /* multiple of 256, >= M                                           */
     int32_t K;             /* multiple of 128                                                 */
@@ -107,6 +118,8 @@ typedef struct svdq_quantize_args {
     int32_t M2, ldx2, split_rows;
     int32_t lora_act_zeroed; /* non-zero: the caller guarantees lora_act is already zero on this stream (e.g. cleared by
                                 svdq_residual_gate_stats' zero_ptr), so the hipMemsetAsync of the K-sliced reduction is skipped */
+    int32_t lora_act_format; /* SVDQ_LORA_ACT_F32 (lora_act: M_pad*R fp32) | SVDQ_LORA_ACT_Q32 (M_pad*R int64, deterministic) */
+    int32_t reserved;
 } svdq_quantize_args;
 
 int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *args, void *stream);
@@ -125,7 +138,7 @@ typedef struct svdq_gemm_args {
     const void *ascales;      /* (K/64)*M_pad 16-bit, scale image                              */
     const void *wscales;      /* (K/64)*N 16-bit, scale image (svdq_repack_wscales)            */
     const void *bias;         /* [N] 16-bit natural order or NULL                              */
-    const float *lora_act_in; /* M_pad*R fp32 or NULL                                          */
+    const void *lora_act_in;  /* M_pad*R fp32 (or int64, see lora_act_format) or NULL          */
     const void *lora_up;      /* [N, R] 16-bit natural row-major (svdq_repack_lowrank(down=0)) */
     const float *lora_scales; /* HOST pointer, R/16 floats, or NULL (= all 1.0)                */
     void *out;                /* [M, N] 16-bit, row stride ldo; required unless GELU_QUANT     */
@@ -134,8 +147,8 @@ typedef struct svdq_gemm_args {
     void *oscales;            /* (N/64)*M_pad 16-bit, scale image                              */
     const void *next_smooth;  /* [N] 16-bit natural order                                      */
     const void *next_lora_down; /* [N*R2] 16-bit, svdq_repack_lowrank(down=1) order, or NULL   */
-    float *lora_act_out;      /* M_pad*R2 fp32; MUST be zeroed by the caller on the same stream
-                                 (reference: lora_act_out.zero_(), launch_impl.cuh:252)        */
+    void *lora_act_out;       /* M_pad*R2 fp32 (or int64, see lora_act_format); MUST be zeroed by the caller on the
+                                 same stream (reference: lora_act_out.zero_(), launch_impl.cuh:252) */
     /* SVDQ_FUSE_RMSNORM_ROPE */
     const void *norm_q;       /* [128] 16-bit                                                   */
     const void *norm_k;       /* [128] 16-bit                                                   */
@@ -151,7 +164,7 @@ typedef struct svdq_gemm_args {
     int32_t dtype;            /* SVDQ_BF16 | SVDQ_FP16                                          */
     int32_t act_unsigned;     /* informational: the FP6 image already encodes signedness        */
     int32_t fuse;             /* SVDQ_FUSE_*                                                    */
-    int32_t variant;          /* 0 = hand-scheduled main loop; 1 = compiler-scheduled twin (same results; A/B debugging) */
+    int32_t variant;          /* must be 0 */
     int32_t reserved;         /* must be 0 */
     /* optional scratch for the stream-K tail (svdq_gemm_workspace_bytes() bytes, zero-filled ONCE by the
      * caller, then reusable by every later call ON THE SAME STREAM; NULL = whole-tile schedule only).
@@ -167,7 +180,11 @@ typedef struct svdq_gemm_args {
      * (text + image) attention passes the same buffer to both GEMMs with out_vt offset by the token start. */
     void *out_vt;
     int32_t ldvt;             /* row stride of out_vt in elements (>= total tokens)              */
-    int32_t reserved2;
+    /* Workgroup geometry: 0 = chosen by the library; 1 = 256 x 128 tiles, one 512-thread workgroup per CU; 2 = 128 x 128
+     * tiles, two 256-thread workgroups per CU running half a tile out of phase (one's epilogue under the other's main
+     * loop); 3 = as 2 without the phase offset (A/B measurements).  Results are bit-identical across geometries for
+     * launches without a stream-K split (the split points, hence the fp32 summation order of a split tile, differ). */
+    int32_t geometry;
     /* Grouped launch (optional): rows [split_rows, M_pad) use a SECOND weight set of the same shape, rank and
      * epilogue -- one launch for the text and the image stream of a joint FLUX block (same layer type, different
      * weights, transformer_flux_v2.py:200-260), whose row-side tensors (act, ascales, lora_act_in, out, qout,
@@ -178,11 +195,18 @@ typedef struct svdq_gemm_args {
     const void *next_smooth2, *next_lora_down2; /* GELU_QUANT */
     const void *norm_q2, *norm_k2;              /* RMSNORM_ROPE */
     int32_t split_rows;       /* multiple of 256, 0 < split_rows < M_pad                         */
-    int32_t reserved3;
+    int32_t lora_act_format;  /* SVDQ_LORA_ACT_F32 | SVDQ_LORA_ACT_Q32: format of lora_act_in AND lora_act_out */
+    /* Optional host-visible status word (pinned, device-accessible host memory: hipHostMalloc / a torch pinned tensor), or
+     * NULL.  A stream-K owner that gives up waiting for partial tiles (see `workspace`) stores 1 here with system scope:
+     * the host can poll it WITHOUT synchronising -- nunchaku_amd/_C.py checks it before every launch on the same stream
+     * and raises.  The co-residency the persistent schedule relies on: the whole grid (<= 1 or 2 workgroups per CU,
+     * depending on the geometry) must become resident while owners wait -- true for a stream that owns the device, not for
+     * a CU-masked stream or beside a long-running co-tenant kernel; pass workspace = NULL there. */
+    int32_t *status;
 } svdq_gemm_args;
 
 int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
-/* size of the stream-K workspace for the current device (255 arrival counters + 1 error word + 2 fp32 tiles per CU) */
+/* size of the stream-K workspace for the current device (1023 arrival counters + 1 error word + 2 fp32 tiles of 256 x 128 per CU) */
 int64_t svdq_gemm_workspace_bytes(void);
 /* Synchronises `stream`, then returns SVDQ_E_HIP (and clears the flag) if a launch that used `workspace` timed out
  * waiting for partial tiles -- see svdq_gemm_args.workspace; SVDQ_OK otherwise.  Test / debugging aid. */
@@ -191,6 +215,9 @@ int svdq_gemm_workspace_status(void *workspace, void *stream);
  * `cap` records of 6 int32 {position, tile, kp0, kp1, partial slot or -1, contributors the owner waits for}
  * and returns the number of segments, or -1 for invalid shapes. */
 int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t *out, int32_t cap);
+/* the same for an explicit geometry (1 or 2, see svdq_gemm_args.geometry); svdq_gemm_schedule is geometry 1 */
+int svdq_gemm_schedule_ex(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t geometry,
+                          int32_t *out, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * Attention over the packed QKV (reference: ops.attention_fp16, nunchaku/csrc/ops.h:114-121,
@@ -226,7 +253,7 @@ typedef struct svdq_attention_args {
      * Rows >= qsplit_rows (a multiple of 256; 0 = off) use qsmooth2 / qlora_down2 (joint attention: text rows first). */
     void *qact;               /* FP6 image, L * (H*128) * 3/4 bytes                                 */
     void *qscales;            /* scale image, (H*128/64) * L 16-bit                                 */
-    float *qlora_act;         /* [L, R] fp32, pre-zeroed                                            */
+    void *qlora_act;          /* [L, R] fp32 (or int64: qlora_act_format), pre-zeroed               */
     const void *qsmooth, *qlora_down;   /* [H*128] natural; [R][H*128] rank-major (svdq_repack_lowrank(down=1)) */
     const void *qsmooth2, *qlora_down2;
     int32_t qR, qsplit_rows;
@@ -239,6 +266,9 @@ typedef struct svdq_attention_args {
      * Results of the two schedules differ by fp32 summation order only. */
     void *workspace;
     int64_t workspace_bytes;
+    int32_t qlora_act_format; /* SVDQ_LORA_ACT_F32 | SVDQ_LORA_ACT_Q32 (deterministic head sum) */
+    int32_t reserved2;
+    int32_t *status;          /* optional host-visible status word, as svdq_gemm_args.status */
 } svdq_attention_args;
 
 int svdq_attention(const svdq_attention_args *args, void *stream);

@@ -12,6 +12,7 @@ SURVEY.md section 5), unsupported reference features raise ``NotImplementedError
 
 from __future__ import annotations
 
+import collections
 import ctypes as C
 
 import torch
@@ -35,33 +36,63 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-_workspaces: dict[tuple[int, int, str], torch.Tensor] = {}
+class _Workspace:
+    """Scratch of one (device, stream, kind): the device buffer + a pinned, device-visible int32 status word the kernels
+    raise when a waiting workgroup gives up (svdq_gemm_args.status): polled WITHOUT synchronising before every launch."""
+
+    __slots__ = ("buf", "status")
+
+    def __init__(self, buf, status):
+        self.buf, self.status = buf, status
+
+    def check(self, what: str):
+        if int(self.status[0]) != 0:  # a plain host read of pinned memory
+            self.status.zero_()
+            self.buf[:8192].zero_()  # counters of the abandoned launch (stream-ordered behind it)
+            raise RuntimeError(
+                f"{what}: an earlier launch on this stream gave up waiting for partial results of its persistent schedule "
+                "(the workspace was shared across streams, or the grid was not co-resident: a CU-masked stream / a long-running "
+                "co-tenant kernel).  Its results are invalid.  Set ops.gemm_use_workspace / ops.attention_use_workspace = False "
+                "for such streams.")
 
 
-def _workspace(device: torch.device, kind: str = "gemm") -> torch.Tensor:
+_WORKSPACE_LIMIT = 8  # per kind: LRU bound (64 MB GEMM / 33 MB attention each); pools of temporary streams recycle entries
+_workspaces: "collections.OrderedDict[tuple[int, int, str], _Workspace]" = collections.OrderedDict()
+
+
+def _workspace(device: torch.device, kind: str = "gemm") -> _Workspace:
     """Scratch of the GEMM's stream-K tail (arrival counters + fp32 partial tiles) or, ``kind="attention"``, of the
     attention kernel's persistent schedule (counters + fp32 partial (O, m, l)); one per (device, STREAM, kind).
 
     The C ABI allows a workspace to be reused only by launches that are ordered on one stream (include/svdq_amd.h,
     ``svdq_gemm_args.workspace``): two GEMMs in flight on different streams of a device would share counters and
     partial-tile slabs.  So the buffer is keyed by the current stream's handle: side streams (the offload manager's
-    schedule, a capturing stream, worker threads with their own streams) each get their own 64 MB (GEMM) / 33 MB
-    (attention) buffer on first use, allocated from the torch caching allocator, zero-filled once; the kernels leave the
-    counters at zero."""
+    schedule, a capturing stream, worker threads with their own streams) each get their own buffer on first use, allocated
+    from the torch caching allocator, zero-filled once; the kernels leave the counters at zero.  The cache is bounded
+    (least recently used entry dropped beyond ``_WORKSPACE_LIMIT`` per kind); a launch that gave up (status word) has its
+    counters cleared by ``_Workspace.check`` before the error is raised, so a later tenant of the stream handle never
+    inherits a stale count."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, _stream(), kind)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream, kind)
     ws = _workspaces.get(key)
     if ws is None:
         lib = _lib.load()
         size = lib.svdq_attention_workspace_bytes() if kind == "attention" else lib.svdq_gemm_workspace_bytes()
         with torch.cuda.device(idx):
-            ws = torch.zeros(int(size), dtype=torch.uint8, device=device)
+            buf = torch.zeros(int(size), dtype=torch.uint8, device=device)
+        status = torch.zeros(1, dtype=torch.int32).pin_memory()
+        ws = _Workspace(buf, status)
         _workspaces[key] = ws
+        same_kind = [k for k in _workspaces if k[2] == kind]
+        for k in same_kind[:max(0, len(same_kind) - _WORKSPACE_LIMIT)]:
+            del _workspaces[k]  # the tensor is freed by the caching allocator once queued work on it has finished
+    else:
+        _workspaces.move_to_end(key)
     return ws
 
 
 def release_workspaces() -> None:
-    """Drop every cached stream-K workspace (e.g. after a pool of temporary streams has been destroyed)."""
+    """Drop every cached workspace (e.g. after a pool of temporary streams has been destroyed)."""
     _workspaces.clear()
 
 
@@ -140,9 +171,10 @@ def _weight(wgt: torch.Tensor, K: int) -> torch.Tensor:
 
 
 class _Ops:
-    # 0 = hand-scheduled main loop, 1 = its compiler-scheduled twin (bit-identical results; A/B debugging and tests).
-    # A plain attribute, not an environment variable: nothing is read from os.environ on the launch path.
-    gemm_variant = 0
+    # Workgroup geometry of gemm_w4a4 (svdq_gemm_args.geometry): 0 = the library's choice, 1 = 256 x 128 tiles / one
+    # workgroup per CU, 2 = 128 x 128 tiles / two workgroups per CU half a tile out of phase, 3 = as 2 without the phase
+    # offset.  A plain attribute, not an environment variable: nothing is read from os.environ on the launch path.
+    gemm_geometry = 0
     # False: launch without the stream-K workspace (whole-tile schedule only); tests compare the two schedules
     gemm_use_workspace = True
 
@@ -153,7 +185,8 @@ class _Ops:
         key = (torch.cuda.current_device(), _stream(), "gemm")
         ws = _workspaces.get(key)
         if ws is not None:
-            _lib.check(_lib.load().svdq_gemm_workspace_status(ws.data_ptr(), _stream()), "gemm_workspace_status")
+            _lib.check(_lib.load().svdq_gemm_workspace_status(ws.buf.data_ptr(), _stream()), "gemm_workspace_status")
+            ws.status.zero_()
 
     # False: plain grid (one workgroup per task) instead of the persistent schedule; tests compare the two
     attention_use_workspace = True
@@ -163,7 +196,8 @@ class _Ops:
         """Raises if an attention launch on the current stream gave up waiting for partial results.  Test / debugging aid."""
         ws = _workspaces.get((torch.cuda.current_device(), _stream(), "attention"))
         if ws is not None:
-            _lib.check(_lib.load().svdq_attention_workspace_status(ws.data_ptr(), _stream()), "attention_workspace_status")
+            _lib.check(_lib.load().svdq_attention_workspace_status(ws.buf.data_ptr(), _stream()), "attention_workspace_status")
+            ws.status.zero_()
 
     @staticmethod
     def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False,
@@ -221,8 +255,10 @@ class _Ops:
             keep2 = (x2, second, sm2, ld2)
         if oscales.numel() != (K // 64) * M_pad:
             raise ValueError("quantize_w4a4_act_fuse_lora: oscales must hold (K/64)*M_pad scales")
-        if R and lora_act_out.numel() != M_pad * R:
-            raise ValueError("quantize_w4a4_act_fuse_lora: lora_act_out must hold M_pad*R floats")
+        if R and (lora_act_out.numel() != M_pad * R or lora_act_out.dtype not in (torch.float32, torch.int64)):
+            raise ValueError("quantize_w4a4_act_fuse_lora: lora_act_out must hold M_pad*R float32 (or int64: the deterministic fixed-point format)")
+        if R and lora_act_out.dtype == torch.int64:
+            a.lora_act_format = _lib.LORA_ACT_Q32
         _lib.check(lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), _stream()), "quantize_w4a4_act_fuse_lora")
         del keep2
 
@@ -293,8 +329,10 @@ class _Ops:
         a.act_unsigned = int(bool(act_unsigned))
         if _Ops.gemm_use_workspace:
             ws = _workspace(act.device)
-            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        a.variant = _Ops.gemm_variant
+            ws.check("gemm_w4a4")  # host-visible status word of the earlier launches on this stream: no synchronisation
+            a.workspace, a.workspace_bytes, a.status = ws.buf.data_ptr(), ws.buf.numel(), ws.status.data_ptr()
+        a.geometry = _Ops.gemm_geometry
+        fmt_in = lora_act_in.dtype if R else None
 
         if qout is not None and oscales is not None:
             a.fuse = _lib.FUSE_GELU_QUANT
@@ -305,6 +343,9 @@ class _Ops:
                 a.R2 = lora_down.shape[-1]
                 lora_down = _param(lora_down, "down")
                 a.next_lora_down, a.lora_act_out = _ptr(lora_down), _ptr(lora_act_out)
+                if lora_act_out.dtype not in (torch.float32, torch.int64) or (fmt_in is not None and lora_act_out.dtype != fmt_in):
+                    raise ValueError("gemm_w4a4: lora_act_in and lora_act_out must share one format (float32, or int64 fixed point)")
+                fmt_in = lora_act_out.dtype
                 if not lora_act_zeroed:  # extension: the caller cleared it already (residual_gate_stats(..., zero=))
                     lora_act_out.zero_()  # launch_impl.cuh:252
         elif rotary_emb is not None:
@@ -347,6 +388,10 @@ class _Ops:
             a.next_lora_down2 = g("lora_down") if a.R2 else None
             a.split_rows = int(split_rows)
             keep2 = (second, conv)  # keeps the tensors alive until the launch has been issued
+        if fmt_in is not None:
+            if fmt_in not in (torch.float32, torch.int64):
+                raise ValueError("gemm_w4a4: lora_act_in must be float32 (or int64: the deterministic fixed-point format)")
+            a.lora_act_format = _lib.LORA_ACT_Q32 if fmt_in == torch.int64 else _lib.LORA_ACT_F32
         if out_vt is not None and a.fuse != _lib.FUSE_RMSNORM_ROPE:
             raise ValueError("gemm_w4a4: out_vt needs the RMSNorm+RoPE epilogue (rotary_emb, norm_q, norm_k)")
         if out_vt is not None and out_vt.shape[1] < a.M:
@@ -510,6 +555,8 @@ class _Ops:
             if quant["act"].numel() != L * Kq * 3 // 4 or quant["ascales"].numel() != (Kq // 64) * L:
                 raise ValueError("attention: quant['act'] / quant['ascales'] must be the [L, 3K/4] / [K/64, L] operand images")
             a.qact, a.qscales, a.qlora_act = _ptr(quant["act"]), _ptr(quant["ascales"]), _ptr(quant.get("lora_act"))
+            if quant.get("lora_act") is not None and quant["lora_act"].dtype == torch.int64:
+                a.qlora_act_format = _lib.LORA_ACT_Q32
             a.qsmooth, a.qlora_down, a.qR = _ptr(quant["smooth"]), _ptr(quant.get("lora_down")), int(quant.get("R", 0))
             a.qsmooth2, a.qlora_down2 = _ptr(quant.get("smooth2")), _ptr(quant.get("lora_down2"))
             a.qsplit_rows = int(quant.get("split_rows", 0))
@@ -522,7 +569,8 @@ class _Ops:
             a.zero_ptr, a.zero_bytes = zero.data_ptr(), zero.numel() * zero.element_size()
         if _Ops.attention_use_workspace and L % 256 == 0:
             ws = _workspace(q.device, "attention")
-            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            ws.check("attention")
+            a.workspace, a.workspace_bytes, a.status = ws.buf.data_ptr(), ws.buf.numel(), ws.status.data_ptr()
         _lib.check(lib.svdq_attention(C.byref(a), _stream()), "attention")
 
 

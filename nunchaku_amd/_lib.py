@@ -12,7 +12,8 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 14
+ABI_VERSION = 15
+LORA_ACT_F32, LORA_ACT_Q32 = 0, 1
 
 
 class QuantizeArgs(C.Structure):
@@ -24,7 +25,7 @@ class QuantizeArgs(C.Structure):
         ("ln_stats", C.c_void_p), ("mod_scale", C.c_void_p), ("mod_shift", C.c_void_p),
         ("x2", C.c_void_p), ("smooth2", C.c_void_p), ("lora_down2", C.c_void_p), ("mod_scale2", C.c_void_p),
         ("mod_shift2", C.c_void_p), ("ln_stats2", C.c_void_p), ("M2", C.c_int32), ("ldx2", C.c_int32),
-        ("split_rows", C.c_int32), ("lora_act_zeroed", C.c_int32),
+        ("split_rows", C.c_int32), ("lora_act_zeroed", C.c_int32), ("lora_act_format", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -50,10 +51,10 @@ class GemmArgs(C.Structure):
         ("R", C.c_int32), ("R2", C.c_int32), ("ldo", C.c_int32), ("dtype", C.c_int32),
         ("act_unsigned", C.c_int32), ("fuse", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("out_vt", C.c_void_p), ("ldvt", C.c_int32), ("reserved2", C.c_int32),
+        ("out_vt", C.c_void_p), ("ldvt", C.c_int32), ("geometry", C.c_int32),
         ("wgt2", C.c_void_p), ("wscales2", C.c_void_p), ("bias2", C.c_void_p), ("lora_up2", C.c_void_p),
         ("next_smooth2", C.c_void_p), ("next_lora_down2", C.c_void_p), ("norm_q2", C.c_void_p), ("norm_k2", C.c_void_p),
-        ("split_rows", C.c_int32), ("reserved3", C.c_int32),
+        ("split_rows", C.c_int32), ("lora_act_format", C.c_int32), ("status", C.c_void_p),
     ]
 
 
@@ -67,6 +68,7 @@ class AttentionArgs(C.Structure):
         ("qact", C.c_void_p), ("qscales", C.c_void_p), ("qlora_act", C.c_void_p), ("qsmooth", C.c_void_p),
         ("qlora_down", C.c_void_p), ("qsmooth2", C.c_void_p), ("qlora_down2", C.c_void_p), ("qR", C.c_int32),
         ("qsplit_rows", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("qlora_act_format", C.c_int32), ("reserved2", C.c_int32), ("status", C.c_void_p),
     ]
 
 
@@ -92,6 +94,7 @@ EXPORTS = {
     "svdq_attention_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "svdq_attention_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
+    "svdq_gemm_schedule_ex": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_repack_qweight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_repack_wscales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_repack_vec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -47,7 +47,9 @@ struct AttnParams {
     // fused quantiser of the following output projection (svdq_attention_args.qact ...)
     uint8_t *qact;
     uint16_t *qscales;
-    float *qlora_act;
+    void *qlora_act;
+    int qlora_q32;     // qlora_act holds Q31.32 fixed point (order-independent integer atomics over the heads)
+    int *status;       // optional host-visible status word (svdq_attention_args.status)
     const uint16_t *qsmooth, *qlora_down, *qsmooth2, *qlora_down2;
     int qR, qsplit_rows;
     // persistent schedule (svdq_attention_args.workspace): arrival counters + error word, then one slab per workgroup
@@ -361,7 +363,10 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
                     int spins = 0;
                     while (__hip_atomic_load(flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < last - g && ++spins < ATT_SPIN_LIMIT)
                         __builtin_amdgcn_s_sleep(8);
-                    if (spins >= ATT_SPIN_LIMIT) __hip_atomic_store(flags + ATT_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (spins >= ATT_SPIN_LIMIT) {
+                        __hip_atomic_store(flags + ATT_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.status) __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     __hip_atomic_store(flags + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -418,9 +423,10 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
                     dl = Half<DT>::mfma32(gv, wv, dl);
                 }
             if (live) { // C layout: column (rank) = lane & 31, rows (i & 3) + 8 (i >> 2) + 4 h
-                float *dst = p.qlora_act + (size_t)(q0 + h * 4) * p.qR + lr;
+                const size_t at = (size_t)(q0 + h * 4) * p.qR + lr;
+                const int mode = 1 | (p.qlora_q32 ? 2 : 0); // the H heads add to the same element
 #pragma unroll
-                for (int i = 0; i < 16; i++) unsafeAtomicAdd(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.qR, dl[i]);
+                for (int i = 0; i < 16; i++) lora_act_add(p.qlora_act, at + (size_t)((i & 3) + 8 * (i >> 2)) * p.qR, dl[i], mode);
             }
         }
         uint32_t rec[12];
@@ -589,6 +595,7 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
             return SVDQ_E_INVALID;
         }
     }
+    if (a->qlora_act_format != SVDQ_LORA_ACT_F32 && a->qlora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_attention: unknown qlora_act_format %d", a->qlora_act_format); return SVDQ_E_INVALID; }
     if (a->head_dim != ATT_D) { set_error("svdq_attention: head_dim=%d (only 128 is implemented, as in the reference kernel)", a->head_dim); return SVDQ_E_UNSUPPORTED; }
     if (a->L <= 0 || a->L % 128 || a->H <= 0) { set_error("svdq_attention: L=%d must be a positive multiple of 128 and H=%d positive", a->L, a->H); return SVDQ_E_INVALID; }
     if (a->ldq % 8 || a->ldk % 8 || a->ldvt % 8 || a->ldo % 8 || a->q_hs % 8 || a->k_hs % 8 || a->vt_hs % 8 || a->o_hs % 8 ||
@@ -608,6 +615,8 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.L = a->L; p.H = a->H; p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;
     p.scale_log2e = a->scale * 1.4426950408889634f;
     p.qact = (uint8_t *)a->qact; p.qscales = (uint16_t *)a->qscales; p.qlora_act = a->qlora_act;
+    p.qlora_q32 = a->qlora_act_format == SVDQ_LORA_ACT_Q32;
+    p.status = a->status;
     p.qsmooth = (const uint16_t *)a->qsmooth; p.qlora_down = (const uint16_t *)a->qlora_down;
     p.qsmooth2 = (const uint16_t *)a->qsmooth2; p.qlora_down2 = (const uint16_t *)a->qlora_down2;
     p.qR = a->qR; p.qsplit_rows = a->qsmooth2 ? a->qsplit_rows : 0;
@@ -623,45 +632,6 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
         }
     }
     hipStream_t st = (hipStream_t)stream;
-#ifdef SVDQ_ABLATE
-    // tools-built ablation library only: reserved = wave-count override << 8 | ablation variant (results are garbage)
-    const int nw = (a->reserved >> 8) & 0xf ? (a->reserved >> 8) & 0xf : (a->L % 256 == 0 ? 8 : 4);
-    if ((nw != 4 && nw != 8) || a->L % (nw * 32)) { set_error("svdq_attention: bad wave-count override %d", nw); return SVDQ_E_INVALID; }
-    p.debug = a->reserved & 0xff;
-    const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
-    if (a->reserved == 0 && attention_groups(p) > 0) {
-        if (a->dtype == SVDQ_FP16) launch_attention_persistent<SVDQ_FP16>(p, attention_groups(p), st); else launch_attention_persistent<SVDQ_BF16>(p, attention_groups(p), st);
-    } else
-    if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8, 0>(p, st); else launch_attention<SVDQ_FP16, 4, 0>(p, st); }
-    else if (nw == 4) {
-        switch (p.debug) { // non-zero: ablations (bf16 only), timing experiments, results are garbage
-        case 0: launch_attention<SVDQ_BF16, 4, 0>(p, st); break;
-        case 1: launch_attention<SVDQ_BF16, 4, 1>(p, st); break;
-        case 2: launch_attention<SVDQ_BF16, 4, 2>(p, st); break;
-        case 8: launch_attention<SVDQ_BF16, 4, 8>(p, st); break;
-        case 16: launch_attention<SVDQ_BF16, 4, 16>(p, st); break;
-        case 24: launch_attention<SVDQ_BF16, 4, 24>(p, st); break;
-        default: prof_end(prof, st); set_error("svdq_attention: unknown debug variant %d", p.debug); return SVDQ_E_INVALID;
-        }
-    } else {
-        switch (p.debug) {
-        case 0: launch_attention<SVDQ_BF16, 8, 0>(p, st); break;
-        case 1: launch_attention<SVDQ_BF16, 8, 1>(p, st); break;
-        case 2: launch_attention<SVDQ_BF16, 8, 2>(p, st); break;
-        case 8: launch_attention<SVDQ_BF16, 8, 8>(p, st); break;
-        case 16: launch_attention<SVDQ_BF16, 8, 16>(p, st); break;
-        case 24: launch_attention<SVDQ_BF16, 8, 24>(p, st); break;
-        case 4: launch_attention<SVDQ_BF16, 8, 4>(p, st); break;
-        case 6: launch_attention<SVDQ_BF16, 8, 6>(p, st); break;
-        case 32: launch_attention<SVDQ_BF16, 8, 32>(p, st); break;
-        case 96: launch_attention<SVDQ_BF16, 8, 96>(p, st); break;
-        case 98: launch_attention<SVDQ_BF16, 8, 98>(p, st); break;
-        case 102: launch_attention<SVDQ_BF16, 8, 102>(p, st); break;
-        case 103: launch_attention<SVDQ_BF16, 8, 103>(p, st); break;
-        default: prof_end(prof, st); set_error("svdq_attention: unknown debug variant %d", p.debug); return SVDQ_E_INVALID;
-        }
-    }
-#else
     if (a->reserved != 0) { set_error("svdq_attention: reserved must be 0 (timing ablations live in tools/ablate, not in this library)"); return SVDQ_E_INVALID; }
     p.debug = 0;
     const int nw = a->L % 256 == 0 ? 8 : 4;
@@ -671,7 +641,6 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     else if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8, 0>(p, st); else launch_attention<SVDQ_FP16, 4, 0>(p, st); }
     else if (nw == 8) launch_attention<SVDQ_BF16, 8, 0>(p, st);
     else launch_attention<SVDQ_BF16, 4, 0>(p, st);
-#endif
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_attention launch");
 }

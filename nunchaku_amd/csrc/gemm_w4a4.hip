@@ -31,20 +31,64 @@
 #include "svdq_common.h"
 #include <stdlib.h>
 
+// Clock / phase stamps of the tools-built probe library (tools/ablate/build.py compiles this file with -DSVDQ_PROBE and
+// tools/ablate/gemm_probe_hooks.inc on the include path).  The product library has no experiment switches: the hooks
+// expand to nothing.
+#ifdef SVDQ_PROBE
+#include "gemm_probe_hooks.inc"
+#else
+#define SVDQ_PROBE_PARAMS
+#define SVDQ_PROBE_BEGIN()
+#define SVDQ_PROBE_STAMP(i)
+#define SVDQ_PROBE_NEXT_SEGMENT()
+#define SVDQ_PROBE_END()
+#define SVDQ_PROBE_FILL(p)
+#endif
+
+// generated main loops (tools/gen_gemm_loop2.py); the probe build substitutes option variants
+#ifndef SVDQ_LOOP_INC_8_BF16
+#define SVDQ_LOOP_INC_8_BF16 "gemm_loop2_bf16.inc"
+#endif
+#ifndef SVDQ_LOOP_INC_8_FP16
+#define SVDQ_LOOP_INC_8_FP16 "gemm_loop2_fp16.inc"
+#endif
+#ifndef SVDQ_LOOP_INC_4_BF16
+#define SVDQ_LOOP_INC_4_BF16 "gemm_loop2_w4_bf16.inc"
+#endif
+#ifndef SVDQ_LOOP_INC_4_FP16
+#define SVDQ_LOOP_INC_4_FP16 "gemm_loop2_w4_fp16.inc"
+#endif
+
 namespace svdq {
 
-constexpr int BM = 256, BN = 128;
-constexpr int NSTAGE = 4;                      // tools/gen_gemm_loop.py: NSTAGE
-constexpr int A_BYTES = (BM / 32) * F6_CHUNK;  // 24576
+constexpr int BN = 128;
 constexpr int W_BYTES = (BN / 32) * F6_CHUNK;  // 12288
-constexpr int AS_BYTES = (BM / 32) * 128;      // 1024
-constexpr int WS_BYTES = 1024;                 // 512 used; the DMA writes whole 1 KiB planes
-constexpr int STAGE_BYTES = A_BYTES + W_BYTES + AS_BYTES + WS_BYTES; // 38912 (tools/gen_gemm_loop.py: STAGE)
-constexpr int EPI_BYTES = 2048;                 // epilogue scratch behind the ring (the ring itself stays live)
+constexpr int AS_BYTES = 1024;                 // (BM / 32) x 128 B used; the DMA writes whole 1 KiB planes
+constexpr int WS_BYTES = 1024;                 // 512 used
 constexpr int MAX_LORA_TILES = 16;             // R <= 256
-// stream-K workspace header: 256 int32 words; words [0, 255) are per-remainder-tile arrival counters (at most CUs - 1
-// remainder tiles; the persistent grid never exceeds 256 workgroups), word 255 is the sticky error flag
-constexpr int SK_ERR_WORD = 255;
+
+// Workgroup geometry (tools/gen_gemm_loop2.py: class Geometry -- keep in step).
+//   NW = 8: 512 threads, tile 256 x 128, ONE workgroup per CU (157 KiB of LDS), 4-stage ring.
+//   NW = 4: 256 threads, tile 128 x 128, TWO workgroups per CU (80 KiB of LDS each), 3-stage ring: the two workgroups
+//           run half a tile out of phase, so one's epilogue (matrix pipe idle: 15-30 % of a K = 3072 tile) and its
+//           K-step barrier stalls sit under the other's main loop.
+// The wave tile (64 x 64 = 2 x 2 MFMA tiles), the register image of the loop and every epilogue's lane map are the same.
+#define SVDQ_GEMM_GEOMETRY_DEFAULT 1
+
+template <int NW> struct Geo {
+    static constexpr int BM = 32 * NW;
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int NSTAGE = NW == 8 ? 4 : 3;
+    static constexpr int A_BYTES = (BM / 32) * F6_CHUNK;
+    static constexpr int STAGE_BYTES = A_BYTES + W_BYTES + AS_BYTES + WS_BYTES; // 38912 | 26624
+    static constexpr int EPI_BYTES = 2 * BM * 4;   // epilogue scratch behind the ring (row sums of the RMSNorm epilogue: [2][BM] fp32)
+    static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + EPI_BYTES;          // 157696 | 80896 (two of them: 158 of 160 KiB)
+    static constexpr int WG_PER_CU = NW == 8 ? 1 : 2;
+};
+// stream-K workspace header: 1024 int32 words; words [0, 1023) are per-remainder-tile arrival counters (at most
+// 2 * CUs - 1 remainder tiles: the persistent grid never exceeds 512 workgroups), word 1023 is the sticky error flag
+constexpr int SK_HEADER_BYTES = 4096;
+constexpr int SK_ERR_WORD = 1023;
 constexpr int SK_SPIN_LIMIT = 1 << 22;         // x (s_sleep 8 + one L2 round trip) ~ 1 s
 
 struct GemmParams {
@@ -53,42 +97,33 @@ struct GemmParams {
     const void *ascales;
     const void *wscales;
     const void *bias;
-    const float *lora_act_in;
+    const void *lora_act_in;
     const void *lora_up;
     void *out;
     uint8_t *qout;
     void *oscales;
     const void *next_smooth;
     const void *next_lora_down;
-    float *lora_act_out;
+    void *lora_act_out;
     const void *norm_q;
     const void *norm_k;
     const float *rotary_emb;
     void *out_vt;            // RMSNORM_ROPE: transposed V output or NULL
     int ldvt;
-    // grouped launch: row blocks >= split_bm use the second weight set (same N, K, R, epilogue); split_bm > TM = off
+    // grouped launch: row blocks >= split_row use the second weight set (same N, K, R, epilogue); 0x7fffffff = off
     const uint8_t *wgt2;
     const void *wscales2, *bias2, *lora_up2, *next_smooth2, *next_lora_down2, *norm_q2, *norm_k2;
-    int split_bm;
+    int split_row;
     int M, M_pad, N, K, R, R2, ldo;
-    uint8_t *workspace;      // stream-K: [256 int32 flags][2*G slabs of BM*BN fp32] or NULL
+    uint8_t *workspace;      // stream-K: [1024 int32 flags][2*G slabs of BM*BN fp32] or NULL
     long long workspace_bytes;
     int sk_gs;               // stream-K: workgroups sharing the remainder tiles (0 = whole tiles only); host heuristic
-#ifdef SVDQ_ABLATE
-    int debug;               // timing experiments (tools/ablate): bit0 skip output stores, bit1 skip bias + low-rank up, ...
-    long long *clk;          // per workgroup {shader cycles, 100 MHz ticks} of the whole kernel (effective clock probe)
-    long long *trace;        // workgroup 0: shader-cycle stamps {loop start, loop end, after bias+low-rank, after GELU+requant (GELU_QUANT), before the stores, end} per segment (<= 32)
-#endif
+    int stagger;             // NW = 4: the second workgroup of a CU starts half a tile late
+    int *status;             // optional host-visible status word (svdq_gemm_args.status)
+    int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
     float lora_scales[MAX_LORA_TILES];
+    SVDQ_PROBE_PARAMS
 };
-
-// Timing-experiment switches exist only in the tools-built ablation library (-DSVDQ_ABLATE, tools/ablate/build.py);
-// in the product library DBG() is the constant 0 and every such branch folds away.
-#ifdef SVDQ_ABLATE
-#define DBG(bits) (p.debug & (bits))
-#else
-#define DBG(bits) (0)
-#endif
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     // reference: gemm_utils.cuh:305-312: x * (0.5 + 0.5 * tanh.approx(u)), u = 0.79788456 * (x + 0.044715 x^3).
@@ -102,24 +137,17 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gvoid;
 
-#define FMT_FP6 2
-// MX block exponents (E8M0, bias 127): codes are value/8 on both sides (x64) and the scale tile is
-// 2*ws*as (x1/2): 2^3 * 2^2 = 32.
-#define MXS_A 0x82828282
-#define MXS_B 0x81818181
-
-template <int DT, int FUSE, int LOOPV /* 0 asm, 1 C++, >= 2 ablations of the asm loop (-DSVDQ_ABLATE builds only) */>
-__global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
+template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q31.32 (deterministic mode) */>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams p) {
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[NSTAGE * STAGE_BYTES + EPI_BYTES];
+    using G_ = Geo<NW>;
+    constexpr int BM = G_::BM, NSTAGE = G_::NSTAGE, A_BYTES = G_::A_BYTES, STAGE_BYTES = G_::STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[G_::LDS_BYTES];
 
     const int tid = threadIdx.x;
-#ifdef SVDQ_ABLATE
-    const long long clk_t0 = __builtin_readcyclecounter(), clk_r0 = wall_clock64();
-#endif
+    SVDQ_PROBE_BEGIN();
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, h = lane >> 5;
@@ -127,10 +155,10 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     const int TM = p.M_pad / BM, TN = p.N / BN, NT = TM * TN;
 
     // ---- persistent schedule ---------------------------------------------------------------------
-    // One workgroup per CU walks a list of segments.  Tiles are enumerated in strips of 8 column
+    // One workgroup per CU slot walks a list of segments.  Tiles are enumerated in strips of 8 column
     // tiles (tile_coords) and workgroup b sits at position (b % 8) * (G / 8) + b / 8 -- workgroups are
-    // dealt round-robin to the 8 XCDs, so the 32 tiles an XCD works on at a time are a 4 x 8 patch that
-    // shares 4 activation panels and 8 weight panels in that XCD's L2.
+    // dealt round-robin to the 8 XCDs, so the tiles an XCD works on at a time (32 of 256 x 128 or 64 of 128 x 128) are a
+    // 1024 x 1024 patch of the output that shares its activation and weight panels in that XCD's L2.
     const int G = gridDim.x;
     const int pos = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     auto tile_coords = [&](int t, int &bm, int &bn) {
@@ -144,45 +172,48 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     v16f acc[2][2]; // [n tile][m tile]
     const v16f zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    // ---- per-wave DMA roles (constant over the kernel) ---------------------------------------------
-    //   every wave: the three planes of A chunk `wave` of the tile;  waves 0..3: W planes 2w, 2w+1;
-    //   waves 4..7: W plane 8 + (w-4);  wave 4 additionally the activation scale image (8 x 128 B),
-    //   wave 5 the weight scale image (4 x 128 B, twice).
+    // ---- per-wave DMA roles (constant over the kernel; tools/gen_gemm_loop2.py issues them) -------------
+    //   NW = 8: every wave the three planes of A chunk `wave`;  waves 0..3: W planes 2w, 2w+1;  waves 4..7: W plane
+    //           8 + (w-4);  wave 4 additionally the activation scale image (8 x 128 B), wave 5 the weight scale image
+    //           (4 x 128 B, twice), waves 6, 7 their W plane once more (5 DMA instructions per wave and K-step).
+    //   NW = 4: every wave the three planes of A chunk `wave` and the three planes of W chunk `wave`;  wave 0 the
+    //           activation scale image (4 x 128 B, twice), wave 1 the weight scale image, waves 2, 3 their first W
+    //           plane once more (7 per wave and K-step).
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lds_base = (unsigned)(size_t)(lds_void *)lds;
-    const int px1 = wv < 4 ? 2 * wv : 8 + (wv - 4);
-    const int px2 = 2 * wv + 1; // waves 0..3 only
-    unsigned dX1 = lds_base + A_BYTES + (px1 / 3) * F6_CHUNK + (px1 % 3) * F6_PLANE;
-    unsigned iX1 = F6_CHUNK, iX2 = F6_CHUNK, nX = 2, dX2 = 0;
-    unsigned offA = lane * 16, offX1 = lane * 16, offX2 = lane * 16;
-    if (wv < 4) {
+    const int px1 = NW == 4 ? 3 * wv : (wv < 4 ? 2 * wv : 8 + (wv - 4));
+    const int px2 = 2 * wv + 1; // NW = 8, waves 0..3 only
+    const unsigned dX1 = lds_base + A_BYTES + (px1 / 3) * F6_CHUNK + (px1 % 3) * F6_PLANE;
+    const int as_wave = NW == 4 ? 0 : 4, ws_wave = as_wave + 1;
+    unsigned dX2 = dX1, iX2v = F6_CHUNK;   // default: the first X1 plane once more (same bytes to the same place)
+    const unsigned offA = lane * 16, offX1 = lane * 16;
+    unsigned offX2 = lane * 16;
+    if (NW == 8 && wv < 4) {
         dX2 = lds_base + A_BYTES + (px2 / 3) * F6_CHUNK + (px2 % 3) * F6_PLANE;
-    } else if (wv == 4) {
-        offX2 = (lane >> 3) * KP * 128 + (lane & 7) * 16;
+    } else if (wv == as_wave) {
+        offX2 = ((lane >> 3) & (BM / 32 - 1)) * KP * 128 + (lane & 7) * 16;
         dX2 = lds_base + A_BYTES + W_BYTES;
-        iX2 = 128;
-    } else if (wv == 5) {
+        iX2v = 128;
+    } else if (wv == ws_wave) {
         offX2 = ((lane >> 3) & 3) * KP * 128 + (lane & 7) * 16;
         dX2 = lds_base + A_BYTES + W_BYTES + AS_BYTES;
-        iX2 = 128;
-    } else {
-        nX = 1;       // v1 loop: no second stream
-        dX2 = dX1;    // v2 loop: the W plane once more (same bytes to the same place) -- every wave issues 5 DMAs per K-step
+        iX2v = 128;
     }
     const unsigned dA = lds_base + wv * F6_CHUNK;
     const unsigned in_la = lds_base + (wm * 2) * F6_CHUNK + lane * 16;
     const unsigned in_lw = lds_base + A_BYTES + (wn * 2) * F6_CHUNK + lane * 16;
     const unsigned in_lsa = lds_base + A_BYTES + W_BYTES + (wm * 2) * 128 + lr * 2;
     const unsigned in_lsw = lds_base + A_BYTES + W_BYTES + AS_BYTES + (wn * 2) * 128 + lr * 2;
+    const int split_bm = p.split_row == 0x7fffffff ? 0x7fffffff : p.split_row / BM;
     // stream bases of (tile, first K-step)
     auto stream_ptrs = [&](int bm, int bn, int kp0, unsigned long long &a, unsigned long long &x1, unsigned long long &x2) {
-        a = (unsigned long long)(p.act + ((size_t)(bm * 8 + wv) * KP + kp0) * F6_CHUNK);
-        const uint8_t *wgt = bm >= p.split_bm ? p.wgt2 : p.wgt; // grouped launch: weight set of this row block
-        const void *wscales = bm >= p.split_bm ? p.wscales2 : p.wscales;
+        a = (unsigned long long)(p.act + ((size_t)(bm * (BM / 32) + wv) * KP + kp0) * F6_CHUNK);
+        const uint8_t *wgt = bm >= split_bm ? p.wgt2 : p.wgt; // grouped launch: weight set of this row block
+        const void *wscales = bm >= split_bm ? p.wscales2 : p.wscales;
         x1 = (unsigned long long)(wgt + ((size_t)(bn * 4 + px1 / 3) * KP + kp0) * F6_CHUNK + (px1 % 3) * F6_PLANE);
-        if (wv < 4) x2 = (unsigned long long)(wgt + ((size_t)(bn * 4 + px2 / 3) * KP + kp0) * F6_CHUNK + (px2 % 3) * F6_PLANE);
-        else if (wv == 4) x2 = (unsigned long long)((const uint8_t *)p.ascales + ((size_t)(bm * 8) * KP + kp0) * 128);
-        else if (wv == 5) x2 = (unsigned long long)((const uint8_t *)wscales + ((size_t)(bn * 4) * KP + kp0) * 128);
+        if (NW == 8 && wv < 4) x2 = (unsigned long long)(wgt + ((size_t)(bn * 4 + px2 / 3) * KP + kp0) * F6_CHUNK + (px2 % 3) * F6_PLANE);
+        else if (wv == as_wave) x2 = (unsigned long long)((const uint8_t *)p.ascales + ((size_t)(bm * (BM / 32)) * KP + kp0) * 128);
+        else if (wv == ws_wave) x2 = (unsigned long long)((const uint8_t *)wscales + ((size_t)(bn * 4) * KP + kp0) * 128);
         else x2 = x1;
     };
 
@@ -193,7 +224,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     // K-steps owns it: it adds the other segments' fp32 partial tiles (published through the workspace) and
     // runs the epilogue.  Without a workspace the first R workgroups take one remainder tile each.
     constexpr long long SLAB_BYTES = (long long)BM * BN * 4;
-    const bool ws_ok = p.workspace != nullptr && p.workspace_bytes >= 1024 + 2LL * G * SLAB_BYTES;
+    const bool ws_ok = p.workspace != nullptr && p.workspace_bytes >= SK_HEADER_BYTES + 2LL * G * SLAB_BYTES;
     GemmSchedule sched;
     sched.init(NT, KP, G, ws_ok ? p.sk_gs : 0, pos);
     const bool sk = sched.gs > 0;
@@ -201,10 +232,25 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
     typedef GemmSegment Seg;
     auto next_seg = [&](Seg &sg) -> bool { return sched.next(sg); };
 
+    if constexpr (NW == 4) {
+        // De-phase the two workgroups of a CU.  They start together and do the same work per tile, so left alone they reach
+        // their epilogues together and the matrix pipe idles exactly as with one big workgroup.  The workgroup whose waves
+        // sit in the ODD wave slot of their SIMD (HW_ID.wave_id: the second tenant) starts half a tile late, once per launch.
+        // (Purely a scheduling hint: results do not depend on which workgroup, if any, waits.)
+        if (p.stagger && F >= 2) {
+            const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1u; // HW_REG_HW_ID[3:0] = wave slot
+            __attribute__((address_space(3))) unsigned *flag = (__attribute__((address_space(3))) unsigned *)(lds + NSTAGE * STAGE_BYTES);
+            if (tid == 0) *flag = slot;
+            __syncthreads();
+            const unsigned late = __builtin_amdgcn_readfirstlane(*flag);
+            __syncthreads();
+            if (late) {
+                for (int i = 0; i < KP; i += 8) __builtin_amdgcn_s_sleep(127); // ~ KP x 1000 cycles = half a tile's loop
+            }
+        }
+    }
+
     unsigned ring = 0, npre = 0, landed = 0;
-#ifdef SVDQ_ABLATE
-    int seg_no = 0;
-#endif
     unsigned long long pA = 0, pX1 = 0, pX2 = 0;
     int bm = 0, bn = 0;
     Seg cur{0, 0, 0, 0}, nxt{0, 0, 0, 0};
@@ -227,13 +273,10 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             ncnt = nxt.kp1 - nxt.kp0;
         }
 
-#ifdef SVDQ_ABLATE
-        static_assert(true, "");
-        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no] = __builtin_readcyclecounter() - clk_t0;
-#endif
-        if constexpr (LOOPV != 1) {
+        SVDQ_PROBE_STAMP(0);
+        {
             // ---- hand-scheduled main loop (generated inline asm, every operand pinned to a physical register;
-            //      DESIGN.md "Main loop").  v2 = tools/gen_gemm_loop2.py.
+            //      DESIGN.md "Main loop"; tools/gen_gemm_loop2.py) ---------------------------------------------
             const unsigned kp_s = kp1 - kp0;
 #define SVDQ_LOOP_CLOBBER_V                                                                                            \
                   "v64", "v65", "v66", "v67", "v68", "v69", "v70",     \
@@ -247,42 +290,18 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                   "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185",  \
                   "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199",  \
                   "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220"
-#ifdef SVDQ_ABLATE
-            if constexpr (LOOPV >= 2 && LOOPV < 100) {
-                // v1 loop (tools/gen_gemm_loop.py) and its instruction-class ablations: timing experiments only
-#define SVDQ_LOOP_OPERANDS                                                                                              \
-                : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
-                  "+{s[40:41]}"(pA), "+{s[42:43]}"(pX1), "+{s[44:45]}"(pX2), "+{s58}"(ring)                                      \
-                : "{v210}"(in_la), "{v211}"(in_lw), "{v212}"(in_lsa), "{v213}"(in_lsw), "{v214}"(offA), "{v215}"(offX1),         \
-                  "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX1), "{s51}"(iX2), "{s52}"(nX), \
-                  "{s59}"(npre), "{s60}"(ncnt), "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed)            \
-                : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", SVDQ_LOOP_CLOBBER_V, "v221", "v222", "v223", "v224"
-                // one wave per SIMD runs the (barrier-free, ablated) loop, its partner idles
-                if (DBG(512) && wv >= 4) { acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16; } else
-                if (DBG(1024) && wv < 4) { acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = zero16; } else
-#include "gemm_ablate_loops.inc" /* generated by tools/ablate/build.py: `if constexpr (LOOPV == n) { asm volatile(...); } else` chain */
-                { asm volatile(
-#include "gemm_loop_bf16.inc"
-                        SVDQ_LOOP_OPERANDS); }
-#undef SVDQ_LOOP_OPERANDS
-                npre = min((unsigned)NSTAGE, ncnt);
-                landed = ((p.bias || p.R > 0) && !DBG(2) && kp1 == KP) ? npre : 0;
-            } else
-#endif
-            {
-                // buffer resources of the three operand streams (raw buffers, no range check: the loop never issues a
-                // DMA beyond the last K-step of the workgroup's last segment)
-                auto srd = [](unsigned long long ptr) {
-                    v4i r;
-                    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ptr);
-                    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ptr >> 32));
-                    r[2] = -1;
-                    r[3] = 0x00020000;
-                    return r;
-                };
-                v4i rA = srd(pA), rX1 = srd(pX1), rX2 = srd(pX2);
-                const unsigned iX2v = wv < 4 || wv >= 6 ? (unsigned)F6_CHUNK : 128u;
-                const unsigned phaseB = wv >= 4 ? 1u : 0u; // "dph" loops only: waves 4..7 issue their DMAs half a K-step later
+            // buffer resources of the three operand streams (raw buffers, no range check: the loop never issues a
+            // DMA beyond the last K-step of the workgroup's last segment)
+            auto srd = [](unsigned long long ptr) {
+                v4i r;
+                r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ptr);
+                r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ptr >> 32));
+                r[2] = -1;
+                r[3] = 0x00020000;
+                return r;
+            };
+            v4i rA = srd(pA), rX1 = srd(pX1), rX2 = srd(pX2);
+            const unsigned phaseB = wv >= NW / 2 ? 1u : 0u; // generator option "dph" only
 #define SVDQ_LOOP2_OPERANDS                                                                                             \
                 : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
                   "+{s[72:75]}"(rA), "+{s[76:79]}"(rX1), "+{s[80:83]}"(rX2)                                                      \
@@ -291,123 +310,35 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                   "{s58}"(ring),                                                                                                   \
                   "{s59}"(npre), "{s60}"(ncnt), "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed)            \
                 : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", "s84", "s85", "s86", "s87", SVDQ_LOOP_CLOBBER_V
-#ifdef SVDQ_ABLATE
-#include "gemm_ablate_loops2.inc" /* generated: option variants of the v2 loop, `if constexpr (LOOPV == n) { asm volatile(...); } else` chain */
-#endif
-                if constexpr (DT == SVDQ_BF16) {
-                    asm volatile(
-#include "gemm_loop2_bf16.inc"
-                        SVDQ_LOOP2_OPERANDS);
-                } else {
-                    asm volatile(
-#include "gemm_loop2_fp16.inc"
-                        SVDQ_LOOP2_OPERANDS);
-                }
+            if constexpr (NW == 8 && DT == SVDQ_BF16) {
+                asm volatile(
+#include SVDQ_LOOP_INC_8_BF16
+                    SVDQ_LOOP2_OPERANDS);
+            } else if constexpr (NW == 8) {
+                asm volatile(
+#include SVDQ_LOOP_INC_8_FP16
+                    SVDQ_LOOP2_OPERANDS);
+            } else if constexpr (DT == SVDQ_BF16) {
+                asm volatile(
+#include SVDQ_LOOP_INC_4_BF16
+                    SVDQ_LOOP2_OPERANDS);
+            } else {
+                asm volatile(
+#include SVDQ_LOOP_INC_4_FP16
+                    SVDQ_LOOP2_OPERANDS);
+            }
 #undef SVDQ_LOOP2_OPERANDS
-                ring = (ring + (kp_s % NSTAGE) * STAGE_BYTES) % (NSTAGE * STAGE_BYTES); // stage of the next segment's K-step 0
-                npre = min((unsigned)NSTAGE, ncnt);
-                // The loop returns with the next segment's first K-steps still in flight (no vmcnt drain: their latency
-                // overlaps the epilogue's own loads).  An epilogue that waits on a global load of its own -- younger than
-                // those DMAs, vmcnt retires in order -- proves them landed; otherwise the next prologue waits itself.
-                landed = ((p.bias || p.R > 0) && !DBG(2) && kp1 == KP) ? npre : 0;
-                pA = nA; pX1 = nX1; pX2 = nX2; // the next segment's bases (set by stream_ptrs above)
-            }
 #undef SVDQ_LOOP_CLOBBER_V
-        } else {
-            npre = 0;
-            // ---- reference C++ main loop (variant 1: same arithmetic, compiler-scheduled, no cross-tile
-            //      prefetch); kept for A/B debugging of the hand-scheduled loop
-            __syncthreads();
-            // ---- operand streams: every wave moves whole 1 KiB planes -------------------------------
-            //   waves 0..7: the three planes of A chunk `wave`;  waves 0..3: the three planes of W chunk
-            //   `wave`;  wave 4: activation scales (8 x 128 B);  wave 5: weight scales (4 x 128 B).
-            const uint8_t *a_src = p.act + ((size_t)(bm * 8 + wave) * KP) * F6_CHUNK + lane * 16;
-            const uint8_t *w_src = (bm >= p.split_bm ? p.wgt2 : p.wgt) + ((size_t)(bn * 4 + (wave & 3)) * KP) * F6_CHUNK + lane * 16;
-            const uint8_t *as_src = (const uint8_t *)p.ascales + ((size_t)(bm * 8 + (lane >> 3)) * KP) * 128 + (lane & 7) * 16;
-            const uint8_t *ws_src = (const uint8_t *)(bm >= p.split_bm ? p.wscales2 : p.wscales) + ((size_t)(bn * 4 + ((lane >> 3) & 3)) * KP) * 128 + (lane & 7) * 16;
-
-            typedef __attribute__((address_space(3))) uint8_t lds_u8; // LDS-typed pointers only: no flat casts
-            typedef __attribute__((address_space(3))) v4i lds_v4i;
-            typedef __attribute__((address_space(3))) unsigned short lds_u16;
-            lds_u8 *const L = (lds_u8 *)lds;
-            auto fetch = [&](int kp, lds_u8 *st) {
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    __builtin_amdgcn_global_load_lds((gvoid *)(a_src + (size_t)kp * F6_CHUNK + pl * F6_PLANE),
-                                                     (lds_void *)(st + wave * F6_CHUNK + pl * F6_PLANE), 16, 0, 0);
-                if (wave < 4) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; pl++)
-                        __builtin_amdgcn_global_load_lds((gvoid *)(w_src + (size_t)kp * F6_CHUNK + pl * F6_PLANE),
-                                                         (lds_void *)(st + A_BYTES + wave * F6_CHUNK + pl * F6_PLANE), 16, 0, 0);
-                } else if (wave == 4) {
-                    __builtin_amdgcn_global_load_lds((gvoid *)(as_src + (size_t)kp * 128), (lds_void *)(st + A_BYTES + W_BYTES), 16, 0, 0);
-                } else if (wave == 5) {
-                    if (lane < 32)
-                        __builtin_amdgcn_global_load_lds((gvoid *)(ws_src + (size_t)kp * 128),
-                                                         (lds_void *)(st + A_BYTES + W_BYTES + AS_BYTES), 16, 0, 0);
-                }
-            };
-
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-            const int cnt = kp1 - kp0;
-            fetch(kp0, L);
-            if (cnt > 1) fetch(kp0 + 1, L + STAGE_BYTES);
-
-            for (int s = 0; s < cnt; s++) {
-                // stage s (and, conservatively, s+1) has landed for this wave; the barrier makes every wave's
-                // planes visible and guarantees everyone is done reading stage s-1 before it is refilled
-                __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
-                __syncthreads();
-                if (s + 2 < cnt) fetch(kp0 + s + 2, L + ((s + 2) % NSTAGE) * STAGE_BYTES);
-                const lds_u8 *st = L + (s % NSTAGE) * STAGE_BYTES;
-
-                // fragments of both groups: 3 x 16 B per (tile, lane)
-                int af[2][12], wf[2][12];
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int pl = 0; pl < 3; pl++) {
-                        v4i a = *(const lds_v4i *)(st + (wm * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
-                        v4i w = *(const lds_v4i *)(st + A_BYTES + (wn * 2 + i) * F6_CHUNK + pl * F6_PLANE + lane * 16);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) { af[i][pl * 4 + e] = a[e]; wf[i][pl * 4 + e] = w[e]; }
-                    }
-                const lds_u16 *as_l = (const lds_u16 *)(st + A_BYTES + W_BYTES);
-                const lds_u16 *ws_l = (const lds_u16 *)(st + A_BYTES + W_BYTES + AS_BYTES);
-#pragma unroll
-                for (int grp = 0; grp < 2; grp++) {
-                    v4i sa[2], sw[2];
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        sa[i] = v4i{(int)as_l[(wm * 2 + i) * 64 + grp * 32 + lr], 0, 0, 0};
-                        sw[i] = v4i{(int)ws_l[(wn * 2 + i) * 64 + grp * 32 + lr], 0, 0, 0};
-                    }
-#pragma unroll
-                    for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                        for (int mi = 0; mi < 2; mi++) {
-                            const int o = grp * 6;
-                            v8i A = {wf[ni][o], wf[ni][o + 1], wf[ni][o + 2], wf[ni][o + 3], wf[ni][o + 4], wf[ni][o + 5], 0, 0};
-                            v8i B = {af[mi][o], af[mi][o + 1], af[mi][o + 2], af[mi][o + 3], af[mi][o + 4], af[mi][o + 5], 0, 0};
-                            v16f P = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, zero16, FMT_FP6, FMT_FP6, 0, MXS_A, 0, MXS_B);
-                            v16f S = Half<DT>::mfma32(__builtin_bit_cast(V8, sw[ni]), __builtin_bit_cast(V8, sa[mi]), zero16);
-#pragma unroll
-                            for (int r = 0; r < 16; r++) acc[ni][mi][r] = __builtin_fmaf(P[r], S[r], acc[ni][mi][r]);
-                        }
-                }
-            }
+            ring = (ring + (kp_s % NSTAGE) * STAGE_BYTES) % (NSTAGE * STAGE_BYTES); // stage of the next segment's K-step 0
+            npre = min((unsigned)NSTAGE, ncnt);
+            // The loop returns with the next segment's first K-steps still in flight (no vmcnt drain: their latency
+            // overlaps the epilogue's own loads).  An epilogue that waits on a global load of its own -- younger than
+            // those DMAs, vmcnt retires in order -- proves them landed; otherwise the next prologue waits itself.
+            landed = ((p.bias || p.R > 0) && kp1 == KP) ? npre : 0;
+            pA = nA; pX1 = nX1; pX2 = nX2; // the next segment's bases (set by stream_ptrs above)
         }
+        SVDQ_PROBE_STAMP(1);
 
-#ifdef SVDQ_ABLATE
-        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 1] = __builtin_readcyclecounter() - clk_t0;
-#endif
         // ---- stream-K: publish or collect partial tiles -----------------------------------------------
         bool run_epilogue = true;
         if (sk && (kp0 > 0 || kp1 < KP)) {
@@ -415,7 +346,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             gint *flags = (gint *)reinterpret_cast<int *>(p.workspace); // explicit global address space: no flat aperture checks
             typedef __attribute__((address_space(1))) float gfloat;
             typedef __attribute__((address_space(1))) v4f gv4f;
-            gfloat *slabs = (gfloat *)reinterpret_cast<float *>(p.workspace + 1024);
+            gfloat *slabs = (gfloat *)reinterpret_cast<float *>(p.workspace + SK_HEADER_BYTES);
             const int trel = cur.tile - F * G;                 // remainder tile index = flag index
             if (kp1 < KP) {
                 // not the owner: store the raw fp32 accumulators (16 coalesced 1 KiB wave stores per wave),
@@ -425,7 +356,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 for (int j = 0; j < 16; j++) {
                     v4f v = {acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 0], acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 1],
                              acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 2], acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + 3]};
-                    *(gv4f *)(slab + ((size_t)(j * 8 + wave) * 64 + lane) * 4) = v;
+                    *(gv4f *)(slab + ((size_t)(j * NW + wave) * 64 + lane) * 4) = v;
                 }
                 __syncthreads();
                 if (tid == 0) {
@@ -440,12 +371,16 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 const int needed = pos - first;
                 if (tid == 0) {
                     // Bounded wait (~1 s): a missing arrival can only come from a broken contract (the workspace shared by
-                    // launches in flight on two streams, or not zero-filled).  Then give up instead of hanging the GPU:
-                    // raise the sticky error word svdq_gemm_workspace_status() reports; this tile's result is garbage.
+                    // launches in flight on two streams, not zero-filled, or a grid that is not co-resident).  Then give up
+                    // instead of hanging the GPU: raise the sticky error word (checked by the host at the next launch on this
+                    // workspace and by svdq_gemm_workspace_status()); this tile's result is garbage.
                     int spins = 0;
                     while (__hip_atomic_load(flags + trel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < needed && ++spins < SK_SPIN_LIMIT)
                         __builtin_amdgcn_s_sleep(8);
-                    if (spins >= SK_SPIN_LIMIT) __hip_atomic_store(flags + SK_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (spins >= SK_SPIN_LIMIT) {
+                        __hip_atomic_store(flags + SK_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.status) __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     __hip_atomic_store(flags + trel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -454,7 +389,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                     const gfloat *slab = slabs + (size_t)sched.contributor_slot(cur, q) * (BM * BN);
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
-                        v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)(j * 8 + wave) * 64 + lane) * 4));
+                        v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)(j * NW + wave) * 64 + lane) * 4));
 #pragma unroll
                         for (int e = 0; e < 4; e++) acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + e] += v[e];
                     }
@@ -474,8 +409,8 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         // Every operand of the tile is requested BEFORE the first one is consumed (one memory round trip per tile
         // instead of one per dependent stage: ~3.8 us -> ~2 us of exposed epilogue at K = 3072).  The arithmetic and its
         // order are unchanged: acc + bias, then one MFMA per 16 ranks in ascending rank order.
-        const bool use_bias = p.bias && !DBG(2);
-        const int Rr = DBG(2) ? 0 : p.R;
+        const bool use_bias = p.bias != nullptr;
+        const int Rr = p.R;
         // uniform base pointer + ONE 32-bit per-lane byte offset per tensor: the loads below differ by immediates only
         // (global_load saddr + voffset form), which keeps the address registers of 20 loads down to three.  The offsets
         // are derived from a lane id that passes through an empty asm statement AFTER the main loop: otherwise the
@@ -485,7 +420,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         asm volatile("" : "+v"(lane_e));
         const unsigned lr_e = lane_e & 31, h_e = lane_e >> 5;
         u16x4 bv[2][4] = {}; // (zero-initialised: conditionally loaded values must not look loop-carried to the register allocator)
-        const char *b_base = (const char *)(bm >= p.split_bm ? p.bias2 : p.bias);
+        const char *b_base = (const char *)(bm >= split_bm ? p.bias2 : p.bias);
         const unsigned b_off = (unsigned)(nw0 + h_e * 4) * 2u;
         if (use_bias) {
 #pragma unroll
@@ -494,51 +429,57 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 for (int c = 0; c < 4; c++) bv[ni][c] = *reinterpret_cast<const u16x4 *>(b_base + b_off + (ni * 32 + c * 8) * 2);
         }
         const char *la_base = (const char *)p.lora_act_in;
-        const char *lu_base = (const char *)(bm >= p.split_bm ? p.lora_up2 : p.lora_up);
-        const unsigned la_off = ((unsigned)(mw0 + lr_e) * (unsigned)Rr + h_e * 8) * 4u;
+        const char *lu_base = (const char *)(bm >= split_bm ? p.lora_up2 : p.lora_up);
+        // lora_act_in: fp32 [M_pad][R], or (LAQ) Q31.32 fixed point in int64 [M_pad][R] -- the order-independent accumulation
+        // format of the deterministic mode (svdq_amd.h "lora_act formats"), converted to fp32 on use
+        constexpr unsigned LA_B = LAQ ? 8u : 4u;
+        const unsigned la_off = ((unsigned)(mw0 + lr_e) * (unsigned)Rr + h_e * 8) * LA_B;
         const unsigned lu_off = ((unsigned)(nw0 + lr_e) * (unsigned)Rr + h_e * 8) * 2u;
-        const unsigned la_mi = 32u * Rr * 4u, lu_ni = 32u * Rr * 2u; // byte strides of the second row tile / column tile
-        auto load_la = [&](int rc, v4f (&x)[2][2]) {
+        const unsigned la_mi = 32u * Rr * LA_B, lu_ni = 32u * Rr * 2u; // byte strides of the second row tile / column tile
+        struct LaRegs { v4i q[2][LAQ ? 4 : 2]; }; // the lane's 8 ranks of both row tiles: 8 fp32 or 8 int64 each
+        auto load_la = [&](int rc, LaRegs &t) {
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                x[mi][0] = *reinterpret_cast<const v4f *>(la_base + (la_off + mi * la_mi + rc * 4));
-                x[mi][1] = *reinterpret_cast<const v4f *>(la_base + (la_off + mi * la_mi + rc * 4 + 16));
-            }
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int j = 0; j < (LAQ ? 4 : 2); j++) t.q[mi][j] = *reinterpret_cast<const v4i *>(la_base + (la_off + mi * la_mi + rc * LA_B + j * 16));
         };
         auto load_lu = [&](int rc, V8 (&u)[2]) {
 #pragma unroll
             for (int ni = 0; ni < 2; ni++) u[ni] = *reinterpret_cast<const V8 *>(lu_base + (lu_off + ni * lu_ni + rc * 2));
         };
-        auto lora_mfma = [&](int rc, const v4f (&x)[2][2], const V8 (&u)[2]) {
+        auto lora_mfma = [&](int rc, const LaRegs &t, const V8 (&u)[2]) {
             const float sc = p.lora_scales[rc >> 4];
             V8 la[2];
 #pragma unroll
             for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    la[mi][j] = f2h<T>(x[mi][0][j] * sc);
-                    la[mi][4 + j] = f2h<T>(x[mi][1][j] * sc);
+                for (int j = 0; j < 8; j++) {
+                    // element j of the lane's 8 ranks: fp32 as stored, or Q31.32 (low word, high word) -> fp32
+                    float v;
+                    if constexpr (LAQ) v = q32_to_float(t.q[mi][j >> 1][2 * (j & 1)], t.q[mi][j >> 1][2 * (j & 1) + 1]);
+                    else { const int w = t.q[mi][j >> 2][j & 3]; v = __builtin_bit_cast(float, w); }
+                    la[mi][j] = f2h<T>(v * sc);
                 }
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(u[ni], la[mi], acc[ni][mi]);
         };
-        v4f x0[2][2] = {}, x1[2][2] = {};
+        LaRegs x0 = {}, x1 = {};
         V8 u0[2] = {}, u1[2] = {};
         if (Rr > 0) { load_la(0, x0); load_lu(0, u0); }
-        if (Rr > 16) { load_la(16, x1); load_lu(16, u1); }
+        if (Rr > 16) { if constexpr (!LAQ) load_la(16, x1); load_lu(16, u1); } // (LAQ: twice the registers per value -- ranks 16..31 follow the first MFMA)
         // GELU_QUANT: the next layer's smoothing factors and the first 32 ranks of its low-rank down projection ride on the
         // same round trip (they are consumed ~2000 instructions later, behind the GELU and the requantisation)
         u16x4 nsv[2][4] = {}, ldw[2][2][2] = {};
         if constexpr (FUSE == SVDQ_FUSE_GELU_QUANT) {
-            const char *ns_base = (const char *)(bm >= p.split_bm ? p.next_smooth2 : p.next_smooth);
+            const char *ns_base = (const char *)(bm >= split_bm ? p.next_smooth2 : p.next_smooth);
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) nsv[ni][c] = *reinterpret_cast<const u16x4 *>(ns_base + b_off + (ni * 32 + c * 8) * 2);
-            if (p.R2 > 0 && !DBG(64) && (int)lr_e < p.R2) {
-                const char *ld_base = (const char *)(bm >= p.split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
+            if (p.R2 > 0 && (int)lr_e < p.R2) {
+                const char *ld_base = (const char *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
                 const unsigned ld_off = (lr_e * (unsigned)p.N + nw0 + h_e * 4) * 2u;
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++)
@@ -560,18 +501,17 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                         for (int e = 0; e < 4; e++) acc[ni][mi][c * 4 + e] += h2f(hfrom<T>(bv[ni][c][e]));
         }
         if (Rr > 0) lora_mfma(0, x0, u0);
-        if (Rr > 16) lora_mfma(16, x1, u1);
+        if (Rr > 16) {
+            if constexpr (LAQ) { load_la(16, x0); lora_mfma(16, x0, u1); }
+            else lora_mfma(16, x1, u1);
+        }
         for (int rc = 32; rc < Rr; rc += 16) { // runtime LoRA beyond rank 32: one round trip per 16 ranks
             load_la(rc, x0);
             load_lu(rc, u0);
             lora_mfma(rc, x0, u0);
         }
+        SVDQ_PROBE_STAMP(2);
 
-#ifdef SVDQ_ABLATE
-        asm volatile("" ::: "memory");
-        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 2] = __builtin_readcyclecounter() - clk_t0;
-        asm volatile("" ::: "memory");
-#endif
         // the single rounding to the 16-bit model dtype (the reference's tile is 16-bit from here on).  With the default
         // epilogue nothing but the store follows, and the store's own conversion IS this rounding (same RNE; the fp16
         // clamp commutes with it): skipping the round trip through fp32 saves ~128 VALU instructions per tile.
@@ -601,7 +541,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             if (is_q || is_k) { // block-uniform
                 // the norm weights and the rotary table entries of this lane's 2 rows x 32 column pairs are requested
                 // BEFORE the row-sum exchange (two barriers): their memory round trip overlaps it instead of following it
-                const T *nw = (const T *)(bm >= p.split_bm ? (is_q ? p.norm_q2 : p.norm_k2) : (is_q ? p.norm_q : p.norm_k));
+                const T *nw = (const T *)(bm >= split_bm ? (is_q ? p.norm_q2 : p.norm_k2) : (is_q ? p.norm_q : p.norm_k));
                 u16x4 wvv[2][4] = {};
                 float2 rot[2][2][4][2] = {};
 #pragma unroll
@@ -625,7 +565,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 }
                 __syncthreads(); // the previous tile's readers of the epilogue scratch are done
                 // LDS-address-space pointer (no flat cast: the aperture compare it needs trips an LLVM verifier bug here)
-                __attribute__((address_space(3))) float *sq = (__attribute__((address_space(3))) float *)(lds + NSTAGE * STAGE_BYTES); // [2 (wn)][256 rows]
+                __attribute__((address_space(3))) float *sq = (__attribute__((address_space(3))) float *)(lds + NSTAGE * STAGE_BYTES); // [2 (wn)][BM rows]
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++) {
                     float s = 0.f;
@@ -634,13 +574,13 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                         for (int r = 0; r < 16; r++) s += acc[ni][mi][r] * acc[ni][mi][r];
                     s += __shfl_xor(s, 32);
-                    if (h == 0) sq[wn * 256 + wm * 64 + mi * 32 + lr] = s;
+                    if (h == 0) sq[wn * BM + wm * 64 + mi * 32 + lr] = s;
                 }
                 __syncthreads();
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++) {
                     const int row = wm * 64 + mi * 32 + lr;
-                    const float tot = sq[row] + sq[256 + row];
+                    const float tot = sq[row] + sq[BM + row];
                     const float coef = 1.0f / sqrtf(tot / 128.0f + 1e-6f);
 #pragma unroll
                     for (int ni = 0; ni < 2; ni++)
@@ -668,7 +608,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = DBG(128) ? acc[ni][mi][r] : round16<T>(gelu_tanh_f(acc[ni][mi][r]));
+                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(gelu_tanh_f(acc[ni][mi][r]));
 
             // EpilogueQuantize<false, unsigned> (gemm_w4a4.cuh:930-1043): 16-bit add of the shift,
             // fp32 divide by the next layer's smooth factor -> 16-bit, per (row, 64 columns) absmax,
@@ -697,7 +637,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         float sh = round16<T>(acc[ni][mi][r] + 0.171875f);
-                        float v = DBG(256) ? sh : round16<T>(sh * smr[ni][r]);
+                        float v = round16<T>(sh * smr[ni][r]);
                         xh[ni * 16 + r] = v;
                         amax = fmaxf(amax, fabsf(v));
                     }
@@ -729,11 +669,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                 }
                 if (h == 0) ((T *)p.oscales)[simg_index(m_abs, g2, KP2)] = f2h<T>(scale);
             }
-#ifdef SVDQ_ABLATE
-            asm volatile("" ::: "memory");
-            if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 3] = __builtin_readcyclecounter() - clk_t0;
-            asm volatile("" ::: "memory");
-#endif
+            SVDQ_PROBE_STAMP(3);
             // EpilogueLoraDown for the NEXT layer on the GELU output, before shift/smooth
             // (issued AFTER the requantisation below in program order: vmcnt retires in order on CDNA, so any load
             //  that followed these fp32 atomics would wait for their memory-side round trip)
@@ -742,8 +678,8 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
             // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.  With
             // the activations as the A operand the result tile has the RANK along the lanes, so every fp32
             // atomic instruction hits two 128-byte lines instead of 64 different ones.
-            if (p.R2 > 0 && !DBG(64)) {
-                const T *ld = (const T *)(bm >= p.split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
+            if (p.R2 > 0) {
+                const T *ld = (const T *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
                 for (int t2 = 0; t2 < p.R2; t2 += 32) {
                     v16f d[2];
 #pragma unroll
@@ -777,15 +713,17 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                         }
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) {
-                        float *dst = p.lora_act_out + (size_t)(mw0 + mi * 32 + h * 4) * p.R2 + t2 + lr;
-                        if (live && !DBG(16)) {
-                            if DBG(32) {
+                        const size_t at = (size_t)(mw0 + mi * 32 + h * 4) * p.R2 + t2 + lr;
+                        if (live && LAQ) {
+                            // deterministic mode: Q31.32 fixed point, 64-bit INTEGER atomics -- the sum does not depend on the order
+                            long long *dst = (long long *)p.lora_act_out + at;
 #pragma unroll
-                                for (int i = 0; i < 16; i++) __hip_atomic_fetch_add(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.R2, d[mi][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            } else {
+                            for (int i = 0; i < 16; i++)
+                                __hip_atomic_fetch_add(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.R2, float_to_q32(d[mi][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else if (live) {
+                            float *dst = (float *)p.lora_act_out + at;
 #pragma unroll
                             for (int i = 0; i < 16; i++) unsafeAtomicAdd(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.R2, d[mi][i]);
-                            }
                         }
                     }
                 }
@@ -793,11 +731,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
 
         }
 
-#ifdef SVDQ_ABLATE
-        asm volatile("" ::: "memory");
-        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 4] = __builtin_readcyclecounter() - clk_t0;
-        asm volatile("" ::: "memory");
-#endif
+        SVDQ_PROBE_STAMP(4);
         // EpilogueDefault (gemm_base.cuh:667-698): store rows < M; fp16 clamps to +-65504.
         // A lane holds 4 consecutive columns per (tile, c); the partner lane (lane ^ 32) holds the next 4.
         // One v_permlane32_swap per dword turns two 8-byte pieces per lane into one 16-byte piece, so a
@@ -835,7 +769,7 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
         for (int mi = 0; mi < 2; mi++) {
             const int m_abs = mw0 + mi * 32 + lr;
             T *orow = (T *)p.out + (size_t)m_abs * p.ldo + nw0 + h * 8;
-            const bool ok = m_abs < p.M && !DBG(1);
+            const bool ok = m_abs < p.M;
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
@@ -858,122 +792,110 @@ __global__ __launch_bounds__(512) void gemm_w4a4_kernel(const GemmParams p) {
                     }
                     if (ok) {
                         v4i o = {(int)x[0], (int)x[1], (int)y[0], (int)y[1]};
-                        if DBG(4) __builtin_nontemporal_store(o, reinterpret_cast<v4i *>(orow + ni * 32 + j * 16));
-                        else *reinterpret_cast<v4i *>(orow + ni * 32 + j * 16) = o;
+                        *reinterpret_cast<v4i *>(orow + ni * 32 + j * 16) = o;
                     }
                 }
         }
         } // FUSE != GELU_QUANT
         } // run_epilogue
-#ifdef SVDQ_ABLATE
-        if (p.trace && blockIdx.x == 0 && tid == 0 && seg_no < 32) p.trace[6 * seg_no + 5] = __builtin_readcyclecounter() - clk_t0;
-        seg_no++;
-#endif
+        SVDQ_PROBE_STAMP(5);
+        SVDQ_PROBE_NEXT_SEGMENT();
         have = have_next;
         cur = nxt;
         bm = nbm;
         bn = nbn;
     }
-#ifdef SVDQ_ABLATE
-    if (p.clk && tid == 0) {
-        p.clk[2 * blockIdx.x] = __builtin_readcyclecounter() - clk_t0;
-        p.clk[2 * blockIdx.x + 1] = wall_clock64() - clk_r0;
-    }
-#endif
+    SVDQ_PROBE_END();
 }
 
-// number of workgroups of the persistent grid: one per CU (the kernel needs 114 KiB of LDS and 8 waves
-// of 230 VGPRs, so exactly one workgroup is resident per CU)
+
+// compute units the persistent grids are sized for (a multiple of 8: the XCD-aware numbering deals workgroups to the 8
+// XCDs; at most 256: the stream-K header holds 1023 arrival counters for up to 2 x 256 workgroups)
 static int device_cus() {
     static int cus = 0; // benign race: every thread computes the same value
     if (cus == 0) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;
-        if (n > 256) n = 256; // the workspace header holds 255 arrival counters
+        if (n > 256) n = 256;
         cus = n >= 8 ? (n / 8) * 8 : n;
     }
     return cus;
 }
-static long long workspace_bytes_needed() { return 1024 + 2LL * device_cus() * BM * BN * 4; }
-// Stream-K heuristic.  The remainder R = tiles % CUs of the last round leaves CUs idle for a whole tile time;
+// one size for both geometries: 2 slabs per workgroup slot, 256 x 128 tiles on `cus` slots == 128 x 128 tiles on 2 * cus
+static long long workspace_bytes_needed() { return SK_HEADER_BYTES + 2LL * device_cus() * 256 * BN * 4; }
+
+// Stream-K heuristic.  The remainder R = tiles % slots of the last round leaves CUs idle for a whole tile time;
 // splitting those tiles along K costs every split ~2 x 128 KiB of fp32 partial traffic plus a prologue
 // (measured ~10 K-steps worth), so it only pays for long K or nearly empty last rounds.  At most two pieces
 // per tile, at least 8 K-steps per piece.  Returns the number of workgroups sharing the remainder (0 = off).
-static int streamk_groups(const GemmParams &p, int tiles, int KP) {
-    const int cus = device_cus();
-    if (!p.workspace || p.workspace_bytes < workspace_bytes_needed() || DBG(8)) return 0;
-    const int R = tiles % cus;
+static int streamk_groups_for(int tiles, int KP, int slots) {
+    const int R = tiles % slots;
     if (R == 0) return 0;
-#ifdef SVDQ_ABLATE
-    static const int max_pieces = getenv("SVDQ_SK_MAXPIECES") ? atoi(getenv("SVDQ_SK_MAXPIECES")) : 2; // experiment knobs
-    static const int min_steps = getenv("SVDQ_SK_MINSTEPS") ? atoi(getenv("SVDQ_SK_MINSTEPS")) : 8;
-#else
     constexpr int max_pieces = 2, min_steps = 8;
-#endif
     long long gs = (long long)R * max_pieces;
-    if (gs > cus) gs = cus;
+    if (gs > slots) gs = slots;
     while (gs > R && (long long)R * KP / gs < min_steps) gs--;
     if (gs <= R) return 0;
     const double with_sk = (double)R * KP / gs + 10.0, without = (double)KP;
     return with_sk < 0.85 * without ? (int)gs : 0;
 }
-// Grid of a launch WITHOUT stream-K.  Whole rounds on fewer workgroups: 1296 tiles are 6 rounds on 256 CUs (the last one 6 % full)
+// Grid of a launch WITHOUT stream-K.  Whole rounds on fewer workgroups: 1296 tiles are 6 rounds on 256 slots (the last one 6 % full)
 // and 6 rounds on 216 -- the same number of tile times, but no CU sits through a nearly empty round and the chip is
-// power-limited: the 40 idle CUs lend their budget to the busy ones (QKV+RoPE 192 -> 185 us, fc1+GELU_QUANT 278 -> 270 us,
-// out-projection 60.7 -> 59.4 us; profiles/r2_gemm_loop_variants_ab.txt).  A multiple of 8 (XCD-aware numbering).
-static int whole_rounds_grid(int tiles, int cus) {
-    if (tiles <= cus) return tiles;
-    const int rounds = (tiles + cus - 1) / cus;
+// power-limited: the idle CUs lend their budget to the busy ones (profiles/r2_gemm_loop_variants_ab.txt).  A multiple of 8
+// (XCD-aware numbering).
+static int whole_rounds_grid(int tiles, int slots) {
+    if (tiles <= slots) return tiles;
+    const int rounds = (tiles + slots - 1) / slots;
     const int g = ((tiles + rounds - 1) / rounds + 7) / 8 * 8;
-    return g <= cus ? g : cus;
+    return g <= slots ? g : slots;
 }
-static int persistent_grid(const GemmParams &p, int tiles) {
-    const int cus = device_cus();
-    if (p.sk_gs > 0) return tiles < cus ? max(tiles, p.sk_gs) : cus;
-    if (DBG(8192)) return tiles < cus ? tiles : cus; // (ablation build: one workgroup per CU as before)
-    return whole_rounds_grid(tiles, cus);
+static int persistent_grid(int tiles, int sk_gs, int slots) {
+    if (sk_gs > 0) return tiles < slots ? max(tiles, sk_gs) : slots;
+    return whole_rounds_grid(tiles, slots);
 }
 
-template <int DT, int FUSE, int LOOPV>
-static void launch_one(const GemmParams &p, hipStream_t st) {
-    dim3 grid(persistent_grid(p, (p.M_pad / BM) * (p.N / BN))), block(512);
-    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, LOOPV>), grid, block, 0, st, p);
+// Geometry of a launch (svdq_gemm_args.geometry; 0 = this heuristic).
+static int pick_geometry(const svdq_gemm_args *a) {
+    if (a->geometry != 0) return a->geometry;
+    return SVDQ_GEMM_GEOMETRY_DEFAULT;
 }
 
-template <int DT, int ASM_LOOP>
-static void launch_fuse(const GemmParams &p, int fuse, hipStream_t st) {
+template <int DT, int FUSE, int NW, bool LAQ>
+static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
+    using G_ = Geo<NW>;
+    const int tiles = (p.M_pad / G_::BM) * (p.N / BN), slots = device_cus() * G_::WG_PER_CU;
+    p.sk_gs = with_ws ? streamk_groups_for(tiles, p.K / 128, slots) : 0;
+    dim3 grid(persistent_grid(tiles, p.sk_gs, slots)), block(G_::THREADS);
+    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ>), grid, block, 0, st, p);
+}
+
+template <int DT, int FUSE, int NW>
+static void launch_one(GemmParams &p, bool with_ws, hipStream_t st) {
+    if (p.lora_fixed) launch_one_laq<DT, FUSE, NW, true>(p, with_ws, st);
+    else launch_one_laq<DT, FUSE, NW, false>(p, with_ws, st);
+}
+template <int DT, int NW>
+static void launch_fuse(GemmParams &p, int fuse, bool with_ws, hipStream_t st) {
     switch (fuse) {
-    case SVDQ_FUSE_NONE: launch_one<DT, SVDQ_FUSE_NONE, ASM_LOOP>(p, st); break;
-    case SVDQ_FUSE_SILU: launch_one<DT, SVDQ_FUSE_SILU, ASM_LOOP>(p, st); break;
-    case SVDQ_FUSE_GELU_QUANT: launch_one<DT, SVDQ_FUSE_GELU_QUANT, ASM_LOOP>(p, st); break;
-    case SVDQ_FUSE_RMSNORM_ROPE: launch_one<DT, SVDQ_FUSE_RMSNORM_ROPE, ASM_LOOP>(p, st); break;
+    case SVDQ_FUSE_NONE: launch_one<DT, SVDQ_FUSE_NONE, NW>(p, with_ws, st); break;
+    case SVDQ_FUSE_SILU: launch_one<DT, SVDQ_FUSE_SILU, NW>(p, with_ws, st); break;
+    case SVDQ_FUSE_GELU_QUANT: launch_one<DT, SVDQ_FUSE_GELU_QUANT, NW>(p, with_ws, st); break;
+    case SVDQ_FUSE_RMSNORM_ROPE: launch_one<DT, SVDQ_FUSE_RMSNORM_ROPE, NW>(p, with_ws, st); break;
     }
 }
-
-#ifdef SVDQ_ABLATE
-static long long *g_ablate_clk = nullptr;
-static long long *g_ablate_trace = nullptr;
-#include "gemm_ablate_launch.inc" /* generated: SVDQ_ABLATE_MAX_VARIANT, launch_ablation() */
-#endif
 
 } // namespace svdq
 
 using namespace svdq;
 
-#ifdef SVDQ_ABLATE
-// tools only: device buffer of 2 * grid int64 that every later gemm launch fills with {shader cycles, 100 MHz ticks} per workgroup
-extern "C" void svdq_ablate_set_clk(long long *dev_buf) { g_ablate_clk = dev_buf; }
-// tools only: device buffer of 192 int64: workgroup 0 stamps 6 phase boundaries (shader cycles) per segment
-extern "C" void svdq_ablate_set_trace(long long *dev_buf) { g_ablate_trace = dev_buf; }
-#endif
-
 extern "C" int64_t svdq_gemm_workspace_bytes(void) { return workspace_bytes_needed(); }
 
 // Reads the sticky error word of a stream-K workspace after the work queued on `stream` has drained (this call
-// SYNCHRONISES the stream: a test / debugging aid, not part of the hot path).  Non-zero means an owner workgroup gave up
-// waiting for partial tiles (gemm_w4a4_kernel, SK_SPIN_LIMIT): the workspace was shared by launches in flight on two
-// streams, or was not zero-filled.  The word is cleared by the call.
+// SYNCHRONISES the stream: a test / debugging aid, not part of the hot path -- the hot path's cheap check is the
+// host-visible svdq_gemm_args.status word).  Non-zero means an owner workgroup gave up waiting for partial tiles
+// (gemm_w4a4_kernel, SK_SPIN_LIMIT): the workspace was shared by launches in flight on two streams, was not zero-filled,
+// or the grid was not co-resident.  The word is cleared by the call.
 extern "C" int svdq_gemm_workspace_status(void *workspace, void *stream) {
     if (!workspace) { set_error("svdq_gemm_workspace_status: workspace is NULL"); return SVDQ_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
@@ -984,29 +906,24 @@ extern "C" int svdq_gemm_workspace_status(void *workspace, void *stream) {
     if (word != 0) {
         (void)hipMemsetAsync(dev, 0, sizeof(int), st);
         set_error("svdq_gemm_w4a4: a stream-K owner timed out waiting for partial tiles -- the workspace was used by launches in "
-                  "flight on more than one stream (or was not zero-filled); results of those launches are invalid");
+                  "flight on more than one stream, was not zero-filled, or the grid was not co-resident; results of those launches are invalid");
         return SVDQ_E_HIP;
     }
     return SVDQ_OK;
 }
 
 // Host-side replay of the persistent schedule (the same GemmSchedule code the kernel runs): for the problem
-// (M_pad, N, K) on `cus` compute units, with or without a stream-K workspace, write up to `cap` records
+// (M_pad, N, K) on `cus` compute units with the given geometry (1: 256 x 128 tiles, one workgroup per CU; 2: 128 x 128
+// tiles, two per CU), with or without a stream-K workspace, write up to `cap` records
 // {position, tile, kp0, kp1, slot-or-minus-one, contributors} and return the number of segments (or -1).
-extern "C" int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t *out, int32_t cap) {
-    if (M_pad <= 0 || N <= 0 || K <= 0 || M_pad % BM || N % BN || K % 128 || cus <= 0) return -1;
-    const int tiles = (M_pad / BM) * (N / BN), KP = K / 128;
-    int gs = 0;
-    if (with_workspace) { // streamk_groups() with an explicit CU count
-        const int R = tiles % cus;
-        if (R) {
-            long long g = (long long)R * 2;
-            if (g > cus) g = cus;
-            while (g > R && (long long)R * KP / g < 8) g--;
-            if (g > R && (double)R * KP / g + 10.0 < 0.85 * KP) gs = (int)g;
-        }
-    }
-    const int G = gs > 0 ? (tiles < cus ? (tiles > gs ? tiles : gs) : cus) : whole_rounds_grid(tiles, cus);
+extern "C" int svdq_gemm_schedule_ex(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t geometry,
+                                     int32_t *out, int32_t cap) {
+    if (geometry != 1 && geometry != 2) return -1;
+    const int bm = geometry == 1 ? 256 : 128, slots = geometry == 1 ? cus : 2 * cus;
+    if (M_pad <= 0 || N <= 0 || K <= 0 || M_pad % 256 || N % BN || K % 128 || cus <= 0) return -1;
+    const int tiles = (M_pad / bm) * (N / BN), KP = K / 128;
+    const int gs = with_workspace ? streamk_groups_for(tiles, KP, slots) : 0;
+    const int G = persistent_grid(tiles, gs, slots);
     int n = 0;
     for (int pos = 0; pos < G; pos++) {
         GemmSchedule sc;
@@ -1024,6 +941,9 @@ extern "C" int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t c
         }
     }
     return n;
+}
+extern "C" int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t *out, int32_t cap) {
+    return svdq_gemm_schedule_ex(M_pad, N, K, cus, with_workspace, 1, out, cap);
 }
 
 extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
@@ -1046,18 +966,12 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     }
     if (a->R > 0 && (!a->lora_act_in || !a->lora_up)) { set_error("svdq_gemm_w4a4: R > 0 needs lora_act_in and lora_up"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemm_w4a4: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
-#ifdef SVDQ_ABLATE
-    if (a->variant < 0 || a->variant > SVDQ_ABLATE_MAX_VARIANT) { set_error("svdq_gemm_w4a4: unknown variant %d", a->variant); return SVDQ_E_INVALID; }
-    if (a->variant >= 2 && (a->dtype != SVDQ_BF16 || a->fuse != SVDQ_FUSE_NONE)) {
-        set_error("svdq_gemm_w4a4: ablation variants (tools only, WRONG results) exist for bf16 / FUSE_NONE only");
+    if (a->variant != 0 || a->reserved != 0) {
+        set_error("svdq_gemm_w4a4: variant and reserved must be 0 (timing experiments live in tools/ablate, not in this library)");
         return SVDQ_E_INVALID;
     }
-#else
-    if (a->variant < 0 || a->variant > 1 || a->reserved != 0) {
-        set_error("svdq_gemm_w4a4: variant must be 0 or 1 and reserved must be 0 (timing ablations live in tools/ablate, not in this library)");
-        return SVDQ_E_INVALID;
-    }
-#endif
+    if (a->geometry < 0 || a->geometry > 3) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto), 1, 2 or 3"); return SVDQ_E_INVALID; }
+    if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_gemm_w4a4: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
     case SVDQ_FUSE_SILU:
@@ -1080,8 +994,8 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         return SVDQ_E_INVALID;
     }
     if (a->wgt2) { // grouped launch: a second weight set for rows >= split_rows
-        if (!a->wscales2 || a->split_rows <= 0 || a->split_rows >= a->M_pad || a->split_rows % BM) {
-            set_error("svdq_gemm_w4a4: grouped launch needs wscales2 and 0 < split_rows=%d < M_pad=%d, a multiple of %d", a->split_rows, a->M_pad, BM);
+        if (!a->wscales2 || a->split_rows <= 0 || a->split_rows >= a->M_pad || a->split_rows % 256) {
+            set_error("svdq_gemm_w4a4: grouped launch needs wscales2 and 0 < split_rows=%d < M_pad=%d, a multiple of 256", a->split_rows, a->M_pad);
             return SVDQ_E_INVALID;
         }
         if ((a->bias != nullptr) != (a->bias2 != nullptr) || (a->R > 0 && !a->lora_up2)) {
@@ -1113,8 +1027,8 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         return SVDQ_E_INVALID;
     }
     if (((uintptr_t)a->out | (uintptr_t)a->bias | (uintptr_t)a->next_smooth | (uintptr_t)a->next_lora_down |
-         (uintptr_t)a->norm_q | (uintptr_t)a->norm_k) & 7) {
-        set_error("svdq_gemm_w4a4: out, bias, next_smooth, next_lora_down, norm_q, norm_k must be 8-byte aligned");
+         (uintptr_t)a->norm_q | (uintptr_t)a->norm_k | (uintptr_t)a->lora_act_out) & 7) {
+        set_error("svdq_gemm_w4a4: out, bias, next_smooth, next_lora_down, norm_q, norm_k, lora_act_out must be 8-byte aligned");
         return SVDQ_E_INVALID;
     }
 
@@ -1137,33 +1051,29 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.rotary_emb = a->rotary_emb;
     p.wgt2 = (const uint8_t *)a->wgt2; p.wscales2 = a->wscales2; p.bias2 = a->bias2; p.lora_up2 = a->lora_up2;
     p.next_smooth2 = a->next_smooth2; p.next_lora_down2 = a->next_lora_down2; p.norm_q2 = a->norm_q2; p.norm_k2 = a->norm_k2;
-    p.split_bm = a->wgt2 ? a->split_rows / BM : 0x7fffffff;
+    p.split_row = a->wgt2 ? a->split_rows : 0x7fffffff;
     p.out_vt = a->fuse == SVDQ_FUSE_RMSNORM_ROPE ? a->out_vt : nullptr;
     p.ldvt = a->ldvt;
-#ifdef SVDQ_ABLATE
-    p.debug = a->reserved;
-    p.clk = g_ablate_clk;
-    p.trace = g_ablate_trace;
-#endif
     p.workspace = (uint8_t *)a->workspace;
     p.workspace_bytes = a->workspace_bytes;
     p.M = a->M; p.M_pad = a->M_pad; p.N = a->N; p.K = a->K; p.R = a->R; p.R2 = a->R2; p.ldo = a->ldo;
+    p.lora_fixed = a->lora_act_format;
+    p.status = a->status;
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;
+    SVDQ_PROBE_FILL(p);
 
-    p.sk_gs = streamk_groups(p, (p.M_pad / BM) * (p.N / BN), p.K / 128);
+    const bool with_ws = p.workspace && p.workspace_bytes >= workspace_bytes_needed();
+    const int geo = pick_geometry(a);
+    p.stagger = geo == 2;
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(0, 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
-    // variant 0: hand-scheduled main loop; variant 1: the compiler-scheduled C++ loop (same arithmetic)
-    if (a->variant == 0) {
-        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, 0>(p, a->fuse, st);
-        else launch_fuse<SVDQ_FP16, 0>(p, a->fuse, st);
-    } else if (a->variant == 1) {
-        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, 1>(p, a->fuse, st);
-        else launch_fuse<SVDQ_FP16, 1>(p, a->fuse, st);
+    if (geo == 1) {
+        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, 8>(p, a->fuse, with_ws, st);
+        else launch_fuse<SVDQ_FP16, 8>(p, a->fuse, with_ws, st);
+    } else {
+        if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, 4>(p, a->fuse, with_ws, st);
+        else launch_fuse<SVDQ_FP16, 4>(p, a->fuse, with_ws, st);
     }
-#ifdef SVDQ_ABLATE
-    else launch_ablation(p, a->variant, st); // generated switch over the ablation loops (tools/ablate/build.py)
-#endif
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_gemm_w4a4 launch");
 }

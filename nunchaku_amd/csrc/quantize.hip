@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
                                                        const typename Half<DT>::T *__restrict__ lora_down, // [R][K]
                                                        uint8_t *__restrict__ act,
                                                        typename Half<DT>::T *__restrict__ ascales,
-                                                       float *__restrict__ lora_act, int M, int K, int R, int ldx,
+                                                       void *__restrict__ lora_act, int M, int K, int R, int ldx,
                                                        int chunks_per_wg, int use_atomics,
                                                        const float *__restrict__ ln_stats,
                                                        const typename Half<DT>::T *__restrict__ mod_scale,
@@ -231,9 +231,7 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
 #pragma unroll
                         for (int i = 0; i < 16; i++) {
                             const int m = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                            float *dst = lora_act + (size_t)m * R + rank;
-                            if (use_atomics) unsafeAtomicAdd(dst, s[i]);
-                            else *dst = s[i];
+                            lora_act_add(lora_act, (size_t)m * R + rank, s[i], use_atomics);
                         }
                     }
                 }
@@ -264,8 +262,8 @@ struct QuantParams {
     const float *ln_stats;
     uint8_t *act;
     void *ascales;
-    float *lora_act;
-    int M, K, R, ldx, use_atomics;
+    void *lora_act;
+    int M, K, R, ldx, use_atomics; // use_atomics: bit 0 = K is sliced over workgroups, bit 1 = Q31.32 format (lora_act_add)
     QuantSecond s2;
 };
 
@@ -518,9 +516,7 @@ __global__ __launch_bounds__(256, 4) void quantize_kernel_v2(QuantParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const int m = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    float *dstl = p.lora_act + (size_t)m * p.R + r;
-                    if (p.use_atomics) unsafeAtomicAdd(dstl, s[i]);
-                    else *dstl = s[i];
+                    lora_act_add(p.lora_act, (size_t)m * p.R + r, s[i], p.use_atomics);
                 }
             }
         }
@@ -532,24 +528,17 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     using T = typename Half<DT>::T;
     const int KP = a->K / 128, tiles = a->M_pad / 32;
     // enough workgroups to fill 256 CUs several times over, but at least one chunk per wave
-#ifdef SVDQ_ABLATE
-    static const int cpw_env = getenv("SVDQ_QUANT_CPW") ? atoi(getenv("SVDQ_QUANT_CPW")) : 0; // experiment knob
-#else
     constexpr int cpw_env = 0;
-#endif
-#ifdef SVDQ_ABLATE
-    static const bool force_general = getenv("SVDQ_QUANT_GENERAL") != nullptr; // A/B against the general kernel
-#else
     constexpr bool force_general = false;
-#endif
     int cpw = cpw_env > 0 ? cpw_env : 4; // chunks per workgroup = 4 waves x 1 chunk: many short waves hide the HBM round trip
     while ((long)tiles * ((KP + cpw - 1) / cpw) > 8192) cpw *= 2;
     if (cpw > KP) cpw = ((KP + 3) / 4) * 4;
     const int slices = (KP + cpw - 1) / cpw;
-    const int atomics = slices > 1;
-    if (a->R > 0 && atomics && !a->lora_act_zeroed) {
+    const int q32 = a->lora_act_format == SVDQ_LORA_ACT_Q32;
+    const int atomics = (slices > 1 ? 1 : 0) | (q32 ? 2 : 0); // lora_act_add mode
+    if (a->R > 0 && (atomics & 1) && !a->lora_act_zeroed) {
         // the reference zeroes the buffer inside the op as well (launch_impl.cuh:487)
-        int rc = hip_check(hipMemsetAsync(a->lora_act, 0, (size_t)a->M_pad * a->R * sizeof(float), st), "svdq_quantize memset");
+        int rc = hip_check(hipMemsetAsync(a->lora_act, 0, (size_t)a->M_pad * a->R * (q32 ? 8 : 4), st), "svdq_quantize memset");
         if (rc) return rc;
     }
     dim3 grid(tiles * slices), block(256);
@@ -568,22 +557,9 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
         }
         return hip_check(hipGetLastError(), "svdq_quantize_w4a4_act_fuse_lora launch");
     }
-#ifdef SVDQ_ABLATE
-    static const int occ_env = getenv("SVDQ_QUANT_OCC") ? atoi(getenv("SVDQ_QUANT_OCC")) : 0; // experiment knob
-#else
     constexpr int occ_env = 0;
-#endif
-#ifdef SVDQ_ABLATE
-#define SVDQ_LAUNCH_Q_OCC4(RT)                                                                                       \
-    if (RT <= 2 && occ_env == 4)                                                                                     \
-    hipLaunchKernelGGL((quantize_kernel<DT, RT, (RT <= 2 ? 4 : 1)>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth, \
-                       (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
-                       a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift, s2);          \
-    else
-#else
 #define SVDQ_LAUNCH_Q_OCC4(RT)
     (void)occ_env;
-#endif
 #define SVDQ_LAUNCH_Q(RT)                                                                                            \
     SVDQ_LAUNCH_Q_OCC4(RT)                                                                                           \
     hipLaunchKernelGGL((quantize_kernel<DT, RT, 1>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,          \
@@ -607,6 +583,8 @@ extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, voi
     if (!a) { set_error("svdq_quantize: args is NULL"); return SVDQ_E_INVALID; }
     if (a->fp4) { set_error("svdq_quantize: fp4 (NVFP4) is not supported on gfx950"); return SVDQ_E_UNSUPPORTED; }
     if (a->fuse_glu) { set_error("svdq_quantize: fuse_glu is not supported"); return SVDQ_E_UNSUPPORTED; }
+    if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_quantize: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
+    if (a->lora_act_format == SVDQ_LORA_ACT_Q32 && ((uintptr_t)a->lora_act & 7)) { set_error("svdq_quantize: a Q31.32 lora_act must be 8-byte aligned"); return SVDQ_E_INVALID; }
     if (!a->x || !a->act || !a->ascales) { set_error("svdq_quantize: x, act and ascales are required"); return SVDQ_E_INVALID; }
     if (a->M <= 0 || a->M_pad < a->M || a->M_pad % 256) {
         set_error("svdq_quantize: need 0 < M=%d <= M_pad=%d and M_pad %% 256 == 0", a->M, a->M_pad);

@@ -87,6 +87,32 @@ __device__ __forceinline__ float div_rn(float a, float b, float rb) {
     return __builtin_fmaf(e, rb, q);
 }
 
+// ---- order-independent accumulation format of the low-rank activations ("deterministic mode") -------------------
+// fp32 atomics make lora_act depend on the arrival order of the K-slice / column-tile partial sums (the reference's own
+// behaviour, lora.cuh:82-94,323).  With SVDQ_LORA_ACT_Q32 the partial sums are converted to Q31.32 fixed point
+// (int64: value * 2^32, floor) and accumulated with 64-bit INTEGER atomics: integer addition is associative, so the
+// result is bit-reproducible whatever the order.  Resolution 2^-32 (finer than an fp32 ulp for |v| >= 2^-8), range +-2^31.
+__device__ __forceinline__ long long float_to_q32(float v) {
+    const float fl = __builtin_floorf(v);
+    const int hi = (int)fl;                                           // saturates
+    const unsigned lo = (unsigned)((v - fl) * 4294967296.0f);         // v - floor(v) is exact; saturates at 2^32 - 1
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | lo);
+}
+__device__ __forceinline__ float q32_to_float(int lo, int hi) {
+    return __builtin_fmaf((float)(unsigned)lo, 0x1p-32f, (float)hi);
+}
+// one partial sum into lora_act[idx]; mode bit 0: other workgroups add to the same element (atomics), bit 1: Q31.32 format
+__device__ __forceinline__ void lora_act_add(void *base, size_t idx, float v, int mode) {
+    if (mode & 2) {
+        const long long q = float_to_q32(v);
+        if (mode & 1) __hip_atomic_fetch_add((long long *)base + idx, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else ((long long *)base)[idx] = q;
+    } else {
+        if (mode & 1) unsafeAtomicAdd((float *)base + idx, v);
+        else ((float *)base)[idx] = v;
+    }
+}
+
 // ---- F6 / S image addressing ----------------------------------------------------------------
 constexpr int F6_CHUNK = 3072; // bytes of one (32 rows x 128 k) chunk
 constexpr int F6_PLANE = 1024;

@@ -8,6 +8,7 @@ import math
 import torch
 
 from .._C import ops
+from ..mode import alloc_lora_act, lora_act_words
 
 
 def alloc_qkv(tokens: int, heads: int, dtype: torch.dtype, device, head_dim: int = 128):
@@ -32,7 +33,8 @@ def attention_packed(qkv: torch.Tensor, vt: torch.Tensor, heads: int, out: torch
         out = torch.empty(L, heads * D, dtype=qkv.dtype, device=qkv.device)
     q = qkv[:, : heads * D].unflatten(1, (heads, D))
     k = qkv[:, heads * D : 2 * heads * D].unflatten(1, (heads, D))
-    zero = torch.empty((zero_floats + 3) // 4 * 4, dtype=torch.float32, device=qkv.device) if zero_floats > 0 else None
+    zwords = zero_floats * lora_act_words()
+    zero = torch.empty((zwords + 3) // 4 * 4, dtype=torch.float32, device=qkv.device) if zero_floats > 0 else None
     ops.attention(q, k, vt.unflatten(0, (heads, D)), out.unflatten(1, (heads, D)), 1.0 / math.sqrt(D) if scale is None else scale, zero)
     if zero_floats > 0:
         from .elementwise import ZeroPool
@@ -57,8 +59,9 @@ def attention_packed_quantized(qkv: torch.Tensor, vt: torch.Tensor, heads: int, 
     dev = qkv.device
     act = torch.empty(L, K * 3 // 4, dtype=torch.uint8, device=dev)
     asc = torch.empty(K // 64, L, dtype=qkv.dtype, device=dev)
-    lact = pool.take(L * R) if pool is not None else None
-    lact = lact.view(L, R) if lact is not None else torch.zeros(L, R, dtype=torch.float32, device=dev)
+    lact, zeroed = alloc_lora_act(L, R, dev, pool)
+    if not zeroed:
+        lact.zero_()
     quant = dict(act=act, ascales=asc, lora_act=lact, R=R)
     if lin_first is not None:  # first parameter set = the rows that come first (text)
         lin_first._ensure_layout()

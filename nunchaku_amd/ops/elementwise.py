@@ -6,10 +6,11 @@ from __future__ import annotations
 import torch
 
 from .._C import ops
+from ..mode import lora_act_words
 
 
 class ZeroPool:
-    """fp32 scratch cleared by a :func:`residual_gate_stats` pass, handed out in pieces to the quantiser /
+    """Scratch words (fp32-sized) cleared by a :func:`residual_gate_stats` pass, handed out in pieces to the quantiser /
     GELU_QUANT calls that follow it on the same stream (their low-rank accumulators need a zeroed buffer: this saves
     one memset launch each).  ``take`` returns None when the pool is exhausted -- the caller then clears its own."""
 
@@ -40,6 +41,7 @@ def residual_gate_stats(res: torch.Tensor, a: torch.Tensor | None = None, gate: 
         out = r2 if inplace else torch.empty_like(r2)
     stats = torch.empty(r2.shape[0], 2, dtype=torch.float32, device=res.device) if want_stats else None
     want_pool = zero_floats > 0
+    zero_floats *= lora_act_words()  # the count is in lora_act elements: two words each in deterministic mode
     zero = torch.empty((zero_floats + 3) // 4 * 4, dtype=torch.float32, device=res.device) if zero_floats > 0 else None
     ops.residual_gate_stats(r2, None if a is None else a.reshape(-1, C), None if b is None else b.reshape(-1, C),
                             None if gate is None else gate.reshape(-1), out, stats, eps, zero, clamp_fp16=int(bool(clamp_fp16)))
@@ -56,7 +58,7 @@ def residual_gate_stats_pair(res_a, a_a, gate_a, res_b, a_b, gate_b, zero_floats
     ra, rb = res_a.reshape(-1, C), res_b.reshape(-1, C)
     sa = torch.empty(ra.shape[0], 2, dtype=torch.float32, device=res_a.device)
     sb = torch.empty(rb.shape[0], 2, dtype=torch.float32, device=res_a.device)
-    zf = zero_floats
+    zf = zero_floats * lora_act_words()
     zero = torch.empty((zf + 3) // 4 * 4, dtype=torch.float32, device=res_a.device) if zf > 0 else None
     ops.residual_gate_stats(ra, a_a.reshape(-1, C), None, gate_a.reshape(-1), ra, sa, eps, zero,
                             second=(rb, a_b.reshape(-1, C), None, gate_b.reshape(-1), rb, sb), clamp_fp16=int(bool(clamp_fp16_a)))

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import torch
 
+from ..mode import alloc_lora_act
 from ..utils import ceil_divide
 from .gemm import svdq_gemm_w4a4_cuda
 
@@ -22,9 +23,7 @@ def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256, ln=None, quan
     q_hidden = torch.empty(M_pad, fc1.out_features * 3 // 4, dtype=torch.uint8, device=dev)  # FP6 operand image
     s_hidden = torch.empty(fc1.out_features // 64, M_pad, dtype=x.dtype, device=dev)
     pool = ln[3] if ln is not None and len(ln) > 3 else None  # scratch cleared by the preceding element-wise pass
-    l_hidden = pool.take(M_pad * fc2.proj_down.shape[1]) if pool is not None else None
-    l_zeroed = l_hidden is not None
-    l_hidden = l_hidden.view(M_pad, -1) if l_zeroed else torch.empty(M_pad, fc2.proj_down.shape[1], dtype=torch.float32, device=dev)
+    l_hidden, l_zeroed = alloc_lora_act(M_pad, fc2.proj_down.shape[1], dev, pool)
     fc1._ensure_layout()
     fc2._ensure_layout()
     svdq_gemm_w4a4_cuda(
@@ -91,11 +90,6 @@ def _pair_ok(la, lb, xa, xb) -> bool:
             and la.act_unsigned == lb.act_unsigned and getattr(la, "lora_scales", None) == getattr(lb, "lora_scales", None))
 
 
-def _take(pool, numel):
-    piece = pool.take(numel) if pool is not None else None
-    return piece, piece is not None
-
-
 def _quantize_pair(xa, la, xb, lb, ln_a=None, ln_b=None, pool=None):
     """Both streams quantised into one set of row-side buffers (stream a first).  Returns (act, ascales, lora_act, Ma)."""
     la._ensure_layout()
@@ -105,8 +99,7 @@ def _quantize_pair(xa, la, xb, lb, ln_a=None, ln_b=None, pool=None):
     Mt, dev = Ma + Mb_pad, xa.device
     act = torch.empty(Mt, K * 3 // 4, dtype=torch.uint8, device=dev)
     asc = torch.empty(K // 64, Mt, dtype=xa.dtype, device=dev)  # opaque scale image: row-tile major, so the streams are slices
-    lact, zeroed = _take(pool, Mt * R)
-    lact = lact.view(Mt, R) if zeroed else torch.empty(Mt, R, dtype=torch.float32, device=dev)
+    lact, zeroed = alloc_lora_act(Mt, R, dev, pool)
     # ONE quantiser launch: stream a's rows first, stream b read from its own tensor with its own parameter set
     sec = dict(input=xb, smooth=lb.smooth_factor, lora_down=lb.proj_down)
     if ln_b is not None:
@@ -160,8 +153,7 @@ def fused_gelu_mlp_pair(xa, fc1a, fc2a, xb, fc1b, fc2b, ln_a=None, ln_b=None):
     Nh, R2 = fc1a.out_features, fc2a.rank
     q_hidden = torch.empty(Mt, Nh * 3 // 4, dtype=torch.uint8, device=dev)
     s_hidden = torch.empty(Nh // 64, Mt, dtype=xa.dtype, device=dev)
-    l_hidden, l_zeroed = _take(pool, Mt * R2)
-    l_hidden = l_hidden.view(Mt, R2) if l_zeroed else torch.empty(Mt, R2, dtype=torch.float32, device=dev)
+    l_hidden, l_zeroed = alloc_lora_act(Mt, R2, dev, pool)
     svdq_gemm_w4a4_cuda(
         act=act, wgt=fc1a.qweight, qout=q_hidden, ascales=asc, wscales=fc1a.wscales, oscales=s_hidden, lora_act_in=lact,
         lora_up=fc1a.proj_up, lora_down=fc2a.proj_down, lora_act_out=l_hidden, bias=fc1a.bias, smooth_factor=fc2a.smooth_factor,
@@ -204,8 +196,7 @@ def quantize_two(x, lin_a, lin_b, ln=None):
     pool = ln[3] if ln is not None and len(ln) > 3 else None
     act = torch.empty(2 * M, K * 3 // 4, dtype=torch.uint8, device=dev)
     asc = torch.empty(K // 64, 2 * M, dtype=x.dtype, device=dev)
-    lact, zeroed = _take(pool, 2 * M * R)
-    lact = lact.view(2 * M, R) if zeroed else torch.empty(2 * M, R, dtype=torch.float32, device=dev)
+    lact, zeroed = alloc_lora_act(2 * M, R, dev, pool)
     sec = dict(input=x, smooth=lin_b.smooth_factor, lora_down=lin_b.proj_down)
     if ln is not None:
         sec.update(ln_stats=ln[0], mod_scale=ln[1], mod_shift=ln[2])

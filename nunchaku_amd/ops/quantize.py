@@ -5,6 +5,7 @@ from __future__ import annotations
 import torch
 
 from .._C import ops
+from ..mode import alloc_lora_act
 from ..utils import ceil_divide
 
 
@@ -49,9 +50,7 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
         # a 4th element of ``ln`` is a ZeroPool of fp32 scratch cleared by the preceding residual_gate_stats pass
         if pool is None:
             pool = ln[3] if ln is not None and len(ln) > 3 else None
-        lora_act_out = pool.take(M_pad * R) if pool is not None else None
-        zeroed = lora_act_out is not None
-        lora_act_out = lora_act_out.view(M_pad, R) if zeroed else torch.empty(M_pad, R, dtype=torch.float32, device=dev)
+        lora_act_out, zeroed = alloc_lora_act(M_pad, R, dev, pool)  # fp32, or int64 fixed point in deterministic mode
     if ln is None:
         ops.quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu, fp4,
                                         lora_act_zeroed=zeroed, second=second)

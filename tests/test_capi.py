@@ -32,13 +32,30 @@ def test_abi_version(built_lib):
     assert lib.svdq_abi_version() == _lib.ABI_VERSION
 
 
-def test_struct_sizes_match_header(built_lib):
-    # 6 pointers + 8 int32 ; 17 pointers + 12 int32
-    assert C.sizeof(_lib.QuantizeArgs) == 6 * 8 + 8 * 4 + 3 * 8 + 6 * 8 + 4 * 4  # + LN front end, second set, M2/ldx2/split_rows/lora_act_zeroed
-    assert C.sizeof(_lib.ResidualArgs) == 6 * 8 + 6 * 4 + 8 + 8 + 6 * 8 + 2 * 4  # + zero_ptr, zero_bytes, second problem
-    assert C.sizeof(_lib.GemmArgs) == 17 * 8 + 12 * 4 + 2 * 8 + 8 + 2 * 4 + 8 * 8 + 2 * 4  # + workspace(+bytes), out_vt, ldvt, second weight set, split_rows
-    assert C.sizeof(_lib.AttentionArgs) == 4 * 8 + 4 * 8 + 8 * 4 + 4 + 4 + 8 + 8 + 7 * 8 + 2 * 4 + 2 * 8  # + zero_ptr/bytes, fused quantiser, workspace(+bytes)
-    assert C.sizeof(_lib.GemvAwqArgs) == 6 * 8 + 6 * 4 + 2 * 4  # + out_chunks, reserved
+_STRUCTS = {"svdq_quantize_args": _lib.QuantizeArgs, "svdq_gemm_args": _lib.GemmArgs, "svdq_attention_args": _lib.AttentionArgs,
+            "svdq_residual_args": _lib.ResidualArgs, "svdq_gemv_awq_args": _lib.GemvAwqArgs}
+
+
+def test_struct_layouts_match_header(built_lib, tmp_path):
+    """sizeof and every field offset of the ctypes twins against what the C compiler makes of include/svdq_amd.h
+    (a host program that includes the header and prints them: no hand-kept arithmetic)."""
+    import subprocess
+
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "svdq_amd.h")}"', "int main(void) {"]
+    for cname, cls in _STRUCTS.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in _STRUCTS.items():
+        assert int(got[cname]) == C.sizeof(cls), f"sizeof({cname}): header {got[cname]} != ctypes {C.sizeof(cls)}"
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"offsetof({cname}, {fname})"
 
 
 def test_attention_validation(built_lib):

@@ -1,0 +1,168 @@
+"""Two properties of the round-3 GEMM that the oracle parity tests do not state:
+
+* the two workgroup geometries (256 x 128 tiles / one workgroup per CU; 128 x 128 tiles / two per CU, half a tile out of
+  phase) compute every output element with the same operations in the same order -- launches whose tiles are not split
+  along K are BIT-IDENTICAL across geometries, for every epilogue, bf16 and fp16;
+* deterministic mode (nunchaku_amd.mode): the low-rank activations are accumulated as Q31.32 fixed point with integer
+  atomics, so the K-sliced quantiser, the GELU epilogue's column-tile sum and the attention epilogue's head sum are
+  bit-reproducible from run to run, and agree with the fp32 format to fp32 accuracy.  (The reference is non-deterministic
+  here: fp32 atomics, lora.cuh:82-94,323.)
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svdq_oracle as O
+from tests.helpers import TORCH_DT, assert_close_16, f32, make_module, t16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built_lib):
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from nunchaku_amd import _lib
+
+    _lib.load()
+
+
+def _with_geometry(g, fn):
+    from nunchaku_amd._C import _Ops
+
+    _Ops.gemm_geometry = g
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        return out
+    finally:
+        _Ops.gemm_geometry = 0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [300, 1536])
+def test_geometries_are_bit_identical_without_k_split(dtype, M):
+    """K = 384 / 768: no stream-K split in either geometry (too few K-steps), so every epilogue must agree bit for bit.
+    Geometry 3 = geometry 2 without the phase offset (a scheduling hint only)."""
+    from nunchaku_amd import layout
+    from nunchaku_amd.ops.fused import fused_gelu_mlp, fused_qkv_norm_rottary
+
+    K, N = 384, 768
+    L = O.make_svdq_layer(K, N, 32, seed=1, dtype=dtype, cheap=True)
+    L2 = O.make_svdq_layer(N, K, 32, seed=2, dtype=dtype, cheap=True)
+    mod, mod2 = make_module(L, dtype), make_module(L2, dtype, act_unsigned=True)
+    x = t16(O.make_activations(M, K, seed=3, dtype=dtype), dtype).view(1, M, K)
+    nq = torch.nn.RMSNorm(128, eps=1e-6, dtype=TORCH_DT[dtype], device="cuda")
+    nk = torch.nn.RMSNorm(128, eps=1e-6, dtype=TORCH_DT[dtype], device="cuda")
+    with torch.no_grad():
+        nq.weight.copy_(torch.rand(128) + 0.5)
+        nk.weight.copy_(torch.rand(128) + 0.5)
+    M_pad = (M + 255) // 256 * 256
+    ang = np.random.default_rng(0).uniform(0, 6.28, (M_pad, 64)).astype(np.float32)
+    rot = torch.from_numpy(O.pack_rotemb_ref(np.stack([np.sin(ang), np.cos(ang)], -1).astype(np.float32))).cuda().view(1, M_pad, 128)
+    Lq = O.make_svdq_layer(K, 768, 32, seed=4, dtype=dtype, cheap=True)  # N = 768 = 3 * 2 heads * 128
+    modq = make_module(Lq, dtype)
+
+    def run():
+        plain = mod(x)
+        silu_out = torch.empty(M, N, dtype=TORCH_DT[dtype], device="cuda")
+        from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
+
+        qx, asc, la = mod.quantize(x.view(M, K))
+        svdq_gemm_w4a4_cuda(act=qx, wgt=mod.qweight, out=silu_out, ascales=asc, wscales=mod.wscales, lora_act_in=la, lora_up=mod.proj_up,
+                            bias=mod.bias, fuse_silu=True)
+        mlp = fused_gelu_mlp(x, mod, mod2)
+        vt = torch.zeros(256, M_pad, dtype=TORCH_DT[dtype], device="cuda")
+        qkv = fused_qkv_norm_rottary(x, modq, nq, nk, rot, out_vt=vt[:, :M])
+        return plain, silu_out, mlp, qkv[..., :512], vt
+
+    ref = _with_geometry(1, run)
+    for g in (2, 3):
+        got = _with_geometry(g, run)
+        for name, a, b in zip(("default", "silu", "gelu_mlp", "qk rope", "v^T"), ref, got):
+            assert torch.equal(a, b), f"geometry {g} vs 1, {name}: {(a != b).float().mean():.2e} of the elements differ"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_geometry2_with_k_split_matches_oracle(dtype):
+    """K = 12288, M = 1024: the 128 x 128 geometry splits its remainder tiles along K at different points than the 256 x 128
+    one (fp32 summation order of a split tile differs): both within 1 ulp of the oracle, and of each other."""
+    K, N, M = 12288, 3072, 1024
+    L = O.make_random_svdq_layer(K, N, 32, seed=5, dtype=dtype)
+    mod = make_module(L, dtype)
+    x = O.make_activations(M, K, seed=6, dtype=dtype)
+    xt = t16(x, dtype).view(1, M, K)
+    rows = np.array(sorted(set([0, 1, 127, 128, 129, 255, 256, 511, 512, 767, 1023]) | set(np.random.default_rng(0).integers(0, M, 40).tolist())))
+    ref = O.svdq_linear(x[rows], L, dtype, "fp32")["out"]
+    outs = {}
+    for g in (1, 2):
+        outs[g] = _with_geometry(g, lambda: mod(xt))
+        # lora_act comes from the GPU quantiser (fp32 order differs from the oracle's float64): 1 ulp + rare flips
+        assert_close_16(f32(outs[g])[0][rows], ref, dtype, f"geometry {g}", max_bad_frac=2e-3, ulps=1.0)
+    assert_close_16(f32(outs[2]), f32(outs[1]), dtype, "geometry 2 vs 1", ulps=1.0)
+    from nunchaku_amd._C import ops
+
+    ops.gemm_workspace_status()
+
+
+def test_deterministic_quantiser_and_fused_mlp():
+    """K-sliced quantiser + GELU epilogue in deterministic mode: int64 lora_act, identical over repeated launches, equal to
+    the fp32-format result to fp32 accuracy, outputs within the usual bounds of the oracle."""
+    from nunchaku_amd import mode
+    from nunchaku_amd.ops.fused import fused_gelu_mlp
+
+    dtype, M, K, N = "bf16", 1024, 3072, 12288
+    L1 = O.make_random_svdq_layer(K, N, 32, seed=7, dtype=dtype)
+    L2 = O.make_random_svdq_layer(N, K, 32, seed=8, dtype=dtype)
+    fc1, fc2 = make_module(L1, dtype), make_module(L2, dtype, act_unsigned=True)
+    x = t16(O.make_activations(M, K, seed=9, dtype=dtype), dtype).view(1, M, K)
+
+    _, _, la32 = fc1.quantize(x.view(M, K))
+    y32 = fused_gelu_mlp(x, fc1, fc2)
+    with mode.deterministic_mode():
+        runs = []
+        for _ in range(4):
+            _, _, la = fc1.quantize(x.view(M, K))
+            assert la.dtype == torch.int64
+            runs.append((la.clone(), fused_gelu_mlp(x, fc1, fc2)))
+        torch.cuda.synchronize()
+    for la, y in runs[1:]:
+        assert torch.equal(la, runs[0][0]), "fixed-point lora_act differs between two launches"
+        assert torch.equal(y, runs[0][1]), "deterministic fused MLP differs between two launches"
+    la_det = mode.lora_act_to_float(runs[0][0])
+    # fp32 atomics vs exact integer accumulation of the same partial sums: fp32 rounding of a handful of adds
+    assert torch.allclose(la_det, la32, rtol=0, atol=4e-6 * float(la32.abs().max()) + 1e-7)
+    # the two formats feed the same GEMMs: 16-bit outputs agree up to rare 1-ulp flips (and 4-bit code flips behind them)
+    d = (runs[0][1].float() - y32.float()).abs()
+    assert float(d.max()) <= 0.05 * float(y32.float().abs().max())
+    assert float((d > 0).float().mean()) < 0.2
+
+
+def test_deterministic_model_forward_is_bit_reproducible():
+    """A FLUX-shaped step (fused norms, grouped launches, attention-side quantiser, stream-K GEMMs, persistent attention):
+    bit-equal outputs over repeated forwards in deterministic mode."""
+    from nunchaku_amd import mode
+    from nunchaku_amd.models.flux import FluxTransformerAMD
+
+    torch.manual_seed(0)
+    model = FluxTransformerAMD(num_layers=2, num_single_layers=2, dim=512, heads=4, in_channels=64, joint_attention_dim=256,
+                               pooled_projection_dim=64, device="cuda").init_synthetic_(seed=0).eval()
+    side, t_txt = 32, 256
+    g = torch.Generator(device="cuda").manual_seed(0)
+    lat = torch.randn(1, side * side, 64, device="cuda", generator=g).bfloat16()
+    enc = torch.randn(1, t_txt, 256, device="cuda", generator=g).bfloat16()
+    pooled = torch.randn(1, 64, device="cuda", generator=g).bfloat16()
+    img_ids = torch.zeros(side * side, 3, device="cuda")
+    img_ids[:, 1] = torch.arange(side, device="cuda").repeat_interleave(side)
+    img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
+    args = (lat, enc, pooled, torch.tensor([0.5], device="cuda"), img_ids, torch.zeros(t_txt, 3, device="cuda"), torch.tensor([3.5], device="cuda"))
+    with torch.no_grad(), mode.deterministic_mode():
+        outs = [model(*args).clone() for _ in range(6)]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0].float()).all())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "deterministic mode: two forwards of one model differ"
+    with torch.no_grad():
+        fast = model(*args)
+    rel = float((fast.float() - outs[0].float()).norm() / outs[0].float().norm())
+    assert rel < 0.05, f"deterministic vs fp32-atomics forward differ by {rel:.3e} (W4A4 code-flip level expected: <= 2e-2)"

@@ -35,6 +35,16 @@ def _need_gpu(built_lib):
     _lib.load()
 
 
+@pytest.fixture(params=[1, 2], ids=["tile256x128", "tile128x128x2"], autouse=True)
+def _geometry(request):
+    """Every test of this module runs under both workgroup geometries of the GEMM (svdq_gemm_args.geometry)."""
+    from nunchaku_amd._C import _Ops
+
+    _Ops.gemm_geometry = request.param
+    yield request.param
+    _Ops.gemm_geometry = 0
+
+
 @functools.lru_cache(maxsize=None)
 def _layer(K, N, seed, dtype):
     return O.make_random_svdq_layer(K, N, R, seed=seed, dtype=dtype)
@@ -60,12 +70,13 @@ def _sample_rows(M, split=0, n=64, seed=0):
 
 def _streamk_on(M_pad, N, K):
     from nunchaku_amd import _lib
+    from nunchaku_amd._C import _Ops
 
     lib = _lib.load()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    cap = 8192
+    cap = 16384
     buf = (C.c_int32 * (6 * cap))()
-    n = lib.svdq_gemm_schedule(M_pad, N, K, cus, 1, buf, cap)
+    n = lib.svdq_gemm_schedule_ex(M_pad, N, K, cus, 1, _Ops.gemm_geometry or 1, buf, cap)
     assert 0 < n <= cap
     return any(buf[6 * i + 4] >= 0 for i in range(n))  # a segment that publishes a partial tile
 
@@ -308,7 +319,7 @@ def test_two_streams_run_stream_k_gemms_concurrently():
                 res[name] = run(8)
     torch.cuda.synchronize()
     keys = {k for k in _workspaces if k[1] in (s1.cuda_stream, s2.cuda_stream)}
-    assert len(keys) == 2 and len({_workspaces[k].data_ptr() for k in keys}) == 2, "each stream must own its workspace"
+    assert len(keys) == 2 and len({_workspaces[k].buf.data_ptr() for k in keys}) == 2, "each stream must own its workspace"
     for name in ("a", "b"):
         for o in res[name]:
             assert torch.equal(o, serial), f"stream {name}: concurrent stream-K launch differs from the serial result"
@@ -325,9 +336,18 @@ def test_workspace_status_reports_a_broken_contract():
 
     ws = _workspace(torch.device("cuda", torch.cuda.current_device()))
     ops.gemm_workspace_status()
-    ws.view(torch.int32)[255] = 1
+    ws.buf.view(torch.int32)[1023] = 1
     with pytest.raises(RuntimeError, match="timed out"):
         ops.gemm_workspace_status()
     ops.gemm_workspace_status()  # cleared by the failing call
-    assert int(ws.view(torch.int32)[255]) == 0
-    assert _lib.load().svdq_gemm_workspace_bytes() == ws.numel()
+    assert int(ws.buf.view(torch.int32)[1023]) == 0
+    assert _lib.load().svdq_gemm_workspace_bytes() == ws.buf.numel()
+    # the hot path's check: the kernels raise the pinned, host-visible status word; the NEXT launch on the stream raises
+    # without any synchronisation and the word (and the counters) are cleared
+    ws.status[0] = 1
+    m = _module(HID, HID, 20, "bf16")
+    x = torch.randn(1, 256, HID, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        m(x)
+    assert int(ws.status[0]) == 0
+    m(x)  # and the stream is usable again

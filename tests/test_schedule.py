@@ -8,12 +8,15 @@ import pytest
 from nunchaku_amd import _lib
 
 
-def schedule(M_pad, N, K, cus, ws):
+def schedule(M_pad, N, K, cus, ws, geometry=1):
+    """geometry 1: 256 x 128 tiles, one workgroup per CU; 2: 128 x 128 tiles, two per CU (svdq_gemm_args.geometry)"""
     lib = _lib.load()
-    n = lib.svdq_gemm_schedule(M_pad, N, K, cus, ws, None, 0)
+    n = lib.svdq_gemm_schedule_ex(M_pad, N, K, cus, ws, geometry, None, 0)
     assert n >= 0
+    if geometry == 1:
+        assert lib.svdq_gemm_schedule(M_pad, N, K, cus, ws, None, 0) == n  # the short form is geometry 1
     buf = (C.c_int32 * (6 * max(n, 1)))()
-    assert lib.svdq_gemm_schedule(M_pad, N, K, cus, ws, buf, n) == n
+    assert lib.svdq_gemm_schedule_ex(M_pad, N, K, cus, ws, geometry, buf, n) == n
     return np.frombuffer(buf, dtype=np.int32)[: 6 * n].reshape(n, 6).copy()
 
 
@@ -21,11 +24,12 @@ SHAPES = [(4096, 3072, 3072), (4096, 9216, 3072), (4096, 3072, 12288), (4608, 30
           (512, 3072, 3072), (512, 3072, 12288), (256, 128, 128), (256, 384, 1024), (2560, 1152, 2048)]
 
 
+@pytest.mark.parametrize("geometry", [1, 2])
 @pytest.mark.parametrize("M_pad,N,K", SHAPES)
 @pytest.mark.parametrize("cus,ws", [(256, 0), (256, 1), (64, 1), (24, 1), (8, 1)])
-def test_every_k_step_of_every_tile_is_computed_exactly_once(M_pad, N, K, cus, ws):
-    seg = schedule(M_pad, N, K, cus, ws)
-    tiles, KP = (M_pad // 256) * (N // 128), K // 128
+def test_every_k_step_of_every_tile_is_computed_exactly_once(M_pad, N, K, cus, ws, geometry):
+    seg = schedule(M_pad, N, K, cus, ws, geometry)
+    tiles, KP = (M_pad // (256 if geometry == 1 else 128)) * (N // 128), K // 128
     cover = np.zeros((tiles, KP), np.int32)
     for pos, tile, k0, k1, slot, contrib in seg:
         assert 0 <= tile < tiles and 0 <= k0 < k1 <= KP
@@ -43,7 +47,10 @@ def test_every_k_step_of_every_tile_is_computed_exactly_once(M_pad, N, K, cus, w
     slots = seg[seg[:, 4] >= 0][:, 4]
     assert len(set(slots.tolist())) == len(slots)
     grid = seg[:, 0].max() + 1
-    assert grid <= max(cus, 1) and (slots < 2 * grid).all() if len(slots) else True
+    assert grid <= max(cus, 1) * geometry  # one or two workgroups per CU
+    assert (slots < 2 * grid).all() if len(slots) else True
+    # the arrival counters of the remainder tiles fit the workspace header (1023 words) and the slabs its body
+    assert grid - 1 < 1023 and 2 * grid * (256 // geometry) * 128 * 4 + 4096 <= _lib.load().svdq_gemm_workspace_bytes() or cus < 256
 
 
 def test_stream_k_only_where_it_pays():
@@ -78,6 +85,7 @@ def test_launches_without_stream_k_run_whole_rounds_on_fewer_workgroups():
 def test_invalid_shapes_are_rejected():
     lib = _lib.load()
     assert lib.svdq_gemm_schedule(100, 128, 128, 256, 0, None, 0) == -1
+    assert lib.svdq_gemm_schedule_ex(256, 128, 128, 256, 0, 3, None, 0) == -1  # the replay knows geometries 1 and 2
     assert lib.svdq_gemm_schedule(256, 128, 64, 256, 0, None, 0) == -1
 
 

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""Build the timing-ablation twin of the product library: tools/ablate/libsvdq_amd_ablate.so (-DSVDQ_ABLATE).
+"""Build the probe twin of the product library: tools/ablate/libsvdq_amd_probe.so (-DSVDQ_PROBE) + tools/ablate/gemm_probe.
 
-The product library (nunchaku_amd/csrc/libsvdq_amd.so) contains no experiment switches.  This build adds, for the
-tools in this directory only:
-  * the ablated variants of the hand-scheduled GEMM main loop (svdq_gemm_args.variant >= 2: instruction classes
-    dropped from the loop -- RESULTS ARE GARBAGE, timing only), generated by tools/gen_gemm_loop.py into gen/;
-  * the svdq_gemm_args.reserved / svdq_attention_args.reserved debug bit masks and the SVDQ_SK_* / SVDQ_QUANT_* knobs;
-  * svdq_ablate_set_clk(): per-workgroup {shader cycles, 100 MHz ticks} of every GEMM launch (effective clock probe).
+The product library (nunchaku_amd/csrc/libsvdq_amd.so) contains no experiment switches.  The probe build is the SAME sources
+plus tools/ablate/gemm_probe_hooks.inc: per-workgroup {shader cycles, 100 MHz ticks} of every GEMM launch (effective clock)
+and workgroup 0's phase stamps per tile.  Optionally the main loops are generated with an option string of
+tools/gen_gemm_loop2.py (timing experiments; "nobar" computes garbage):
 
-    python tools/ablate/build.py            # -> tools/ablate/libsvdq_amd_ablate.so, tools/ablate/gemm_probe
+    python tools/ablate/build.py                 # probe library with the product loops
+    python tools/ablate/build.py nobar           # -> libsvdq_amd_probe_nobar.so with the loops generated with option "nobar"
+
+(The round-1 loop generator and its instruction-class ablations were removed in round 3; their measurements are
+profiles/r1_gemm_ablation_*.txt and profiles/r2_gemm_ablation_cycles.txt, the code is in the git history.)
 """
 import os
 import subprocess
@@ -19,55 +21,27 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "nunchaku_amd", "csrc")
 GEN = os.path.join(HERE, "gen")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-import gen_gemm_loop as G  # noqa: E402
 import gen_gemm_loop2 as G2  # noqa: E402
 
 SOURCES = ["repack.hip", "quantize.hip", "gemm_w4a4.hip", "attention.hip", "gemv_awq.hip", "residual.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-DSVDQ_ABLATE"]
-
-# variant number -> ablation string of tools/gen_gemm_loop.py (0 / 1 are the product's asm (v2) / C++ loops, 2 is the round-1
-# v1 loop the ablations are derived from)
-VARIANTS = {i + 3: ab for i, ab in enumerate(G.ABLATIONS)}
-# option variants of the v2 loop (tools/gen_gemm_loop2.py), numbered from 100: same results as the product loop
-V2_OPTIONS = os.environ.get("SVDQ_V2_OPTIONS", "lgkf,dph,pkf,nobar,prio1").split(",")
-VARIANTS2 = {100 + i: o for i, o in enumerate(V2_OPTIONS)}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-DSVDQ_PROBE", f"-I{HERE}"]
 
 
-def generate():
-    os.makedirs(GEN, exist_ok=True)
-    loops, launch = [], []
-    for v, ab in VARIANTS.items():
-        name = f"gemm_loop_bf16_{ab.replace('+', '_')}.inc"
-        G.emit(os.path.join(GEN, name), "v_mfma_f32_32x32x16_bf16", ab)
-        loops.append(f'if constexpr (LOOPV == {v}) {{ asm volatile(\n#include "{name}"\nSVDQ_LOOP_OPERANDS); }} else')
-        launch.append(f"    case {v}: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, {v}>(p, st); break; // {ab}")
-    G.emit(os.path.join(GEN, "gemm_loop_bf16.inc"), "v_mfma_f32_32x32x16_bf16")  # the v1 loop itself (variant 2)
-    launch.insert(0, "    case 2: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, 2>(p, st); break; // v1 loop")
-    with open(os.path.join(GEN, "gemm_ablate_loops.inc"), "w") as f:
-        f.write("// GENERATED by tools/ablate/build.py\n" + "\n".join(loops) + "\n")
-    loops2 = []
-    for v, o in VARIANTS2.items():
-        name = f"gemm_loop2_bf16_{o.replace('+', '_')}.inc"
-        G2.emit(os.path.join(GEN, name), "v_mfma_f32_32x32x16_bf16", o)
-        loops2.append(f'if constexpr (LOOPV == {v}) {{ asm volatile(\n#include "{name}"\nSVDQ_LOOP2_OPERANDS); }} else')
-        launch.append(f"    case {v}: launch_one<SVDQ_BF16, SVDQ_FUSE_NONE, {v}>(p, st); break; // v2 + {o}")
-    with open(os.path.join(GEN, "gemm_ablate_launch.inc"), "w") as f:
-        f.write("// GENERATED by tools/ablate/build.py\n"
-                f"#define SVDQ_ABLATE_MAX_VARIANT {max(list(VARIANTS) + list(VARIANTS2))}\n"
-                "static void launch_ablation(const GemmParams &p, int variant, hipStream_t st) {\n    switch (variant) {\n"
-                + "\n".join(launch) + "\n    default: break;\n    }\n}\n")
-    with open(os.path.join(GEN, "gemm_ablate_loops2.inc"), "w") as f:
-        f.write("// GENERATED by tools/ablate/build.py\n" + "\n".join(loops2) + "\n")
-    with open(os.path.join(GEN, "variants.txt"), "w") as f:
-        f.write("0 asm_v2\n1 cxx\n2 asm_v1\n" + "".join(f"{v} no_{ab.replace('+', '_')}\n" for v, ab in VARIANTS.items())
-                + "".join(f"{v} v2_{o.replace('+', '_')}\n" for v, o in VARIANTS2.items()))
-
-
-def build():
-    generate()
-    lib = os.path.join(HERE, "libsvdq_amd_ablate.so")
+def build(opts: str = ""):
+    flags = list(FLAGS)
+    suffix = ""
+    if opts:
+        os.makedirs(GEN, exist_ok=True)
+        suffix = "_" + opts.replace("+", "_")
+        for nw, tag in ((8, "8"), (4, "4")):
+            for dt, mf in (("BF16", "v_mfma_f32_32x32x16_bf16"), ("FP16", "v_mfma_f32_32x32x16_f16")):
+                name = f"gemm_loop2_w{nw}_{dt.lower()}{suffix}.inc"
+                G2.emit(os.path.join(GEN, name), mf, opts, nw=nw)
+                flags.append(f'-DSVDQ_LOOP_INC_{tag}_{dt}="{name}"')
+        flags.append(f"-I{GEN}")
+    lib = os.path.join(HERE, f"libsvdq_amd_probe{suffix}.so")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.run([hipcc, *FLAGS, f"-I{GEN}", "-o", lib, *SOURCES], cwd=CSRC, check=True)
+    subprocess.run([hipcc, *flags, "-o", lib, *SOURCES], cwd=CSRC, check=True)
     probe = os.path.join(HERE, "gemm_probe")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}", "-o", probe,
                     os.path.join(HERE, "gemm_probe.hip"), "-ldl"], check=True)
@@ -75,4 +49,4 @@ def build():
 
 
 if __name__ == "__main__":
-    print(*build(), sep="\n")
+    print(*build(sys.argv[1] if len(sys.argv) > 1 else ""), sep="\n")

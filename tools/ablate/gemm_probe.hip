@@ -2,9 +2,9 @@
 // `import torch`; this binary starts in milliseconds).  Loads any build of the library with dlopen, fills the operand
 // images with synthetic codes / scales, and prints one JSON line per (shape, variant):
 //   us per launch (hipEvent over `iters` back-to-back launches), TOP/s = (2 M N K + 2 M N R) / t,
-//   and -- with the tools-built ablation library -- the effective shader clock of a launch
+//   a checksum of the output (compare geometries bit for bit), and -- with the tools-built probe library -- the effective shader clock of a launch
 //   (per-workgroup s_memtime cycles / s_memrealtime 100 MHz ticks, svdq_ablate_set_clk).
-// build: tools/ablate/build.py          run: tools/ablate/gemm_probe --lib <so> --shape 4096 12288 3072 --variants 0,2,3
+// build: tools/ablate/build.py          run: tools/ablate/gemm_probe --lib <so> --shape 4096 12288 3072 --geoms 1,2,3
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -67,9 +67,9 @@ typedef const char *(*err_fn)(void);
 int main(int argc, char **argv) {
     std::string lib = "nunchaku_amd/csrc/libsvdq_amd.so";
     int M = 4096, K = 12288, N = 3072, R = 32, fuse = 0, iters = 20, warm = 1500, dtype = SVDQ_BF16, reserved = 0, use_ws = 1, split = 0;
-    bool zero = false, do_trace = false;
+    bool zero = false, do_trace = false, q32 = false;
     double sustain = 0;
-    std::vector<int> variants = {0};
+    std::vector<int> variants = {1}; // svdq_gemm_args.geometry values
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--lib") lib = argv[++i];
@@ -85,7 +85,8 @@ int main(int argc, char **argv) {
         else if (a == "--trace") do_trace = true;
         else if (a == "--split") split = atoi(argv[++i]);
         else if (a == "--sustain") sustain = atof(argv[++i]);
-        else if (a == "--variants") { variants.clear(); char *s = argv[++i]; for (char *t = strtok(s, ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
+        else if (a == "--q32") q32 = true;
+        else if (a == "--geoms") { variants.clear(); char *s = argv[++i]; for (char *t = strtok(s, ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     void *h = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -106,7 +107,7 @@ int main(int argc, char **argv) {
     a.ascales = dev_half((size_t)G * M_pad, dtype, 0.05f, 0.4f, zero);
     a.wscales = dev_half((size_t)G * N, dtype, 0.002f, 0.01f, zero);
     a.bias = dev_half(N, dtype, -0.1f, 0.1f, zero);
-    if (R > 0) { a.lora_act_in = dev_f32((size_t)M_pad * R, -1.f, 1.f, zero); a.lora_up = dev_half((size_t)N * R, dtype, -0.05f, 0.05f, zero); }
+    if (R > 0) { a.lora_act_in = dev_f32((size_t)M_pad * R * (q32 ? 2 : 1), -1.f, 1.f, zero || q32); a.lora_act_format = q32 ? SVDQ_LORA_ACT_Q32 : SVDQ_LORA_ACT_F32; a.lora_up = dev_half((size_t)N * R, dtype, -0.05f, 0.05f, zero); }
     a.M = M; a.M_pad = M_pad; a.N = N; a.K = K; a.R = R; a.ldo = N; a.dtype = dtype; a.fuse = fuse; a.reserved = reserved;
     a.act_unsigned = act_unsigned;
     void *out; CK(hipMalloc(&out, (size_t)M_pad * N * 2)); a.out = out;
@@ -117,7 +118,7 @@ int main(int argc, char **argv) {
         a.next_smooth = dev_half(N, dtype, 0.5f, 2.0f, false);
         a.R2 = 32;
         a.next_lora_down = dev_half((size_t)N * a.R2, dtype, -0.05f, 0.05f, zero);
-        CK(hipMalloc((void **)&a.lora_act_out, (size_t)M_pad * a.R2 * 4)); CK(hipMemset(a.lora_act_out, 0, (size_t)M_pad * a.R2 * 4));
+        CK(hipMalloc((void **)&a.lora_act_out, (size_t)M_pad * a.R2 * 8)); CK(hipMemset(a.lora_act_out, 0, (size_t)M_pad * a.R2 * 8));
     } else if (fuse == SVDQ_FUSE_RMSNORM_ROPE) {
         a.norm_q = dev_half(128, dtype, 0.5f, 1.5f, false); a.norm_k = dev_half(128, dtype, 0.5f, 1.5f, false);
         a.rotary_emb = dev_f32((size_t)M_pad * 128, -1.f, 1.f, false);
@@ -137,7 +138,8 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double ops = 2.0 * M_pad * (double)N * K + 2.0 * M_pad * (double)N * R;
     for (int v : variants) {
-        a.variant = v;
+        a.variant = 0;
+        a.geometry = v;
         if (set_clk) set_clk(nullptr);
         for (int i = 0; i < 3; i++)
             if (gemm(&a, st)) { fprintf(stderr, "variant %d: %s\n", v, last_error()); goto next; }
@@ -178,7 +180,17 @@ int main(int argc, char **argv) {
                 printf("]}\n");
                 CK(hipFree(tr));
             }
-            printf("{\"M\":%d,\"K\":%d,\"N\":%d,\"R\":%d,\"fuse\":%d,\"variant\":%d,\"reserved\":%d,\"zero\":%d,\"ws\":%d,\"split\":%d,\"us\":%.2f,\"TOPS\":%.1f,"
+            unsigned long long sum = 1469598103934665603ull; // FNV-1a over the 16-bit output (or the code image)
+            {
+                const void *src = fuse == SVDQ_FUSE_GELU_QUANT ? a.qout : a.out;
+                const size_t bytes = fuse == SVDQ_FUSE_GELU_QUANT ? (size_t)M_pad * N * 3 / 4 : (size_t)M * N * 2;
+                std::vector<uint8_t> hb(bytes);
+                CK(hipMemcpy(hb.data(), src, bytes, hipMemcpyDeviceToHost));
+                const uint64_t *w = (const uint64_t *)hb.data();
+                for (size_t i = 0; i < bytes / 8; i++) { sum ^= w[i]; sum *= 1099511628211ull; }
+            }
+            printf("{\"sum\":\"%016llx\",", sum);
+            printf("\"M\":%d,\"K\":%d,\"N\":%d,\"R\":%d,\"fuse\":%d,\"geometry\":%d,\"reserved\":%d,\"zero\":%d,\"ws\":%d,\"split\":%d,\"us\":%.2f,\"TOPS\":%.1f,"
                    "\"wg_cycles\":%.0f,\"eff_GHz\":%.3f}\n", M, K, N, R, fuse, v, reserved, (int)zero, use_ws, split, us, ops / us * 1e-6, cyc, eff_ghz);
             fflush(stdout);
             if (sustain > 0) { // keep the GPU on this kernel for `sustain` seconds (rocm-smi power / clock sampling)

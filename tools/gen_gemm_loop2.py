@@ -32,10 +32,24 @@ Register plan (the C++ side pins its asm operands to the same registers, gemm_w4
 """
 import os
 
-STAGE = 24576 + 12288 + 1024 + 1024
-NSTAGE = 4
 CHUNK, PLANE = 3072, 1024
-DMA_PER_STEP = 5
+
+
+class Geometry:
+    """Workgroup geometry of the loop.  nw = 8: 512 threads, tile 256 x 128, one workgroup per CU, 4-stage ring, 5 DMA
+    instructions per wave and K-step (three A planes, one W plane, one W plane / scale image / repeat).  nw = 4: 256 threads,
+    tile 128 x 128, TWO workgroups per CU (80 KiB of LDS each), 3-stage ring, 7 DMA instructions per wave and K-step (the
+    three planes of A chunk `wave`, the three planes of W chunk `wave`, one scale image / repeat).  The wave tile (64 x 64),
+    the register plan and the arithmetic are the same."""
+
+    def __init__(self, nw):
+        assert nw in (4, 8)
+        self.nw = nw
+        self.a_bytes = nw * CHUNK
+        self.stage = self.a_bytes + 4 * CHUNK + 1024 + 1024
+        self.nstage = 4 if nw == 8 else 3
+        self.x1_planes = 1 if nw == 8 else 3
+        self.dma_per_step = 3 + self.x1_planes + 1
 
 ACC = 0
 PBUF = [64, 96]
@@ -64,8 +78,9 @@ def sr(a, n=1):
 
 
 class Gen:
-    def __init__(self, smfma, opts=""):
+    def __init__(self, smfma, opts="", nw=8):
         self.smfma = smfma
+        self.geo = Geometry(nw)
         self.opts = set(o for o in opts.split("+") if o)
         self.lines = []
         self.label = 0
@@ -81,8 +96,8 @@ class Gen:
     def lds(self, kind, stage):
         """(address VGPR, immediate) of operand kind 0..3 in ring stage `stage`"""
         if stage < 2:
-            return IN_L[kind], stage * STAGE
-        return HI_L[kind], (stage - 2) * STAGE
+            return IN_L[kind], stage * self.geo.stage
+        return HI_L[kind], (stage - 2) * self.geo.stage
 
     def frag_reads(self, buf, grp, stage):
         out = []
@@ -139,7 +154,8 @@ class Gen:
             f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen offset:{2 * PLANE} lds",
             m0(S_DX1),
             "s_nop 0",
-            f"{ld} {vr(OFF_X1)}, {sr(SRD_X1, 4)}, {sr(S_KOFF)} offen lds",
+        ] + [f"{ld} {vr(OFF_X1)}, {sr(SRD_X1, 4)}, {sr(S_KOFF)} offen" + (f" offset:{pl * PLANE}" if pl else "") + " lds"
+             for pl in range(self.geo.x1_planes)] + [
             m0(S_DX2),
             f"s_add_u32 {sr(S_KOFF)}, {sr(S_KOFF)}, {CHUNK}",
             f"{ld} {vr(OFF_X2)}, {sr(SRD_X2, 4)}, {sr(S_KOFF2)} offen lds",
@@ -163,8 +179,8 @@ class Gen:
         that the two waves of a SIMD are never both busy with their DMA bursts; returns the label to enter this body at
         (phase 1: behind the deferred-issue block, which the first K-step of a segment must skip)."""
         e = self.e
-        nj = (j + 1) % NSTAGE
-        pj = (j - 1) % NSTAGE
+        nj = (j + 1) % self.geo.nstage
+        pj = (j - 1) % self.geo.nstage
         reads_g1 = self.frag_reads(1, 1, j)
         reads_n0 = self.frag_reads(0, 0, nj)
         if phase == 1:
@@ -175,7 +191,7 @@ class Gen:
             e(f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}")
             e(f"s_cbranch_scc1 {Lsw}")
             e(f"{Lbsw}:")
-            for ln in self.dma_issue(pj * STAGE):
+            for ln in self.dma_issue(pj * self.geo.stage):
                 e(ln)
             e(f"{Lskip}:")
             ool += [f"{Lsw}:"] + self.switch_segment() + [f"s_branch {Lbsw}"]
@@ -206,11 +222,11 @@ class Gen:
                     f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_TOT4)}",
                     f"s_cbranch_scc0 {Ltail}",
                     # my 5 DMAs of K-step step+1 have landed: the 10 younger ones (step+2, step+3) may stay in flight
-                    f"s_waitcnt vmcnt({2 * DMA_PER_STEP})",
+                    f"s_waitcnt vmcnt({(self.geo.nstage - 2) * self.geo.dma_per_step})",
                     "s_nop 0" if "nobar" in self.opts else "s_barrier",  # "nobar": timing ablation only (waves race: wrong results)
                 ]
                 if phase == 0:
-                    misc += [f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}", f"s_cbranch_scc1 {Lsw}", f"{Lbsw}:"] + self.dma_issue(j * STAGE)
+                    misc += [f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}", f"s_cbranch_scc1 {Lsw}", f"{Lbsw}:"] + self.dma_issue(j * self.geo.stage)
                     ool += [f"{Lsw}:"] + self.switch_segment() + [f"s_branch {Lbsw}"]
                 misc += [f"{Lback}:"] + reads_n0[0:4]
                 ool += [f"{Ltail}:", "s_waitcnt vmcnt(0)", "s_barrier", f"s_branch {Lback}"]
@@ -237,7 +253,7 @@ class Gen:
             Lstub = self.new_label("xstub")
             e(f"s_cbranch_scc0 {Lstub}")
             ool += [f"{Lstub}:", f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_TOT4)}", f"s_cbranch_scc0 {exit_label}"] + \
-                self.dma_issue(j * STAGE) + [f"s_branch {exit_label}"]
+                self.dma_issue(j * self.geo.stage) + [f"s_branch {exit_label}"]
         return Lin
 
     # ---- the whole asm block ---------------------------------------------------------------
@@ -261,14 +277,14 @@ class Gen:
         e(f"v_mov_b32 {vr(MXA)}, 0x82828282")
         e(f"v_mov_b32 {vr(MXB)}, 0x81818181")
         for k in range(4):
-            e(f"v_add_u32 {vr(HI_L[k])}, {2 * STAGE}, {vr(IN_L[k])}")
+            e(f"v_add_u32 {vr(HI_L[k])}, {2 * self.geo.stage}, {vr(IN_L[k])}")
         e(f"s_mov_b32 {sr(S_STEP)}, 0")
         e(f"s_add_u32 {sr(S_TOT)}, {sr(S_KP)}, {sr(S_NCNT)}")
         # thresholds on `step`: DMA of K-step step+4 exists iff step < tot-4; it is the next segment's first iff step == kp-4
         if "dph" in self.opts:  # phase-1 waves run their DMA stream one K-step later: thresholds tot-3 / kp-3
-            e(f"s_sub_u32 {sr(S_TMP)}, {NSTAGE}, {sr(S_PHASE)}")
+            e(f"s_sub_u32 {sr(S_TMP)}, {self.geo.nstage}, {sr(S_PHASE)}")
         else:
-            e(f"s_mov_b32 {sr(S_TMP)}, {NSTAGE}")
+            e(f"s_mov_b32 {sr(S_TMP)}, {self.geo.nstage}")
         e(f"s_sub_u32 {sr(S_TOT4)}, {sr(S_TOT)}, {sr(S_TMP)}")
         e(f"s_cselect_b32 {sr(S_TOT4)}, 0, {sr(S_TOT4)}")          # borrow (tot < 4): never
         e(f"s_sub_u32 {sr(S_KP4)}, {sr(S_KP)}, {sr(S_TMP)}")
@@ -277,16 +293,16 @@ class Gen:
         e(f"s_mov_b32 {sr(S_DSTEP)}, {sr(S_NPRE)}")
         e(f"s_mul_i32 {sr(S_KOFF)}, {sr(S_NPRE)}, {CHUNK}")
         e(f"s_mul_i32 {sr(S_KOFF2)}, {sr(S_NPRE)}, {sr(S_IX2)}")
-        # prologue: top the stream up to NSTAGE K-steps in flight (all of them for a workgroup's first segment, normally
+        # prologue: top the stream up to self.geo.nstage K-steps in flight (all of them for a workgroup's first segment, normally
         # none afterwards: the previous segment has fetched them).  Generic, branchy, rare.
-        e(f"s_mul_i32 {sr(S_TMP)}, {sr(S_NPRE)}, {STAGE}")
+        e(f"s_mul_i32 {sr(S_TMP)}, {sr(S_NPRE)}, {self.geo.stage}")
         e(f"s_add_u32 {sr(S_STG)}, {sr(S_RING)}, {sr(S_TMP)}")
-        e(f"s_cmp_lt_u32 {sr(S_STG)}, {NSTAGE * STAGE}")
-        e(f"s_cselect_b32 {sr(S_TMP)}, 0, {NSTAGE * STAGE}")
-        e(f"s_sub_u32 {sr(S_STG)}, {sr(S_STG)}, {sr(S_TMP)}")     # ring + npre*STAGE mod ring size (npre <= NSTAGE)
+        e(f"s_cmp_lt_u32 {sr(S_STG)}, {self.geo.nstage * self.geo.stage}")
+        e(f"s_cselect_b32 {sr(S_TMP)}, 0, {self.geo.nstage * self.geo.stage}")
+        e(f"s_sub_u32 {sr(S_STG)}, {sr(S_STG)}, {sr(S_TMP)}")     # ring + npre*self.geo.stage mod ring size (npre <= self.geo.nstage)
         Ltop, Ltopdone, Lnosw = self.new_label("top"), self.new_label("topdone"), self.new_label("nosw")
         e(f"{Ltop}:")
-        e(f"s_cmp_lt_u32 {sr(S_DSTEP)}, {NSTAGE}")
+        e(f"s_cmp_lt_u32 {sr(S_DSTEP)}, {self.geo.nstage}")
         e(f"s_cbranch_scc0 {Ltopdone}")
         e(f"s_cmp_lt_u32 {sr(S_DSTEP)}, {sr(S_TOT)}")
         e(f"s_cbranch_scc0 {Ltopdone}")
@@ -297,8 +313,8 @@ class Gen:
         e(f"{Lnosw}:")
         for ln in self.dma_issue(None):
             e(ln)
-        e(f"s_add_u32 {sr(S_STG)}, {sr(S_STG)}, {STAGE}")
-        e(f"s_cmp_lt_u32 {sr(S_STG)}, {NSTAGE * STAGE}")
+        e(f"s_add_u32 {sr(S_STG)}, {sr(S_STG)}, {self.geo.stage}")
+        e(f"s_cmp_lt_u32 {sr(S_STG)}, {self.geo.nstage * self.geo.stage}")
         e(f"s_cselect_b32 {sr(S_STG)}, {sr(S_STG)}, 0")
         e(f"s_branch {Ltop}")
         e(f"{Ltopdone}:")
@@ -309,15 +325,15 @@ class Gen:
         e(f"{Lpw}:")
         e("s_barrier")
         # enter the unrolled ring at this segment's stage
-        entry = [self.new_label(f"in{j}_") for j in range(NSTAGE)]
-        for j in range(1, NSTAGE):
-            e(f"s_cmp_eq_u32 {sr(S_RING)}, {j * STAGE}")
+        entry = [self.new_label(f"in{j}_") for j in range(self.geo.nstage)]
+        for j in range(1, self.geo.nstage):
+            e(f"s_cmp_eq_u32 {sr(S_RING)}, {j * self.geo.stage}")
             e(f"s_cbranch_scc1 {entry[j]}")
         nph = 2 if "dph" in self.opts else 1
-        body_in = [[self.new_label(f"b{ph}in{j}_") for j in range(NSTAGE)] for ph in range(nph)]
+        body_in = [[self.new_label(f"b{ph}in{j}_") for j in range(self.geo.nstage)] for ph in range(nph)]
         Lexit = self.new_label("exit")
         # per entry: first fragments + the first tile-group's MFMAs from that stage, then into the ring
-        for j in range(NSTAGE):
+        for j in range(self.geo.nstage):
             e(f"{entry[j]}:")
             for ln in self.frag_reads(0, 0, j):
                 e(ln)
@@ -333,7 +349,7 @@ class Gen:
         for ph in range(nph):
             top = self.new_label(f"top{ph}_")
             e(f"{top}:")
-            for j in range(NSTAGE):
+            for j in range(self.geo.nstage):
                 # the body's own entry label sits behind a phase-1 body's deferred-issue block: alias it
                 start = len(self.lines)
                 lin = self.kstep(j, Lexit, ool, ph)
@@ -354,8 +370,8 @@ class Gen:
         return self.lines
 
 
-def emit(path, smfma, opts=""):
-    g = Gen(smfma, opts)
+def emit(path, smfma, opts="", nw=8):
+    g = Gen(smfma, opts, nw)
     lines = g.build()
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_loop2.py -- do not edit.\n")
@@ -369,4 +385,6 @@ if __name__ == "__main__":
     opts = os.environ.get("SVDQ_GEN2_OPTS", "")
     n = emit(os.path.join(root, "gemm_loop2_bf16.inc"), "v_mfma_f32_32x32x16_bf16", opts)
     emit(os.path.join(root, "gemm_loop2_fp16.inc"), "v_mfma_f32_32x32x16_f16", opts)
-    print(f"wrote gemm_loop2_{{bf16,fp16}}.inc ({n} lines each)")
+    n4 = emit(os.path.join(root, "gemm_loop2_w4_bf16.inc"), "v_mfma_f32_32x32x16_bf16", opts, nw=4)
+    emit(os.path.join(root, "gemm_loop2_w4_fp16.inc"), "v_mfma_f32_32x32x16_f16", opts, nw=4)
+    print(f"wrote gemm_loop2_{{bf16,fp16}}.inc ({n} lines each), gemm_loop2_w4_{{bf16,fp16}}.inc ({n4} lines each)")
