@@ -368,6 +368,14 @@ int svdq_repack_vec(const void *src, void *dst, int32_t N, void *stream);
  * (packer.py:362-398, lora.cuh:43-59).  C = N or K. */
 int svdq_repack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_t down, void *stream);
 
+/* Inverse re-layouts (kernel order -> the reference's checkpoint order): what state_dict() of a repacked layer returns and
+ * what the host-offload manager keeps in pinned memory (4-bit nibbles: 2/3 of the FP6 image's bytes on the PCIe link).
+ * Exact inverses of svdq_repack_*: repack(unrepack(x)) == x and unrepack(repack(c)) == c bit for bit. */
+int svdq_unrepack_qweight(const void *src, void *dst, int32_t N, int32_t K, void *stream); /* FP6 image -> [N, K/2] int8 */
+int svdq_unrepack_wscales(const void *src, void *dst, int32_t G, int32_t N, void *stream);
+int svdq_unrepack_vec(const void *src, void *dst, int32_t N, void *stream);
+int svdq_unrepack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_t down, void *stream);
+
 /* Inverse helpers used by the tests to read the opaque formats back:
  * FP6 image -> one int8 code per element, natural [ROWS, K];  scale image -> natural [G][ROWS]. */
 int svdq_unpack_act(const void *act, int8_t *codes, int32_t M_pad, int32_t K, int32_t is_unsigned, void *stream);

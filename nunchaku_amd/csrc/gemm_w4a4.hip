@@ -43,6 +43,7 @@
 #define SVDQ_PROBE_NEXT_SEGMENT()
 #define SVDQ_PROBE_END()
 #define SVDQ_PROBE_FILL(p)
+#define SVDQ_PROBE_GRID(g, tiles, slots) (g)
 #endif
 
 // generated main loops (tools/gen_gemm_loop2.py); the probe build substitutes option variants
@@ -866,7 +867,7 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
     using G_ = Geo<NW>;
     const int tiles = (p.M_pad / G_::BM) * (p.N / BN), slots = device_cus() * G_::WG_PER_CU;
     p.sk_gs = with_ws ? streamk_groups_for(tiles, p.K / 128, slots) : 0;
-    dim3 grid(persistent_grid(tiles, p.sk_gs, slots)), block(G_::THREADS);
+    dim3 grid(SVDQ_PROBE_GRID(persistent_grid(tiles, p.sk_gs, slots), tiles, slots)), block(G_::THREADS);
     hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ>), grid, block, 0, st, p);
 }
 

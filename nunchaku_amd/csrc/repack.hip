@@ -143,6 +143,59 @@ __global__ void repack_lowrank_kernel(const uint16_t *__restrict__ src, uint16_t
     }
 }
 
+// ---- inverse re-layouts: kernel order -> the reference's checkpoint order (state_dict() of a repacked layer, host offload) ----
+// One thread per 32-bit word of the reference qweight (8 consecutive k of one output channel, low nibble first): its
+// nibbles 0..3 are elements j = 16t + 4c + e of the h = 0 lane record of (n, group g), nibbles 4..7 those of the h = 1 record.
+__global__ void unrepack_qweight_kernel(const uint8_t *__restrict__ img, uint32_t *__restrict__ dst, int N, int KP) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KT = KP * 2;
+    if (i >= (size_t)(N / 128) * KT * 8 * 32 * 4) return;
+    const int jj = i & 3, lane_ref = (i >> 2) & 31, npk = (i >> 7) & 7;
+    const size_t q = i >> 10;
+    const int g = q % KT, nt = q / KT;
+    const int n_lane = lane_ref >> 2, c = lane_ref & 3, n_pack = jj >> 1, t = jj & 1;
+    const int n = nt * 128 + npk * 16 + n_pack * 8 + n_lane;
+    const int kp = g >> 1, grp = g & 1;
+    uint32_t w = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint8_t *rec = img + ((size_t)(n >> 5) * KP + kp) * F6_CHUNK + (size_t)((n & 31) | (h << 5)) * 16;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int bit = 192 * grp + 6 * (16 * t + 4 * c + e);
+            const int b = bit >> 3;
+            unsigned v = rec[(b >> 4) * F6_PLANE + (b & 15)];
+            if (b < 47) v |= (unsigned)rec[((b + 1) >> 4) * F6_PLANE + ((b + 1) & 15)] << 8;
+            const int code = f6_dec((v >> (bit & 7)) & 63, 0);
+            w |= (uint32_t)(code & 15) << (4 * (4 * h + e));
+        }
+    }
+    dst[i] = w;
+}
+
+// natural [g][n] (SIMG == 0) or the S image (SIMG == 1) -> the reference's [g][n]-packed order
+template <int SIMG>
+__global__ void unrepack_wscales_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int G, int N) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)G * N) return;
+    int g = i / N, n = i % N;
+    int nt = n >> 7;
+    dst[((size_t)nt * G + g) * 128 + scale_pos128(n & 127)] = SIMG ? src[simg_index(n, g, G / 2)] : src[i];
+}
+
+__global__ void unrepack_lowrank_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int C, int R, int down) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * R) return;
+    int RP = R / 16;
+    if (!down) {
+        int n = i / R, r = i % R;
+        dst[lowrank_src(n >> 4, r >> 4, RP, n & 15, r & 15)] = src[i];
+    } else {
+        int r = i / C, k = i % C;
+        dst[lowrank_src(k >> 4, r >> 4, RP, r & 15, k & 15)] = src[i];
+    }
+}
+
 // F6 image -> one int8 per element, natural [ROWS, K] (test helper)
 __global__ void unpack_act_kernel(const uint8_t *__restrict__ act, int8_t *__restrict__ codes, int M_pad, int K,
                                   int is_unsigned) {
@@ -211,6 +264,48 @@ int svdq_repack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_
     hipLaunchKernelGGL(repack_lowrank_kernel, dim3(nblk((size_t)C * R, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)src, (uint16_t *)dst, C, R, down ? 1 : 0);
     return hip_check(hipGetLastError(), "svdq_repack_lowrank launch");
+}
+
+int svdq_unrepack_qweight(const void *src, void *dst, int32_t N, int32_t K, void *stream) {
+    if (!src || !dst || src == dst) { set_error("svdq_unrepack_qweight: null or aliasing pointers"); return SVDQ_E_INVALID; }
+    if (N <= 0 || K <= 0 || N % 128 || K % 128) {
+        set_error("svdq_unrepack_qweight: N=%d and K=%d must be positive multiples of 128", N, K);
+        return SVDQ_E_INVALID;
+    }
+    const size_t words = (size_t)N * K / 8;
+    hipLaunchKernelGGL(unrepack_qweight_kernel, dim3(nblk(words, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)src, (uint32_t *)dst, N, K / 128);
+    return hip_check(hipGetLastError(), "svdq_unrepack_qweight launch");
+}
+
+int svdq_unrepack_wscales(const void *src, void *dst, int32_t G, int32_t N, void *stream) {
+    if (!src || !dst || src == dst) { set_error("svdq_unrepack_wscales: null or aliasing pointers"); return SVDQ_E_INVALID; }
+    if (G <= 0 || G % 2 || N <= 0 || N % 128) {
+        set_error("svdq_unrepack_wscales: G=%d must be a positive even number and N=%d a positive multiple of 128", G, N);
+        return SVDQ_E_INVALID;
+    }
+    hipLaunchKernelGGL(unrepack_wscales_kernel<1>, dim3(nblk((size_t)G * N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)src, (uint16_t *)dst, G, N);
+    return hip_check(hipGetLastError(), "svdq_unrepack_wscales launch");
+}
+
+int svdq_unrepack_vec(const void *src, void *dst, int32_t N, void *stream) {
+    if (!src || !dst || src == dst) { set_error("svdq_unrepack_vec: null or aliasing pointers"); return SVDQ_E_INVALID; }
+    if (N <= 0 || N % 128) { set_error("svdq_unrepack_vec: N=%d must be a positive multiple of 128", N); return SVDQ_E_INVALID; }
+    hipLaunchKernelGGL(unrepack_wscales_kernel<0>, dim3(nblk((size_t)N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)src, (uint16_t *)dst, 1, N);
+    return hip_check(hipGetLastError(), "svdq_unrepack_vec launch");
+}
+
+int svdq_unrepack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_t down, void *stream) {
+    if (!src || !dst || src == dst) { set_error("svdq_unrepack_lowrank: null or aliasing pointers"); return SVDQ_E_INVALID; }
+    if (C <= 0 || R <= 0 || C % 16 || R % 16) {
+        set_error("svdq_unrepack_lowrank: C=%d and R=%d must be positive multiples of 16", C, R);
+        return SVDQ_E_INVALID;
+    }
+    hipLaunchKernelGGL(unrepack_lowrank_kernel, dim3(nblk((size_t)C * R, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)src, (uint16_t *)dst, C, R, down ? 1 : 0);
+    return hip_check(hipGetLastError(), "svdq_unrepack_lowrank launch");
 }
 
 int svdq_unpack_act(const void *act, int8_t *codes, int32_t M_pad, int32_t K, int32_t is_unsigned, void *stream) {

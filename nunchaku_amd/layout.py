@@ -60,6 +60,34 @@ def repack_lowrank(w: torch.Tensor, down: bool) -> torch.Tensor:
     return _run("svdq_repack_lowrank", w, C_, R, 1 if down else 0)
 
 
+# ---- inverses: kernel layout -> the reference's checkpoint layout (state_dict(), host offload) -----------------------------
+def unrepack_qweight(img: torch.Tensor) -> torch.Tensor:
+    """[N, 3K/4] FP6 operand image -> [N, K/2] int8 in the reference order (exact inverse of :func:`repack_qweight`)."""
+    lib = _lib.load()
+    if not img.is_cuda:
+        raise RuntimeError("nunchaku_amd.layout: tensors must be on the GPU (no CPU path)")
+    img = img.contiguous()
+    N, B = img.shape
+    K = B * 4 // 3
+    dst = torch.empty(N, K // 2, dtype=torch.int8, device=img.device)
+    _lib.check(lib.svdq_unrepack_qweight(img.data_ptr(), dst.data_ptr(), N, K, torch.cuda.current_stream().cuda_stream), "svdq_unrepack_qweight")
+    return dst
+
+
+def unrepack_wscales(simg: torch.Tensor) -> torch.Tensor:
+    G, N = simg.shape
+    return _run("svdq_unrepack_wscales", simg, G, N)
+
+
+def unrepack_vec(v: torch.Tensor) -> torch.Tensor:
+    return _run("svdq_unrepack_vec", v, v.numel())
+
+
+def unrepack_lowrank(w: torch.Tensor, down: bool) -> torch.Tensor:
+    C_, R = w.shape
+    return _run("svdq_unrepack_lowrank", w, C_, R, 1 if down else 0)
+
+
 def unpack_act(act: torch.Tensor, K: int, unsigned: bool = False) -> torch.Tensor:
     """Opaque packed activations -> int8 codes [M_pad, K] (test/debug helper)."""
     lib = _lib.load()

@@ -7,7 +7,11 @@ operand images the HIP kernels read: ``qweight`` becomes the [out, 3*in/4]-byte 
 image of v_mfma_scale_f32_32x32x64_f8f6f4 (a 4-bit code is exactly an FP6 value), the other tensors
 are permuted in place.  It runs lazily before the first kernel call and again after every
 ``load_state_dict``, PER TENSOR: only the tensors a (possibly partial) state dict actually brought are
-converted again; ``state_dict()`` of a repacked layer raises (it would not be a checkpoint).
+converted again.  ``state_dict()`` of a repacked layer returns CHECKPOINT-layout tensors (the exact inverse
+permutations, ``svdq_unrepack_*``): load -> forward -> ``state_dict()`` -> load into a fresh module reproduces the
+layer bit for bit.  ``_amd_names`` (which parameters hold the kernel layout) is the single source of truth; the
+per-tensor marks ``nunchaku_amd._C`` reads are re-stamped from it before every launch, so ``copy.deepcopy`` of a
+repacked layer (which drops tensor attributes) stays correct.
 """
 
 from __future__ import annotations
@@ -78,7 +82,7 @@ class SVDQW4A4Linear(nn.Module):
         self._incoming: tuple[str, ...] = ()
         self._register_load_state_dict_pre_hook(self._before_load, with_module=True)
         self.register_load_state_dict_post_hook(self._after_load)
-        self._register_state_dict_hook(self._refuse_repacked_state_dict)
+        self._register_state_dict_hook(self._export_checkpoint_layout)
 
     # ------------------------------------------------------------------ layout
     _LAYOUT_PARAMS = ("qweight", "wscales", "smooth_factor", "bias", "proj_down", "proj_up")
@@ -124,21 +128,47 @@ class SVDQW4A4Linear(nn.Module):
         module._incoming = ()
 
     @staticmethod
-    def _refuse_repacked_state_dict(module, state_dict, prefix, local_metadata):
-        if module._amd_names:
-            raise RuntimeError(
-                f"{prefix or 'SVDQW4A4Linear'}: {sorted(module._amd_names)} hold the MI355X operand layout (repack_() ran): "
-                "state_dict() of a repacked layer is not a checkpoint.  Save the model before its first forward / repack_(), "
-                "or keep the original checkpoint file.")
+    def _export_checkpoint_layout(module, state_dict, prefix, local_metadata):
+        """state_dict hook: entries of parameters that hold the kernel layout are replaced by their checkpoint-layout form
+        (new tensors on the same device; the module's own parameters are untouched).  A runtime LoRA (``set_lora``) is not
+        part of the checkpoint: the base low-rank factors are exported."""
+        if not module._amd_names:
+            return
+        with torch.no_grad():
+            for n in module._layout_params():
+                key = prefix + n
+                if n not in module._amd_names or key not in state_dict:
+                    continue
+                t = getattr(module, n).data
+                if n.startswith("proj_") and module._base_lowrank is not None:
+                    t = module._base_lowrank[0 if n == "proj_down" else 1]
+                dev = t.device
+                if not t.is_cuda:  # a host-resident copy in the kernel layout (offloaded block): convert on the GPU, hand back on the host
+                    if not torch.cuda.is_available():
+                        raise RuntimeError(f"{key}: holds the MI355X operand layout; converting it back to the checkpoint layout "
+                                           "needs the GPU (svdq_unrepack_*: there is no CPU path)")
+                    t = t.cuda()
+                if n == "qweight":
+                    conv = layout.unrepack_qweight(t)
+                elif n == "wscales":
+                    conv = layout.unrepack_wscales(t)
+                elif n in ("smooth_factor", "bias"):
+                    conv = layout.unrepack_vec(t)
+                else:
+                    conv = layout.unrepack_lowrank(t, down=(n == "proj_down"))
+                state_dict[key] = conv.to(dev)
 
     @torch.no_grad()
-    def repack_(self) -> "SVDQW4A4Linear":
-        """Permute the checkpoint-layout parameters into the kernel layout, in place (idempotent, per tensor)."""
+    def repack_(self, skip: tuple[str, ...] = ()) -> "SVDQW4A4Linear":
+        """Permute the checkpoint-layout parameters into the kernel layout, in place (idempotent, per tensor).  ``skip``: names
+        left as they are (the host-offload manager keeps ``qweight`` in nibble form on the host)."""
         if self._amd_layout:
             return self
         if not self.qweight.is_cuda:
             raise RuntimeError("SVDQW4A4Linear.repack_(): move the layer to the GPU first (no CPU path)")
-        todo = [n for n in self._layout_params() if n not in self._amd_names]
+        todo = [n for n in self._layout_params() if n not in self._amd_names and n not in skip]
+        for n in self._amd_names:  # marks may be stale after a deepcopy: _param() must not convert these a second time
+            getattr(self, n)._svdq_amd = True
         for n in todo:
             t = getattr(self, n)
             if n == "qweight":
@@ -156,6 +186,10 @@ class SVDQW4A4Linear(nn.Module):
     def _ensure_layout(self):
         if not self._amd_layout:
             self.repack_()
+        # the per-tensor marks nunchaku_amd._C reads: derived state, re-stamped from _amd_names (deepcopy / pickling of a
+        # Parameter drops python attributes, `_amd_names` survives them)
+        for n in self._amd_names:
+            getattr(self, n)._svdq_amd = True
 
     # ------------------------------------------------------------------ API of the reference
     @classmethod

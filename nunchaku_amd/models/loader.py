@@ -100,11 +100,8 @@ def convert_flux_state_dict(state_dict: dict) -> dict:
 
 
 def export_legacy_state_dict(model: FluxTransformerAMD) -> dict:
-    """Inverse of :func:`convert_flux_state_dict` for a model still in the checkpoint layout (tests, tooling):
-    FluxTransformerAMD names -> the reference's legacy names."""
-    for m in model.svdq_layers():
-        if getattr(m, "_amd_names", None):
-            raise RuntimeError("export_legacy_state_dict needs parameters in the checkpoint layout (before repack_())")
+    """Inverse of :func:`convert_flux_state_dict`: FluxTransformerAMD names -> the reference's legacy names.  Works before
+    and after the first forward: ``state_dict()`` of a repacked ``SVDQW4A4Linear`` returns checkpoint-layout tensors."""
     inv_param = {new: old for old, new in _PARAM}
     out = {}
     for k, v in model.state_dict().items():
@@ -143,7 +140,7 @@ def model_from_config(config: dict, rank: int = 32, torch_dtype: torch.dtype = t
 def load_flux_state_dict(model: FluxTransformerAMD, state_dict: dict, strict: bool = True) -> FluxTransformerAMD:
     """Convert + ``load_state_dict``; dtype mismatches are errors as in ``patch_scale_key`` (utils.py:165-167)."""
     sd = convert_flux_state_dict(state_dict)
-    own = dict(model.named_parameters())  # (not state_dict(): that refuses repacked layers)
+    own = dict(model.named_parameters())  # (the live tensors; state_dict() would convert repacked layers back first)
     own.update(dict(model.named_buffers()))
     for k, v in sd.items():
         if k in own and own[k].dtype != v.dtype:

@@ -1,21 +1,26 @@
-"""Layer-wise host offload with a two-slot ping-pong on two HIP streams (SURVEY.md section 8 row f2 / BASELINE config 5).
+"""Layer-wise host offload of transformer blocks over a ring of device slots (SURVEY.md section 8 row f2 / BASELINE config 5).
 
-Reference: ``CPUOffloadManager`` (nunchaku/models/utils.py:52-262) -- same constructor, attributes and methods
-(``set_device``, ``load_block``, ``step``, ``get_block``, ``initialize``), same schedule: while block ``i`` computes on the
-current stream, block ``i+1`` travels host -> device on ``memory_stream`` into the other buffer slot; two events order
-"slot free" (compute of the previous tenant done) and "slot filled" (copy done).
+Public surface of the reference's ``CPUOffloadManager`` (nunchaku/models/utils.py:52-262): constructor arguments,
+``set_device``, ``initialize``, ``get_block``, ``step``, ``load_block``, the attributes ``blocks`` / ``buffer_blocks`` /
+``memory_stream`` / ``current_block_idx`` / ``forward_counter``.  The mechanism behind it is this package's own:
 
-MI355X specifics:
-  * a device has 288 GB of HBM3E, so offload is never needed for the models of this package (Qwen-Image int4: ~11 GB); it
-    exists for API parity and for co-locating many models on one GPU.  It is OFF unless ``set_offload(True)`` is called.
-  * the PCIe Gen5 link (~50 GB/s), not the kernels, bounds an offloaded step: a Qwen-Image block computes in ~1.3 ms but
-    weighs 113 MB as 4-bit nibbles and 170 MB as the FP6 operand image the GEMM reads.  The host copies therefore keep
-    ``qweight`` in the CHECKPOINT (nibble) layout -- two thirds of the bytes on the link -- and the expansion to the FP6
-    image (``svdq_repack_qweight``, HBM-bound, ~0.1 ms per block) runs on the memory stream right behind the copy, into the
-    buffer slot.  Every other tensor is converted once at ``set_device`` time and travels as is.
-  * host memory is pinned (``hipHostMalloc`` through ``Tensor.pin_memory``): pageable copies would serialise on the
-    staging buffer of the runtime and never overlap.  A block is ONE flat pinned buffer and ONE copy (the reference issues
-    one copy per tensor, ~120 per block: at ~10 us of submission each that is a quarter of the copy time here).
+* **Host side.**  Every offloaded block is ONE flat pinned byte image (all its tensors back to back, 256-byte aligned) and
+  its parameters are VIEWS into that image -- the block stays a complete, valid CPU module (``state_dict()``, ``.to()``,
+  turning offload off again all work).  SVDQuant layers are converted once: every tensor to the kernel layout except
+  ``qweight``, which stays in -- or is converted back to -- the checkpoint's 4-bit nibble form (``svdq_unrepack_qweight``):
+  two thirds of the FP6 operand image's bytes on the PCIe link, which bounds an offloaded step (a Qwen-Image block
+  computes in ~1.3 ms and weighs 113 MB as nibbles, 170 MB as images).
+* **Device side.**  ``num_slots`` (default 2) slots, each ONE flat device buffer with the host image's layout plus the FP6
+  images its code tensors are expanded into (``svdq_repack_qweight`` on the memory stream, right behind the copy): a block
+  load is a single H2D copy (one SDMA submission; the reference issues one per tensor, ~120).
+* **Schedule.**  Offloaded blocks are numbered by a running sequence ``t`` (never reset: it continues from one forward to
+  the next); block ``t`` lives in slot ``t % num_slots``.  Two events per slot: ``free`` (recorded on the compute stream
+  when the slot's tenant has been computed) and ``filled`` (recorded on the memory stream behind copy + expansion).
+  Finishing block ``t`` frees its slot and immediately queues the load of block ``t + num_slots`` into it -- at the end of a
+  forward that is already the next forward's first blocks, so a denoise loop never starts cold.  More slots = deeper prefetch.
+
+MI355X: 288 GB of HBM make offload unnecessary for the models of this package (Qwen-Image int4: ~11 GB); it exists for API
+parity and for co-locating many models on one GPU, and is off unless ``set_offload(True)`` is called.
 """
 
 from __future__ import annotations
@@ -25,8 +30,10 @@ import copy
 import torch
 from torch import nn
 
-from .. import _lib
+from .. import _lib, layout
 from .linear import SVDQW4A4Linear
+
+_ALIGN = 256
 
 
 def copy_params_into(src: nn.Module, dst: nn.Module, non_blocking: bool = True):
@@ -38,185 +45,267 @@ def copy_params_into(src: nn.Module, dst: nn.Module, non_blocking: bool = True):
             bd.copy_(bs, non_blocking=non_blocking)
 
 
+def _named_tensors(block: nn.Module):
+    """(module name, tensor name, tensor) of every parameter and buffer of ``block``, in a fixed order"""
+    out = []
+    for mn, m in block.named_modules():
+        for pn, p in m.named_parameters(recurse=False):
+            out.append((mn, pn, p))
+        for bn, b in m.named_buffers(recurse=False):
+            out.append((mn, bn, b))
+    return out
+
+
+class _Slot:
+    """One device-side home of an offloaded block: a module whose tensors view pieces of ``flat`` (the code tensors: FP6
+    images expanded from the nibble pieces), the block index it currently holds, and its two events."""
+
+    def __init__(self, module: nn.Module, flat: torch.Tensor, expand: list, device):
+        self.module, self.flat, self.expand = module, flat, expand
+        self.tenant = -1
+        self.filled = torch.cuda.Event()  # memory stream: copy + expansion of the tenant are done
+        self.free = torch.cuda.Event()    # compute stream: the tenant has been computed, the slot may be overwritten
+        self.used = False                 # free has been recorded at least once
+
+
 class CPUOffloadManager:
     def __init__(self, blocks: list[nn.Module], device: str | torch.device = torch.device("cuda"), use_pin_memory: bool = True,
-                 on_gpu_modules: list[nn.Module] = [], num_blocks_on_gpu: int = 1, empty_cache_freq: int = 0):
+                 on_gpu_modules: list[nn.Module] = [], num_blocks_on_gpu: int = 1, empty_cache_freq: int = 0, num_slots: int = 2):
+        if num_blocks_on_gpu <= 0:
+            raise ValueError("num_blocks_on_gpu must be positive")
+        if num_slots < 2:
+            raise ValueError("num_slots must be at least 2 (one slot computes while another fills)")
         self.blocks = blocks
         self.use_pin_memory = use_pin_memory
         self.on_gpu_modules = on_gpu_modules
-        self.num_blocks_on_gpu = num_blocks_on_gpu
-        assert self.num_blocks_on_gpu > 0
-        self.memory_stream = None  # created in set_device
-        self.compute_done = torch.cuda.Event(blocking=False)
-        self.memory_done = torch.cuda.Event(blocking=False)
-        self.buffer_blocks: list[nn.Module] = []
-        self._host_flat: list = []      # per offloaded block: ONE pinned byte buffer with all its tensors
-        self._dev_flat: list = [{}, {}]  # per buffer slot: the matching flat device buffer(s)
+        self.num_blocks_on_gpu = min(num_blocks_on_gpu, len(blocks))
+        self.num_slots = num_slots
+        self.empty_cache_freq = empty_cache_freq
+        self.memory_stream = None
         self.device = None
-        self.set_device(device)
         self.current_block_idx = 0
         self.forward_counter = 0
-        self.empty_cache_freq = empty_cache_freq
+        self._images: dict[int, torch.Tensor] = {}   # offloaded block index -> flat pinned byte image
+        self._entries: list | None = None            # [(module name, tensor name, offset, nbytes, (N, K) of a nibble tensor or None)]
+        self._slots: list[_Slot] = []
+        self._seq = 0                                # sequence number of the first offloaded block of the CURRENT forward
+        self._queued = 0                             # sequence numbers < _queued have had their load issued
+        self.set_device(device)
+
+    # ------------------------------------------------------------------ public views of the internals
+    @property
+    def buffer_blocks(self) -> list[nn.Module]:
+        return [s.module for s in self._slots]
+
+    @property
+    def n_offloaded(self) -> int:
+        return len(self.blocks) - self.num_blocks_on_gpu
+
+    def host_bytes_per_block(self, block_idx: int | None = None) -> int:
+        """Bytes that cross the link for one offloaded block (its flat image: nibble code tensors + every other tensor)."""
+        i = self.num_blocks_on_gpu if block_idx is None else block_idx
+        return self._images[i].numel() if i in self._images else 0
+
+    def nibble_bytes(self, block_idx: int | None = None) -> int:
+        """Bytes of an offloaded block's image that are 4-bit code tensors in checkpoint (nibble) form."""
+        return sum(n for _, _, _, n, nib in (self._entries or []) if nib is not None)
 
     # ------------------------------------------------------------------ placement
-    @staticmethod
-    def _tensors(block: nn.Module):
-        """(module name, tensor name, tensor) of every parameter and buffer, in a fixed order"""
-        out = []
-        for mn, m in block.named_modules():
-            for pn, p in m.named_parameters(recurse=False):
-                out.append((mn, pn, p))
-            for bn, b in m.named_buffers(recurse=False):
-                out.append((mn, bn, b))
-        return out
+    @torch.no_grad()
+    def _to_offload_form(self, block: nn.Module):
+        """On the GPU: every SVDQuant tensor of ``block`` in the kernel layout, except ``qweight`` in nibble form."""
+        for m in block.modules():
+            if not isinstance(m, SVDQW4A4Linear):
+                continue
+            m.reset_lora()  # a runtime LoRA is not part of the host image
+            if "qweight" in m._amd_names:
+                m.qweight.data = layout.unrepack_qweight(m.qweight.data)
+                m._amd_names.discard("qweight")
+                m.qweight._svdq_amd = False
+            m.repack_(skip=("qweight",))
+
+    @torch.no_grad()
+    def _build_host_image(self, idx: int, device: torch.device):
+        block = self.blocks[idx]
+        block.to(device)
+        self._to_offload_form(block)
+        entries, off = [], 0
+        tensors = _named_tensors(block)
+        mods = dict(block.named_modules())
+        for mn, tn, t in tensors:
+            m = mods[mn]
+            nib = (m.out_features, m.in_features) if isinstance(m, SVDQW4A4Linear) and tn == "qweight" else None
+            size = t.numel() * t.element_size()
+            entries.append((mn, tn, off, size, nib))
+            off = (off + size + _ALIGN - 1) // _ALIGN * _ALIGN
+        if self._entries is None:
+            self._entries, self._image_bytes = entries, off
+        elif entries != self._entries:
+            raise RuntimeError(f"offload: block {idx} does not have the tensor layout of the first offloaded block (all "
+                               "offloaded blocks must share one structure)")
+        flat = torch.empty(off, dtype=torch.uint8, device="cpu")
+        if self.use_pin_memory:
+            flat = flat.pin_memory()
+        for (mn, tn, o, size, _), (_, _, t) in zip(entries, tensors):
+            piece = flat[o:o + size]
+            piece.copy_(t.data.contiguous().view(-1).view(torch.uint8))
+            t.data = piece.view(t.dtype).view(t.shape)  # the block's tensor IS the piece of the pinned image from now on
+        self._images[idx] = flat
+
+    @torch.no_grad()
+    def _build_slots(self, device: torch.device):
+        """``num_slots`` device modules shaped like an offloaded block.  Built from the first offloaded block's host image."""
+        first = self.num_blocks_on_gpu
+        self._slots = []
+        if first >= len(self.blocks):
+            return
+        template = self.blocks[first]
+        for _ in range(self.num_slots):
+            module = copy.deepcopy(template)  # CPU copy of the structure (tensors: copies of the host views)
+            flat = torch.empty(self._image_bytes, dtype=torch.uint8, device=device)
+            mods = dict(module.named_modules())
+            expand = []
+            for mn, tn, o, size, nib in self._entries:
+                m = mods[mn]
+                t = getattr(m, tn)
+                if nib is not None:
+                    N, K = nib
+                    img = torch.empty(N, K * 3 // 4, dtype=torch.int8, device=device)
+                    t.data = img
+                    expand.append((flat[o:o + size], img, N, K))
+                else:
+                    t.data = flat[o:o + size].view(t.dtype).view(t.shape)
+            for m in module.modules():
+                if isinstance(m, SVDQW4A4Linear):
+                    m._set_amd_names(set(m._layout_params()))  # everything in the kernel layout once a load has landed
+            self._slots.append(_Slot(module, flat, expand, device))
 
     def set_device(self, device: torch.device | str, force: bool = False):
-        """Buffers and resident blocks to ``device``, the other blocks to (pinned) host memory.  SVDQuant layers are
-        converted to the kernel layout HERE, once; every offloaded block becomes ONE flat pinned byte buffer (all its tensors
-        back to back, 256-byte aligned; ``qweight`` in nibble form where the layer had not been repacked before), each buffer
-        slot ONE flat device buffer of the same layout whose pieces the slot's parameters view -- a block load is a single
-        H2D copy (one SDMA submission instead of ~120) plus the nibble -> FP6 expansions."""
+        """Resident blocks and the device slots to ``device``; offloaded blocks to their pinned host images (built once: they
+        do not depend on the device).  Calling it again with another device (or ``force=True``) rebuilds the slots only."""
         if isinstance(device, str):
             device = torch.device(device)
-        assert device.type == "cuda"
+        if device.type != "cuda":
+            raise ValueError("CPUOffloadManager: the compute device must be a GPU")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         if self.device == device and not force:
             return
+        if self.memory_stream is not None:
+            torch.cuda.synchronize(self.device)  # nothing of the old device's schedule may still be in flight
         self.device = device
         self.memory_stream = torch.cuda.Stream(device=device)
         for module in self.on_gpu_modules:
             module.to(device)
-        self._host_flat = [None] * len(self.blocks)
-        self._layout = None      # [(module name, tensor name, byte offset, byte size, is_nibble_qweight)], same for every block
-        self._nibble_mode = [False] * len(self.blocks)
         for i, block in enumerate(self.blocks):
-            block.to(device)
-            svdq = {n: m for n, m in block.named_modules() if isinstance(m, SVDQW4A4Linear)}
-            nibbles = {}
-            if i >= self.num_blocks_on_gpu:
-                for n, m in svdq.items():  # keep the nibble image for the link before the repack replaces it
-                    if "qweight" not in m._amd_names:
-                        nibbles[n] = m.qweight.data.clone()
-            for m in svdq.values():
-                m.repack_()
-            if i == 0:
-                # two buffer slots shaped like a converted block (FP6-image qweights, marked as kernel layout)
-                self.buffer_blocks = [copy.deepcopy(block), copy.deepcopy(block)]
-                for b in self.buffer_blocks:
-                    for m in b.modules():
-                        if isinstance(m, SVDQW4A4Linear):
-                            m._set_amd_names(m._amd_names)
             if i < self.num_blocks_on_gpu:
-                continue
-            # flat host image of this block
-            items, off = [], 0
-            for mn, tn, t in self._tensors(block):
-                nib = tn == "qweight" and mn in nibbles
-                src = nibbles[mn] if nib else t.data
-                size = src.numel() * src.element_size()
-                items.append((mn, tn, off, size, nib, src))
-                off = (off + size + 255) // 256 * 256
-            if self._layout is None or len(self._layout) != len(items):
-                self._layout = None
-            flat = torch.empty(off, dtype=torch.uint8, device="cpu")
-            if self.use_pin_memory:
-                flat = flat.pin_memory()
-            for mn, tn, o, size, nib, src in items:
-                flat[o:o + size].copy_(src.contiguous().view(-1).view(torch.uint8))
-            self._host_flat[i] = flat
-            self._nibble_mode[i] = bool(nibbles)
-            lay = [(mn, tn, o, size, nib) for mn, tn, o, size, nib, _ in items]
-            self._block_layouts = getattr(self, "_block_layouts", {})
-            self._block_layouts[i] = lay
-            # the block object keeps its structure but not its data (everything lives in the flat image now)
-            for _, _, t in self._tensors(block):
-                t.data = torch.empty(0, dtype=t.dtype)
-        # device side: one flat buffer per slot and layout kind (nibble / image), parameters of the slot view into it
-        self._dev_flat = [{}, {}]
+                block.to(device)
+                for m in block.modules():
+                    if isinstance(m, SVDQW4A4Linear):
+                        m.repack_()
+            elif i not in self._images:
+                self._build_host_image(i, device)
+        torch.cuda.synchronize(device)  # the images are complete before anything reads them
+        self._build_slots(device)
+        self._seq = self._queued = 0
+        self.current_block_idx = 0
 
-    def _bind_slot(self, slot: int, block_idx: int):
-        """Point the slot's parameters at the pieces of its flat device buffer for the layout of block ``block_idx``."""
-        lay = self._block_layouts[block_idx]
-        key = self._nibble_mode[block_idx]
-        total = self._host_flat[block_idx].numel()
-        bound = self._dev_flat[slot].get(key)
-        if bound is not None and bound[0].numel() == total:
-            return bound
-        flat = torch.empty(total, dtype=torch.uint8, device=self.device)
-        mods = dict(self.buffer_blocks[slot].named_modules())
-        expand = []  # (nibble view, FP6 image tensor, N, K)
-        for mn, tn, o, size, nib in lay:
-            m = mods[mn]
-            t = getattr(m, tn)
-            if nib:
-                img = t.data if t.data.numel() == m.out_features * m.in_features * 3 // 4 and t.data.is_cuda else \
-                    torch.empty(m.out_features, m.in_features * 3 // 4, dtype=torch.int8, device=self.device)
-                t.data = img
-                expand.append((flat[o:o + size], img, m.out_features, m.in_features))
-            else:
-                shape = tuple(t.shape) if t.data.numel() * t.element_size() == size else None
-                if shape is None:
-                    raise RuntimeError(f"offload: {mn}.{tn} of block {block_idx} does not match the buffer slot's shape")
-                t.data = flat[o:o + size].view(t.dtype).view(shape)
-        self._dev_flat[slot][key] = (flat, expand)
-        return self._dev_flat[slot][key]
+    @torch.no_grad()
+    def restore(self, device: torch.device | str | None = None):
+        """Undo the offload: every block becomes an ordinary module on ``device`` again (its tensors copied out of the pinned
+        images; code tensors return to the FP6 image lazily, at their first use).  The manager is unusable afterwards."""
+        device = torch.device(device) if device is not None else self.device
+        if self.memory_stream is not None:
+            torch.cuda.synchronize(self.device)
+        for i in sorted(self._images):
+            blk = self.blocks[i]
+            for _, _, t in _named_tensors(blk):
+                t.data = t.data.to(device, copy=True)
+        self._images.clear()
+        self._slots = []
+        self._entries = None
 
-    # ------------------------------------------------------------------ the ping-pong
-    def load_block(self, block_idx: int, non_blocking: bool = True):
-        """Host -> buffer slot ``block_idx % 2`` on the CURRENT stream (``step`` calls it under ``memory_stream``): one copy
-        of the block's flat image, then the nibble -> FP6 expansion of its code tensors."""
+    # ------------------------------------------------------------------ the ring
+    def _block_of(self, seq: int) -> int:
+        return self.num_blocks_on_gpu + seq % self.n_offloaded
+
+    def load_block(self, block_idx: int, non_blocking: bool = True, slot: int | None = None):
+        """Host image of block ``block_idx`` -> device slot (default: the slot the running sequence assigns) on the CURRENT
+        stream: one copy of the flat image, then the nibble -> FP6 expansion of its code tensors."""
         if block_idx < self.num_blocks_on_gpu or block_idx >= len(self.blocks):
             return
-        slot = block_idx % 2
-        flat, expand = self._bind_slot(slot, block_idx)
-        flat.copy_(self._host_flat[block_idx], non_blocking=non_blocking)
-        if expand:
+        if slot is None:
+            slot = (self._seq + block_idx - self.num_blocks_on_gpu) % self.num_slots
+        s = self._slots[slot]
+        s.flat.copy_(self._images[block_idx], non_blocking=non_blocking)
+        if s.expand:
             lib = _lib.load()
             st = torch.cuda.current_stream().cuda_stream
-            for nib, img, N, K in expand:
+            for nib, img, N, K in s.expand:
                 _lib.check(lib.svdq_repack_qweight(nib.data_ptr(), img.data_ptr(), N, K, st), "svdq_repack_qweight")
+        s.tenant = block_idx
 
-    def step(self, compute_stream: torch.cuda.Stream | None = None):
-        """Advance to the next block: its predecessor's compute is recorded, the successor's copy is queued behind the
-        event that frees its slot, and the compute stream waits for the copy of the block it is about to run."""
-        if compute_stream is None:
-            compute_stream = torch.cuda.current_stream()
-        next_compute_done = torch.cuda.Event()
-        next_compute_done.record(compute_stream)
+    def _queue_load(self, seq: int):
+        """Issue the load of sequence number ``seq`` on the memory stream, behind the event that frees its slot."""
+        s = self._slots[seq % self.num_slots]
         with torch.cuda.stream(self.memory_stream):
-            self.memory_stream.wait_event(self.compute_done)
-            self.load_block(self.current_block_idx + 1)
-            next_memory_done = torch.cuda.Event()
-            next_memory_done.record(self.memory_stream)
-        self.memory_done = next_memory_done
-        self.compute_done = next_compute_done
-        self.current_block_idx += 1
-        if self.current_block_idx < len(self.blocks):
-            compute_stream.wait_event(self.memory_done)
-        else:
-            compute_stream.wait_event(self.compute_done)
-            self.current_block_idx = 0
-            self.forward_counter += 1
-            if self.empty_cache_freq > 0 and self.forward_counter % self.empty_cache_freq == 0:
-                torch.cuda.empty_cache()
+            if s.used:
+                self.memory_stream.wait_event(s.free)
+            self.load_block(self._block_of(seq), slot=seq % self.num_slots)
+            s.filled.record(self.memory_stream)
+
+    def initialize(self, stream: torch.cuda.Stream | None = None):
+        """Start of a forward on ``stream``: make sure the first ``num_slots`` offloaded blocks are on their way (after the
+        first forward they already are: the previous forward's last steps queued them)."""
+        if self.n_offloaded <= 0:
+            return
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        if self.current_block_idx != 0:  # an aborted forward: restart the ring from a clean state
+            self.reset()
+        while self._queued < self._seq + min(self.num_slots, self.n_offloaded):
+            self._queue_load(self._queued)
+            self._queued += 1
+        if self.num_blocks_on_gpu == 0:
+            stream.wait_event(self._slots[self._seq % self.num_slots].filled)
+
+    def reset(self):
+        """Drop the ring's state (after an exception in the middle of a forward): the next ``initialize`` reloads."""
+        torch.cuda.synchronize(self.device)
+        for s in self._slots:
+            s.tenant, s.used = -1, False
+        self._seq = self._queued = 0
+        self.current_block_idx = 0
 
     def get_block(self, block_idx: int | None = None) -> nn.Module:
         if block_idx is None:
             block_idx = self.current_block_idx
         if block_idx < self.num_blocks_on_gpu:
             return self.blocks[block_idx]
-        return self.buffer_blocks[block_idx % 2]
+        return self._slots[(self._seq + block_idx - self.num_blocks_on_gpu) % self.num_slots].module
 
-    def initialize(self, stream: torch.cuda.Stream | None = None):
-        if stream is None:
-            stream = torch.cuda.current_stream()
-        self.compute_done.record(stream)
-        self.memory_done.record(stream)
-
-    def host_bytes_per_block(self, block_idx: int | None = None) -> int:
-        """Bytes that cross the link for one offloaded block (its flat image: nibble qweights + every other tensor)."""
-        i = self.num_blocks_on_gpu if block_idx is None else block_idx
-        return 0 if i >= len(self.blocks) or self._host_flat[i] is None else self._host_flat[i].numel()
-
-    def nibble_bytes(self, block_idx: int) -> int:
-        """Bytes of block ``block_idx``'s flat image that are 4-bit code tensors in checkpoint (nibble) form."""
-        return sum(size for _, _, _, size, nib in self._block_layouts.get(block_idx, []) if nib)
+    def step(self, compute_stream: torch.cuda.Stream | None = None):
+        """Block ``current_block_idx`` has been queued for compute on ``compute_stream``: free its slot behind it, queue the
+        load that reuses the slot, and make the compute stream wait for the block it runs next."""
+        if compute_stream is None:
+            compute_stream = torch.cuda.current_stream()
+        cur, nb = self.current_block_idx, self.num_blocks_on_gpu
+        if cur >= nb:
+            seq = self._seq + cur - nb
+            s = self._slots[seq % self.num_slots]
+            s.free.record(compute_stream)
+            s.used = True
+            if self._queued == seq + self.num_slots:  # the next tenant of exactly this slot (steady state: always)
+                self._queue_load(self._queued)
+                self._queued += 1
+        self.current_block_idx = cur + 1
+        if self.current_block_idx < len(self.blocks):
+            nxt = self.current_block_idx
+            if nxt >= nb:
+                compute_stream.wait_event(self._slots[(self._seq + nxt - nb) % self.num_slots].filled)
+        else:
+            self._seq += self.n_offloaded
+            self.current_block_idx = 0
+            self.forward_counter += 1
+            if self.empty_cache_freq > 0 and self.forward_counter % self.empty_cache_freq == 0:
+                torch.cuda.empty_cache()

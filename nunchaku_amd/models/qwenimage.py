@@ -292,8 +292,11 @@ class NunchakuQwenImageTransformer2DModel(nn.Module):
             self.offload_manager = CPUOffloadManager(
                 list(self.transformer_blocks), device=kwargs.get("device", self.device), use_pin_memory=kwargs.get("use_pin_memory", True),
                 on_gpu_modules=[self.img_in, self.txt_in, self.txt_norm, self.time_text_embed, self.norm_out, self.proj_out],
-                num_blocks_on_gpu=kwargs.get("num_blocks_on_gpu", 1))
+                num_blocks_on_gpu=kwargs.get("num_blocks_on_gpu", 1), num_slots=kwargs.get("num_slots", 2))
         else:
+            # the blocks are complete modules on pinned host memory: bring them back (the reference leaves them on the CPU and
+            # relies on a later .to(device); a model that has just been told "no offload" should simply run)
+            self.offload_manager.restore()
             self.offload_manager = None
             torch.cuda.empty_cache()
 

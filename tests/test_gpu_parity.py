@@ -322,8 +322,37 @@ def test_partial_state_dict_update_of_a_repacked_layer():
     ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=new_bias, lora_act_in=la.cpu().numpy(), lora_up=L["proj_up"])["out"][:M]
     assert_close_16(f32(mod.forward_quant(qx, asc, la))[:M], ref, dtype, "after the bias-only update")
     assert np.abs(y1 - y0).max() > 0.1  # the bias really changed
-    with pytest.raises(RuntimeError, match="not a checkpoint"):
-        mod.state_dict()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_state_dict_round_trip_after_forward_and_deepcopy(dtype):
+    """load -> forward (parameters repacked to the kernel layout) -> state_dict() returns CHECKPOINT-layout tensors, bit for bit
+    the ones that were loaded; loading them into a fresh module reproduces the output bit for bit; a deepcopy of the repacked
+    layer computes the same output (it used to convert its parameters a second time, silently)."""
+    import copy
+
+    from tests.helpers import reference_state_dict
+
+    M, K, N = 300, 384, 256
+    L, x = _gemm_inputs(M, K, N, 32, dtype, seed=91)
+    mod = make_module(L, dtype)
+    tx = t16(x, dtype).view(1, M, K)
+    qx, asc, la = mod.quantize(tx.view(M, K))
+    y0 = mod.forward_quant(qx, asc, la).clone()
+    assert mod._amd_layout
+    sd = mod.state_dict()
+    src = reference_state_dict(L, dtype)
+    for k, v in src.items():
+        assert sd[k].shape == v.shape and sd[k].dtype == v.dtype, k
+        assert torch.equal(sd[k].cpu(), v), f"{k}: state_dict() of the repacked layer is not the checkpoint tensor"
+    assert mod._amd_layout and mod.qweight.shape[-1] == K * 3 // 4, "state_dict() must not touch the module's own parameters"
+    fresh = make_module(L, dtype)
+    fresh.load_state_dict({k: v.clone() for k, v in sd.items()})
+    assert torch.equal(fresh.forward_quant(qx, asc, la), y0)
+    twin = copy.deepcopy(mod)
+    assert torch.equal(twin.forward_quant(qx, asc, la), y0), "deepcopy of a repacked layer computes a different output"
+    wrapped = torch.nn.Sequential(copy.deepcopy(mod))
+    assert torch.equal(wrapped.state_dict()["0.qweight"].cpu(), src["qweight"])
 
 
 def test_reference_style_calls_with_reference_sized_buffers_and_checkpoint_layout():

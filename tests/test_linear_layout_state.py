@@ -44,15 +44,34 @@ def test_full_load_restores_the_checkpoint_shape_and_marks_everything():
     assert lin._amd_names == set() and not lin._amd_layout
 
 
-def test_state_dict_of_a_repacked_layer_refuses():
+def test_state_dict_of_a_repacked_layer_goes_through_the_inverse_repack():
+    """state_dict() of a layer in the kernel layout is converted back to the checkpoint layout by the GPU's inverse
+    permutations (tests/test_gpu_parity.py checks the round trip bit for bit); without a GPU that is an error, never a
+    silently wrong "checkpoint"."""
     lin = _layer()
     assert set(lin.state_dict()) >= {"qweight", "wscales", "bias", "proj_down", "proj_up", "smooth_factor"}
     _stage_repacked(lin)
-    with pytest.raises(RuntimeError, match="not a checkpoint"):
-        lin.state_dict()
-    wrapper = torch.nn.Sequential(lin)
-    with pytest.raises(RuntimeError, match="not a checkpoint"):
-        wrapper.state_dict()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="GPU|cuda|CUDA|HIP"):
+            lin.state_dict()
+        with pytest.raises(RuntimeError, match="GPU|cuda|CUDA|HIP"):
+            torch.nn.Sequential(lin).state_dict()
+
+
+def test_deepcopy_of_a_repacked_layer_keeps_its_layout_state():
+    """Parameter.__deepcopy__ drops python attributes (the per-tensor `_svdq_amd` marks); `_amd_names` survives
+    and the marks are re-stamped from it, so the copy is NOT converted a second time."""
+    import copy
+
+    lin = _layer()
+    _stage_repacked(lin)
+    twin = copy.deepcopy(lin)
+    assert twin._amd_names == lin._amd_names and twin._amd_layout
+    assert not getattr(twin.bias, "_svdq_amd", False), "torch drops tensor attributes on deepcopy (if this fails the re-stamp is moot)"
+    twin._ensure_layout()  # nothing to repack, marks restored
+    for n in twin._amd_names:
+        assert getattr(getattr(twin, n), "_svdq_amd", False), n
+    assert torch.equal(twin.qweight.data, lin.qweight.data)
 
 
 def test_runtime_lora_is_dropped_only_when_low_rank_tensors_arrive():

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -132,7 +133,7 @@ int main(int argc, char **argv) {
     }
     if (use_ws) { a.workspace_bytes = wsb(); CK(hipMalloc(&a.workspace, a.workspace_bytes)); CK(hipMemset(a.workspace, 0, a.workspace_bytes)); }
     long long *clk = nullptr;
-    if (set_clk) { CK(hipMalloc((void **)&clk, 2 * 512 * sizeof(long long))); }
+    if (set_clk) { CK(hipMalloc((void **)&clk, 4 * 512 * sizeof(long long))); }
 
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -155,16 +156,43 @@ int main(int argc, char **argv) {
             const double us = ms * 1e3 / iters;
             double eff_ghz = 0, cyc = 0;
             if (set_clk) {
-                CK(hipMemset(clk, 0, 2 * 512 * sizeof(long long)));
+                CK(hipMemset(clk, 0, 4 * 512 * sizeof(long long)));
                 set_clk(clk);
                 gemm(&a, st);
                 CK(hipStreamSynchronize(st));
                 set_clk(nullptr);
-                std::vector<long long> hc(2 * 512);
+                std::vector<long long> hc(4 * 512);
                 CK(hipMemcpy(hc.data(), clk, hc.size() * sizeof(long long), hipMemcpyDeviceToHost));
                 double sc = 0, st_ = 0; int n = 0;
-                for (int i = 0; i < 512; i++) if (hc[2 * i + 1] > 0) { sc += hc[2 * i]; st_ += hc[2 * i + 1]; n++; }
+                long long t_min = 0x7fffffffffffffffLL, t_max = 0, life_max = 0, life_min = 0x7fffffffffffffffLL;
+                std::vector<unsigned> cu_key;
+                for (int i = 0; i < 512; i++) if (hc[4 * i + 1] > 0) {
+                    sc += hc[4 * i]; st_ += hc[4 * i + 1]; n++;
+                    t_min = std::min(t_min, hc[4 * i + 2]); t_max = std::max(t_max, hc[4 * i + 2] + hc[4 * i + 1]);
+                    life_max = std::max(life_max, hc[4 * i + 1]); life_min = std::min(life_min, hc[4 * i + 1]);
+                    const unsigned hw = (unsigned)hc[4 * i + 3], xcc = (unsigned)(hc[4 * i + 3] >> 32);
+                    cu_key.push_back((xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)); // xcc, se, sh, cu
+                }
                 if (n) { cyc = sc / n; eff_ghz = sc / (st_ * 10.0); } // ticks are 10 ns
+                // placement: workgroups per physical CU, and for CUs with two tenants how much of their lifetimes overlap
+                std::vector<unsigned> uniq = cu_key; std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+                int cus2 = 0, cus1 = 0, cus3 = 0; double ov = 0, life2 = 0, life1 = 0; int n2 = 0, n1 = 0;
+                for (unsigned k : uniq) {
+                    std::vector<int> w; int idx = 0;
+                    for (int i = 0; i < 512; i++) if (hc[4 * i + 1] > 0) { if (cu_key[idx] == k) w.push_back(i); idx++; }
+                    if (w.size() == 1) { cus1++; life1 += hc[4 * w[0] + 1]; n1++; }
+                    else if (w.size() == 2) {
+                        cus2++;
+                        const long long s0 = hc[4 * w[0] + 2], e0_ = s0 + hc[4 * w[0] + 1], s1 = hc[4 * w[1] + 2], e1_ = s1 + hc[4 * w[1] + 1];
+                        const long long o = std::min(e0_, e1_) - std::max(s0, s1);
+                        ov += (double)std::max(0LL, o) / std::max(1LL, std::min(e0_ - s0, e1_ - s1));
+                        life2 += hc[4 * w[0] + 1] + hc[4 * w[1] + 1]; n2 += 2;
+                    } else cus3++;
+                }
+                printf("{\"placement\":{\"wgs\":%d,\"cus_used\":%zu,\"cus_with_1\":%d,\"cus_with_2\":%d,\"cus_with_3plus\":%d,\"pair_overlap\":%.3f,"
+                       "\"life_us_alone\":%.2f,\"life_us_paired\":%.2f,\"life_us_min\":%.2f,\"life_us_max\":%.2f,\"span_us\":%.2f}}\n",
+                       n, uniq.size(), cus1, cus2, cus3, cus2 ? ov / cus2 : 0.0, n1 ? life1 / n1 * 0.01 : 0.0, n2 ? life2 / n2 * 0.01 : 0.0,
+                       life_min * 0.01, life_max * 0.01, (t_max - t_min) * 0.01);
             }
             if (set_trace && do_trace) { // per-segment phase stamps of workgroup 0
                 long long *tr; CK(hipMalloc((void **)&tr, 192 * sizeof(long long))); CK(hipMemset(tr, 0, 192 * sizeof(long long)));
