@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events in the timed region (their cost: ~0.5 %%)")
     ap.add_argument("--layers", type=int, nargs=2, default=(19, 38), help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--geometry", type=int, default=0, choices=[0, 1, 2, 3],
+    ap.add_argument("--geometry", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="workgroup geometry of the W4A4 GEMM (svdq_gemm_args.geometry): 0 = the library's choice, 1 = 256x128 "
                          "tiles / one workgroup per CU, 2 = 128x128 tiles / two per CU out of phase, 3 = 2 without the phase offset")
     ap.add_argument("--deterministic", action="store_true",

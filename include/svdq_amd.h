@@ -180,10 +180,13 @@ typedef struct svdq_gemm_args {
      * (text + image) attention passes the same buffer to both GEMMs with out_vt offset by the token start. */
     void *out_vt;
     int32_t ldvt;             /* row stride of out_vt in elements (>= total tokens)              */
-    /* Workgroup geometry: 0 = chosen by the library; 1 = 256 x 128 tiles, one 512-thread workgroup per CU; 2 = 128 x 128
-     * tiles, two 256-thread workgroups per CU running half a tile out of phase (one's epilogue under the other's main
-     * loop); 3 = as 2 without the phase offset (A/B measurements).  Results are bit-identical across geometries for
-     * launches without a stream-K split (the split points, hence the fp32 summation order of a split tile, differ). */
+    /* Workgroup geometry: 0 = chosen by the library; 1 = 256 x 128 tiles, one 512-thread workgroup per CU, fixed tile list
+     * per workgroup + stream-K tail; 2 = 128 x 128 tiles, two 256-thread workgroups per CU (one's epilogue and barrier
+     * stalls under the other's main loop) that DRAW their tiles from per-XCD queues in the workspace (falls back to 3 without
+     * a workspace, for launches of at most one tile per workgroup, and where a stream-K split pays); 3 = 128 x 128 tiles,
+     * fixed tile lists + stream-K tail; 4 / 5 = 2 / 3 with the second workgroup of a CU started half a tile late (A/B
+     * measurements).  Results are bit-identical across geometries for launches without a stream-K split (the split points,
+     * hence the fp32 summation order of a split tile, differ). */
     int32_t geometry;
     /* Grouped launch (optional): rows [split_rows, M_pad) use a SECOND weight set of the same shape, rank and
      * epilogue -- one launch for the text and the image stream of a joint FLUX block (same layer type, different

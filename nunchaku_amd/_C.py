@@ -172,8 +172,9 @@ def _weight(wgt: torch.Tensor, K: int) -> torch.Tensor:
 
 class _Ops:
     # Workgroup geometry of gemm_w4a4 (svdq_gemm_args.geometry): 0 = the library's choice, 1 = 256 x 128 tiles / one
-    # workgroup per CU, 2 = 128 x 128 tiles / two workgroups per CU half a tile out of phase, 3 = as 2 without the phase
-    # offset.  A plain attribute, not an environment variable: nothing is read from os.environ on the launch path.
+    # workgroup per CU, 2 = 128 x 128 tiles / two workgroups per CU drawing tiles from per-XCD queues, 3 = 128 x 128 with
+    # fixed tile lists, 4 / 5 = 2 / 3 with a phase offset between a CU's two workgroups.  A plain attribute, not an
+    # environment variable: nothing is read from os.environ on the launch path.
     gemm_geometry = 0
     # False: launch without the stream-K workspace (whole-tile schedule only); tests compare the two schedules
     gemm_use_workspace = True

@@ -83,13 +83,17 @@ template <int NW> struct Geo {
     static constexpr int A_BYTES = (BM / 32) * F6_CHUNK;
     static constexpr int STAGE_BYTES = A_BYTES + W_BYTES + AS_BYTES + WS_BYTES; // 38912 | 26624
     static constexpr int EPI_BYTES = 2 * BM * 4;   // epilogue scratch behind the ring (row sums of the RMSNorm epilogue: [2][BM] fp32)
-    static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + EPI_BYTES;          // 157696 | 80896 (two of them: 158 of 160 KiB)
+    static constexpr int MAIL_BYTES = 16;          // one word: the tile id a workgroup's thread 0 drew from the dynamic queue
+    static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + EPI_BYTES + MAIL_BYTES; // 157712 | 80912 (two of them: 158 of 160 KiB)
     static constexpr int WG_PER_CU = NW == 8 ? 1 : 2;
 };
-// stream-K workspace header: 1024 int32 words; words [0, 1023) are per-remainder-tile arrival counters (at most
-// 2 * CUs - 1 remainder tiles: the persistent grid never exceeds 512 workgroups), word 1023 is the sticky error flag
-constexpr int SK_HEADER_BYTES = 4096;
+// workspace header: 2048 int32 words.  Words [0, 1023): per-remainder-tile arrival counters of the stream-K split (at most
+// 2 * CUs - 1 remainder tiles: the persistent grid never exceeds 512 workgroups); word 1023: the sticky error flag;
+// words 1024 + 32 x (x = 0..7): ticket counter of XCD x's tile queue (dynamic schedule, one 128-byte line each);
+// word 1024 + 32 * 8: workgroups that have left the queue (the last one clears the counters for the next launch)
+constexpr int SK_HEADER_BYTES = 8192;
 constexpr int SK_ERR_WORD = 1023;
+constexpr int DQ_BASE = 1024, DQ_STRIDE = 32, DQ_DONE = DQ_BASE + 8 * DQ_STRIDE;
 constexpr int SK_SPIN_LIMIT = 1 << 22;         // x (s_sleep 8 + one L2 round trip) ~ 1 s
 
 struct GemmParams {
@@ -120,6 +124,7 @@ struct GemmParams {
     long long workspace_bytes;
     int sk_gs;               // stream-K: workgroups sharing the remainder tiles (0 = whole tiles only); host heuristic
     int stagger;             // NW = 4: the second workgroup of a CU starts half a tile late
+    int dynamic;             // NW = 4: tiles are drawn from per-XCD queues in the workspace instead of a fixed list per workgroup
     int *status;             // optional host-visible status word (svdq_gemm_args.status)
     int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
     float lora_scales[MAX_LORA_TILES];
@@ -233,12 +238,55 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
     typedef GemmSegment Seg;
     auto next_seg = [&](Seg &sg) -> bool { return sched.next(sg); };
 
+    // ---- dynamic schedule (NW = 4, p.dynamic) -----------------------------------------------------------------------
+    // Two workgroups share a CU's issue slots unevenly (the SIMD arbiter favours the older wave: one tenant finishes
+    // 30-40 % earlier than the other, profiles/r3_gemm_placement.txt) and epilogues differ per tile, so a fixed tile list per
+    // workgroup ends in a long tail of half-empty CUs.  Instead every workgroup DRAWS its tiles: the tile space is cut into
+    // chunks of 64 consecutive tiles (an 8 x 8 patch = 1024 x 1024 outputs sharing 8 activation and 8 weight panels), chunk c
+    // belongs to the queue of XCD c % 8, a workgroup takes tickets from the queue of the XCD it runs on (XCC_ID) -- so the
+    // tiles an XCD works on at a time still share its L2 -- and from the other XCDs' queues when its own is empty.  Thread 0
+    // draws two tiles ahead (the main loop prefetches the next tile's first K-steps, so the next tile must be known at loop
+    // entry); the draw is issued at the start of an epilogue and read at its end.  Results do not depend on who computes a tile.
+    typedef __attribute__((address_space(1))) int gqint;
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_int *mail = (lds_int *)(lds + NSTAGE * STAGE_BYTES + G_::EPI_BYTES);
+    const bool dyn = NW == 4 && p.dynamic != 0;
+    const int NC = (NT + 63) / 64;
+    const int my_xcd = dyn ? (int)(__builtin_amdgcn_s_getreg(3 << 11 | 20) & 7) : 0;
+    auto draw = [&]() -> int { // thread 0 only: next tile of this workgroup or -1
+        gqint *q = (gqint *)reinterpret_cast<int *>(p.workspace) + DQ_BASE;
+        for (int a = 0; a < 8; a++) {
+            const int x = (my_xcd + a) & 7;
+            if (x >= NC) continue;
+            int len = ((NC - x + 7) / 8) * 64;            // tiles of XCD x's chunks x, x + 8, ...
+            if ((NC - 1) % 8 == x) len -= NC * 64 - NT;   // the last chunk may be partial
+            const int k = __hip_atomic_fetch_add(q + x * DQ_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k < len) return ((k >> 6) * 8 + x) * 64 + (k & 63);
+        }
+        return -1;
+    };
+    auto leave_queue = [&]() { // thread 0, once, after its last draw: the last workgroup out clears the counters
+        gqint *q = (gqint *)reinterpret_cast<int *>(p.workspace) + DQ_BASE;
+        if (__hip_atomic_fetch_add(q + (DQ_DONE - DQ_BASE), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+            for (int x = 0; x < 8; x++) __hip_atomic_store(q + x * DQ_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + (DQ_DONE - DQ_BASE), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto share = [&](int v) -> int { // thread 0's value to the whole workgroup
+        __syncthreads();
+        if (tid == 0) *mail = v;
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(*mail);
+    };
+    int dq_pending = -1;   // the tile drawn for the iteration after next
+    bool dq_left = false;
+
     if constexpr (NW == 4) {
         // De-phase the two workgroups of a CU.  They start together and do the same work per tile, so left alone they reach
         // their epilogues together and the matrix pipe idles exactly as with one big workgroup.  The workgroup whose waves
         // sit in the ODD wave slot of their SIMD (HW_ID.wave_id: the second tenant) starts half a tile late, once per launch.
         // (Purely a scheduling hint: results do not depend on which workgroup, if any, waits.)
-        if (p.stagger && F >= 2) {
+        if (p.stagger && (F >= 2 || dyn)) {
             const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1u; // HW_REG_HW_ID[3:0] = wave slot
             __attribute__((address_space(3))) unsigned *flag = (__attribute__((address_space(3))) unsigned *)(lds + NSTAGE * STAGE_BYTES);
             if (tid == 0) *flag = slot;
@@ -255,7 +303,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
     unsigned long long pA = 0, pX1 = 0, pX2 = 0;
     int bm = 0, bn = 0;
     Seg cur{0, 0, 0, 0}, nxt{0, 0, 0, 0};
-    bool have = next_seg(cur);
+    bool have;
+    if (dyn) {
+        int t0 = -1, t1 = -1;
+        if (tid == 0) {
+            t0 = draw();
+            t1 = t0 >= 0 ? draw() : -1;
+            if (t1 < 0) { leave_queue(); dq_left = true; }
+        }
+        t0 = share(t0);
+        dq_pending = share(t1);
+        have = t0 >= 0;
+        cur = Seg{t0, 0, KP, 0};
+    } else {
+        have = next_seg(cur);
+    }
     if (have) {
         tile_coords(cur.tile, bm, bn);
         stream_ptrs(bm, bn, cur.kp0, pA, pX1, pX2);
@@ -264,7 +326,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         const int kp0 = cur.kp0, kp1 = cur.kp1;
         const int m0 = bm * BM, n0 = bn * BN;
         // the next segment (its first operands are prefetched by the tail of this one)
-        const bool have_next = next_seg(nxt);
+        bool have_next;
+        if (dyn) {
+            have_next = dq_pending >= 0;
+            nxt = Seg{dq_pending, 0, KP, 0};
+        } else {
+            have_next = next_seg(nxt);
+        }
         int nbm = 0, nbn = 0;
         unsigned ncnt = 0;
         unsigned long long nA = 0, nX1 = 0, nX2 = 0;
@@ -339,6 +407,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             pA = nA; pX1 = nX1; pX2 = nX2; // the next segment's bases (set by stream_ptrs above)
         }
         SVDQ_PROBE_STAMP(1);
+        int dq_drawn = -1;
+        if (dyn && have_next && tid == 0 && !dq_left) { // the tile after next: requested now, consumed behind the epilogue
+            dq_drawn = draw();
+            if (dq_drawn < 0) { leave_queue(); dq_left = true; }
+        }
 
         // ---- stream-K: publish or collect partial tiles -----------------------------------------------
         bool run_epilogue = true;
@@ -800,6 +873,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         } // FUSE != GELU_QUANT
         } // run_epilogue
         SVDQ_PROBE_STAMP(5);
+        if (dyn) dq_pending = have_next ? share(dq_drawn) : -1;
         SVDQ_PROBE_NEXT_SEGMENT();
         have = have_next;
         cur = nxt;
@@ -867,10 +941,14 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
     using G_ = Geo<NW>;
     const int tiles = (p.M_pad / G_::BM) * (p.N / BN), slots = device_cus() * G_::WG_PER_CU;
     p.sk_gs = with_ws ? streamk_groups_for(tiles, p.K / 128, slots) : 0;
-    dim3 grid(SVDQ_PROBE_GRID(persistent_grid(tiles, p.sk_gs, slots), tiles, slots)), block(G_::THREADS);
+    // dynamic tile queues (128 x 128 geometry): when every slot has more than one tile to do and the remainder is not
+    // better served by a K split (long K: few, long tiles -- a queue cannot balance 1.7 tiles per workgroup)
+    p.dynamic = NW == 4 && p.dynamic && with_ws && tiles > slots && p.sk_gs == 0;
+    int g = persistent_grid(tiles, p.sk_gs, slots);
+    if (p.dynamic) g = slots; // every CU hosts two workgroups; the queue balances them
+    dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
     hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ>), grid, block, 0, st, p);
 }
-
 template <int DT, int FUSE, int NW>
 static void launch_one(GemmParams &p, bool with_ws, hipStream_t st) {
     if (p.lora_fixed) launch_one_laq<DT, FUSE, NW, true>(p, with_ws, st);
@@ -971,7 +1049,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         set_error("svdq_gemm_w4a4: variant and reserved must be 0 (timing experiments live in tools/ablate, not in this library)");
         return SVDQ_E_INVALID;
     }
-    if (a->geometry < 0 || a->geometry > 3) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto), 1, 2 or 3"); return SVDQ_E_INVALID; }
+    if (a->geometry < 0 || a->geometry > 5) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto) .. 5"); return SVDQ_E_INVALID; }
     if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_gemm_w4a4: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
@@ -1065,7 +1143,8 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
 
     const bool with_ws = p.workspace && p.workspace_bytes >= workspace_bytes_needed();
     const int geo = pick_geometry(a);
-    p.stagger = geo == 2;
+    p.dynamic = geo == 2 || geo == 4;
+    p.stagger = geo == 4 || geo == 5;
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(0, 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
     if (geo == 1) {

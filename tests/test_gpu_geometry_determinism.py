@@ -1,8 +1,8 @@
 """Two properties of the round-3 GEMM that the oracle parity tests do not state:
 
-* the two workgroup geometries (256 x 128 tiles / one workgroup per CU; 128 x 128 tiles / two per CU, half a tile out of
-  phase) compute every output element with the same operations in the same order -- launches whose tiles are not split
-  along K are BIT-IDENTICAL across geometries, for every epilogue, bf16 and fp16;
+* the workgroup geometries and schedules (256 x 128 tiles / one workgroup per CU; 128 x 128 tiles / two per CU with tiles drawn
+  from per-XCD queues or from fixed lists) compute every output element with the same operations in the same order --
+  launches whose tiles are not split along K are BIT-IDENTICAL across them, for every epilogue, bf16 and fp16;
 * deterministic mode (nunchaku_amd.mode): the low-rank activations are accumulated as Q31.32 fixed point with integer
   atomics, so the K-sliced quantiser, the GELU epilogue's column-tile sum and the attention epilogue's head sum are
   bit-reproducible from run to run, and agree with the fp32 format to fp32 accuracy.  (The reference is non-deterministic
@@ -40,14 +40,16 @@ def _with_geometry(g, fn):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("M", [300, 1536])
-def test_geometries_are_bit_identical_without_k_split(dtype, M):
-    """K = 384 / 768: no stream-K split in either geometry (too few K-steps), so every epilogue must agree bit for bit.
-    Geometry 3 = geometry 2 without the phase offset (a scheduling hint only)."""
+@pytest.mark.parametrize("M,N", [(300, 768), (1536, 768), (4608, 3072)], ids=["M300", "M1536", "M4608-queued"])
+def test_geometries_are_bit_identical_without_k_split(dtype, M, N):
+    """K = 384 / N: no stream-K split in any geometry (too few K-steps), so every epilogue must agree bit for bit: 256 x 128
+    tiles (1), 128 x 128 tiles drawn from the per-XCD queues (2; at M = 4608 there are 864 tiles for 512 workgroups, so the
+    queues are really used -- the smaller cases fall back to fixed lists), fixed lists (3), and both with the phase offset
+    (4, 5).  Which workgroup computes a tile must not matter."""
     from nunchaku_amd import layout
     from nunchaku_amd.ops.fused import fused_gelu_mlp, fused_qkv_norm_rottary
 
-    K, N = 384, 768
+    K = 384
     L = O.make_svdq_layer(K, N, 32, seed=1, dtype=dtype, cheap=True)
     L2 = O.make_svdq_layer(N, K, 32, seed=2, dtype=dtype, cheap=True)
     mod, mod2 = make_module(L, dtype), make_module(L2, dtype, act_unsigned=True)
@@ -60,7 +62,7 @@ def test_geometries_are_bit_identical_without_k_split(dtype, M):
     M_pad = (M + 255) // 256 * 256
     ang = np.random.default_rng(0).uniform(0, 6.28, (M_pad, 64)).astype(np.float32)
     rot = torch.from_numpy(O.pack_rotemb_ref(np.stack([np.sin(ang), np.cos(ang)], -1).astype(np.float32))).cuda().view(1, M_pad, 128)
-    Lq = O.make_svdq_layer(K, 768, 32, seed=4, dtype=dtype, cheap=True)  # N = 768 = 3 * 2 heads * 128
+    Lq = O.make_svdq_layer(K, N, 32, seed=4, dtype=dtype, cheap=True)  # N = 3 * heads * 128
     modq = make_module(Lq, dtype)
 
     def run():
@@ -72,16 +74,16 @@ def test_geometries_are_bit_identical_without_k_split(dtype, M):
         svdq_gemm_w4a4_cuda(act=qx, wgt=mod.qweight, out=silu_out, ascales=asc, wscales=mod.wscales, lora_act_in=la, lora_up=mod.proj_up,
                             bias=mod.bias, fuse_silu=True)
         mlp = fused_gelu_mlp(x, mod, mod2)
-        vt = torch.zeros(256, M_pad, dtype=TORCH_DT[dtype], device="cuda")
+        vt = torch.zeros(N // 3, M_pad, dtype=TORCH_DT[dtype], device="cuda")
         qkv = fused_qkv_norm_rottary(x, modq, nq, nk, rot, out_vt=vt[:, :M])
-        return plain, silu_out, mlp, qkv[..., :512], vt
+        return plain, silu_out, mlp, qkv[..., : 2 * N // 3].clone(), vt
 
     from nunchaku_amd import mode
 
     with mode.deterministic_mode():  # (fp32 atomics in the low-rank sums would add run-to-run noise of their own)
         ref = _with_geometry(1, run)
-        got23 = {g: _with_geometry(g, run) for g in (2, 3)}
-    for g in (2, 3):
+        got23 = {g: _with_geometry(g, run) for g in (2, 3, 4, 5)}
+    for g in (2, 3, 4, 5):
         got = got23[g]
         for name, a, b in zip(("default", "silu", "gelu_mlp", "qk rope", "v^T"), ref, got):
             assert torch.equal(a, b), f"geometry {g} vs 1, {name}: {(a != b).float().mean():.2e} of the elements differ"
@@ -100,11 +102,12 @@ def test_geometry2_with_k_split_matches_oracle(dtype):
     ref = O.svdq_linear(x[rows], L, dtype, "fp32")["out"]
     outs = {}
     qx, asc, la = mod.quantize(xt.view(M, K))  # one quantiser run for both (its K-sliced low-rank sum uses fp32 atomics)
-    for g in (1, 2):
+    for g in (1, 2, 3):
         outs[g] = _with_geometry(g, lambda: mod.forward_quant(qx, asc, la)[None])
         # lora_act comes from the GPU quantiser (fp32 order differs from the oracle's float64): 1 ulp + rare flips
         assert_close_16(f32(outs[g])[0][rows], ref, dtype, f"geometry {g}", max_bad_frac=2e-3, ulps=1.0)
     assert_close_16(f32(outs[2]), f32(outs[1]), dtype, "geometry 2 vs 1", ulps=1.0)
+    assert torch.equal(outs[2], outs[3]), "long K: geometry 2 takes the fixed lists + stream-K of geometry 3"
     from nunchaku_amd._C import ops
 
     ops.gemm_workspace_status()
