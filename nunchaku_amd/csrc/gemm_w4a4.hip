@@ -74,8 +74,6 @@ constexpr int MAX_LORA_TILES = 16;             // R <= 256
 //           run half a tile out of phase, so one's epilogue (matrix pipe idle: 15-30 % of a K = 3072 tile) and its
 //           K-step barrier stalls sit under the other's main loop.
 // The wave tile (64 x 64 = 2 x 2 MFMA tiles), the register image of the loop and every epilogue's lane map are the same.
-#define SVDQ_GEMM_GEOMETRY_DEFAULT 1
-
 template <int NW> struct Geo {
     static constexpr int BM = 32 * NW;
     static constexpr int THREADS = 64 * NW;
@@ -124,6 +122,7 @@ struct GemmParams {
     long long workspace_bytes;
     int sk_gs;               // stream-K: workgroups sharing the remainder tiles (0 = whole tiles only); host heuristic
     int stagger;             // NW = 4: the second workgroup of a CU starts half a tile late
+    int xcd_walk;            // whole rounds are walked XCD-contiguously (tile_coords); 0 only in probe builds (A/B)
     int dynamic;             // NW = 4: tiles are drawn from per-XCD queues in the workspace instead of a fixed list per workgroup
     int *status;             // optional host-visible status word (svdq_gemm_args.status)
     int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
@@ -167,7 +166,19 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
     // 1024 x 1024 patch of the output that shares its activation and weight panels in that XCD's L2.
     const int G = gridDim.x;
     const int pos = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    // XCD-contiguous walk: the tiles of the whole rounds are renumbered so that the G/8 workgroups of XCD x walk ONE contiguous
+    // run of the strip enumeration, round after round (x * F * G/8 + i * G/8 + j), instead of jumping G tiles ahead each
+    // round: consecutive rounds of an XCD then stay inside one strip of 8 column tiles and find its weight panels (and part
+    // of the activation panels) still in that XCD's L2.  A bijection on the tile indices: the schedule (which workgroup, which
+    // round, stream-K remainder) is untouched, only which output tile an index means.
+    const int Fw = NT / G, G8 = G / 8;
+    const bool xcd_walk = p.xcd_walk && G % 8 == 0 && Fw >= 2 && !(NW == 4 && p.dynamic);
     auto tile_coords = [&](int t, int &bm, int &bn) {
+        if (xcd_walk && t < Fw * G) {
+            const int i = t / G, ps = t - i * G;
+            const int x = ps / G8, j = ps - x * G8;
+            t = (x * Fw + i) * G8 + j;
+        }
         const int strip = t / (8 * TM);
         const int w = min(8, TN - 8 * strip);
         const int r = t - strip * 8 * TM;
@@ -242,8 +253,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
     // Two workgroups share a CU's issue slots unevenly (the SIMD arbiter favours the older wave: one tenant finishes
     // 30-40 % earlier than the other, profiles/r3_gemm_placement.txt) and epilogues differ per tile, so a fixed tile list per
     // workgroup ends in a long tail of half-empty CUs.  Instead every workgroup DRAWS its tiles: the tile space is cut into
-    // chunks of 64 consecutive tiles (an 8 x 8 patch = 1024 x 1024 outputs sharing 8 activation and 8 weight panels), chunk c
-    // belongs to the queue of XCD c % 8, a workgroup takes tickets from the queue of the XCD it runs on (XCC_ID) -- so the
+    // chunks of 64 consecutive tiles (an 8 x 8 patch = 1024 x 1024 outputs sharing 8 activation and 8 weight panels), every XCD
+    // owns a contiguous run of chunks, a workgroup takes tickets from the queue of the XCD it runs on (XCC_ID) -- so the
     // tiles an XCD works on at a time still share its L2 -- and from the other XCDs' queues when its own is empty.  Thread 0
     // draws two tiles ahead (the main loop prefetches the next tile's first K-steps, so the next tile must be known at loop
     // entry); the draw is issued at the start of an epilogue and read at its end.  Results do not depend on who computes a tile.
@@ -257,11 +268,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         gqint *q = (gqint *)reinterpret_cast<int *>(p.workspace) + DQ_BASE;
         for (int a = 0; a < 8; a++) {
             const int x = (my_xcd + a) & 7;
-            if (x >= NC) continue;
-            int len = ((NC - x + 7) / 8) * 64;            // tiles of XCD x's chunks x, x + 8, ...
-            if ((NC - 1) % 8 == x) len -= NC * 64 - NT;   // the last chunk may be partial
+            // XCD x's queue: the contiguous run of chunks [x * NC / 8, (x + 1) * NC / 8) -- consecutive chunks of a run lie in
+            // the same strip of 8 column tiles, so its weight panels stay in the XCD's L2 from one chunk to the next
+            const int c0 = x * NC / 8, c1 = (x + 1) * NC / 8;
+            int len = (c1 - c0) * 64;
+            if (c1 == NC) len -= NC * 64 - NT;            // the very last chunk may be partial
+            if (len <= 0) continue;
             const int k = __hip_atomic_fetch_add(q + x * DQ_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k < len) return ((k >> 6) * 8 + x) * 64 + (k & 63);
+            if (k < len) return c0 * 64 + k;
         }
         return -1;
     };
@@ -931,9 +945,19 @@ static int persistent_grid(int tiles, int sk_gs, int slots) {
 }
 
 // Geometry of a launch (svdq_gemm_args.geometry; 0 = this heuristic).
-static int pick_geometry(const svdq_gemm_args *a) {
+// Measured rule (profiles/r3_gemm_geometry.txt): a tile costs the same CU-cycles in both geometries (the SIMDs are
+// throughput-bound in the loop AND in the epilogues: co-residency hides no work), so the 128 x 128 queue wins exactly where
+// the 256 x 128 schedule cannot use the chip evenly: whole rounds that leave >= 10 % of the CUs out (1296 tiles = 6 rounds
+// on 216 of 256 CUs), provided the queue has >= 2 tiles per workgroup to balance with.  Long K stays on geometry 1 (stream-K).
+static int pick_geometry(const svdq_gemm_args *a, bool with_ws) {
     if (a->geometry != 0) return a->geometry;
-    return SVDQ_GEMM_GEOMETRY_DEFAULT;
+    if (!with_ws) return 1;
+    const int cus = device_cus();
+    const int tiles1 = (a->M_pad / 256) * (a->N / BN), tiles2 = 2 * tiles1;
+    if (tiles1 <= cus || streamk_groups_for(tiles1, a->K / 128, cus) > 0) return 1;
+    const int rounds1 = (tiles1 + cus - 1) / cus;
+    const double use1 = (double)tiles1 / ((double)rounds1 * cus);
+    return (use1 < 0.9 && tiles2 >= 4 * cus) ? 2 : 1;
 }
 
 template <int DT, int FUSE, int NW, bool LAQ>
@@ -1138,11 +1162,12 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.M = a->M; p.M_pad = a->M_pad; p.N = a->N; p.K = a->K; p.R = a->R; p.R2 = a->R2; p.ldo = a->ldo;
     p.lora_fixed = a->lora_act_format;
     p.status = a->status;
+    p.xcd_walk = 1;
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;
     SVDQ_PROBE_FILL(p);
 
     const bool with_ws = p.workspace && p.workspace_bytes >= workspace_bytes_needed();
-    const int geo = pick_geometry(a);
+    const int geo = pick_geometry(a, with_ws);
     p.dynamic = geo == 2 || geo == 4;
     p.stagger = geo == 4 || geo == 5;
     hipStream_t st = (hipStream_t)stream;

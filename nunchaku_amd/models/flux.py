@@ -59,6 +59,25 @@ class _MLPEmbedder(nn.Module):
         return self.linear_2(F.silu(self.linear_1(x)))
 
 
+class _TimeTextEmbed(nn.Module):
+    """diffusers' CombinedTimestep(Guidance)TextProjEmbeddings: ``timestep_embedder`` / ``guidance_embedder`` / ``text_embedder``,
+    each ``linear_1 -> SiLU -> linear_2``."""
+
+    def __init__(self, dim, pooled_dim, guidance, dtype, device):
+        super().__init__()
+        self.timestep_embedder = _MLPEmbedder(256, dim, dtype, device)
+        self.guidance_embedder = _MLPEmbedder(256, dim, dtype, device) if guidance else None
+        self.text_embedder = _MLPEmbedder(pooled_dim, dim, dtype, device)
+
+
+class _AdaLNContinuous(nn.Module):
+    """diffusers' AdaLayerNormContinuous of the output head: ``linear`` (dim -> 2 dim); the LayerNorm has no parameters."""
+
+    def __init__(self, dim, dtype, device):
+        super().__init__()
+        self.linear = nn.Linear(dim, 2 * dim, dtype=dtype, device=device)
+
+
 class FluxAttentionAMD(nn.Module):
     """Joint (img + txt) or single-stream attention with fused QKV/RMSNorm/RoPE projections."""
 
@@ -68,7 +87,9 @@ class FluxAttentionAMD(nn.Module):
         self.to_qkv = SVDQW4A4Linear(dim, 3 * dim, **kw)
         self.norm_q = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=kw["torch_dtype"], device=kw["device"])
         self.norm_k = nn.RMSNorm(self.head_dim, eps=1e-6, dtype=kw["torch_dtype"], device=kw["device"])
-        self.to_out = SVDQW4A4Linear(dim, dim, **kw)
+        # diffusers' FluxAttention keeps `to_out = [Linear, Dropout]` in joint blocks (checkpoint key `attn.to_out.0`); the
+        # single blocks' output projection is the V2 key `attn.to_out` (transformer_flux_v2.py:564-625)
+        self.to_out = nn.ModuleList([SVDQW4A4Linear(dim, dim, **kw), nn.Identity()]) if joint else SVDQW4A4Linear(dim, dim, **kw)
         self.joint = joint
         self.added_kv_proj_dim = dim if joint else None  # the attribute the reference's processors test (flux.py:84,177)
         if joint:
@@ -85,6 +106,10 @@ class FluxAttentionAMD(nn.Module):
     grouped = True  # plain class attribute (set False for A/B runs); nothing is read from the environment
     # True: the attention epilogue emits the output projection's quantised activation (svdq_attention_args.qact)
     fused_out_quant = True
+
+    @property
+    def out_proj(self) -> SVDQW4A4Linear:
+        return self.to_out[0] if self.joint else self.to_out
 
     def _use_svdq(self, B, tokens):
         return self.attention_impl == "svdq" and B == 1 and self.head_dim == 128 and tokens % 128 == 0
@@ -116,18 +141,18 @@ class FluxAttentionAMD(nn.Module):
             fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary, output=qkv.view(B * tokens, -1),
                                    out_vt=vt, ln=ln, quantized=quantized)
         pool = None
-        if svdq and self.fused_out_quant and B == 1 and (not self.joint or (self.grouped and _pair_compatible(self.to_add_out, self.to_out))):
+        if svdq and self.fused_out_quant and B == 1 and (not self.joint or (self.grouped and _pair_compatible(self.to_add_out, self.out_proj))):
             src = ln_ctx if self.joint else ln  # the pool of the stream whose rows come first carries the scratch
             qpool = src[3] if src is not None and len(src) > 3 else None
-            qres = attention_packed_quantized(qkv[0], vt, self.heads, self.to_out, lin_first=self.to_add_out if self.joint else None,
+            qres = attention_packed_quantized(qkv[0], vt, self.heads, self.out_proj, lin_first=self.to_add_out if self.joint else None,
                                               split_rows=t_txt, pool=qpool)
             if qres is not None:  # the 16-bit attention output never exists: straight into the output projection(s)
                 if self.joint:
-                    ca, a = linear_pair_quantized(*qres, self.to_add_out, self.to_out, t_txt)
+                    ca, a = linear_pair_quantized(*qres, self.to_add_out, self.out_proj, t_txt)
                     return a, ca
-                return self.to_out.forward_quant(*qres).view(B, tokens, -1)
+                return self.out_proj.forward_quant(*qres).view(B, tokens, -1)
         if svdq:  # the same launch clears the low-rank accumulators of the output projections' quantisers
-            zf = _pad256(hidden.shape[1]) * self.to_out.rank + (_pad256(t_txt) * self.to_add_out.rank if self.joint else 0)
+            zf = _pad256(hidden.shape[1]) * self.out_proj.rank + (_pad256(t_txt) * self.to_add_out.rank if self.joint else 0)
             o, pool = attention_packed(qkv[0], vt, self.heads, zero_floats=zf)
             o = o.unsqueeze(0)
         else:
@@ -138,37 +163,74 @@ class FluxAttentionAMD(nn.Module):
             o = o.transpose(1, 2).reshape(B, -1, hd)
         if self.joint:
             if self.grouped and B == 1:
-                ca, a = linear_pair(o[:, :t_txt], self.to_add_out, o[:, t_txt:], self.to_out, pool=pool)
+                ca, a = linear_pair(o[:, :t_txt], self.to_add_out, o[:, t_txt:], self.out_proj, pool=pool)
                 return a, ca
-            return self.to_out(o[:, t_txt:], pool=pool), self.to_add_out(o[:, :t_txt], pool=pool)
-        return self.to_out(o, pool=pool)
+            return self.out_proj(o[:, t_txt:], pool=pool), self.to_add_out(o[:, :t_txt], pool=pool)
+        return self.out_proj(o, pool=pool)
+
+
+class _GELUProj(nn.Module):
+    """``net.0`` of a diffusers FeedForward(activation_fn="gelu-approximate"): holds ``proj``; the activation itself runs in
+    the projection's GEMM epilogue."""
+
+    def __init__(self, dim, hidden, kw):
+        super().__init__()
+        self.proj = SVDQW4A4Linear(dim, hidden, **kw)
 
 
 class _FeedForward(nn.Module):
-    """fc1 -> GELU(tanh) -> fc2 with the requantisation fused into fc1's epilogue
-    (reference: NunchakuFeedForward, models/attention.py:76-123)."""
+    """fc1 -> GELU(tanh) -> fc2 with the requantisation fused into fc1's epilogue (reference: NunchakuFeedForward,
+    models/attention.py:76-123).  Module names are diffusers' ``net = [GELU(proj), Dropout, Linear]``: checkpoint keys
+    ``ff.net.0.proj.*`` / ``ff.net.2.*``."""
 
     def __init__(self, dim, kw):
         super().__init__()
-        self.fc1 = SVDQW4A4Linear(dim, 4 * dim, **kw)
-        self.fc2 = SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})
+        self.net = nn.ModuleList([_GELUProj(dim, 4 * dim, kw), nn.Identity(), SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})])
+
+    @property
+    def fc1(self) -> SVDQW4A4Linear:
+        return self.net[0].proj
+
+    @property
+    def fc2(self) -> SVDQW4A4Linear:
+        return self.net[2]
 
     def forward(self, x, ln=None):
         return fused_gelu_mlp(x, self.fc1, self.fc2, ln=ln)
 
 
+class _AdaLNZero(nn.Module):
+    """Parameter holder with the reference's / diffusers' module name: ``norm1.linear`` = the AdaLayerNormZero modulation
+    projection, an AWQ W4A16 GEMV (normalization.py:85-98, linear.py:277-414).  The LayerNorm itself has no parameters and
+    runs inside the quantiser (fused path) or as a torch op (block forward)."""
+
+    def __init__(self, dim, chunks, dt, dev):
+        super().__init__()
+        self.linear = AWQW4A16Linear(dim, chunks * dim, torch_dtype=dt, device=dev)
+        self.linear.out_chunks = chunks  # the GEMV writes the `chunks` [dim] vectors contiguously
+
+
 class FluxJointBlockAMD(nn.Module):
+    """reference: NunchakuFluxTransformerBlock (transformer_flux_v2.py:143-257); same sub-module names, so a V2 checkpoint's
+    keys (``transformer_blocks.N.norm1.linear.qweight``, ``...attn.to_out.0.proj_up``, ``...ff.net.0.proj.wscales``) load as they are."""
+
     def __init__(self, dim, heads, kw):
         super().__init__()
         dt, dev = kw["torch_dtype"], kw["device"]
-        # AdaLayerNormZero.linear: AWQ W4A16 GEMV as in the reference (normalization.py:85-98, linear.py:277-414)
-        self.mod = AWQW4A16Linear(dim, 6 * dim, torch_dtype=dt, device=dev)
-        self.mod_context = AWQW4A16Linear(dim, 6 * dim, torch_dtype=dt, device=dev)
-        self.mod.out_chunks = self.mod_context.out_chunks = 6  # the GEMV writes the six [dim] vectors contiguously
+        self.norm1 = _AdaLNZero(dim, 6, dt, dev)
+        self.norm1_context = _AdaLNZero(dim, 6, dt, dev)
         self.attn = FluxAttentionAMD(dim, heads, True, kw)
         self.ff = _FeedForward(dim, kw)
         self.ff_context = _FeedForward(dim, kw)
         self.dim = dim
+
+    @property
+    def mod(self) -> AWQW4A16Linear:
+        return self.norm1.linear
+
+    @property
+    def mod_context(self) -> AWQW4A16Linear:
+        return self.norm1_context.linear
 
     @staticmethod
     def _ln_mod(x, scale, shift):
@@ -215,7 +277,7 @@ class FluxJointBlockAMD(nn.Module):
             ffc, ff = fused_gelu_mlp_pair(encoder_hidden, self.ff_context.fc1, self.ff_context.fc2, hidden, self.ff.fc1, self.ff.fc2,
                                           ln_a=(e_stats, c_scale_mlp, c_shift_mlp, e_pool), ln_b=(h_stats, scale_mlp, shift_mlp))
             encoder_hidden, e_stats, hidden, h_stats, e_pool = residual_gate_stats_pair(
-                encoder_hidden, ffc, c_gate_mlp, hidden, ff, gate_mlp, zero_floats=(mp_e + mp_h) * (self.attn.to_qkv.rank + self.attn.to_out.rank),
+                encoder_hidden, ffc, c_gate_mlp, hidden, ff, gate_mlp, zero_floats=(mp_e + mp_h) * (self.attn.to_qkv.rank + self.attn.out_proj.rank),
                 clamp_fp16_a=True)  # the reference clips the text stream at the end of an fp16 joint block
             return encoder_hidden, hidden, ((h_stats, None), (e_stats, e_pool))
         hidden, h_stats, h_pool = residual_gate_stats(hidden, a, gate_msa, zero_floats=mp_h * r_mlp)
@@ -229,14 +291,20 @@ class FluxJointBlockAMD(nn.Module):
 
 
 class FluxSingleBlockAMD(nn.Module):
+    """reference: NunchakuFluxSingleTransformerBlock (transformer_flux_v2.py:260-342): ``norm.linear``, ``attn.to_qkv``,
+    ``attn.to_out``, ``mlp_fc1``, ``mlp_fc2``."""
+
     def __init__(self, dim, heads, kw):
         super().__init__()
         dt, dev = kw["torch_dtype"], kw["device"]
-        self.mod = AWQW4A16Linear(dim, 3 * dim, torch_dtype=dt, device=dev)  # AdaLayerNormZeroSingle.linear (:155-165)
-        self.mod.out_chunks = 3
+        self.norm = _AdaLNZero(dim, 3, dt, dev)  # AdaLayerNormZeroSingle.linear (normalization.py:155-165)
         self.mlp_fc1 = SVDQW4A4Linear(dim, 4 * dim, **kw)
         self.mlp_fc2 = SVDQW4A4Linear(4 * dim, dim, **{**kw, "act_unsigned": True})
         self.attn = FluxAttentionAMD(dim, heads, False, kw)
+
+    @property
+    def mod(self) -> AWQW4A16Linear:
+        return self.norm.linear
 
     def forward(self, hidden, temb_act, rotary, stats=None, mods=None):
         if stats is None:
@@ -257,12 +325,16 @@ class FluxSingleBlockAMD(nn.Module):
         att = self.attn(hidden, rotary=rotary, ln=ln, quantized=q_qkv)
         # hidden + gate * (att + mlp), the next block's statistics and its three low-rank accumulators, one pass
         hidden, st, pool = residual_gate_stats(hidden, att, gate, b=mlp, zero_floats=_pad256(hidden.shape[1]) * (
-            self.mlp_fc1.rank + self.mlp_fc2.rank + self.attn.to_qkv.rank + self.attn.to_out.rank), clamp_fp16=True)
+            self.mlp_fc1.rank + self.mlp_fc2.rank + self.attn.to_qkv.rank + self.attn.out_proj.rank), clamp_fp16=True)
         return hidden, (st, pool)
 
 
-class FluxTransformerAMD(nn.Module):
-    """One denoising step: ``forward(latents, text states, pooled text, timestep, guidance, ids)``."""
+class FluxEngineMixin:
+    """Everything of the FLUX.1 transformer that is not construction: the denoising-step forward over the module tree
+    ``x_embedder / context_embedder / time_text_embed / transformer_blocks / single_transformer_blocks / norm_out / proj_out``
+    (diffusers' names), the runtime-LoRA entry points and the synthetic initialiser.  Shared by the stand-alone
+    :class:`FluxTransformerAMD` and -- when diffusers is importable -- the ``diffusers.FluxTransformer2DModel`` subclass of
+    nunchaku_amd/models/transformer_flux.py, whose sub-modules are these same classes."""
 
     # True: AdaLayerNormZero runs inside the quantisers and the gated residuals are one fused pass each
     # (svdq_quantize_args.ln_stats, svdq_residual_gate_stats); False: the reference's torch-op sequence.
@@ -270,22 +342,46 @@ class FluxTransformerAMD(nn.Module):
     # True: all modulation GEMVs of a step in one batched launch before the first block
     batched_mods = True
 
-    def __init__(self, num_layers=19, num_single_layers=38, dim=3072, heads=24, in_channels=64,
-                 joint_attention_dim=4096, pooled_projection_dim=768, rank=32, guidance_embeds=True,
-                 axes_dims_rope=(16, 56, 56), torch_dtype=torch.bfloat16, device="cuda"):
-        super().__init__()
+    def _build_engine(self, num_layers=19, num_single_layers=38, dim=3072, heads=24, in_channels=64,
+                      joint_attention_dim=4096, pooled_projection_dim=768, rank=32, guidance_embeds=True,
+                      axes_dims_rope=(16, 56, 56), torch_dtype=torch.bfloat16, device="cuda"):
+        """Create (or replace) the module tree on ``device``; parameters are uninitialised (load a checkpoint next)."""
         kw = dict(rank=rank, torch_dtype=torch_dtype, device=device)
         self.dim, self.axes = dim, tuple(axes_dims_rope)
         self.x_embedder = nn.Linear(in_channels, dim, dtype=torch_dtype, device=device)
         self.context_embedder = nn.Linear(joint_attention_dim, dim, dtype=torch_dtype, device=device)
-        self.time_embed = _MLPEmbedder(256, dim, torch_dtype, device)
-        self.guidance_embed = _MLPEmbedder(256, dim, torch_dtype, device) if guidance_embeds else None
-        self.text_embed = _MLPEmbedder(pooled_projection_dim, dim, torch_dtype, device)
-        self.blocks = nn.ModuleList([FluxJointBlockAMD(dim, heads, kw) for _ in range(num_layers)])
-        self.single_blocks = nn.ModuleList([FluxSingleBlockAMD(dim, heads, kw) for _ in range(num_single_layers)])
-        self.norm_out_mod = nn.Linear(dim, 2 * dim, dtype=torch_dtype, device=device)
+        # module names = diffusers' FluxTransformer2DModel / the reference's V2 model: V2 checkpoints load key for key
+        self.time_text_embed = _TimeTextEmbed(dim, pooled_projection_dim, guidance_embeds, torch_dtype, device)
+        self.transformer_blocks = nn.ModuleList([FluxJointBlockAMD(dim, heads, kw) for _ in range(num_layers)])
+        self.single_transformer_blocks = nn.ModuleList([FluxSingleBlockAMD(dim, heads, kw) for _ in range(num_single_layers)])
+        self.norm_out = _AdaLNContinuous(dim, torch_dtype, device)
         self.proj_out = nn.Linear(dim, in_channels, dtype=torch_dtype, device=device)
         self.dtype_ = torch_dtype
+
+    # short names used throughout this package (and by its tests / tools)
+    @property
+    def blocks(self):
+        return self.transformer_blocks
+
+    @property
+    def single_blocks(self):
+        return self.single_transformer_blocks
+
+    @property
+    def time_embed(self):
+        return self.time_text_embed.timestep_embedder
+
+    @property
+    def guidance_embed(self):
+        return self.time_text_embed.guidance_embedder
+
+    @property
+    def text_embed(self):
+        return self.time_text_embed.text_embedder
+
+    @property
+    def norm_out_mod(self):
+        return self.norm_out.linear
 
     def svdq_layers(self):
         return [m for m in self.modules() if isinstance(m, SVDQW4A4Linear)]
@@ -370,8 +466,8 @@ class FluxTransformerAMD(nn.Module):
                 m.weight.fill_(1.0)
         return self
 
-    def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
-                guidance=None):
+    def engine_forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                       guidance=None):
         """hidden_states [1, T_img, 64]; encoder_hidden_states [1, T_txt, 4096]; pooled [1, 768];
         timestep/guidance [1]; img_ids [T_img, 3]; txt_ids [T_txt, 3]  ->  [1, T_img, 64]
         (transformer_flux_v2.py:430-561; batch 1 -- the fused QKV epilogue takes one rotary table)."""
@@ -382,7 +478,7 @@ class FluxTransformerAMD(nn.Module):
             # is a loop over samples here -- the data-parallel unit of this library is the replica, not the batch axis.
             def per(t, i):
                 return t[i:i + 1] if t is not None and t.dim() > 0 and t.shape[0] == hidden_states.shape[0] else t
-            return torch.cat([self.forward(hidden_states[i:i + 1], encoder_hidden_states[i:i + 1], pooled_projections[i:i + 1],
+            return torch.cat([self.engine_forward(hidden_states[i:i + 1], encoder_hidden_states[i:i + 1], pooled_projections[i:i + 1],
                                            per(timestep, i), img_ids, txt_ids, per(guidance, i))
                               for i in range(hidden_states.shape[0])], dim=0)
         hidden = self.x_embedder(hidden_states)
@@ -417,3 +513,17 @@ class FluxTransformerAMD(nn.Module):
         scale, shift = self.norm_out_mod(temb_act).chunk(2, dim=-1)  # AdaLayerNormContinuous
         hidden = F.layer_norm(hidden, (self.dim,), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]
         return self.proj_out(hidden)
+
+
+class FluxTransformerAMD(nn.Module, FluxEngineMixin):
+    """One denoising step: ``forward(latents, text states, pooled text, timestep, guidance, ids)`` (stand-alone; no diffusers)."""
+
+    def __init__(self, num_layers=19, num_single_layers=38, dim=3072, heads=24, in_channels=64,
+                 joint_attention_dim=4096, pooled_projection_dim=768, rank=32, guidance_embeds=True,
+                 axes_dims_rope=(16, 56, 56), torch_dtype=torch.bfloat16, device="cuda"):
+        super().__init__()
+        self._build_engine(num_layers, num_single_layers, dim, heads, in_channels, joint_attention_dim, pooled_projection_dim,
+                           rank, guidance_embeds, axes_dims_rope, torch_dtype, device)
+
+    def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance=None):
+        return self.engine_forward(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance)

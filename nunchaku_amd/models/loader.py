@@ -4,7 +4,7 @@ Reference: ``NunchakuFluxTransformer2DModelV2.from_pretrained`` (nunchaku/models
 373-428) = safetensors file with a ``config`` / ``quantization_config`` metadata header -> ``convert_flux_state_dict``
 (:564-625, legacy C++-model key names -> V2 module names) -> ``patch_scale_key`` (transformers/utils.py:151-173) ->
 ``load_state_dict``.  Here the same file loads into :class:`FluxTransformerAMD`: the key conversion goes from either
-naming (legacy or V2) to this package's module names, NVFP4-only tensors (``wtscale`` / ``wcscales``) are dropped, and
+naming to V2 naming -- which is this package's own (module names follow diffusers' FluxTransformer2DModel) --, NVFP4-only tensors (``wtscale`` / ``wcscales``) are dropped, and
 the SVDQuant tensors are re-laid out for CDNA4 lazily by ``SVDQW4A4Linear.repack_()`` on first use (AWQ tensors are
 consumed as stored).  Pure host-side code: no kernels, testable without a GPU.
 """
@@ -19,41 +19,35 @@ import torch
 
 from .flux import FluxTransformerAMD
 
-# (legacy name, V2 name, name here) of the sub-modules of a joint block / a single block
+# (legacy name, V2 name) of the sub-modules of a joint block / a single block.  FluxTransformerAMD's own module names ARE the V2
+# (diffusers) names, so a V2 state dict loads key for key and only the legacy (C++ model) spelling needs conversion.
 _JOINT = [
-    ("norm1.linear", "norm1.linear", "mod"),
-    ("norm1_context.linear", "norm1_context.linear", "mod_context"),
-    ("qkv_proj_context", "attn.add_qkv_proj", "attn.add_qkv_proj"),
-    ("qkv_proj", "attn.to_qkv", "attn.to_qkv"),
-    ("norm_added_q", "attn.norm_added_q", "attn.norm_added_q"),
-    ("norm_added_k", "attn.norm_added_k", "attn.norm_added_k"),
-    ("norm_q", "attn.norm_q", "attn.norm_q"),
-    ("norm_k", "attn.norm_k", "attn.norm_k"),
-    ("out_proj_context", "attn.to_add_out", "attn.to_add_out"),
-    ("out_proj", "attn.to_out.0", "attn.to_out"),
-    ("mlp_context_fc1", "ff_context.net.0.proj", "ff_context.fc1"),
-    ("mlp_context_fc2", "ff_context.net.2", "ff_context.fc2"),
-    ("mlp_fc1", "ff.net.0.proj", "ff.fc1"),
-    ("mlp_fc2", "ff.net.2", "ff.fc2"),
+    ("norm1.linear", "norm1.linear"),
+    ("norm1_context.linear", "norm1_context.linear"),
+    ("qkv_proj_context", "attn.add_qkv_proj"),
+    ("qkv_proj", "attn.to_qkv"),
+    ("norm_added_q", "attn.norm_added_q"),
+    ("norm_added_k", "attn.norm_added_k"),
+    ("norm_q", "attn.norm_q"),
+    ("norm_k", "attn.norm_k"),
+    ("out_proj_context", "attn.to_add_out"),
+    ("out_proj", "attn.to_out.0"),
+    ("mlp_context_fc1", "ff_context.net.0.proj"),
+    ("mlp_context_fc2", "ff_context.net.2"),
+    ("mlp_fc1", "ff.net.0.proj"),
+    ("mlp_fc2", "ff.net.2"),
 ]
 _SINGLE = [
-    ("norm.linear", "norm.linear", "mod"),
-    ("qkv_proj", "attn.to_qkv", "attn.to_qkv"),
-    ("norm_q", "attn.norm_q", "attn.norm_q"),
-    ("norm_k", "attn.norm_k", "attn.norm_k"),
-    ("out_proj", "attn.to_out", "attn.to_out"),
-    ("mlp_fc1", "mlp_fc1", "mlp_fc1"),
-    ("mlp_fc2", "mlp_fc2", "mlp_fc2"),
+    ("norm.linear", "norm.linear"),
+    ("qkv_proj", "attn.to_qkv"),
+    ("norm_q", "attn.norm_q"),
+    ("norm_k", "attn.norm_k"),
+    ("out_proj", "attn.to_out"),
+    ("mlp_fc1", "mlp_fc1"),
+    ("mlp_fc2", "mlp_fc2"),
 ]
-_TOP = [  # diffusers FluxTransformer2DModel names of the 16-bit parts -> names here
-    ("time_text_embed.timestep_embedder", "time_embed"),
-    ("time_text_embed.guidance_embedder", "guidance_embed"),
-    ("time_text_embed.text_embedder", "text_embed"),
-    ("norm_out.linear", "norm_out_mod"),
-    ("x_embedder", "x_embedder"),
-    ("context_embedder", "context_embedder"),
-    ("proj_out", "proj_out"),
-]
+_TOP = ("time_text_embed.timestep_embedder", "time_text_embed.guidance_embedder", "time_text_embed.text_embedder",
+        "norm_out.linear", "x_embedder", "context_embedder", "proj_out")  # the 16-bit parts: diffusers names, unchanged
 # legacy -> V2 parameter names of an SVDQuant layer (transformer_flux_v2.py:595-601)
 _PARAM = [("lora_down", "proj_down"), ("lora_up", "proj_up"), ("smooth_orig", "smooth_factor_orig"), ("smooth", "smooth_factor")]
 _DROP = ("wtscale", "wcscales")  # NVFP4 only (patch_scale_key pops / defaults them)
@@ -67,27 +61,27 @@ def _convert_param(rest: str) -> str:
 
 
 def convert_key(key: str) -> str | None:
-    """One checkpoint key (legacy or V2 naming) -> the FluxTransformerAMD state-dict key, or None for a tensor this
+    """One checkpoint key (legacy or V2 naming) -> the V2 / FluxTransformerAMD state-dict key, or None for a tensor this
     model does not use.  Raises ``KeyError`` for a name it does not recognise."""
     if key.rsplit(".", 1)[-1] in _DROP:
         return None
     m = re.match(r"(single_transformer_blocks|transformer_blocks)\.(\d+)\.(.+)$", key)
     if m:
         kind, idx, rest = m.groups()
-        table, prefix = (_SINGLE, "single_blocks") if kind.startswith("single") else (_JOINT, "blocks")
-        for legacy, v2, mine in table:
+        table = _SINGLE if kind.startswith("single") else _JOINT
+        for legacy, v2 in table:
             for src in (v2, legacy):
                 if rest.startswith(src + "."):
-                    return f"{prefix}.{idx}.{mine}.{_convert_param(rest[len(src) + 1:])}"
+                    return f"{kind}.{idx}.{v2}.{_convert_param(rest[len(src) + 1:])}"
         raise KeyError(f"unrecognised FLUX block tensor: {key}")
-    for src, mine in _TOP:
+    for src in _TOP:
         if key.startswith(src + "."):
-            return f"{mine}.{key[len(src) + 1:]}"
+            return key
     raise KeyError(f"unrecognised FLUX tensor: {key}")
 
 
 def convert_flux_state_dict(state_dict: dict) -> dict:
-    """Checkpoint state dict (legacy ``NunchakuFluxTransformer2dModel`` or V2 naming) -> FluxTransformerAMD naming."""
+    """Checkpoint state dict (legacy ``NunchakuFluxTransformer2dModel`` or V2 naming) -> V2 naming (= this package's)."""
     out = {}
     for k, v in state_dict.items():
         nk = convert_key(k)
@@ -100,29 +94,25 @@ def convert_flux_state_dict(state_dict: dict) -> dict:
 
 
 def export_legacy_state_dict(model: FluxTransformerAMD) -> dict:
-    """Inverse of :func:`convert_flux_state_dict`: FluxTransformerAMD names -> the reference's legacy names.  Works before
-    and after the first forward: ``state_dict()`` of a repacked ``SVDQW4A4Linear`` returns checkpoint-layout tensors."""
+    """Inverse of :func:`convert_flux_state_dict`: V2 names -> the reference's legacy names.  Works before and after the first
+    forward: ``state_dict()`` of a repacked ``SVDQW4A4Linear`` returns checkpoint-layout tensors."""
     inv_param = {new: old for old, new in _PARAM}
     out = {}
     for k, v in model.state_dict().items():
-        m = re.match(r"(single_blocks|blocks)\.(\d+)\.(.+)$", k)
+        m = re.match(r"(single_transformer_blocks|transformer_blocks)\.(\d+)\.(.+)$", k)
         if m:
             kind, idx, rest = m.groups()
-            table, prefix = (_SINGLE, "single_transformer_blocks") if kind == "single_blocks" else (_JOINT, "transformer_blocks")
-            for legacy, _, mine in table:
-                if rest.startswith(mine + "."):
-                    p = rest[len(mine) + 1:]
-                    out[f"{prefix}.{idx}.{legacy}.{inv_param.get(p, p)}"] = v
+            for legacy, v2 in (_SINGLE if kind.startswith("single") else _JOINT):
+                if rest.startswith(v2 + "."):
+                    p = rest[len(v2) + 1:]
+                    out[f"{kind}.{idx}.{legacy}.{inv_param.get(p, p)}"] = v
                     break
             else:
                 raise KeyError(k)
             continue
-        for src, mine in _TOP:
-            if k.startswith(mine + "."):
-                out[f"{src}.{k[len(mine) + 1:]}"] = v
-                break
-        else:
+        if not k.startswith(tuple(t + "." for t in _TOP)):
             raise KeyError(k)
+        out[k] = v
     return out
 
 

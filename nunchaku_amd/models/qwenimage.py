@@ -19,6 +19,7 @@ on the attention module selects the reference's op-for-op sequence (plain projec
 
 from __future__ import annotations
 
+import json
 import math
 from types import SimpleNamespace
 
@@ -32,6 +33,7 @@ from ..utils import pad_tensor
 from .embeddings import pack_rotemb
 from .linear import AWQW4A16Linear, SVDQW4A4Linear
 from .offload import CPUOffloadManager
+from .transformer_flux import NunchakuModelLoaderMixin
 
 
 def _pad256(n: int) -> int:
@@ -246,39 +248,98 @@ class _TimestepEmbed(nn.Module):
         return self.timestep_embedder["linear_2"](F.silu(self.timestep_embedder["linear_1"](emb)))
 
 
-class NunchakuQwenImageTransformer2DModel(nn.Module):
-    """reference :309-560 (``diffusers.QwenImageTransformer2DModel`` subclass there; diffusers is not a dependency here,
-    the pipeline duck-types its transformer): 60 dual-stream blocks, ``set_offload`` for layer-wise host offload."""
+try:  # guarded, as transformer_flux.py: a real diffusers subclass when diffusers is importable
+    from diffusers import QwenImageTransformer2DModel as _DiffusersQwen
+
+    HAVE_DIFFUSERS_QWEN = True
+except Exception:
+    _DiffusersQwen = None
+    HAVE_DIFFUSERS_QWEN = False
+
+_QWEN_DEFAULT_CONFIG = dict(num_layers=60, num_attention_heads=24, attention_head_dim=128, in_channels=64, out_channels=16,
+                            joint_attention_dim=3584, patch_size=2, axes_dims_rope=(16, 56, 56), guidance_embeds=False)
+
+
+class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN else nn.Module, NunchakuModelLoaderMixin):
+    """reference :309-560 (a ``diffusers.QwenImageTransformer2DModel`` subclass + ``NunchakuModelLoaderMixin``; here the same
+    when diffusers is importable -- skeleton on the meta device, every parametrised sub-module replaced under its diffusers
+    name by ``_patch_model`` -- and a plain ``nn.Module`` with the pipeline's call contract otherwise): 60 dual-stream blocks,
+    ``from_pretrained`` for nunchaku ``.safetensors`` checkpoints, ``set_offload`` for layer-wise host offload."""
 
     def __init__(self, num_layers: int = 60, num_attention_heads: int = 24, attention_head_dim: int = 128, in_channels: int = 64,
                  out_channels: int = 16, joint_attention_dim: int = 3584, patch_size: int = 2, axes_dims_rope=(16, 56, 56),
-                 rank: int = 32, torch_dtype: torch.dtype = torch.bfloat16, device="cuda"):
-        super().__init__()
-        dim = num_attention_heads * attention_head_dim
-        self.inner_dim, self.axes = dim, tuple(axes_dims_rope)
-        self.config = SimpleNamespace(num_layers=num_layers, num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
-                                      in_channels=in_channels, out_channels=out_channels, joint_attention_dim=joint_attention_dim,
-                                      patch_size=patch_size, axes_dims_rope=self.axes, guidance_embeds=False)
+                 rank: int = 32, torch_dtype: torch.dtype = torch.bfloat16, device="cuda", guidance_embeds: bool = False,
+                 _patch: bool = True, **kwargs):
+        self.offload = kwargs.pop("offload", False) and False  # set_offload() switches it on once the weights are loaded
+        self.offload_manager = None
+        cfg = dict(num_layers=num_layers, num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+                   in_channels=in_channels, out_channels=out_channels, joint_attention_dim=joint_attention_dim, patch_size=patch_size,
+                   axes_dims_rope=tuple(axes_dims_rope), guidance_embeds=guidance_embeds)
+        if HAVE_DIFFUSERS_QWEN:
+            with torch.device("meta"):
+                super().__init__(**cfg, **kwargs)
+        else:
+            nn.Module.__init__(self)
+            self.config = SimpleNamespace(**cfg)
+        self.offload, self.offload_manager = False, None
+        if _patch:
+            self._patch_model(rank=rank, torch_dtype=torch_dtype, device=device)
+
+    def _patch_model(self, rank: int = 32, torch_dtype: torch.dtype = torch.bfloat16, device="cuda", **kwargs):
+        """reference :339-356 -- the blocks (and here every other parametrised module: the skeleton is on the meta device)."""
+        if kwargs.get("precision", "int4") not in ("int4",):
+            raise NotImplementedError("NVFP4 checkpoints need Blackwell's block-scaled mma; use the int4 checkpoint on MI355X")
+        c = self.config
+        get = (lambda k: c[k]) if hasattr(c, "keys") else (lambda k: getattr(c, k))
+        heads, hd = get("num_attention_heads"), get("attention_head_dim")
+        dim = heads * hd
+        self.inner_dim, self.axes = dim, tuple(get("axes_dims_rope"))
         self.time_text_embed = _TimestepEmbed(dim, torch_dtype, device)
-        self.txt_norm = nn.RMSNorm(joint_attention_dim, eps=1e-6, dtype=torch_dtype, device=device)
-        self.img_in = nn.Linear(in_channels, dim, dtype=torch_dtype, device=device)
-        self.txt_in = nn.Linear(joint_attention_dim, dim, dtype=torch_dtype, device=device)
+        self.txt_norm = nn.RMSNorm(get("joint_attention_dim"), eps=1e-6, dtype=torch_dtype, device=device)
+        self.img_in = nn.Linear(get("in_channels"), dim, dtype=torch_dtype, device=device)
+        self.txt_in = nn.Linear(get("joint_attention_dim"), dim, dtype=torch_dtype, device=device)
         self.transformer_blocks = nn.ModuleList([
-            NunchakuQwenImageTransformerBlock(dim, num_attention_heads, attention_head_dim, rank=rank, torch_dtype=torch_dtype, device=device)
-            for _ in range(num_layers)])
+            NunchakuQwenImageTransformerBlock(dim, heads, hd, rank=rank, torch_dtype=torch_dtype, device=device)
+            for _ in range(get("num_layers"))])
         self.norm_out = nn.ModuleDict({"linear": nn.Linear(dim, 2 * dim, dtype=torch_dtype, device=device)})  # AdaLayerNormContinuous
-        self.proj_out = nn.Linear(dim, patch_size * patch_size * out_channels, dtype=torch_dtype, device=device)
+        self.proj_out = nn.Linear(dim, get("patch_size") ** 2 * get("out_channels"), dtype=torch_dtype, device=device)
+        if hasattr(self, "pos_embed"):
+            self.pos_embed = nn.Identity()  # rotary tables: qwen_rope_freqs (restated QwenEmbedRope)
         self.dtype_ = torch_dtype
-        self.offload = False
-        self.offload_manager: CPUOffloadManager | None = None
+        self._is_initialized = True
+        return self
 
-    @property
-    def dtype(self):
-        return self.dtype_
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
+        """A nunchaku Qwen-Image ``.safetensors`` file (reference :358-413): the checkpoint's keys ARE the module names of this
+        class (``transformer_blocks.N.attn.to_qkv.qweight`` ...), NVFP4-only tensors are dropped, ``offload=True`` switches the
+        layer-wise host offload on after loading."""
+        sd, meta = cls._read_safetensors(pretrained_model_name_or_path)
+        config = dict(_QWEN_DEFAULT_CONFIG)
+        config.update({k: v for k, v in json.loads(meta.get("config", "{}")).items() if k in _QWEN_DEFAULT_CONFIG})
+        qcfg = json.loads(meta.get("quantization_config", "{}"))
+        if any(k.endswith(".wcscales") for k in sd) or qcfg.get("weight", {}).get("dtype", "int4") not in ("int4",):
+            raise NotImplementedError("NVFP4 checkpoints need Blackwell's block-scaled mma; use the int4 checkpoint on MI355X")
+        model = cls(**config, rank=qcfg.get("rank", 32), torch_dtype=kwargs.get("torch_dtype", torch.bfloat16), device=kwargs.get("device", "cuda"))
+        sd = {k: v for k, v in sd.items() if k.rsplit(".", 1)[-1] not in ("wtscale", "wcscales")}  # patch_scale_key (utils.py:151-173)
+        own = dict(model.named_parameters())
+        for k, v in sd.items():
+            if k in own and own[k].dtype != v.dtype:
+                raise TypeError(f"{k}: checkpoint dtype {v.dtype} != model dtype {own[k].dtype}")
+        model.load_state_dict(sd)
+        if kwargs.get("offload", False):
+            model.set_offload(True, **{k: kwargs[k] for k in ("num_blocks_on_gpu", "use_pin_memory", "num_slots") if k in kwargs})
+        return model
 
-    @property
-    def device(self):
-        return self.proj_out.weight.device
+    if not HAVE_DIFFUSERS_QWEN:  # ModelMixin provides these
+
+        @property
+        def dtype(self):
+            return self.dtype_
+
+        @property
+        def device(self):
+            return self.proj_out.weight.device
 
     def svdq_layers(self):
         return [m for m in self.modules() if isinstance(m, SVDQW4A4Linear)]

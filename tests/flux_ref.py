@@ -72,24 +72,24 @@ class Ref:
         rot = flux_pos_embed(torch.cat([txt_ids, img_ids], 0), m.axes)[0, :, :, 0].numpy()  # [T, 64, (sin, cos)]
         tt = e.shape[0]
         b = m.blocks[0]
-        mm = self.awq("blocks.0.mod", ta).view(-1, 6).T
-        cc = self.awq("blocks.0.mod_context", ta).view(-1, 6).T
+        mm = self.awq("transformer_blocks.0.norm1.linear", ta).view(-1, 6).T
+        cc = self.awq("transformer_blocks.0.norm1_context.linear", ta).view(-1, 6).T
         n_h, n_e = self.ln_mod(hidden, mm[1], mm[0]), self.ln_mod(e, cc[1], cc[0])
-        qkv = torch.cat([self.qkv("blocks.0.attn.add_qkv_proj", n_e, b.attn.norm_added_q.weight, b.attn.norm_added_k.weight, rot[:tt]),
-                         self.qkv("blocks.0.attn.to_qkv", n_h, b.attn.norm_q.weight, b.attn.norm_k.weight, rot[tt:])])
+        qkv = torch.cat([self.qkv("transformer_blocks.0.attn.add_qkv_proj", n_e, b.attn.norm_added_q.weight, b.attn.norm_added_k.weight, rot[:tt]),
+                         self.qkv("transformer_blocks.0.attn.to_qkv", n_h, b.attn.norm_q.weight, b.attn.norm_k.weight, rot[tt:])])
         o = self.attend(qkv, b.attn.heads)
-        a, ca = self.svdq("blocks.0.attn.to_out", o[tt:]), self.svdq("blocks.0.attn.to_add_out", o[:tt])
+        a, ca = self.svdq("transformer_blocks.0.attn.to_out.0", o[tt:]), self.svdq("transformer_blocks.0.attn.to_add_out", o[:tt])
         hidden = r16(hidden + r16(mm[2][None] * a))
-        hidden = r16(hidden + r16(mm[5][None] * self.mlp("blocks.0.ff.fc1", "blocks.0.ff.fc2", self.ln_mod(hidden, mm[4], mm[3]))))
+        hidden = r16(hidden + r16(mm[5][None] * self.mlp("transformer_blocks.0.ff.net.0.proj", "transformer_blocks.0.ff.net.2", self.ln_mod(hidden, mm[4], mm[3]))))
         e = r16(e + r16(cc[2][None] * ca))
-        e = r16(e + r16(cc[5][None] * self.mlp("blocks.0.ff_context.fc1", "blocks.0.ff_context.fc2", self.ln_mod(e, cc[4], cc[3]))))
+        e = r16(e + r16(cc[5][None] * self.mlp("transformer_blocks.0.ff_context.net.0.proj", "transformer_blocks.0.ff_context.net.2", self.ln_mod(e, cc[4], cc[3]))))
         x = torch.cat([e, hidden])
         s = m.single_blocks[0]
-        sm = self.awq("single_blocks.0.mod", ta).view(-1, 3).T
+        sm = self.awq("single_transformer_blocks.0.norm.linear", ta).view(-1, 3).T
         n = self.ln_mod(x, sm[1], sm[0])
-        mlp = self.mlp("single_blocks.0.mlp_fc1", "single_blocks.0.mlp_fc2", n)
-        att = self.svdq("single_blocks.0.attn.to_out",
-                        self.attend(self.qkv("single_blocks.0.attn.to_qkv", n, s.attn.norm_q.weight, s.attn.norm_k.weight, rot), s.attn.heads))
+        mlp = self.mlp("single_transformer_blocks.0.mlp_fc1", "single_transformer_blocks.0.mlp_fc2", n)
+        att = self.svdq("single_transformer_blocks.0.attn.to_out",
+                        self.attend(self.qkv("single_transformer_blocks.0.attn.to_qkv", n, s.attn.norm_q.weight, s.attn.norm_k.weight, rot), s.attn.heads))
         x = r16(x + r16(sm[2][None] * r16(att + mlp)))[tt:]
         sc, sh = self.lin(m.norm_out_mod, ta).chunk(2, dim=-1)
         x = r16(r16(F.layer_norm(x, (x.shape[-1],), eps=1e-6)) * r16(1 + sc) + sh)

@@ -15,7 +15,8 @@ def _small(device="cpu"):
 
 
 def test_key_conversion_agrees_with_reference_converter(golden_dir):
-    """legacy key -> (reference converter) V2 key; both spellings must land on the same parameter here."""
+    """legacy key -> (reference converter) V2 key: this package's converter must produce EXACTLY the reference's V2 key (its
+    module tree uses the V2 / diffusers names), and a V2 key must pass through unchanged."""
     table = json.load(open(f"{golden_dir}/flux_keys.json"))
     assert len(table) > 100
     own = set(_small().state_dict().keys())
@@ -24,12 +25,13 @@ def test_key_conversion_agrees_with_reference_converter(golden_dir):
         a, b = loader.convert_key(legacy), loader.convert_key(v2)
         assert a == b, (legacy, v2, a, b)
         if a is not None:
+            assert a == v2, f"{legacy}: converted to {a}, the reference's convert_flux_state_dict gives {v2}"
             import re
             a = re.sub(r"blocks\.(18|37)\.", "blocks.1.", a)  # the fixture names FLUX.1's last blocks; the test model has two
             assert a in own, f"{legacy} -> {a} is not a parameter of FluxTransformerAMD"
             seen.add(a)
     # every SVDQ / AWQ / norm parameter of block 0 and single block 0 is reachable from a checkpoint key
-    need = {k for k in own if k.startswith(("blocks.0.", "single_blocks.0."))}
+    need = {k for k in own if k.startswith(("transformer_blocks.0.", "single_transformer_blocks.0."))}
     assert need <= seen, sorted(need - seen)[:5]
 
 
