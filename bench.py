@@ -30,6 +30,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / CUDA-tensor sharing fail with the legacy mode): set it before
+# torch initialises the HIP runtime, so that a bare `python -m torch.distributed.run ... bench.py --gpus N` works
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
@@ -45,13 +48,24 @@ FLUX_STEP_GOP = 59.5e3 + 0.83e3
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_profile_bench.sh), FETCH_SIZE doubled as
 # MI355X_MICROARCH.md prescribes for gfx950.  PMC counters cannot be read from inside the timed run: the line carries the
 # COMMITTED measurement of the same command and says so ("traffic_source"); null when the profile file is absent.
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r2_bench_gemm_hbm_counters.json")
+TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r3_bench_gemm_hbm_counters.json", "r2_bench_gemm_hbm_counters.json")]
+MFMA_PROFILE = os.path.join(ROOT, "profiles", "r3_bench_gemm_mfma_util.json")
 
 
 def committed_traffic():
+    for path in TRAFFIC_PROFILES:
+        try:
+            d = json.load(open(path))
+            return (2 * d["FETCH_SIZE"]["avg_per_dispatch_KB"] + d["WRITE_SIZE"]["avg_per_dispatch_KB"]) * 1024, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def committed_mfma_util():
+    """SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES over the gemm_w4a4 dispatches of this command (tools/gpu/r3_profile_bench.sh)."""
     try:
-        d = json.load(open(TRAFFIC_PROFILE))
-        return (2 * d["FETCH_SIZE"]["avg_per_dispatch_KB"] + d["WRITE_SIZE"]["avg_per_dispatch_KB"]) * 1024
+        return json.load(open(MFMA_PROFILE))
     except Exception:
         return None
 
@@ -98,10 +112,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)   # the headline config is a 50-step denoise loop (~3 s at N=1)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["dev1024", "schnell512"], default="dev1024",
+    ap.add_argument("--config", choices=["dev1024", "schnell512", "qwen1024"], default="dev1024",
                     help="dev1024: BASELINE config 3 (FLUX.1-dev, 1024^2, guidance embedding, 4096+512 tokens; the headline). "
                          "schnell512: BASELINE config 2 (FLUX.1-schnell, 512^2, no guidance embedding, 1024+512 tokens, "
-                         "4 timed steps per image by default)")
+                         "4 timed steps per image by default).  qwen1024: BASELINE config 5 (Qwen-Image, 60 dual-stream blocks, "
+                         "1024^2 = 4096 image + 512 text tokens); with --offload N the blocks live in pinned host memory and N stay resident")
+    ap.add_argument("--offload", type=int, default=0, metavar="N",
+                    help="qwen1024 only: layer-wise host offload with N blocks resident on the GPU (0 = everything resident)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                    help="torch.distributed backend for --gpus > 1 (default: nccl = RCCL; gloo lets several ranks share one GPU: smoke tests)")
     ap.add_argument("--resolution", type=int, default=None)
     ap.add_argument("--txt-tokens", type=int, default=512)
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events in the timed region (their cost: ~0.5 %%)")
@@ -117,6 +136,11 @@ def main():
                          "measured on one extra eager step after the timed region)")
     args = ap.parse_args()
     schnell = args.config == "schnell512"
+    qwen = args.config == "qwen1024"
+    if args.offload and not qwen:
+        ap.error("--offload needs --config qwen1024")
+    if qwen and "--steps" not in " ".join(sys.argv):
+        args.steps, args.warmup = 10, 2
     if args.resolution is None:
         args.resolution = 512 if schnell else 1024
     if schnell and "--steps" not in " ".join(sys.argv):
@@ -130,26 +154,36 @@ def main():
 
     _Ops.gemm_geometry = args.geometry
     mode.set_deterministic(args.deterministic)
-    rank, local_rank, world = replica.init_process_group()
+    rank, local_rank, world = replica.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    if args.backend == "gloo":  # several ranks may share a device (single-GPU smoke test of the N > 1 path)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = _lib.load()
 
     # ---- model: rank 0 initialises, RCCL broadcasts the parameters (the only collective) ------
-    model = FluxTransformerAMD(num_layers=args.layers[0], num_single_layers=args.layers[1], guidance_embeds=not schnell, device=dev)
+    if qwen:
+        from nunchaku_amd.models.qwenimage import NunchakuQwenImageTransformer2DModel
+
+        n_blocks = args.layers[0] if "--layers" in " ".join(sys.argv) else 60
+        model = NunchakuQwenImageTransformer2DModel(num_layers=n_blocks, device=dev)
+    else:
+        model = FluxTransformerAMD(num_layers=args.layers[0], num_single_layers=args.layers[1], guidance_embeds=not schnell, device=dev)
     if rank == 0:
         model.init_synthetic_(seed=0)
     bcast_bytes = replica.broadcast_module_(model, src=0)
     model.eval()
+    if qwen and args.offload:
+        model.set_offload(True, num_blocks_on_gpu=args.offload)
 
     # ---- one independent image per rank ------------------------------------------------------
     side = args.resolution // 16
     t_img, t_txt = side * side, args.txt_tokens
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     latents = torch.randn(1, t_img, 64, generator=g, device=dev, dtype=torch.bfloat16)
-    enc = torch.randn(1, t_txt, 4096, generator=g, device=dev, dtype=torch.bfloat16)
+    enc = torch.randn(1, t_txt, 3584 if qwen else 4096, generator=g, device=dev, dtype=torch.bfloat16)
     pooled = torch.randn(1, 768, generator=g, device=dev, dtype=torch.bfloat16)
     img_ids = torch.zeros(t_img, 3, device=dev)
     img_ids[:, 1] = torch.arange(side, device=dev).repeat_interleave(side)
@@ -161,7 +195,10 @@ def main():
 
     def step(i, lat):
         with torch.no_grad():
-            v = model(lat, enc, pooled, sigmas[i].reshape(1), img_ids, txt_ids, guidance)
+            if qwen:
+                v = model(lat, enc, None, sigmas[i].reshape(1), [(1, side, side)], return_dict=False)[0]
+            else:
+                v = model(lat, enc, pooled, sigmas[i].reshape(1), img_ids, txt_ids, guidance)
             return lat + (sigmas[i + 1] - sigmas[i]).to(v.dtype) * v  # Euler / flow-matching update
 
     for i in range(args.warmup):
@@ -227,8 +264,19 @@ def main():
 
     if rank == 0:
         achieved = ops_g / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
+        traffic, traffic_file = committed_traffic()
+        if qwen:
+            workload = (f"Qwen-Image-shaped transformer step, {args.resolution}x{args.resolution} ({t_img} image + {t_txt} text tokens), bs=1 "
+                        f"per GPU, {len(model.transformer_blocks)} dual-stream blocks, int4 rank-32, random-init weights, " +
+                        (f"layer-wise host offload with {args.offload} blocks resident ({model.offload_manager.host_bytes_per_block() / 1e6:.0f} MB "
+                         f"per block over PCIe)" if args.offload else "all blocks resident"))
+        else:
+            workload = (f"FLUX.1-{'schnell' if schnell else 'dev'}-shaped transformer step, {args.resolution}x{args.resolution} "
+                        f"({t_img} image + {t_txt} text tokens), bs=1 per GPU, {args.layers[0]} joint + "
+                        f"{args.layers[1]} single blocks, guidance embedding {'off' if schnell else 'on'}, int4 rank-32, random-init weights")
         line = {
-            "metric": ("denoise steps/sec FLUX.1-schnell 512^2 bs=1 (4-bit SVDQuant W4A4 + rank-32)" if schnell else
+            "metric": ("denoise steps/sec Qwen-Image 1024^2 bs=1 (4-bit SVDQuant W4A4 + rank-32)" if qwen else
+                       "denoise steps/sec FLUX.1-schnell 512^2 bs=1 (4-bit SVDQuant W4A4 + rank-32)" if schnell else
                        "denoise steps/sec FLUX.1-dev 1024^2 bs=1 (4-bit SVDQuant W4A4 + rank-32)"),
             "value": world * args.steps / elapsed,
             "unit": "steps/s",
@@ -242,9 +290,9 @@ def main():
             "dtype": "int4 codes as FP6 (e2m3) operands of the MX-scaled MFMA (exact), fp32 accumulate, bf16 I/O",
             "data": "synthetic",
             "config": {
-                "workload": f"FLUX.1-{'schnell' if schnell else 'dev'}-shaped transformer step, {args.resolution}x{args.resolution} "
-                            f"({t_img} image + {t_txt} text tokens), bs=1 per GPU, {args.layers[0]} joint + "
-                            f"{args.layers[1]} single blocks, guidance embedding {'off' if schnell else 'on'}, int4 rank-32, random-init weights",
+                "workload": workload,
+                "gemm_geometry": args.geometry, "deterministic": args.deterministic,
+                "weights": "uniform-random 4-bit codes (not SVD-residual codes: the clock of a power-limited kernel is data dependent)",
                 "parallelism": f"{world} independent replica(s), one image each; weights broadcast once over RCCL "
                                f"({bcast_bytes / 1e9:.2f} GB)" + ("; step replayed as one HIP graph" if args.graph else ""),
                 "output_finite": finite,
@@ -258,9 +306,10 @@ def main():
                 "frac": achieved / INT8_PEAK_TOPS,
                 "frac_int8": achieved / INT8_PEAK_TOPS,   # BASELINE.json's yardstick
                 "frac_fp6": achieved / FP6_PEAK_TOPS,     # the matrix pipe the 4-bit product actually runs on
-                "traffic": committed_traffic(),
-                "traffic_source": "committed: profiles/r2_bench_gemm_hbm_counters.json (rocprofv3 PMC passes of this command: "
+                "traffic": traffic,
+                "traffic_source": f"committed: {traffic_file} (rocprofv3 PMC passes of this command: "
                                   "2*FETCH_SIZE + WRITE_SIZE per gemm_w4a4 dispatch); not measured in this run",
+                "mfma_util": committed_mfma_util(),
                 "launches": n_g,
                 "avg_launch_us": ms_g * 1e3 / max(n_g, 1),
                 "gemm_ms_per_step": ms_g / prof_steps,

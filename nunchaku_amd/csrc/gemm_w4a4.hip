@@ -122,7 +122,6 @@ struct GemmParams {
     long long workspace_bytes;
     int sk_gs;               // stream-K: workgroups sharing the remainder tiles (0 = whole tiles only); host heuristic
     int stagger;             // NW = 4: the second workgroup of a CU starts half a tile late
-    int xcd_walk;            // whole rounds are walked XCD-contiguously (tile_coords); 0 only in probe builds (A/B)
     int dynamic;             // NW = 4: tiles are drawn from per-XCD queues in the workspace instead of a fixed list per workgroup
     int *status;             // optional host-visible status word (svdq_gemm_args.status)
     int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
@@ -166,19 +165,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
     // 1024 x 1024 patch of the output that shares its activation and weight panels in that XCD's L2.
     const int G = gridDim.x;
     const int pos = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    // XCD-contiguous walk: the tiles of the whole rounds are renumbered so that the G/8 workgroups of XCD x walk ONE contiguous
-    // run of the strip enumeration, round after round (x * F * G/8 + i * G/8 + j), instead of jumping G tiles ahead each
-    // round: consecutive rounds of an XCD then stay inside one strip of 8 column tiles and find its weight panels (and part
-    // of the activation panels) still in that XCD's L2.  A bijection on the tile indices: the schedule (which workgroup, which
-    // round, stream-K remainder) is untouched, only which output tile an index means.
-    const int Fw = NT / G, G8 = G / 8;
-    const bool xcd_walk = p.xcd_walk && G % 8 == 0 && Fw >= 2 && !(NW == 4 && p.dynamic);
     auto tile_coords = [&](int t, int &bm, int &bn) {
-        if (xcd_walk && t < Fw * G) {
-            const int i = t / G, ps = t - i * G;
-            const int x = ps / G8, j = ps - x * G8;
-            t = (x * Fw + i) * G8 + j;
-        }
         const int strip = t / (8 * TM);
         const int w = min(8, TN - 8 * strip);
         const int r = t - strip * 8 * TM;
@@ -1162,7 +1149,6 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.M = a->M; p.M_pad = a->M_pad; p.N = a->N; p.K = a->K; p.R = a->R; p.R2 = a->R2; p.ldo = a->ldo;
     p.lora_fixed = a->lora_act_format;
     p.status = a->status;
-    p.xcd_walk = 1;
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;
     SVDQ_PROBE_FILL(p);
 

@@ -1,0 +1,47 @@
+"""bench.py's N > 1 path on ONE GPU: two ranks launched exactly as the driver launches them (torch.distributed.run), with
+``--backend gloo`` so that both may share cuda:0 (RCCL refuses two ranks on one device).  Checks the contract line: ``n_gpus``,
+``scaling``, whole-job ``value`` = ranks x steps / max-over-ranks time, the weight broadcast really happened."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _line(out: str) -> dict:
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config", ["dev1024", "qwen1024"])
+def test_bench_two_ranks_on_one_gpu(config):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--config", config, "--resolution", "256", "--txt-tokens", "256"]
+    layers = ["--layers", "1", "1"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)  # bench.py must set it itself
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", *layers, *common]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["config"]["output_finite"] is True and "2 independent replica" in d["config"]["parallelism"]
+    assert "0.00 GB" not in d["config"]["parallelism"], "the weight broadcast moved no bytes"
+    # whole-job value: all ranks' steps over the max-over-ranks time
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2.0) < 1e-6
+    assert d["cpu_baseline"] is None and d["roofline"]["launches"] > 0

@@ -41,10 +41,14 @@ def _worker(rank, world, port, out):
     enc = torch.randn(1, 128, 128, device=dev, generator=g).bfloat16()
     pooled = torch.randn(1, 64, device=dev, generator=g).bfloat16()
     ids = torch.zeros(256, 3, device=dev)
-    with torch.no_grad():
+    from nunchaku_amd import mode
+
+    with torch.no_grad(), mode.deterministic_mode():  # fixed-point low-rank sums: bit-equality across ranks is legitimate
         y = model(lat, enc, pooled, torch.tensor([0.5], device=dev), ids, torch.zeros(128, 3, device=dev), torch.tensor([3.5], device=dev))
     torch.cuda.synchronize()
-    out.put((rank, nbytes, y.float().cpu().sum().item(), bool(torch.isfinite(y.float()).all())))
+    import hashlib
+
+    out.put((rank, nbytes, hashlib.sha256(y.float().cpu().numpy().tobytes()).hexdigest(), bool(torch.isfinite(y.float()).all())))
     replica.barrier()
     dist.destroy_process_group()
 

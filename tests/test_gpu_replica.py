@@ -36,7 +36,9 @@ def _worker(rank, world, port, out):
     img_ids = torch.zeros(side * side, 3, device="cuda")
     img_ids[:, 1] = torch.arange(side, device="cuda").repeat_interleave(side)
     img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
-    with torch.no_grad():
+    from nunchaku_amd import mode
+
+    with torch.no_grad(), mode.deterministic_mode():  # fixed-point low-rank sums: replicas must agree BIT FOR BIT
         y = model(lat, enc, pooled, torch.tensor([0.5], device="cuda"), img_ids, torch.zeros(t_txt, 3, device="cuda"),
                   torch.tensor([3.5], device="cuda")).float()
     torch.cuda.synchronize()
@@ -63,4 +65,4 @@ def test_two_replicas_agree_after_the_weight_broadcast(built_lib):
     (_, n0, y0), (_, n1, y1) = res
     y0, y1 = torch.from_numpy(y0), torch.from_numpy(y1)
     assert n0 == n1 > 0 and torch.isfinite(y0).all()
-    assert (y0 - y1).norm() / y0.norm() < 2e-2  # same weights, same inputs; fp32-atomic noise only
+    assert torch.equal(y0, y1), "same weights, same inputs, deterministic mode: the two replicas must agree bit for bit"

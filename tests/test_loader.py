@@ -82,3 +82,37 @@ def test_zero_pool_hands_out_aligned_pieces_once():
     assert a.numel() == 10 and b.numel() == 50
     assert (b.data_ptr() - a.data_ptr()) == 12 * 4  # pieces start on 16-byte boundaries
     assert pool.take(40) is None and pool.take(36) is not None
+
+
+def test_qwen_image_safetensors_round_trip(tmp_path):
+    """NunchakuQwenImageTransformer2DModel.from_pretrained (reference transformer_qwenimage.py:358-413): the checkpoint's keys are
+    the module names themselves; NVFP4-only tensors are dropped; dtype mismatches are errors."""
+    from safetensors.torch import save_file
+
+    from nunchaku_amd.models.qwenimage import NunchakuQwenImageTransformer2DModel as Q
+
+    cfg = dict(num_layers=2, num_attention_heads=2, attention_head_dim=128, in_channels=64, out_channels=16, joint_attention_dim=128,
+               patch_size=2, axes_dims_rope=[16, 56, 56])
+    torch.manual_seed(1)
+    src = Q(**cfg, device="cpu")
+    with torch.no_grad():
+        for p in src.parameters():
+            p.copy_(torch.randint(-100, 100, p.shape, dtype=torch.int64) if p.dtype in (torch.int8, torch.int32) else torch.randn(p.shape))
+    sd = {k: v.contiguous() for k, v in src.state_dict().items()}
+    for k in ("transformer_blocks.0.attn.to_qkv.qweight", "transformer_blocks.1.attn.to_out.0.proj_up", "transformer_blocks.0.img_mod.1.wzeros",
+              "transformer_blocks.1.txt_mlp.net.0.proj.wscales", "transformer_blocks.0.img_mlp.net.2.smooth_factor",
+              "time_text_embed.timestep_embedder.linear_1.weight", "txt_norm.weight", "img_in.weight", "norm_out.linear.bias", "proj_out.weight"):
+        assert k in sd, k
+    path = str(tmp_path / "svdq-int4_r32-qwen-tiny.safetensors")
+    extra = dict(sd)
+    extra["transformer_blocks.0.attn.to_qkv.wtscale"] = torch.ones(1)  # NVFP4-only tensor: ignored
+    save_file(extra, path, metadata={"config": json.dumps(cfg), "quantization_config": json.dumps({"rank": 32})})
+    dst = Q.from_pretrained(path, device="cpu")
+    b = dst.state_dict()
+    assert sd.keys() == b.keys() and all(torch.equal(sd[k], b[k]) for k in sd)
+    assert dst.config.num_layers == 2 and not dst.offload
+    bad = dict(sd)
+    bad["img_in.weight"] = bad["img_in.weight"].float()
+    save_file(bad, path, metadata={"config": json.dumps(cfg)})
+    with pytest.raises(TypeError):
+        Q.from_pretrained(path, device="cpu")
