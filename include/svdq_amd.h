@@ -224,7 +224,7 @@ int svdq_gemm_schedule_ex(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int3
 
 /* ------------------------------------------------------------------------------------------
  * Attention over the packed QKV (reference: ops.attention_fp16, nunchaku/csrc/ops.h:114-121,
- * src/kernels/zgemm/attention.cu:11-94).  Non-causal, no mask,
+ * src/kernels/zgemm/attention.cu:11-94).  Non-causal, optional key-padding mask,
  * head_dim 128, one batch element per call:
  *   O[l, h, :] = softmax_j(scale * Q[l, h, :] . K[j, h, :]) V[j, h, :]
  * element addresses (in 16-bit elements):
@@ -272,6 +272,13 @@ typedef struct svdq_attention_args {
     int32_t qlora_act_format; /* SVDQ_LORA_ACT_F32 | SVDQ_LORA_ACT_Q32 (deterministic head sum) */
     int32_t reserved2;
     int32_t *status;          /* optional host-visible status word, as svdq_gemm_args.status */
+    /* Key-padding mask (optional; kv_len0 == 0: every one of the L keys is real).  Keys [0, kv_len0) and [kv_start1, kv_end1) are
+     * real tokens, all others are padding and get probability 0 -- the token buffers of a pipeline are padded to a multiple of
+     * 128 / 256 rows (L itself stays a multiple of 128), a joint [text | image] sequence padded per stream has its padding in the
+     * middle: hence two ranges (kv_start1 = kv_end1 = 0: one range).  Padded K / Q rows may hold anything, including NaN; padded
+     * V^T columns must be FINITE (0 * NaN is NaN in the matrix unit): zero them.  Output rows of padded queries are unspecified.
+     * Role of the reference's padded-row masking (epilogues.cuh:427-550, attention.cuh). */
+    int32_t kv_len0, kv_start1, kv_end1, reserved3;
 } svdq_attention_args;
 
 int svdq_attention(const svdq_attention_args *args, void *stream);

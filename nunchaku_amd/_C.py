@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import weakref
 
 import torch
 
@@ -101,29 +102,75 @@ def release_workspaces() -> None:
 #
 # The reference's ops/quantize.py, ops/fused.py and models/linear.py allocate the opaque activation-code buffers as
 # [M_pad, K/2] bytes and hand over parameters in the checkpoint (NVIDIA fragment) layout.  This library's images are
-# [M_pad, 3K/4] (FP6) and its parameters are re-laid out once.  So that those callers run UNCHANGED against this module:
-#   * a code buffer of the reference size gets the real FP6 image ATTACHED to the tensor object (`_svdq_fp6`): callers
-#     only ever pass the buffer on to gemm_w4a4, which finds the image there; the bytes of the small buffer stay unused;
-#   * a weight-side tensor that does not carry the `_svdq_amd` mark (set by SVDQW4A4Linear.repack_() on its Parameters) is
-#     taken to be in the checkpoint layout and converted on first use; the converted copy is cached on the tensor object
-#     and reused until the tensor is modified in place or reallocated.
+# [M_pad, 3K/4] (FP6) and its parameters are re-laid out once.  So that those callers run UNCHANGED against this module,
+# side data is kept PER STORAGE (the C++ allocation behind a tensor), not per tensor object:
+#   * a code buffer of the reference size owns an FP6 image covering its whole storage; any view of the buffer -- .view(),
+#     a row slice, the tensor a HIP-graph replay sees again -- resolves to the matching rows of that image.  Callers only
+#     ever pass the buffer on to gemm_w4a4; the bytes of the small buffer stay unused;
+#   * a weight-side tensor that does not carry the `_svdq_amd` mark (set by SVDQW4A4Linear on its Parameters) is taken to be
+#     in the checkpoint layout and converted on first use; the converted copy is cached per storage and reused until the
+#     tensor is modified through torch (``_version``) or ``invalidate()`` is called (writes through ``.data`` do not bump
+#     the version: LoRA / offload code that updates weights that way must call it);
+#   * packed Q / K / V buffers of the "nunchaku-fp16" attention surface remember which token rows are real.
+# An entry dies with its storage (weakref.finalize on the storage object: the last view going away frees the side data too,
+# stream-ordered through the caching allocator like the buffer itself).
 # The fast path of this package (nunchaku_amd.models / nunchaku_amd.ops) allocates FP6-sized buffers and repacks its
-# parameters in place: neither mechanism is touched there.
+# parameters in place: none of this is touched there.
 # ----------------------------------------------------------------------------------------------------------------------
+class _SideTable:
+    """side data per tensor STORAGE (weakly keyed)"""
+
+    def __init__(self):
+        self._d: dict[int, object] = {}
+
+    def get(self, t: torch.Tensor):
+        return self._d.get(t.untyped_storage()._cdata)
+
+    def put(self, t: torch.Tensor, value):
+        st = t.untyped_storage()
+        key = st._cdata
+        if key not in self._d:
+            weakref.finalize(st, self._d.pop, key, None)
+        self._d[key] = value
+
+    def pop(self, t: torch.Tensor):
+        return self._d.pop(t.untyped_storage()._cdata, None)
+
+    def __len__(self):
+        return len(self._d)
+
+
+_fp6_images = _SideTable()    # storage of a reference-sized code buffer -> {K: image over the whole storage}
+_converted = _SideTable()     # storage of a checkpoint-layout parameter -> {(kind, offset, shape): (version, converted)}
+_packed_rows = _SideTable()   # storage of a packed K buffer -> {row offset: (valid rows, padded rows)}
+
+
 def _fp6_image(buf: torch.Tensor, rows: int, K: int, create: bool, what: str) -> torch.Tensor:
-    """The FP6 operand image behind the opaque code buffer ``buf`` ([rows, 3K/4]: itself; [rows, K/2]: attached)."""
+    """The FP6 operand image behind the opaque code buffer ``buf`` ([rows, 3K/4]: itself; a view of a [*, K/2] buffer: the
+    matching rows of the image that storage owns)."""
     if buf.shape[-1] * 4 == K * 3:
         return buf
     if buf.shape[-1] * 2 != K:
         raise ValueError(f"{what}: the code buffer must be [M_pad, 3K/4] bytes (this library's FP6 image) or the reference's [M_pad, K/2]")
-    img = getattr(buf, "_svdq_fp6", None)
-    if img is None or tuple(img.shape) != (rows, K * 3 // 4) or img.device != buf.device:
+    if not buf.is_contiguous():
+        raise ValueError(f"{what}: the code buffer must be contiguous")
+    row_bytes = K // 2
+    off_bytes = buf.storage_offset() * buf.element_size()
+    if off_bytes % row_bytes:
+        raise ValueError(f"{what}: a view of a code buffer must start at a row boundary")
+    total_rows = buf.untyped_storage().nbytes() // row_bytes
+    row0 = off_bytes // row_bytes
+    per_k = _fp6_images.get(buf)
+    img = per_k.get(K) if per_k else None
+    if img is None or img.shape[0] != total_rows or img.device != buf.device:
         if not create:
-            raise ValueError(f"{what}: this reference-sized code buffer was not produced by quantize_w4a4_act_fuse_lora / "
-                             "gemm_w4a4 of this library (its FP6 image is attached to the tensor OBJECT: pass the same object on)")
-        img = torch.empty(rows, K * 3 // 4, dtype=torch.uint8, device=buf.device)
-        buf._svdq_fp6 = img
-    return img
+            raise ValueError(f"{what}: this reference-sized code buffer was not produced by quantize_w4a4_act_fuse_lora / gemm_w4a4 of "
+                             "this library (its FP6 image belongs to the buffer's STORAGE: pass the buffer or a view of it on, not a copy)")
+        img = torch.empty(total_rows, K * 3 // 4, dtype=torch.uint8, device=buf.device)
+        per_k = dict(per_k or {})
+        per_k[K] = img
+        _fp6_images.put(buf, per_k)
+    return img[row0:row0 + rows]
 
 
 def mark_amd(t: torch.Tensor | None) -> torch.Tensor | None:
@@ -133,41 +180,47 @@ def mark_amd(t: torch.Tensor | None) -> torch.Tensor | None:
     return t
 
 
+def invalidate(t: torch.Tensor | None) -> None:
+    """Forget the cached kernel-layout conversion of the checkpoint-layout tensor ``t`` (call after writing to it through
+    ``.data`` -- such writes do not bump ``t._version``, so the cache cannot see them)."""
+    if t is not None:
+        _converted.pop(t)
+
+
+def _cached_conversion(t: torch.Tensor, kind: str, convert):
+    key = (kind, t.storage_offset(), tuple(t.shape))
+    per = _converted.get(t)
+    hit = per.get(key) if per else None
+    if hit is not None and hit[0] == t._version:
+        return hit[1]
+    conv = convert(t.detach())
+    per = dict(per or {})
+    per[key] = (t._version, conv)
+    _converted.put(t, per)
+    return conv
+
+
 def _param(t: torch.Tensor | None, kind: str):
     """A weight-side tensor in the kernel layout: ``t`` itself when marked, else its cached conversion from the checkpoint
     layout (kind: "vec" bias / smooth, "wscales", "up" / "down" low-rank factors)."""
     if t is None or getattr(t, "_svdq_amd", False):
         return t
-    key = (t._version, t.data_ptr(), tuple(t.shape))
-    cache = getattr(t, "_svdq_cache", None)
-    if cache is not None and cache[0] == key:
-        return cache[1]
     from . import layout
 
-    src = t.detach()
     if kind == "vec":
-        conv = layout.repack_vec(src)
-    elif kind == "wscales":
-        conv = layout.repack_wscales(src)
-    else:
-        conv = layout.repack_lowrank(src, down=(kind == "down"))
-    t._svdq_cache = (key, conv)
-    return conv
+        return _cached_conversion(t, kind, layout.repack_vec)
+    if kind == "wscales":
+        return _cached_conversion(t, kind, layout.repack_wscales)
+    return _cached_conversion(t, kind, lambda src: layout.repack_lowrank(src, down=(kind == "down")))
 
 
 def _weight(wgt: torch.Tensor, K: int) -> torch.Tensor:
-    """qweight: [N, 3K/4] FP6 image (kernel layout) or the checkpoint's [N, K/2] int8 (converted once, cached on the tensor)."""
+    """qweight: [N, 3K/4] FP6 image (kernel layout) or the checkpoint's [N, K/2] int8 (converted once, cached per storage)."""
     if wgt.shape[-1] * 4 == K * 3:
         return wgt
-    key = (wgt._version, wgt.data_ptr(), tuple(wgt.shape))
-    cache = getattr(wgt, "_svdq_cache", None)
-    if cache is not None and cache[0] == key:
-        return cache[1]
     from . import layout
 
-    conv = layout.repack_qweight(wgt.detach().view(torch.int8))
-    wgt._svdq_cache = (key, conv)
-    return conv
+    return _cached_conversion(wgt, "qweight", lambda src: layout.repack_qweight(src.view(torch.int8)))
 
 
 class _Ops:
@@ -401,14 +454,24 @@ class _Ops:
         del keep, keep2
         if packed_qkv is not None:
             oq, ok, ov, tokens = packed_qkv
-            H, M = oq.shape[1], out.shape[0]
+            H, M, T_pad = oq.shape[1], out.shape[0], oq.shape[2]
             if tokens and tokens != M:
                 raise ValueError("gemm_w4a4: attn_tokens must equal the number of rows of the projection")
-            if M != oq.shape[2]:
-                # the reference masks the padded key rows inside its attention kernel; this library's kernel has no mask
-                raise NotImplementedError("gemm_w4a4: packed Q/K/V need a token count that is a multiple of the pad size (no padded rows)")
+            if M > T_pad:
+                raise ValueError("gemm_w4a4: packed Q/K/V buffers are shorter than the projection's rows")
             for dst, third in zip((oq, ok, ov), out.view(M, 3, H, 128).unbind(1)):
-                dst[0].copy_(third.transpose(0, 1))  # [H, T, 128] head-major, the layout ops.attention_fp16 reads
+                dst[0][:, :M].copy_(third.transpose(0, 1))  # [H, T, 128] head-major, the layout ops.attention_fp16 reads
+            if M < T_pad:
+                # padded token rows (the reference masks them inside its attention kernel, epilogues.cuh:427-550): V must be
+                # finite there, K / Q may hold anything -- attention_fp16 masks the keys by the row counts remembered here
+                ov[0][:, M:].zero_()
+                ok[0][:, M:].zero_()
+                oq[0][:, M:].zero_()
+            base_tokens = ok.stride(1) // 128 if ok.stride(1) % 128 == 0 else T_pad
+            row0 = (ok.storage_offset() // 128) % max(base_tokens, 1)
+            rows = dict(_packed_rows.get(ok) or {})
+            rows[row0] = (M, T_pad)
+            _packed_rows.put(ok, rows)
 
     @staticmethod
     def residual_gate_stats(res, a, b, gate, out, stats, eps=1e-6, zero=None, second=None, clamp_fp16=0):
@@ -522,14 +585,22 @@ class _Ops:
         if tuple(o.shape) != (1, T, H * 128) or not o.is_contiguous():
             raise ValueError("attention_fp16: o must be a contiguous [1, T_pad, H*128] tensor")
         vt = v[0].transpose(1, 2).contiguous()  # [H, 128, T]
-        _Ops.attention(q[0].transpose(0, 1), k[0].transpose(0, 1), vt, o[0].view(T, H, 128), scale)
+        # which key rows are real tokens: remembered per storage by the gemm_w4a4 calls that filled k (one per stream)
+        kv_valid = None
+        segs = sorted((r0, n, pad) for r0, (n, pad) in (_packed_rows.get(k) or {}).items() if r0 < T)
+        if any(n < pad for _, n, pad in segs):
+            if len(segs) > 2 or segs[0][0] != 0:
+                raise NotImplementedError("attention_fp16: at most two padded token streams ([text | image]) are supported")
+            kv_valid = (segs[0][1],) if len(segs) == 1 else (segs[0][1], segs[1][0], segs[1][0] + segs[1][1])
+        _Ops.attention(q[0].transpose(0, 1), k[0].transpose(0, 1), vt, o[0].view(T, H, 128), scale, kv_valid=kv_valid)
 
     @staticmethod
-    def attention(q, k, vt, out, scale, zero=None, quant=None):
+    def attention(q, k, vt, out, scale, zero=None, quant=None, kv_valid=None):
         """Non-causal attention, head_dim 128 (role of the reference's ``ops.attention_fp16``, csrc/ops.h:114-121
         -> attention.cu:11-94).  Strided views, no copies: ``q``/``k``/``out`` are ``[L, H, 128]`` (any token and head
         stride, unit channel stride), ``vt`` is ``[H, 128, L]`` with unit token stride (V transposed, as the QKV
-        GEMM's ``out_vt`` writes it).  L must be a multiple of 128."""
+        GEMM's ``out_vt`` writes it).  L must be a multiple of 128 (pad the buffers; ``kv_valid = (n,)`` or ``(n0, start1, end1)``
+        masks the padded keys: keys ``[0, n0)`` and ``[start1, end1)`` are real; padded V^T columns must be finite)."""
         lib = _lib.load()
         for name, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
             if name == "out" and t is None and quant is not None:
@@ -564,6 +635,13 @@ class _Ops:
         a.vt_hs, a.ldvt = vt.stride(0), vt.stride(1)
         a.L, a.H, a.head_dim, a.dtype = L, H, D, _DT[q.dtype]
         a.scale = float(scale)
+        if kv_valid is not None:
+            kv = tuple(int(v) for v in kv_valid)
+            a.kv_len0 = kv[0]
+            if len(kv) == 3:
+                a.kv_start1, a.kv_end1 = kv[1], kv[2]
+            elif len(kv) != 1:
+                raise ValueError("attention: kv_valid must be (n,) or (n0, start1, end1)")
         if zero is not None:  # scratch cleared by the same launch (see residual_gate_stats)
             if not zero.is_cuda or not zero.is_contiguous() or (zero.numel() * zero.element_size()) % 16:
                 raise ValueError("attention: zero must be a contiguous GPU tensor of a multiple of 16 bytes")

@@ -69,6 +69,7 @@ class AttentionArgs(C.Structure):
         ("qlora_down", C.c_void_p), ("qsmooth2", C.c_void_p), ("qlora_down2", C.c_void_p), ("qR", C.c_int32),
         ("qsplit_rows", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("qlora_act_format", C.c_int32), ("reserved2", C.c_int32), ("status", C.c_void_p),
+        ("kv_len0", C.c_int32), ("kv_start1", C.c_int32), ("kv_end1", C.c_int32), ("reserved3", C.c_int32),
     ]
 
 

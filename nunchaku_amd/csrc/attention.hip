@@ -50,6 +50,7 @@ struct AttnParams {
     void *qlora_act;
     int qlora_q32;     // qlora_act holds Q31.32 fixed point (order-independent integer atomics over the heads)
     int *status;       // optional host-visible status word (svdq_attention_args.status)
+    int kv_len0, kv_start1, kv_end1; // key mask: keys [0, kv_len0) and [kv_start1, kv_end1) are real, the rest padding (kv_len0 == 0: no mask)
     const uint16_t *qsmooth, *qlora_down, *qsmooth2, *qlora_down2;
     int qR, qsplit_rows;
     // persistent schedule (svdq_attention_args.workspace): arrival counters + error word, then one slab per workgroup
@@ -210,6 +211,24 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
 
         if (j + 1 < j_end && !(DBG & 2)) load_tile((j + 1) * ATT_KB); // in flight under the softmax and the PV MFMAs
 
+        // ---- key-padding mask (svdq_attention_args.kv_len0 ...): padded keys score -inf, i.e. probability 0.  Only tiles
+        //      that contain padding pay for it (workgroup-uniform branch); role of the reference's padded-row handling in
+        //      EpiloguePackQKV / attention.cuh (K rows beyond the token count never contribute)
+        if (p.kv_len0 > 0) {
+            const int k0 = j * ATT_KB;
+            const bool all_real = k0 + ATT_KB <= p.kv_len0 || (k0 >= p.kv_start1 && k0 + ATT_KB <= p.kv_end1);
+            if (!all_real) {
+#pragma unroll
+                for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int key = k0 + 32 * kt + 8 * (r >> 2) + 4 * h + (r & 3); // C layout of S^T: row (key) = 8 (r / 4) + 4 h + r % 4
+                        const bool real = key < p.kv_len0 || (key >= p.kv_start1 && key < p.kv_end1);
+                        s[kt][r] = real ? s[kt][r] : -INFINITY;
+                    }
+            }
+        }
+
         // ---- online softmax: lane holds 32 of the 64 scores of query row lr (the partner lane the others) --
         float mloc = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
 #pragma unroll
             for (int dt = 0; dt < 4; dt++) o[dt] = o[dt] * alpha;
         }
-        const float mc = m_run * c;
+        const float mc = m_run == -INFINITY ? 0.f : m_run * c; // (a segment that starts inside the padding: every score so far is -inf)
         const v2f c2 = {c, c}, mc2 = {-mc, -mc};
 #pragma unroll
         for (int kt = 0; kt < 2; kt++)
@@ -596,6 +615,11 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
         }
     }
     if (a->qlora_act_format != SVDQ_LORA_ACT_F32 && a->qlora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_attention: unknown qlora_act_format %d", a->qlora_act_format); return SVDQ_E_INVALID; }
+    if (a->kv_len0 < 0 || a->kv_len0 > a->L || (a->kv_len0 == 0 && (a->kv_start1 || a->kv_end1)) ||
+        (a->kv_len0 > 0 && (a->kv_start1 < a->kv_len0 || a->kv_end1 < a->kv_start1 || a->kv_end1 > a->L) && (a->kv_start1 || a->kv_end1))) {
+        set_error("svdq_attention: key mask needs 0 < kv_len0 <= kv_start1 <= kv_end1 <= L=%d (kv_len0 = 0: no mask; kv_start1 = kv_end1 = 0: one range)", a->L);
+        return SVDQ_E_INVALID;
+    }
     if (a->head_dim != ATT_D) { set_error("svdq_attention: head_dim=%d (only 128 is implemented, as in the reference kernel)", a->head_dim); return SVDQ_E_UNSUPPORTED; }
     if (a->L <= 0 || a->L % 128 || a->H <= 0) { set_error("svdq_attention: L=%d must be a positive multiple of 128 and H=%d positive", a->L, a->H); return SVDQ_E_INVALID; }
     if (a->ldq % 8 || a->ldk % 8 || a->ldvt % 8 || a->ldo % 8 || a->q_hs % 8 || a->k_hs % 8 || a->vt_hs % 8 || a->o_hs % 8 ||
@@ -617,6 +641,7 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.qact = (uint8_t *)a->qact; p.qscales = (uint16_t *)a->qscales; p.qlora_act = a->qlora_act;
     p.qlora_q32 = a->qlora_act_format == SVDQ_LORA_ACT_Q32;
     p.status = a->status;
+    p.kv_len0 = a->kv_len0; p.kv_start1 = a->kv_start1; p.kv_end1 = a->kv_end1;
     p.qsmooth = (const uint16_t *)a->qsmooth; p.qlora_down = (const uint16_t *)a->qlora_down;
     p.qsmooth2 = (const uint16_t *)a->qsmooth2; p.qlora_down2 = (const uint16_t *)a->qlora_down2;
     p.qR = a->qR; p.qsplit_rows = a->qsmooth2 ? a->qsplit_rows : 0;
