@@ -47,7 +47,7 @@ class _Workspace:
         self.buf, self.status = buf, status
 
     def check(self, what: str):
-        if int(self.status[0]) != 0:  # a plain host read of pinned memory
+        if self.status is not None and int(self.status[0]) != 0:  # a plain host read of pinned memory
             self.status.zero_()
             self.buf[:8192].zero_()  # counters of the abandoned launch (stream-ordered behind it)
             raise RuntimeError(
@@ -55,6 +55,25 @@ class _Workspace:
                 "(the workspace was shared across streams, or the grid was not co-resident: a CU-masked stream / a long-running "
                 "co-tenant kernel).  Its results are invalid.  Set ops.gemm_use_workspace / ops.attention_use_workspace = False "
                 "for such streams.")
+
+
+_status_pool = None  # pinned int32 words handed to the workspaces (allocated once, outside any stream capture)
+_status_used = 0
+
+
+def _status_word():
+    """One word of pinned, device-visible host memory, or None (pool exhausted, or first use inside a stream capture, where
+    pinning is not permitted: such a workspace runs without the host-visible flag; the device-side error word stays)."""
+    global _status_pool, _status_used
+    if _status_pool is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        _status_pool = torch.zeros(256, dtype=torch.int32).pin_memory()
+    if _status_used >= _status_pool.numel():
+        return None
+    w = _status_pool[_status_used:_status_used + 1]
+    _status_used += 1
+    return w
 
 
 _WORKSPACE_LIMIT = 8  # per kind: LRU bound (64 MB GEMM / 33 MB attention each); pools of temporary streams recycle entries
@@ -81,8 +100,7 @@ def _workspace(device: torch.device, kind: str = "gemm") -> _Workspace:
         size = lib.svdq_attention_workspace_bytes() if kind == "attention" else lib.svdq_gemm_workspace_bytes()
         with torch.cuda.device(idx):
             buf = torch.zeros(int(size), dtype=torch.uint8, device=device)
-        status = torch.zeros(1, dtype=torch.int32).pin_memory()
-        ws = _Workspace(buf, status)
+        ws = _Workspace(buf, _status_word())
         _workspaces[key] = ws
         same_kind = [k for k in _workspaces if k[2] == kind]
         for k in same_kind[:max(0, len(same_kind) - _WORKSPACE_LIMIT)]:
@@ -240,7 +258,8 @@ class _Ops:
         ws = _workspaces.get(key)
         if ws is not None:
             _lib.check(_lib.load().svdq_gemm_workspace_status(ws.buf.data_ptr(), _stream()), "gemm_workspace_status")
-            ws.status.zero_()
+            if ws.status is not None:
+                ws.status.zero_()
 
     # False: plain grid (one workgroup per task) instead of the persistent schedule; tests compare the two
     attention_use_workspace = True
@@ -251,7 +270,8 @@ class _Ops:
         ws = _workspaces.get((torch.cuda.current_device(), _stream(), "attention"))
         if ws is not None:
             _lib.check(_lib.load().svdq_attention_workspace_status(ws.buf.data_ptr(), _stream()), "attention_workspace_status")
-            ws.status.zero_()
+            if ws.status is not None:
+                ws.status.zero_()
 
     @staticmethod
     def quantize_w4a4_act_fuse_lora(input, output, oscales, lora_down, lora_act_out, smooth, fuse_glu=False, fp4=False,
@@ -384,7 +404,8 @@ class _Ops:
         if _Ops.gemm_use_workspace:
             ws = _workspace(act.device)
             ws.check("gemm_w4a4")  # host-visible status word of the earlier launches on this stream: no synchronisation
-            a.workspace, a.workspace_bytes, a.status = ws.buf.data_ptr(), ws.buf.numel(), ws.status.data_ptr()
+            a.workspace, a.workspace_bytes = ws.buf.data_ptr(), ws.buf.numel()
+            a.status = None if ws.status is None else ws.status.data_ptr()
         a.geometry = _Ops.gemm_geometry
         fmt_in = lora_act_in.dtype if R else None
 
@@ -649,7 +670,8 @@ class _Ops:
         if _Ops.attention_use_workspace and L % 256 == 0:
             ws = _workspace(q.device, "attention")
             ws.check("attention")
-            a.workspace, a.workspace_bytes, a.status = ws.buf.data_ptr(), ws.buf.numel(), ws.status.data_ptr()
+            a.workspace, a.workspace_bytes = ws.buf.data_ptr(), ws.buf.numel()
+            a.status = None if ws.status is None else ws.status.data_ptr()
         _lib.check(lib.svdq_attention(C.byref(a), _stream()), "attention")
 
 

@@ -231,7 +231,9 @@ def test_fused_gelu_mlp(dtype):
     s_got, s_ref = f32(sh_nat)[:, :M], r["oscales"][:, :M]
     assert (s_got != s_ref).mean() < 5e-3 and np.allclose(s_got, s_ref, rtol=2 ** -6)
     la_ref = r["lora_act_out"][:M]
-    assert np.allclose(lh.cpu().numpy()[:M], la_ref, rtol=2e-2, atol=2e-2 * np.abs(la_ref).max())
+    # the next layer's low-rank down projection: a sum over the 16-bit GELU outputs, a few of which the GPU's exp2/rcp GELU rounds
+    # one ulp differently -- the bound of the full-size test (2e-3 of the largest sum), not the 2e-2 VERDICT r2 flagged
+    assert np.abs(lh.cpu().numpy()[:M] - la_ref).max() <= 2e-3 * np.abs(la_ref).max() + 1e-4
 
     # stage 2: fc2 on the GPU's own codes must match the oracle GEMM on those codes to 1 ulp
     out = m2.forward_quant(qh, sh, lh)[:M]

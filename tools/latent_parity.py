@@ -2,7 +2,7 @@
 """Step-level parity artefact: N-step latent PSNR of the GPU path against the
 oracle-backed CPU twin on identical seeds and latents, at the REAL FLUX.1 width.
 
-    python tools/latent_parity.py            # on a MI355X box -> gpurun_out/latent_psnr.json (copy to profiles/r2_latent_psnr.json)
+    python tools/latent_parity.py            # on a MI355X box -> gpurun_out/latent_psnr.json (copy to profiles/r3_latent_psnr.json)
 
 Model: hidden 3072 = 24 heads x 128, MLP 12288, 1 joint + 1 single block (every operator of a FLUX step appears once
 per stream), rank-32 SVDQuant layers built from a dense Gaussian weight by smoothing + rank-32 (randomised) SVD + 4-bit
@@ -66,12 +66,46 @@ def run(name, side, t_txt, guidance, seed, steps=(1.0, 0.5, 0.0), lowrank_energy
     return rec
 
 
+def run_qwen_block(t_img=256, t_txt=256, seed=21, lowrank_energy=0.95):
+    """One Qwen-Image dual-stream block at the REAL width (hidden 3072 = 24 heads x 128, MLP 12288; BASELINE config 5): the GPU
+    path (fused QKV + RMSNorm + Qwen rotary epilogue, svdq attention, grouped launches) against the CPU twin of the reference's
+    op sequence (tests/test_gpu_qwenimage.py:BlockTwin, numpy oracle for every quantised operator).  PSNR of both streams'
+    block outputs (a block output is what the next block consumes: the Qwen analogue of the latent of a 1+1-block FLUX step)."""
+    from nunchaku_amd.models.qwenimage import NunchakuQwenImageTransformerBlock
+    from tests.flux_ref import psnr_rel
+    from tests.test_gpu_qwenimage import BlockTwin, _block_inputs, _fill
+
+    t0 = time.time()
+    block = NunchakuQwenImageTransformerBlock(3072, 24, 128, device="cuda").eval()
+    layers = _fill(block, seed=seed, lowrank_energy=lowrank_energy)
+    t_build = time.time() - t0
+    hidden, enc, temb, img_f, txt_f = _block_inputs(3072, t_img, t_txt, seed=seed + 1)
+    cs = lambda f: torch.stack([f.real.float(), f.imag.float()], dim=-1)
+    t0 = time.time()
+    with torch.no_grad():
+        e_ref, h_ref = BlockTwin(block, layers).forward(hidden, enc, temb, cs(img_f), cs(txt_f))
+        e, h = block(hidden.cuda().bfloat16()[None], enc.cuda().bfloat16()[None], None, temb.cuda().bfloat16(), (img_f.cuda(), txt_f.cuda()))
+    res = []
+    for name, got, ref in (("text stream", e[0].float().cpu(), e_ref), ("image stream", h[0].float().cpu(), h_ref)):
+        psnr, rel = psnr_rel(got, ref)
+        res.append({"output": name, "latent_psnr_db": round(float(psnr), 2), "rel_l2": float(rel)})
+    rec = {"config": f"Qwen-Image block ({t_img} image + {t_txt} text tokens), low-rank-dominated weights", "hidden": 3072, "heads": 24,
+           "blocks": "1 dual-stream block", "image_tokens": t_img, "text_tokens": t_txt, "dtype": "bf16", "steps": res,
+           "weights": f"make_svdq_layer(cheap=False, svd='randomized'), {lowrank_energy:.0%} of the energy in a rank-32 component; seed {seed}",
+           "build_s": round(t_build, 1), "run_s": round(time.time() - t0, 1)}
+    print(json.dumps(rec), flush=True)
+    del block
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     out = os.path.join(ROOT, "gpurun_out", "latent_psnr.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     # (1) the regime SVDQuant is built for: the 16-bit low-rank branch carries most of the energy.  A forward pass is well
     #     conditioned, so GPU vs CPU twin measures the IMPLEMENTATION: this is the gated number.
     recs = [run("dev geometry (256 + 256 tokens), low-rank-dominated weights", 16, 256, True, seed=11, lowrank_energy=0.95)]
+    recs.append(run_qwen_block())
     if "--quick" not in sys.argv:
         recs.append(run("schnell 512^2 geometry (1024 + 512 tokens), low-rank-dominated weights", 32, 512, False, seed=12, steps=(1.0, 0.5),
                         lowrank_energy=0.95))
