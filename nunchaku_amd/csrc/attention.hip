@@ -41,7 +41,6 @@ struct AttnParams {
     long long q_hs, k_hs, vt_hs, o_hs;
     int L, H, ldq, ldk, ldvt, ldo;
     float scale_log2e; // softmax scale * log2(e)
-    int debug;         // timing experiments (tools/bench_attention.py): results are WRONG when non-zero
     v4i *zero_ptr;     // optional scratch cleared by this launch (svdq_attention_args.zero_ptr)
     long long zero_vec; // its size in 16-byte units
     // fused quantiser of the following output projection (svdq_attention_args.qact ...)
@@ -114,8 +113,8 @@ template <int DT> __device__ __forceinline__ float sum2(unsigned packed, float l
     else return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, packed), __builtin_bit_cast(f16x2, 0x3c003c00u), l, false);
 }
 
-// NW waves = NW * 32 query rows of one head per workgroup.  DBG: ablation bits (bench only).
-template <int DT, int NW, int DBG, bool PERSIST>
+// NW waves = NW * 32 query rows of one head per workgroup.
+template <int DT, int NW, bool PERSIST>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnParams p) {
     static_assert(!PERSIST || NW == 8, "the persistent schedule is built for the 8-wave workgroup");
     using V8 = typename Half<DT>::V8;
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
     int j_end = 0;           // end of the current segment's KV tiles
 
     auto step = [&](auto bufc, int j) {
-        constexpr int BUF = (DBG & 2) ? 0 : decltype(bufc)::value;
+        constexpr int BUF = decltype(bufc)::value;
         constexpr int BO = BUF * 2 * ATT_TILE;
 
         // ---- S^T[k][q] = sum_d K[k][d] Q[q][d]: two 32-key tiles x 8 d-steps ------------------------------
@@ -201,15 +200,12 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             for (int r = 0; r < 16; r++) s[kt][r] = 0.f;
 #pragma unroll
             for (int ds = 0; ds < 8; ds++) {
-                v4i kw;
-                if constexpr (DBG & 32) kw = __builtin_bit_cast(v4i, qf[(ds + kt) & 7]);
-                else kw = *(const lds_v4i *)(L8 + (ka[ds] + (BO + kt * 8192)));
-                if constexpr (!(DBG & 16)) s[kt] = Half<DT>::mfma32(__builtin_bit_cast(V8, kw), qf[ds], s[kt]);
-                else s[kt][ds] += (float)kw[0];
+                const v4i kw = *(const lds_v4i *)(L8 + (ka[ds] + (BO + kt * 8192)));
+                s[kt] = Half<DT>::mfma32(__builtin_bit_cast(V8, kw), qf[ds], s[kt]);
             }
         }
 
-        if (j + 1 < j_end && !(DBG & 2)) load_tile((j + 1) * ATT_KB); // in flight under the softmax and the PV MFMAs
+        if (j + 1 < j_end) load_tile((j + 1) * ATT_KB); // in flight under the softmax and the PV MFMAs
 
         // ---- key-padding mask (svdq_attention_args.kv_len0 ...): padded keys score -inf, i.e. probability 0.  Only tiles
         //      that contain padding pay for it (workgroup-uniform branch); role of the reference's padded-row handling in
@@ -255,16 +251,13 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             for (int dt = 0; dt < 4; dt++) o[dt] = o[dt] * alpha;
         }
         const float mc = m_run == -INFINITY ? 0.f : m_run * c; // (a segment that starts inside the padding: every score so far is -inf)
-        const v2f c2 = {c, c}, mc2 = {-mc, -mc};
+        // scalar FMAs on purpose: beside running MFMAs a packed fp32 instruction (v_pk_fma_f32) costs ~22 cycles more than the two
+        // v_fma_f32 it replaces (MI355X_MICROARCH.md "price of one filler beside MFMAs")
+        const float nmc = -mc;
 #pragma unroll
         for (int kt = 0; kt < 2; kt++)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                v2f t = __builtin_elementwise_fma((v2f){s[kt][r], s[kt][r + 1]}, c2, mc2);
-                if constexpr (!(DBG & 1)) { t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]); }
-                s[kt][r] = t[0];
-                s[kt][r + 1] = t[1];
-            }
+            for (int r = 0; r < 16; r++) s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, nmc));
 
         // ---- P -> 16-bit B-operand fragments of the PV MFMA: lane (q = lr, keys 16*ks + 8h .. +7) ------------
         // regs 8*(ks&1) + {0..3} hold keys 4h + {0..3}, regs + {4..7} keys 8 + 4h + {0..3} of that 16-key step
@@ -291,16 +284,13 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
         for (int dt = 0; dt < 4; dt++) {
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
-                v4i vw;
-                if constexpr (DBG & 64) vw = __builtin_bit_cast(v4i, qf[(ks + dt) & 7]);
-                else vw = *(const lds_v4i *)(L8 + (va[ks] + (BO + dt * 4096)));
-                if constexpr (!(DBG & 8)) o[dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw), pf[ks], o[dt]);
-                else o[dt][ks] += (float)vw[0] * (float)__builtin_bit_cast(v4i, pf[ks])[0];
+                const v4i vw = *(const lds_v4i *)(L8 + (va[ks] + (BO + dt * 4096)));
+                o[dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw), pf[ks], o[dt]);
             }
         }
 
-        if (j + 1 < j_end && !(DBG & 2)) store_tile((BUF ^ 1) * 2 * ATT_TILE); // that buffer was last read in iteration j-1
-        if constexpr (!(DBG & 4)) __syncthreads();
+        if (j + 1 < j_end) store_tile((BUF ^ 1) * 2 * ATT_TILE); // that buffer was last read in iteration j-1
+        __syncthreads();
     };
     while (true) {
         // ---- one segment: KV tiles [j0, j1) of one task.  tl: the task's index among the remainder tasks (-1: a whole task)
@@ -511,12 +501,12 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
     } // segments
 }
 
-template <int DT, int NW, int DBG> static void launch_attention(const AttnParams &p, hipStream_t st) {
+template <int DT, int NW> static void launch_attention(const AttnParams &p, hipStream_t st) {
     dim3 grid(p.L / (NW * 32), p.H), block(NW * 64);
-    hipLaunchKernelGGL((attention_kernel<DT, NW, DBG, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((attention_kernel<DT, NW, false>), grid, block, 0, st, p);
 }
 template <int DT> static void launch_attention_persistent(const AttnParams &p, int groups, hipStream_t st) {
-    hipLaunchKernelGGL((attention_kernel<DT, 8, 0, true>), dim3(groups), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((attention_kernel<DT, 8, true>), dim3(groups), dim3(512), 0, st, p);
 }
 
 // workgroups of the persistent schedule: one per CU (64 KiB of LDS and 8 waves of ~230 VGPRs: exactly one is resident per CU)
@@ -658,14 +648,13 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (a->reserved != 0) { set_error("svdq_attention: reserved must be 0 (timing ablations live in tools/ablate, not in this library)"); return SVDQ_E_INVALID; }
-    p.debug = 0;
     const int nw = a->L % 256 == 0 ? 8 : 4;
     const int groups = attention_groups(p);
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
     if (groups > 0) { if (a->dtype == SVDQ_FP16) launch_attention_persistent<SVDQ_FP16>(p, groups, st); else launch_attention_persistent<SVDQ_BF16>(p, groups, st); }
-    else if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8, 0>(p, st); else launch_attention<SVDQ_FP16, 4, 0>(p, st); }
-    else if (nw == 8) launch_attention<SVDQ_BF16, 8, 0>(p, st);
-    else launch_attention<SVDQ_BF16, 4, 0>(p, st);
+    else if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8>(p, st); else launch_attention<SVDQ_FP16, 4>(p, st); }
+    else if (nw == 8) launch_attention<SVDQ_BF16, 8>(p, st);
+    else launch_attention<SVDQ_BF16, 4>(p, st);
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_attention launch");
 }

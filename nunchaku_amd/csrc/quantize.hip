@@ -528,9 +528,7 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     using T = typename Half<DT>::T;
     const int KP = a->K / 128, tiles = a->M_pad / 32;
     // enough workgroups to fill 256 CUs several times over, but at least one chunk per wave
-    constexpr int cpw_env = 0;
-    constexpr bool force_general = false;
-    int cpw = cpw_env > 0 ? cpw_env : 4; // chunks per workgroup = 4 waves x 1 chunk: many short waves hide the HBM round trip
+    int cpw = 4; // chunks per workgroup = 4 waves x 1 chunk: many short waves hide the HBM round trip
     while ((long)tiles * ((KP + cpw - 1) / cpw) > 8192) cpw *= 2;
     if (cpw > KP) cpw = ((KP + 3) / 4) * 4;
     const int slices = (KP + cpw - 1) / cpw;
@@ -544,7 +542,7 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     dim3 grid(tiles * slices), block(256);
     const int rt32 = (a->R + 31) / 32;
     QuantSecond s2{a->x2, a->smooth2, a->lora_down2, a->mod_scale2, a->mod_shift2, a->ln_stats2, a->M2, a->ldx2, a->split_rows};
-    if (rt32 <= 1 && cpw == 4 && !force_general && (long long)a->M_pad * (a->ldx > a->ldx2 ? a->ldx : a->ldx2) * 2 < 0x7fffffffLL) {
+    if (rt32 <= 1 && cpw == 4 && (long long)a->M_pad * (a->ldx > a->ldx2 ? a->ldx : a->ldx2) * 2 < 0x7fffffffLL) {
         // fast path: one chunk per wave, 4 waves = 4 neighbouring chunks of one row tile (same grid as the general kernel at cpw = 4)
         QuantParams qp{a->x, a->smooth, a->lora_down, a->mod_scale, a->mod_shift, a->ln_stats, (uint8_t *)a->act, a->ascales, a->lora_act,
                        a->M, a->K, a->R, a->ldx, atomics, s2};
@@ -557,11 +555,7 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
         }
         return hip_check(hipGetLastError(), "svdq_quantize_w4a4_act_fuse_lora launch");
     }
-    constexpr int occ_env = 0;
-#define SVDQ_LAUNCH_Q_OCC4(RT)
-    (void)occ_env;
 #define SVDQ_LAUNCH_Q(RT)                                                                                            \
-    SVDQ_LAUNCH_Q_OCC4(RT)                                                                                           \
     hipLaunchKernelGGL((quantize_kernel<DT, RT, 1>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,          \
                        (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
                        a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift, s2)
@@ -571,7 +565,6 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     else if (rt32 <= 4) SVDQ_LAUNCH_Q(4);
     else SVDQ_LAUNCH_Q(8);
 #undef SVDQ_LAUNCH_Q
-#undef SVDQ_LAUNCH_Q_OCC4
     return hip_check(hipGetLastError(), "svdq_quantize_w4a4_act_fuse_lora launch");
 }
 

@@ -1,6 +1,8 @@
 """svdq_attention vs torch SDPA at the FLUX.1 shape (1 x 24 heads x 4608 tokens x 128), plus the QKV GEMM with and
 without the transposed-V side output."""
-import math, sys, torch, torch.nn.functional as F
+import math, os, sys, torch, torch.nn.functional as F
+import nunchaku_amd._lib as _L
+_L._LIB_PATH = os.environ.get("SVDQ_LIB", _L._LIB_PATH)  # same-box A/B against another build of the library (tools only)
 from nunchaku_amd.ops.attention import attention_packed
 
 L, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4608, 24)
