@@ -27,8 +27,11 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops.attention import attention_packed
-from ..ops.fused import fused_gelu_mlp, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair, linear_pair
+from ..ops.attention import attention_packed, attention_packed_quantized
+from ..ops.elementwise import residual_gate_stats, residual_gate_stats_pair
+from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair, linear_pair,
+                         linear_pair_quantized)
+from ..ops.gemv import awq_gemv_w4a16_batched, awq_gemv_w4a16_cuda
 from ..utils import pad_tensor
 from .embeddings import pack_rotemb
 from .linear import AWQW4A16Linear, SVDQW4A4Linear
@@ -112,6 +115,27 @@ class NunchakuQwenAttention(nn.Module):
             txt, img = linear_pair(o[:, :t_txt], self.to_add_out, o[:, t_txt:], self.to_out[0])
             return img, txt
         return self.to_out[0](o[:, t_txt:]), self.to_add_out(o[:, :t_txt])
+
+    def forward_fused_norm(self, hidden, enc, packed, ln_img, ln_txt):
+        """The block's fused path (``NunchakuQwenImageTransformerBlock.forward_fused``): ``hidden`` / ``enc`` are the UN-normalised
+        streams, LayerNorm + modulation run inside the QKV quantiser (``ln_* = (stats, scale incl. +1, shift, ZeroPool)``), both
+        streams share every launch, the attention epilogue emits the output projections' quantised input.  B = 1, token counts
+        multiples of 256.  -> (image stream output, text stream output)."""
+        t_txt, t_img = enc.shape[1], hidden.shape[1]
+        tokens, hd = t_txt + t_img, self.heads * self.head_dim
+        qkv = torch.empty(tokens, 3 * hd, dtype=hidden.dtype, device=hidden.device)
+        vt = torch.empty(hd, tokens, dtype=hidden.dtype, device=hidden.device)
+        ok = fused_qkv_norm_rottary_pair(enc, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, hidden, self.to_qkv, self.norm_q,
+                                         self.norm_k, packed["all"], qkv, out_vt=vt, ln_a=ln_txt, ln_b=ln_img)
+        if not ok:
+            raise RuntimeError("forward_fused_norm: the two streams' projections cannot share a launch (shapes / ranks differ)")
+        qres = attention_packed_quantized(qkv, vt, self.heads, self.to_out[0], lin_first=self.to_add_out, split_rows=t_txt, pool=ln_txt[3])
+        if qres is not None:
+            txt, img = linear_pair_quantized(*qres, self.to_add_out, self.to_out[0], t_txt)
+            return img, txt
+        o = attention_packed(qkv, vt, self.heads).unsqueeze(0)
+        txt, img = linear_pair(o[:, :t_txt], self.to_add_out, o[:, t_txt:], self.to_out[0])
+        return img, txt
 
     def _reference_ops(self, hidden_states, encoder_hidden_states, packed):
         """NunchakuQwenImageNaiveFA2Processor, op for op: plain quantised projections, torch RMSNorm, rotary as the complex
@@ -207,6 +231,38 @@ class NunchakuQwenImageTransformerBlock(nn.Module):
             scale = scale + self.scale_shift
         return x * scale.unsqueeze(1) + shift.unsqueeze(1), gate.unsqueeze(1)
 
+    def modulation(self, temb_act):
+        """Both streams' modulation vectors, de-interleaved by the GEMV itself: (img [6, dim], txt [6, dim]) with rows
+        shift1, scale1 (+1 included), gate1, shift2, scale2 (+1), gate2 -- what :meth:`forward_fused` takes as ``mods``."""
+        outs = []
+        for lin in (self.img_mod[1], self.txt_mod[1]):
+            m = awq_gemv_w4a16_cuda(temb_act, lin.qweight, lin.wscales, lin.wzeros, 1, lin.out_features, lin.in_features, lin.group_size,
+                                    lin.bias, out_chunks=6).view(6, -1)
+            if self.scale_shift != 0:
+                m[1::3] += self.scale_shift  # a 16-bit add, as the reference's `scale + scale_shift` (:203-205)
+            outs.append(m)
+        return outs
+
+    def forward_fused(self, hidden, enc, temb_act, packed_rot, stats, mods=None):
+        """The block on this library's fused passes (B = 1, token counts multiples of 256): LayerNorm + modulation inside the
+        quantisers, gated residual + the next LayerNorm's statistics in one element-wise pass per stage (both streams per launch),
+        grouped GEMM launches, attention-side quantiser.  Same 16-bit rounding points as :meth:`forward`'s torch ops (the fused
+        passes are bit-exact restatements of them).  ``stats`` = ((txt stats, ZeroPool), img stats) of the
+        block's inputs; returns (enc, hidden, stats of the outputs)."""
+        (e_stats, pool), h_stats = stats
+        im, tm = mods if mods is not None else self.modulation(temb_act)
+        att = self.attn
+        img_a, txt_a = att.forward_fused_norm(hidden, enc, packed_rot, ln_img=(h_stats, im[1], im[0]), ln_txt=(e_stats, tm[1], tm[0], pool))
+        mp = _pad256(hidden.shape[1]) + _pad256(enc.shape[1])
+        r_mlp = self.img_mlp.net[0].proj.rank + self.img_mlp.net[2].rank
+        enc, e_stats, hidden, h_stats, pool = residual_gate_stats_pair(enc, txt_a, tm[2], hidden, img_a, im[2], zero_floats=mp * r_mlp)
+        txt_f, img_f = fused_gelu_mlp_pair(enc, self.txt_mlp.net[0].proj, self.txt_mlp.net[2], hidden, self.img_mlp.net[0].proj, self.img_mlp.net[2],
+                                           ln_a=(e_stats, tm[4], tm[3], pool), ln_b=(h_stats, im[4], im[3]))
+        fp16 = hidden.dtype == torch.float16  # the reference clips both streams at the end of an fp16 block (:300-303)
+        enc, e_stats, hidden, h_stats, pool = residual_gate_stats_pair(
+            enc, txt_f, tm[5], hidden, img_f, im[5], zero_floats=mp * (att.to_qkv.rank + att.to_out[0].rank), clamp_fp16_a=fp16, clamp_fp16_b=fp16)
+        return enc, hidden, ((e_stats, pool), h_stats)
+
     def forward(self, hidden_states, encoder_hidden_states, encoder_hidden_states_mask=None, temb=None, image_rotary_emb=None,
                 joint_attention_kwargs=None):
         B = temb.shape[0]
@@ -265,6 +321,12 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
     when diffusers is importable -- skeleton on the meta device, every parametrised sub-module replaced under its diffusers
     name by ``_patch_model`` -- and a plain ``nn.Module`` with the pipeline's call contract otherwise): 60 dual-stream blocks,
     ``from_pretrained`` for nunchaku ``.safetensors`` checkpoints, ``set_offload`` for layer-wise host offload."""
+
+    # True (and B == 1, token counts multiples of 256): the blocks run on the fused AdaLayerNormZero / residual passes and grouped
+    # launches (NunchakuQwenImageTransformerBlock.forward_fused); False: the reference's torch-op sequence per block
+    fused_norm = True
+    # True: all modulation GEMVs of a step in one batched launch (resident models only)
+    batched_mods = True
 
     def __init__(self, num_layers: int = 60, num_attention_heads: int = 24, attention_head_dim: int = 128, in_channels: int = 64,
                  out_channels: int = 16, joint_attention_dim: int = 3584, patch_size: int = 2, axes_dims_rope=(16, 56, 56),
@@ -417,11 +479,31 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
         compute_stream = torch.cuda.current_stream()
         if self.offload:
             self.offload_manager.initialize(compute_stream)
+        fused = (self.fused_norm and hidden.shape[0] == 1 and t_txt % 256 == 0 and hidden.shape[1] % 256 == 0 and NunchakuQwenAttention.fused_qkv
+                 and not attention_kwargs and encoder_hidden_states_mask is None)
+        stats = mods = temb_act = None
+        if fused:
+            temb_act = F.silu(temb)  # img_mod[0] / txt_mod[0] of every block: the same SiLU of the same embedding
+            stats = ((residual_gate_stats(enc)[1], None), residual_gate_stats(hidden)[1])
+            if not self.offload and self.batched_mods:
+                # all 2 x num_layers modulation projections depend on temb only: ONE batched GEMV launch, +1 on the scale rows in two ops
+                lins = [SimpleNamespace(qweight=l.qweight, wscales=l.wscales, wzeros=l.wzeros, bias=l.bias, out_features=l.out_features,
+                                        in_features=l.in_features, group_size=l.group_size, out_chunks=6)
+                        for b in self.transformer_blocks for l in (b.img_mod[1], b.txt_mod[1])]
+                outs = awq_gemv_w4a16_batched(temb_act, lins)
+                base = outs[0]._base if outs[0]._base is not None else outs[0]  # the launch's one output buffer: the layers' vectors back to back
+                allm = base.reshape(-1)[: len(lins) * 6 * self.inner_dim].view(len(lins), 6, self.inner_dim)
+                if self.transformer_blocks[0].scale_shift != 0:
+                    allm[:, 1::3] += self.transformer_blocks[0].scale_shift
+                mods = [(allm[2 * i], allm[2 * i + 1]) for i in range(len(self.transformer_blocks))]
         for i, block in enumerate(self.transformer_blocks):
             if self.offload:
                 block = self.offload_manager.get_block(i)
-            enc, hidden = block(hidden_states=hidden, encoder_hidden_states=enc, encoder_hidden_states_mask=encoder_hidden_states_mask,
-                                temb=temb, image_rotary_emb=rot, joint_attention_kwargs=attention_kwargs)
+            if fused:
+                enc, hidden, stats = block.forward_fused(hidden, enc, temb_act, rot, stats, mods=None if mods is None else mods[i])
+            else:
+                enc, hidden = block(hidden_states=hidden, encoder_hidden_states=enc, encoder_hidden_states_mask=encoder_hidden_states_mask,
+                                    temb=temb, image_rotary_emb=rot, joint_attention_kwargs=attention_kwargs)
             if self.offload:
                 self.offload_manager.step(compute_stream)
         scale, shift = self.norm_out["linear"](F.silu(temb)).chunk(2, dim=-1)  # AdaLayerNormContinuous

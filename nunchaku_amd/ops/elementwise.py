@@ -51,7 +51,8 @@ def residual_gate_stats(res: torch.Tensor, a: torch.Tensor | None = None, gate: 
     return y, stats
 
 
-def residual_gate_stats_pair(res_a, a_a, gate_a, res_b, a_b, gate_b, zero_floats: int = 0, eps: float = 1e-6, clamp_fp16_a: bool = False):
+def residual_gate_stats_pair(res_a, a_a, gate_a, res_b, a_b, gate_b, zero_floats: int = 0, eps: float = 1e-6, clamp_fp16_a: bool = False,
+                             clamp_fp16_b: bool = False):
     """Two independent gated residuals (the two streams of a joint block: same width, different row counts) and their
     statistics in ONE launch, both in place.  Returns ``(y_a, stats_a, y_b, stats_b[, ZeroPool])``."""
     C = res_a.shape[-1]
@@ -61,7 +62,8 @@ def residual_gate_stats_pair(res_a, a_a, gate_a, res_b, a_b, gate_b, zero_floats
     zf = zero_floats * lora_act_words()
     zero = torch.empty((zf + 3) // 4 * 4, dtype=torch.float32, device=res_a.device) if zf > 0 else None
     ops.residual_gate_stats(ra, a_a.reshape(-1, C), None, gate_a.reshape(-1), ra, sa, eps, zero,
-                            second=(rb, a_b.reshape(-1, C), None, gate_b.reshape(-1), rb, sb), clamp_fp16=int(bool(clamp_fp16_a)))
+                            second=(rb, a_b.reshape(-1, C), None, gate_b.reshape(-1), rb, sb),
+                            clamp_fp16=int(bool(clamp_fp16_a)) | (2 if clamp_fp16_b else 0))
     if zero_floats > 0:
         return res_a, sa, res_b, sb, ZeroPool(zero if zero is not None else torch.empty(0, dtype=torch.float32, device=res_a.device))
     return res_a, sa, res_b, sb

@@ -230,6 +230,42 @@ def test_qwen_model_offload_equals_resident(late, num_slots):
         assert torch.equal(model(lat, enc, None, t, [(1, 16, 16)]).sample, ref), "forward after set_offload(False)"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_qwen_model_fused_passes_match_the_torch_op_blocks(dtype):
+    """The model's fused path (LayerNorm + modulation inside the quantisers, gated residuals + statistics in one pass, grouped
+    launches, attention-side quantiser, one batched modulation GEMV per step) against the reference's torch-op block sequence on
+    the same weights: the fused passes restate the torch ops' 16-bit rounding points, so the two agree up to the W4A4 code-flip
+    level of a last-bit difference (fp32 summation orders of the attention / low-rank sums differ between the two paths)."""
+    from nunchaku_amd import mode
+    from nunchaku_amd.models.qwenimage import NunchakuQwenImageTransformer2DModel
+
+    model = NunchakuQwenImageTransformer2DModel(num_layers=3, num_attention_heads=2, attention_head_dim=128, in_channels=64, out_channels=16,
+                                                joint_attention_dim=128, torch_dtype=dtype, device="cuda").init_synthetic_(seed=5).eval()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    lat = torch.randn(1, 256, 64, device="cuda", generator=g).to(dtype)
+    enc = torch.randn(1, 256, 128, device="cuda", generator=g).to(dtype)
+    t = torch.tensor([0.4], device="cuda")
+    outs = {}
+    with torch.no_grad(), mode.deterministic_mode():
+        for fused in (True, False):
+            NunchakuQwenImageTransformer2DModel.fused_norm = fused
+            try:
+                outs[fused] = model(lat, enc, None, t, [(1, 16, 16)]).sample.float()
+                again = model(lat, enc, None, t, [(1, 16, 16)]).sample.float()
+            finally:
+                NunchakuQwenImageTransformer2DModel.fused_norm = True
+            assert torch.equal(outs[fused], again), f"fused={fused}: two forwards differ in deterministic mode"
+        NunchakuQwenImageTransformer2DModel.batched_mods = False
+        try:
+            per_block = model(lat, enc, None, t, [(1, 16, 16)]).sample.float()
+        finally:
+            NunchakuQwenImageTransformer2DModel.batched_mods = True
+    assert torch.equal(per_block, outs[True]), "batched modulation GEMVs differ from the per-block ones"
+    psnr, rel = psnr_rel(outs[True], outs[False])
+    print(f"qwen model fused vs torch-op blocks ({dtype}): PSNR {psnr:.1f} dB rel {rel:.2e}")
+    assert torch.isfinite(outs[True]).all() and psnr > 40.0 and rel < 3e-2, (psnr, rel)
+
+
 def test_qwen_rope_tables():
     from nunchaku_amd.models.qwenimage import pack_qwen_rotary, qwen_rope_freqs
 
