@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 15
+#define SVDQ_ABI_VERSION 16
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -278,7 +278,10 @@ typedef struct svdq_attention_args {
      * middle: hence two ranges (kv_start1 = kv_end1 = 0: one range).  Padded K / Q rows may hold anything, including NaN; padded
      * V^T columns must be FINITE (0 * NaN is NaN in the matrix unit): zero them.  Output rows of padded queries are unspecified.
      * Role of the reference's padded-row masking (epilogues.cuh:427-550, attention.cuh). */
-    int32_t kv_len0, kv_start1, kv_end1, reserved3;
+    int32_t kv_len0, kv_start1, kv_end1;
+    /* workgroup geometry: 0 = automatic; 1 = 8 waves x 32 query rows (two waves per SIMD); 2 = 4 waves x 64 query rows (one wave
+     * per SIMD with the whole register file; needs L % 256 == 0).  Same arithmetic per row: results are bit-identical. */
+    int32_t geometry;
 } svdq_attention_args;
 
 int svdq_attention(const svdq_attention_args *args, void *stream);

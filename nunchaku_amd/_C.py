@@ -263,6 +263,9 @@ class _Ops:
 
     # False: plain grid (one workgroup per task) instead of the persistent schedule; tests compare the two
     attention_use_workspace = True
+    # Workgroup geometry of the attention kernel (svdq_attention_args.geometry): 0 = the library's choice, 1 = 8 waves x 32 query
+    # rows, 2 = 4 waves x 64 query rows (L % 256 == 0 only; other lengths always run geometry 1)
+    attention_geometry = 0
 
     @staticmethod
     def attention_workspace_status() -> None:
@@ -667,6 +670,7 @@ class _Ops:
             if not zero.is_cuda or not zero.is_contiguous() or (zero.numel() * zero.element_size()) % 16:
                 raise ValueError("attention: zero must be a contiguous GPU tensor of a multiple of 16 bytes")
             a.zero_ptr, a.zero_bytes = zero.data_ptr(), zero.numel() * zero.element_size()
+        a.geometry = _Ops.attention_geometry if L % 256 == 0 else 0
         if _Ops.attention_use_workspace and L % 256 == 0:
             ws = _workspace(q.device, "attention")
             ws.check("attention")

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 15
+ABI_VERSION = 16
 LORA_ACT_F32, LORA_ACT_Q32 = 0, 1
 
 
@@ -69,7 +69,7 @@ class AttentionArgs(C.Structure):
         ("qlora_down", C.c_void_p), ("qsmooth2", C.c_void_p), ("qlora_down2", C.c_void_p), ("qR", C.c_int32),
         ("qsplit_rows", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("qlora_act_format", C.c_int32), ("reserved2", C.c_int32), ("status", C.c_void_p),
-        ("kv_len0", C.c_int32), ("kv_start1", C.c_int32), ("kv_end1", C.c_int32), ("reserved3", C.c_int32),
+        ("kv_len0", C.c_int32), ("kv_start1", C.c_int32), ("kv_end1", C.c_int32), ("geometry", C.c_int32),
     ]
 
 

@@ -29,6 +29,18 @@
 #include "svdq_common.h"
 #include <type_traits>
 
+// tools/ablate/build_attn.py builds timing variants of geometry 2's iteration (the placement under other generator options; the
+// per-tile barrier / the staging removed: wrong results, timing only) by redefining these three; the product build has no switches
+#ifndef SVDQ_ATTN_STEP_INC
+#define SVDQ_ATTN_STEP_INC "attention_step64.inc"
+#endif
+#ifndef SVDQ_ATTN_TILE_BARRIER
+#define SVDQ_ATTN_TILE_BARRIER() __syncthreads()
+#endif
+#ifndef SVDQ_ATTN_STAGE
+#define SVDQ_ATTN_STAGE(statement) statement
+#endif
+
 namespace svdq {
 
 constexpr int ATT_D = 128;     // head dimension (FLUX; the reference's attention kernel is also fixed to 128)
@@ -66,6 +78,7 @@ constexpr int ATT_SPIN_LIMIT = 1 << 22;                // x s_sleep(8) ~ 1 s: a 
 // scale*log2(e) factor): until then P = exp2(s - m_stale) <= 2^8, exact in fp32 and with the same RELATIVE rounding
 // in the 16-bit P fragments; later tiles almost never rescale (64 multiplies + exp per wave-tile saved)
 constexpr float ATT_DEFER_LOG2 = 8.0f;
+constexpr int ATT_DEFAULT_GEOMETRY = 1; // svdq_attention_args.geometry = 0 resolves to this (when L % 256 == 0; otherwise geometry 1)
 
 // The persistent schedule's arithmetic, shared by the kernel and its host replay (svdq_attention_schedule).
 // Workgroup g first takes F = tasks / G WHOLE tasks (task f*G + g: the workgroups of an XCD, numbered contiguously, walk the keys
@@ -111,6 +124,114 @@ template <int DT> __device__ __forceinline__ unsigned pack2(float a, float b) {
 template <int DT> __device__ __forceinline__ float sum2(unsigned packed, float l) {
     if constexpr (DT == SVDQ_BF16) return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), __builtin_bit_cast(bf16x2, 0x3f803f80u), l, false);
     else return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, packed), __builtin_bit_cast(f16x2, 0x3c003c00u), l, false);
+}
+
+// Normalise one 32-row tile of a wave and store it: lane owns query row q0 + lr and channels 32*dt + 8c + 4h + e of o[dt].
+// Either the 16-bit output, or (p.qact) the output projection's quantised activation, or both.
+template <int DT>
+__device__ __forceinline__ void finish_rows(const AttnParams &p, const v16f (&o)[4], float l_run, int q0, int head, int lane) {
+    using V8 = typename Half<DT>::V8;
+    const int lr = lane & 31, h = lane >> 5;
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    if (p.qact) {
+        // ---- fused quantiser of the output projection (quantize.hip, same arithmetic): this wave's 32 rows x 128
+        //      channels = F6 chunk (row tile q0/32, kp = head); lane (lr, h) holds exactly its lane record's channels
+        using T = typename Half<DT>::T;
+        const bool s2 = p.qsplit_rows > 0 && q0 >= p.qsplit_rows; // wave-uniform
+        const T *smooth = (const T *)(s2 ? p.qsmooth2 : p.qsmooth) + head * ATT_D;
+        const int K = p.H * ATT_D, KP = p.H;
+        if (p.qR > 0) { // lora_act[q][rank] += sum_d o16[q][d] * down[d][rank] over this head's 128 channels
+            const T *ld = (const T *)(s2 ? p.qlora_down2 : p.qlora_down) + head * ATT_D; // rank-major [R][K]
+            v16f dl;
+#pragma unroll
+            for (int i = 0; i < 16; i++) dl[i] = 0.f;
+            const bool live = lr < p.qR;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int qq = 0; qq < 2; qq++) {
+                    V8 wv, gv;
+                    if (live) {
+                        const T *src = ld + (size_t)lr * K + dt * 32 + qq * 16 + h * 4;
+                        const u16x4 w0 = *reinterpret_cast<const u16x4 *>(src);
+                        const u16x4 w1 = *reinterpret_cast<const u16x4 *>(src + 8);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { wv[j] = hfrom<T>(w0[j]); wv[4 + j] = hfrom<T>(w1[j]); }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) wv[j] = (T)0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) gv[j] = f2h<T>(o[dt][qq * 8 + j] * inv);
+                    dl = Half<DT>::mfma32(gv, wv, dl);
+                }
+            if (live) { // C layout: column (rank) = lane & 31, rows (i & 3) + 8 (i >> 2) + 4 h
+                const size_t at = (size_t)(q0 + h * 4) * p.qR + lr;
+                const int mode = 1 | (p.qlora_q32 ? 2 : 0); // the H heads add to the same element
+#pragma unroll
+                for (int i = 0; i < 16; i++) lora_act_add(p.qlora_act, at + (size_t)((i & 3) + 8 * (i >> 2)) * p.qR, dl[i], mode);
+            }
+        }
+        uint32_t rec[12];
+        T sc16[2];
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            float xh[32];
+            float amax = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int dt = 2 * g + t;
+                    const u16x4 sv = *reinterpret_cast<const u16x4 *>(smooth + dt * 32 + c * 8 + h * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float o16 = round16<T>(o[dt][c * 4 + e] * inv);
+                        const float sm = h2f(hfrom<T>(sv[e]));
+                        const float v = round16<T>(div_rn(o16, sm, __builtin_amdgcn_rcpf(sm)));
+                        xh[16 * t + c * 4 + e] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+                }
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            const float scale = amax * (1.0f / 7.0f);
+            const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
+            sc16[g] = f2h<T>(scale);
+            v16f ev, od;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                ev[i] = xh[2 * i] * rscale;
+                od[i] = xh[2 * i + 1] * rscale;
+            }
+            const v6i pk = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, 8.0f);
+#pragma unroll
+            for (int i = 0; i < 6; i++) rec[6 * g + i] = (uint32_t)pk[i];
+        }
+        const int rt = q0 >> 5;
+        uint8_t *dst = p.qact + ((size_t)rt * KP + head) * F6_CHUNK + (size_t)lane * 16;
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        *reinterpret_cast<uint4 *>(dst + F6_PLANE) = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+        *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[8], rec[9], rec[10], rec[11]);
+        p.qscales[(((size_t)rt * KP + head) * 2 + h) * 32 + lr] = hbits(sc16[h]);
+    }
+    if (p.out) {
+    uint16_t *orow = p.out + (size_t)(q0 + lr) * p.ldo + (size_t)head * p.o_hs + 8 * h;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; j2++) {
+            unsigned x[2], y[2];
+#pragma unroll
+            for (int d2 = 0; d2 < 2; d2++) {
+                x[d2] = pack2<DT>(o[dt][8 * j2 + 2 * d2] * inv, o[dt][8 * j2 + 2 * d2 + 1] * inv);
+                y[d2] = pack2<DT>(o[dt][8 * j2 + 4 + 2 * d2] * inv, o[dt][8 * j2 + 4 + 2 * d2 + 1] * inv);
+                auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
+                x[d2] = sw[0];
+                y[d2] = sw[1];
+            }
+            *reinterpret_cast<v4i *>(orow + 32 * dt + 16 * j2) = v4i{(int)x[0], (int)x[1], (int)y[0], (int)y[1]};
+        }
+    } // p.out
 }
 
 // NW waves = NW * 32 query rows of one head per workgroup.
@@ -397,109 +518,401 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
             }
         }
 
-    // ---- normalise and store: lane owns query row q0 + lr and channels 32*dt + 8c + 4h + e ------------------
-    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
-    if (p.qact) {
-        // ---- fused quantiser of the output projection (quantize.hip, same arithmetic): this wave's 32 rows x 128
-        //      channels = F6 chunk (row tile q0/32, kp = head); lane (lr, h) holds exactly its lane record's channels
-        using T = typename Half<DT>::T;
-        const bool s2 = p.qsplit_rows > 0 && q0 >= p.qsplit_rows; // wave-uniform
-        const T *smooth = (const T *)(s2 ? p.qsmooth2 : p.qsmooth) + head * ATT_D;
-        const int K = p.H * ATT_D, KP = p.H;
-        if (p.qR > 0) { // lora_act[q][rank] += sum_d o16[q][d] * down[d][rank] over this head's 128 channels
-            const T *ld = (const T *)(s2 ? p.qlora_down2 : p.qlora_down) + head * ATT_D; // rank-major [R][K]
-            v16f dl;
+    finish_rows<DT>(p, o, l_run, q0, head, lane);
+    } // segments
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Geometry 2: 4 waves x 64 query rows, ONE wave per SIMD with the whole 512-register file (O: 128 registers, two score
+// sets: 128, Q: 64).  Against the 8 x 32 geometry above a K / V^T fragment read from LDS feeds two MFMAs instead of one,
+// and the instruction stream itself overlaps what the two co-resident waves of a SIMD used to overlap by chance:
+//   iteration j:   exp / pack of S(j)   beside the 32 MFMAs of  S(j+1) = K(j+1) Q^T        (two score sets in registers)
+//                  row maxima of S(j+1) beside the 32 MFMAs of  O += V^T(j) P(j)
+// K tiles are staged two iterations ahead, V^T tiles one: K(j+2) -> the buffer K(j) was read from in iteration j-1,
+// V^T(j+1) -> the buffer of V^T(j-1); the global loads are issued one iteration before their LDS writes (the registers
+// carry them across the barrier), one barrier per tile.  Same arithmetic per row as geometry 1 (per 32-row tile: maxima,
+// deferred rescale, rounded-probability row sums), same task / persistent-schedule / slab definitions (task = 256 rows).
+template <int DT, bool PERSIST>
+__global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p) {
+    using V8 = typename Half<DT>::V8;
+    constexpr int NT = 256, RT = 2;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * ATT_TILE]; // [buf][K | V^T]: K(t) and V^T(t) live in buffer t & 1
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef __attribute__((address_space(3))) v4i lds_v4i;
+    lds_u8 *const L8 = (lds_u8 *)lds;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, h = lane >> 5;
+    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * NT + tid; i < p.zero_vec; i += (long long)gridDim.x * gridDim.y * NT)
+        p.zero_ptr[i] = v4i{0, 0, 0, 0}; // side job: clear the next quantiser's low-rank accumulators
+
+    const int ntiles = p.L / ATT_KB;
+    const int QT = p.L / 256; // tasks per head
+    const int G = PERSIST ? (int)gridDim.x : 1;
+    const int g = !PERSIST ? 0 : (G % 8 == 0 ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x);
+    AttnSchedule sched;
+    sched.init(p.H * QT, ntiles, G);
+    int whole_left = PERSIST ? sched.F : 1;
+    int pos = PERSIST && g < sched.Gs ? sched.bound(g) : 0;
+    const int run_hi = PERSIST && g < sched.Gs ? sched.bound(g + 1) : 0;
+
+    // staging: LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = one 1 KiB piece per instruction, written lane-linearly at
+    // M0), no registers, no ds_write; a tile is requested at the top of an iteration and must have landed at its end.  A K piece = 4 key rows, a V^T piece = 8 channel rows; wave w issues pieces
+    // 4w .. 4w+3 of each matrix.  The XOR swizzle of the fragment reads (conflict-free ds_read_b128) is applied on the SOURCE side:
+    // the lane that writes 16-byte position p of a row fetches the chunk p ^ f(row) of that row.
+    unsigned kdma[4], vdma[4];
 #pragma unroll
-            for (int i = 0; i < 16; i++) dl[i] = 0.f;
-            const bool live = lr < p.qR;
+    for (int i = 0; i < 4; i++) {
+        const int kr = 16 * wave + 4 * i + (lane >> 4), vd = 32 * wave + 8 * i + (lane >> 3);
+        kdma[i] = (unsigned)kr * (unsigned)p.ldk * 2u + (((lane & 15) ^ (kr & 15)) << 4);
+        vdma[i] = (unsigned)vd * (unsigned)p.ldvt * 2u + (((lane & 7) ^ ((vd >> 1) & 7)) << 4);
+    }
+    unsigned ka[8], va[4];
+#pragma unroll
+    for (int ds = 0; ds < 8; ds++) ka[ds] = lr * 256 + (((2 * ds + h) ^ (lr & 15)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) va[ks] = ATT_TILE + lr * 128 + (((2 * ks + h) ^ ((lr >> 1) & 7)) << 4);
+    const unsigned lds0 = (unsigned)(uintptr_t)L8 + __builtin_amdgcn_readfirstlane(wave) * 4096; // this wave's pieces of slot 0's K; V^T: + ATT_TILE
+
+    const uint8_t *kbase = nullptr, *vtbase = nullptr;
+    // The DMA is inline asm on purpose: the compiler orders every later LDS read behind an LDS-DMA builtin with vmcnt(0); here the
+    // waits are counted by hand (tile_landed below).  Its own vmcnt bookkeeping stays safe: in-order retirement, extra operations it
+    // does not know about can only make its waits longer.
+    auto dma_k = [&](int kv0, int slot) {
+        const uint8_t *src = kbase + (size_t)kv0 * p.ldk * 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + slot * 2 * ATT_TILE + i * 1024), "v"(kdma[i]), "s"(src) : "memory", "m0");
+    };
+    auto dma_v = [&](int kv0, int slot) {
+        const uint8_t *src = vtbase + (size_t)kv0 * 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + slot * 2 * ATT_TILE + ATT_TILE + i * 1024), "v"(vdma[i]), "s"(src) : "memory", "m0");
+    };
+    V8 qf[RT][8];
+    v16f o[RT][4];
+    v16f s[2][RT][2]; // two score sets: S(j) being exponentiated, S(j+1) being accumulated
+    float m_run[RT];
+    // row sums over the ROUNDED probabilities (v_dot2c against (1, 1) on the packed fragments the PV MFMA reads), this lane's share
+    // as two chains.  A v_dot2c beside an MFMA waits for the matrix pipe: ~20 cycles for the first one behind an MFMA, 4 for each
+    // further one (profiles/r3_mfma_filler_prices.txt) -- so the 8 of a key step sit together in ONE slot (A64_DOT8), 4 such slots
+    // per tile, instead of 32 slots with one each
+    float l2a[RT], l2b[RT];
+    const float c = p.scale_log2e;
+    int j_end = 0;
+
+    // S^T[k][q] of the K tile in buffer BUF: per d-step two K fragments, each feeding the MFMAs of both row tiles (4 chains).
+    // These MFMAs are inline asm: with 512 registers the compiler selects the AGPR form for every MFMA builtin and then copies the
+    // scores out for the softmax (and the zeros in): 320 v_accvgpr moves per tile.  The asm pins what the design needs -- scores
+    // in arch VGPRs (the VALU reads them), Q in AGPRs (only MFMAs read it); O stays with the builtins (AGPR accumulators).
+    // Hazards the compiler cannot see through asm: MFMA result -> VALU read needs 11 wait states (8-pass MFMA): settle() below.
+    auto qk_mfma = [&](auto firstc, v16f &acc, const v4i &kw, const V8 &q) {
+        if constexpr (decltype(firstc)::value) {
+            if constexpr (DT == SVDQ_BF16) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(kw), "a"(q));
+            else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(kw), "a"(q));
+        } else {
+            if constexpr (DT == SVDQ_BF16) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(kw), "a"(q));
+            else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(kw), "a"(q));
+        }
+    };
+    auto qk = [&](auto bufc, v16f (&sd)[RT][2]) {
+        constexpr int BO = decltype(bufc)::value * 2 * ATT_TILE; // ring slot
+#pragma unroll
+        for (int ds = 0; ds < 8; ds++)
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+                const v4i kw = *(const lds_v4i *)(L8 + (ka[ds] + (BO + kt * 8192)));
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    if (ds == 0) qk_mfma(std::true_type{}, sd[rt][kt], kw, qf[rt][ds]);
+                    else qk_mfma(std::false_type{}, sd[rt][kt], kw, qf[rt][ds]);
+                }
+            }
+    };
+    // every consumer of a score set sits behind this: >= 24 wait states after the last asm MFMA that wrote it
+    auto settle = [&](v16f (&sd)[RT][2]) {
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sd[0][0]), "+v"(sd[0][1]), "+v"(sd[1][0]), "+v"(sd[1][1]));
+    };
+    // key-padding mask of tile j (workgroup-uniform branch: only tiles that contain padding pay)
+    auto mask = [&](v16f (&sd)[RT][2], int j) {
+        if (__builtin_expect(p.kv_len0 > 0, 0)) {
+            const int k0 = j * ATT_KB;
+            const bool all_real = k0 + ATT_KB <= p.kv_len0 || (k0 >= p.kv_start1 && k0 + ATT_KB <= p.kv_end1);
+            if (!all_real) {
+#pragma unroll
+                for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int key = k0 + 32 * kt + 8 * (r >> 2) + 4 * h + (r & 3);
+                        const bool real = (key < p.kv_len0) | ((key >= p.kv_start1) & (key < p.kv_end1));
+#pragma unroll
+                        for (int rt = 0; rt < RT; rt++) sd[rt][kt][r] = real ? sd[rt][kt][r] : -INFINITY;
+                    }
+            }
+        }
+    };
+    // exchange the row maxima between the two lanes of a row, then the (deferred) rescale of O and l -- every MFMA of the previous
+    // tile's PV has been issued
+    auto row_max_finish = [&](float (&mloc_)[RT]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            float mloc = mloc_[rt];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
+            const unsigned mine = sw[0], other = sw[1]; // (scalar copies: bit_cast on a vector element reads element 0 in this clang)
+            mloc = fmaxf(__builtin_bit_cast(float, mine), __builtin_bit_cast(float, other));
+            if (__builtin_amdgcn_ballot_w64((mloc - m_run[rt]) * c > ATT_DEFER_LOG2) != 0) {
+                const float m_new = fmaxf(m_run[rt], mloc);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[rt] - m_new) * c);
+                m_run[rt] = m_new;
+                l2a[rt] *= alpha;
+                l2b[rt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++) o[rt][dt] = o[rt][dt] * alpha;
+            }
+        }
+    };
+    // row maxima of a score set (the prologue's form; the steady-state iteration computes them slice by slice)
+    auto row_max = [&](v16f (&sd)[RT][2]) {
+        float mloc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            mloc[rt] = fmaxf(sd[rt][0][0], sd[rt][1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; r += 2) {
+                mloc[rt] = fmaxf(fmaxf(mloc[rt], sd[rt][0][r]), r + 1 < 16 ? sd[rt][0][r + 1] : sd[rt][0][r]);
+                mloc[rt] = fmaxf(fmaxf(mloc[rt], sd[rt][1][r]), r + 1 < 16 ? sd[rt][1][r + 1] : sd[rt][1][r]);
+            }
+        }
+        row_max_finish(mloc);
+    };
+    // P = 2^(s c - m c) -> the 16-bit B fragments of the PV MFMA; row sums over the rounded probabilities
+    auto exp_pack = [&](v16f (&sd)[RT][2], V8 (&pf)[RT][4]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const float nmc = m_run[rt] == -INFINITY ? 0.f : -(m_run[rt] * c);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const int kt = ks >> 1, r0 = 8 * (ks & 1);
+                float e[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sd[rt][kt][r0 + i], c, nmc));
+                unsigned x[2], y[2];
+#pragma unroll
+                for (int d2 = 0; d2 < 2; d2++) {
+                    x[d2] = pack2<DT>(e[2 * d2], e[2 * d2 + 1]);
+                    y[d2] = pack2<DT>(e[4 + 2 * d2], e[4 + 2 * d2 + 1]);
+                    auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
+                    x[d2] = sw[0];
+                    y[d2] = sw[1];
+                }
+                pf[rt][ks] = __builtin_bit_cast(V8, v4i{(int)x[0], (int)x[1], (int)y[0], (int)y[1]});
+                l2a[rt] = sum2<DT>(y[0], sum2<DT>(x[0], l2a[rt]));
+                l2b[rt] = sum2<DT>(y[1], sum2<DT>(x[1], l2b[rt]));
+            }
+        }
+    };
+    // O^T[d][q] += V^T[d][k] P^T[k][q]: per key step four V^T fragments, each feeding both row tiles (8 chains)
+    auto pv = [&](auto bufc, const V8 (&pf)[RT][4]) {
+        constexpr int BO = decltype(bufc)::value * 2 * ATT_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                const v4i vw = *(const lds_v4i *)(L8 + (va[ks] + (BO + dt * 4096)));
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) o[rt][dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw), pf[rt][ks], o[rt][dt]);
+            }
+    };
+    // iteration j (buffer parity BUF = j & 1, relative to the segment's first tile); MORE: tile j+1 exists.  Requested here: K(j+2)
+    // into the buffer K(j) was read from in iteration j-1, V^T(j+1) into the buffer of V^T(j-1); both have landed (this wave's
+    // pieces: vmcnt(0); everybody's: the barrier) when the iteration ends.
+    auto step = [&](auto bufc, auto morec, int j) {
+        constexpr int BUF = decltype(bufc)::value;
+        constexpr bool MORE = decltype(morec)::value;
+        SVDQ_ATTN_STAGE(if (j + 2 < j_end) dma_k((j + 2) * ATT_KB, BUF);)
+        SVDQ_ATTN_STAGE(if constexpr (MORE) dma_v((j + 1) * ATT_KB, BUF ^ 1);)
+        V8 pf[RT][4];
+        if constexpr (MORE) {
+            // the steady-state iteration, placed slot by slot (tools/gen_attn_step.py -> attention_step64.inc): one MFMA per slot
+            // with its share of the exp / pack of S(j), of the fragment reads and of the row maxima of S(j+1); the order in the
+            // source is the order in the binary (sched_barrier between slots)
+            v16f (&sc)[RT][2] = s[BUF];
+            v16f (&sn)[RT][2] = s[BUF ^ 1];
+            constexpr int KBO = (BUF ^ 1) * 2 * ATT_TILE, VBO = BUF * 2 * ATT_TILE;
+            v4i kw[16], vw[16];
+            float nmc[RT], e[RT * 4][8], mloc[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) nmc[rt] = m_run[rt] == -INFINITY ? 0.f : -(m_run[rt] * c);
+            unsigned px[RT * 4][2], py[RT * 4][2];
+#define A64_SB __builtin_amdgcn_sched_barrier(0);
+#define A64_KREAD(ds, kt) kw[(ds) * 2 + (kt)] = *(const lds_v4i *)(L8 + (ka[ds] + (KBO + (kt) * 8192)));
+#define A64_VREAD(ks, dt) vw[(ks) * 4 + (dt)] = *(const lds_v4i *)(L8 + (va[ks] + (VBO + (dt) * 4096)));
+#define A64_QK(ds, kt, rt) qk_mfma(std::integral_constant<bool, (ds) == 0>{}, sn[rt][kt], kw[(ds) * 2 + (kt)], qf[rt][ds]);
+#define A64_PV(ks, dt, rt) o[rt][dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw[(ks) * 4 + (dt)]), pf[rt][ks], o[rt][dt]);
+#define A64_FMA(rt, ks, i) e[(rt) * 4 + (ks)][i] = __builtin_fmaf(sc[rt][(ks) >> 1][8 * ((ks) & 1) + (i)], c, nmc[rt]);
+#define A64_EXP(rt, ks, i) e[(rt) * 4 + (ks)][i] = __builtin_amdgcn_exp2f(e[(rt) * 4 + (ks)][i]);
+#define A64_CVT(rt, ks, d) { if ((d) < 2) px[(rt) * 4 + (ks)][(d) & 1] = pack2<DT>(e[(rt) * 4 + (ks)][2 * ((d) & 1)], e[(rt) * 4 + (ks)][2 * ((d) & 1) + 1]); \
+                             else py[(rt) * 4 + (ks)][(d) & 1] = pack2<DT>(e[(rt) * 4 + (ks)][4 + 2 * ((d) & 1)], e[(rt) * 4 + (ks)][4 + 2 * ((d) & 1) + 1]); }
+#define A64_DOT8(ks) { _Pragma("unroll") for (int rt_ = 0; rt_ < RT; rt_++) { const v4i w_ = __builtin_bit_cast(v4i, pf[rt_][ks]); \
+                           l2a[rt_] = sum2<DT>((unsigned)w_[2], sum2<DT>((unsigned)w_[0], l2a[rt_])); l2b[rt_] = sum2<DT>((unsigned)w_[3], sum2<DT>((unsigned)w_[1], l2b[rt_])); } \
+                       asm volatile("" : "+v"(l2a[0]), "+v"(l2b[0]), "+v"(l2a[1]), "+v"(l2b[1])); } // (pinned to the slot: machine sinking would move them to the loop's end)
+#define A64_SWAP(rt, ks, d2) { auto sw = __builtin_amdgcn_permlane32_swap(px[(rt) * 4 + (ks)][d2], py[(rt) * 4 + (ks)][d2], false, false); \
+                               px[(rt) * 4 + (ks)][d2] = sw[0]; py[(rt) * 4 + (ks)][d2] = sw[1]; }
+#define A64_FIN(rt, ks) pf[rt][ks] = __builtin_bit_cast(V8, v4i{(int)px[(rt) * 4 + (ks)][0], (int)px[(rt) * 4 + (ks)][1], (int)py[(rt) * 4 + (ks)][0], (int)py[(rt) * 4 + (ks)][1]});
+            // the row maxima of S(j+1) start >= 18 MFMAs (> 500 cycles) after the last asm MFMA that wrote it: the 11 wait states of
+            // that hazard have long passed; the empty asm only orders the reads behind the writes for the compiler.  The mask of a
+            // tile with padding (rare, workgroup-uniform) sits at the same point.
+#define A64_SETTLE asm volatile("" : "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1])); mask(sn, j + 1);
+#define A64_RMAX(rt, i) { if ((i) == 0) mloc[rt] = fmaxf(sn[rt][0][0], sn[rt][1][0]); \
+                          else { constexpr int r_ = 2 * (((i) - 1) >> 1) + 1, kt_ = ((i) - 1) & 1; mloc[rt] = fmaxf(fmaxf(mloc[rt], sn[rt][kt_][r_]), r_ + 1 < 16 ? sn[rt][kt_][r_ + 1] : sn[rt][kt_][r_]); } }
+#include SVDQ_ATTN_STEP_INC
+#undef A64_SB
+#undef A64_KREAD
+#undef A64_VREAD
+#undef A64_QK
+#undef A64_PV
+#undef A64_FMA
+#undef A64_EXP
+#undef A64_CVT
+#undef A64_DOT8
+#undef A64_SWAP
+#undef A64_FIN
+#undef A64_SETTLE
+#undef A64_RMAX
+            row_max_finish(mloc);
+        } else {
+            exp_pack(s[BUF], pf);
+            pv(bufc, pf);
+        }
+        SVDQ_ATTN_STAGE(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");)
+        SVDQ_ATTN_TILE_BARRIER();
+    };
+
+    while (true) {
+        int task, j0, j1, tl = -1;
+        if (whole_left > 0) {
+            if constexpr (PERSIST) task = (sched.F - whole_left) * G + g;
+            else {
+                const int b = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, N = (int)(gridDim.x * gridDim.y);
+                task = N % 8 == 0 ? (b % 8) * (N / 8) + b / 8 : b;
+            }
+            j0 = 0; j1 = ntiles;
+            whole_left--;
+        } else if (pos < run_hi) {
+            tl = pos / ntiles;
+            j0 = pos - tl * ntiles;
+            j1 = min(ntiles, j0 + (run_hi - pos));
+            pos += j1 - j0;
+            task = sched.F * G + tl;
+        } else break;
+        const int head = task / QT;
+        const int q0 = (task - head * QT) * 256 + wave * 64;
+        kbase = (const uint8_t *)(p.k + (size_t)head * p.k_hs);
+        vtbase = (const uint8_t *)(p.vt + (size_t)head * p.vt_hs);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const uint16_t *qrow = p.q + (size_t)(q0 + 32 * rt + lr) * p.ldq + (size_t)head * p.q_hs + 8 * h;
+#pragma unroll
+            for (int ds = 0; ds < 8; ds++) {
+                // the fragment is BORN in an AGPR (tied operand: the copy happens here, once per task): every later use is an "a"
+                // operand of an asm MFMA, and a value that lives in arch VGPRs between them is reloaded from scratch per use
+                const V8 qv = *reinterpret_cast<const V8 *>(qrow + 16 * ds);
+                asm volatile("" : "=a"(qf[rt][ds]) : "0"(qv));
+            }
 #pragma unroll
             for (int dt = 0; dt < 4; dt++)
 #pragma unroll
-                for (int qq = 0; qq < 2; qq++) {
-                    V8 wv, gv;
-                    if (live) {
-                        const T *src = ld + (size_t)lr * K + dt * 32 + qq * 16 + h * 4;
-                        const u16x4 w0 = *reinterpret_cast<const u16x4 *>(src);
-                        const u16x4 w1 = *reinterpret_cast<const u16x4 *>(src + 8);
+                for (int r = 0; r < 16; r++) o[rt][dt][r] = 0.f;
+            m_run[rt] = -INFINITY;
+            l2a[rt] = l2b[rt] = 0.f;
+        }
+        j_end = j1;
+        // prologue: K(j0), V^T(j0) -> buffer 0, K(j0+1) -> buffer 1 (a segment has at least two tiles); every wave passed the barrier
+        // that ends the previous segment's last step: all buffers are free
+        dma_k(j0 * ATT_KB, 0);
+        dma_v(j0 * ATT_KB, 0);
+        dma_k((j0 + 1) * ATT_KB, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        qk(std::integral_constant<int, 0>{}, s[0]);
+        settle(s[0]);
+        mask(s[0], j0);
+        row_max(s[0]);
+        __syncthreads(); // K(j0) has been read by every wave before the first step requests K(j0+2) into its buffer
+        for (int j = j0; j < j1 - 2; j += 2) {
+            step(std::integral_constant<int, 0>{}, std::true_type{}, j);
+            step(std::integral_constant<int, 1>{}, std::true_type{}, j + 1);
+        }
+        step(std::integral_constant<int, 0>{}, std::true_type{}, j1 - 2);
+        step(std::integral_constant<int, 1>{}, std::false_type{}, j1 - 1);
+        float l_run[RT];
 #pragma unroll
-                        for (int j = 0; j < 4; j++) { wv[j] = hfrom<T>(w0[j]); wv[4 + j] = hfrom<T>(w1[j]); }
-                    } else {
+        for (int rt = 0; rt < RT; rt++) l_run[rt] = l2a[rt] + l2b[rt];
+
+        if constexpr (PERSIST) {
+            typedef __attribute__((address_space(1))) int gint;
+            typedef __attribute__((address_space(1))) v4f gv4f;
+            typedef __attribute__((address_space(1))) v2f gv2f;
+            gint *flags = (gint *)p.ws_flags;
+            if (j0 > 0) { // not the owner: publish (same slab image as geometry 1, [wave][rt][j][lane])
+                float *slab = p.ws_slabs + (size_t)g * ATT_SLAB_FLOATS;
 #pragma unroll
-                        for (int j = 0; j < 8; j++) wv[j] = (T)0.f;
+                for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const v4f v = {o[rt][j >> 2][(j & 3) * 4 + 0], o[rt][j >> 2][(j & 3) * 4 + 1], o[rt][j >> 2][(j & 3) * 4 + 2], o[rt][j >> 2][(j & 3) * 4 + 3]};
+                        *(gv4f *)(slab + ((size_t)((wave * RT + rt) * 16 + j) * 64 + lane) * 4) = v;
                     }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) gv[j] = f2h<T>(o[dt][qq * 8 + j] * inv);
-                    dl = Half<DT>::mfma32(gv, wv, dl);
+                    *(gv2f *)(slab + ATT_SLAB_O + (size_t)((wave * RT + rt) * 64 + lane) * 2) = v2f{m_run[rt], l_run[rt]};
                 }
-            if (live) { // C layout: column (rank) = lane & 31, rows (i & 3) + 8 (i >> 2) + 4 h
-                const size_t at = (size_t)(q0 + h * 4) * p.qR + lr;
-                const int mode = 1 | (p.qlora_q32 ? 2 : 0); // the H heads add to the same element
-#pragma unroll
-                for (int i = 0; i < 16; i++) lora_act_add(p.qlora_act, at + (size_t)((i & 3) + 8 * (i >> 2)) * p.qR, dl[i], mode);
+                const int owner = sched.owner_of(g, tl);
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(flags + owner, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                continue;
             }
-        }
-        uint32_t rec[12];
-        T sc16[2];
+            if (j1 < ntiles) { // owner of a split task: fold in the other segments, ascending workgroup order
+                const int last = sched.last_contributor(g, tl);
+                if (tid == 0) {
+                    int spins = 0; // bounded wait, as in geometry 1
+                    while (__hip_atomic_load(flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < last - g && ++spins < ATT_SPIN_LIMIT)
+                        __builtin_amdgcn_s_sleep(8);
+                    if (spins >= ATT_SPIN_LIMIT) {
+                        __hip_atomic_store(flags + ATT_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.status) __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    __hip_atomic_store(flags + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                for (int q = g + 1; q <= last; q++) {
+                    const float *slab = p.ws_slabs + (size_t)q * ATT_SLAB_FLOATS;
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
-            float xh[32];
-            float amax = 0.f;
+                    for (int rt = 0; rt < RT; rt++) {
+                        const v2f ml = __builtin_nontemporal_load((const gv2f *)(slab + ATT_SLAB_O + (size_t)((wave * RT + rt) * 64 + lane) * 2));
+                        const float m_new = fmaxf(m_run[rt], ml[0]);
+                        const float fa = __builtin_amdgcn_exp2f((m_run[rt] - m_new) * c), fb = __builtin_amdgcn_exp2f((ml[0] - m_new) * c);
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+                        for (int j = 0; j < 16; j++) {
+                            const v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)((wave * RT + rt) * 16 + j) * 64 + lane) * 4));
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int dt = 2 * g + t;
-                    const u16x4 sv = *reinterpret_cast<const u16x4 *>(smooth + dt * 32 + c * 8 + h * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float o16 = round16<T>(o[dt][c * 4 + e] * inv);
-                        const float sm = h2f(hfrom<T>(sv[e]));
-                        const float v = round16<T>(div_rn(o16, sm, __builtin_amdgcn_rcpf(sm)));
-                        xh[16 * t + c * 4 + e] = v;
-                        amax = fmaxf(amax, fabsf(v));
+                            for (int e = 0; e < 4; e++) o[rt][j >> 2][(j & 3) * 4 + e] = o[rt][j >> 2][(j & 3) * 4 + e] * fa + v[e] * fb;
+                        }
+                        l_run[rt] = l_run[rt] * fa + ml[1] * fb;
+                        m_run[rt] = m_new;
                     }
                 }
-            amax = fmaxf(amax, __shfl_xor(amax, 32));
-            const float scale = amax * (1.0f / 7.0f);
-            const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
-            sc16[g] = f2h<T>(scale);
-            v16f ev, od;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                ev[i] = xh[2 * i] * rscale;
-                od[i] = xh[2 * i + 1] * rscale;
             }
-            const v6i pk = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, 8.0f);
-#pragma unroll
-            for (int i = 0; i < 6; i++) rec[6 * g + i] = (uint32_t)pk[i];
         }
-        const int rt = q0 >> 5;
-        uint8_t *dst = p.qact + ((size_t)rt * KP + head) * F6_CHUNK + (size_t)lane * 16;
-        *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-        *reinterpret_cast<uint4 *>(dst + F6_PLANE) = make_uint4(rec[4], rec[5], rec[6], rec[7]);
-        *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[8], rec[9], rec[10], rec[11]);
-        p.qscales[(((size_t)rt * KP + head) * 2 + h) * 32 + lr] = hbits(sc16[h]);
-    }
-    if (p.out) {
-    uint16_t *orow = p.out + (size_t)(q0 + lr) * p.ldo + (size_t)head * p.o_hs + 8 * h;
 #pragma unroll
-    for (int dt = 0; dt < 4; dt++)
-#pragma unroll
-        for (int j2 = 0; j2 < 2; j2++) {
-            unsigned x[2], y[2];
-#pragma unroll
-            for (int d2 = 0; d2 < 2; d2++) {
-                x[d2] = pack2<DT>(o[dt][8 * j2 + 2 * d2] * inv, o[dt][8 * j2 + 2 * d2 + 1] * inv);
-                y[d2] = pack2<DT>(o[dt][8 * j2 + 4 + 2 * d2] * inv, o[dt][8 * j2 + 4 + 2 * d2 + 1] * inv);
-                auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
-                x[d2] = sw[0];
-                y[d2] = sw[1];
-            }
-            *reinterpret_cast<v4i *>(orow + 32 * dt + 16 * j2) = v4i{(int)x[0], (int)x[1], (int)y[0], (int)y[1]};
-        }
-    } // p.out
+        for (int rt = 0; rt < RT; rt++) finish_rows<DT>(p, o[rt], l_run[rt], q0 + 32 * rt, head, lane);
     } // segments
 }
+
 
 template <int DT, int NW> static void launch_attention(const AttnParams &p, hipStream_t st) {
     dim3 grid(p.L / (NW * 32), p.H), block(NW * 64);
@@ -507,6 +920,10 @@ template <int DT, int NW> static void launch_attention(const AttnParams &p, hipS
 }
 template <int DT> static void launch_attention_persistent(const AttnParams &p, int groups, hipStream_t st) {
     hipLaunchKernelGGL((attention_kernel<DT, 8, true>), dim3(groups), dim3(512), 0, st, p);
+}
+template <int DT> static void launch_attention64(const AttnParams &p, int groups, hipStream_t st) {
+    if (groups > 0) hipLaunchKernelGGL((attention_kernel64<DT, true>), dim3(groups), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attention_kernel64<DT, false>), dim3(p.L / 256, p.H), dim3(256), 0, st, p);
 }
 
 // workgroups of the persistent schedule: one per CU (64 KiB of LDS and 8 waves of ~230 VGPRs: exactly one is resident per CU)
@@ -648,10 +1065,16 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (a->reserved != 0) { set_error("svdq_attention: reserved must be 0 (timing ablations live in tools/ablate, not in this library)"); return SVDQ_E_INVALID; }
+    if (a->geometry < 0 || a->geometry > 2 || (a->geometry == 2 && a->L % 256)) {
+        set_error("svdq_attention: geometry=%d (0 = automatic, 1 = 8 waves x 32 rows, 2 = 4 waves x 64 rows: needs L %% 256 == 0)", a->geometry);
+        return SVDQ_E_INVALID;
+    }
     const int nw = a->L % 256 == 0 ? 8 : 4;
     const int groups = attention_groups(p);
+    const int geometry = a->geometry ? a->geometry : ATT_DEFAULT_GEOMETRY;
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
-    if (groups > 0) { if (a->dtype == SVDQ_FP16) launch_attention_persistent<SVDQ_FP16>(p, groups, st); else launch_attention_persistent<SVDQ_BF16>(p, groups, st); }
+    if (geometry == 2 && a->L % 256 == 0) { if (a->dtype == SVDQ_FP16) launch_attention64<SVDQ_FP16>(p, groups, st); else launch_attention64<SVDQ_BF16>(p, groups, st); }
+    else if (groups > 0) { if (a->dtype == SVDQ_FP16) launch_attention_persistent<SVDQ_FP16>(p, groups, st); else launch_attention_persistent<SVDQ_BF16>(p, groups, st); }
     else if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8>(p, st); else launch_attention<SVDQ_FP16, 4>(p, st); }
     else if (nw == 8) launch_attention<SVDQ_BF16, 8>(p, st);
     else launch_attention<SVDQ_BF16, 4>(p, st);

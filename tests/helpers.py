@@ -52,3 +52,12 @@ def assert_close_16(got: np.ndarray, ref: np.ndarray, dtype: str, what: str, max
     bad = err > rel * np.abs(ref) + atol
     frac = bad.mean()
     assert frac <= max_bad_frac, f"{what}: {bad.sum()} / {bad.size} elements off by more than {ulps} ulp (max err {err.max():.4g})"
+
+
+def psnr_db(got, ref) -> float:
+    """10 log10(max|ref|^2 / mean (got - ref)^2) of two torch tensors"""
+    import torch
+
+    got, ref = got.float(), ref.float()
+    mse = ((got - ref) ** 2).mean().item()
+    return float("inf") if mse == 0 else 10.0 * float(torch.log10(ref.abs().max() ** 2 / mse))

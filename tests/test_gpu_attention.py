@@ -24,6 +24,46 @@ def _need_gpu(built_lib):
         pytest.skip("needs an MI355X")
 
 
+@pytest.fixture(autouse=True, params=[1, 2], ids=["8x32", "4x64"])
+def _geometry(request):
+    """Every test of this module runs under both workgroup geometries of the attention kernel (svdq_attention_args.geometry;
+    lengths that are not a multiple of 256 always run geometry 1)."""
+    from nunchaku_amd._C import _Ops
+
+    _Ops.attention_geometry = request.param
+    yield request.param
+    _Ops.attention_geometry = 0
+
+
+def test_attention_geometries_agree():
+    """Same arithmetic per query row in both geometries (per 32-row tile: maxima, deferred rescale, ascending key tiles, row sums over
+    the ROUNDED probabilities) except the summation order of the row sums (v_dot2c chains in geometry 1, the matrix pipe in
+    geometry 2): outputs agree to one 16-bit ulp, and almost everywhere exactly."""
+    from nunchaku_amd._C import _Ops
+    from nunchaku_amd.ops.attention import attention_packed
+
+    saved = (_Ops.attention_geometry, _Ops.attention_use_workspace)
+    try:
+        for dtype in (torch.bfloat16, torch.float16):
+            ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+            for L, H in ((256, 2), (1024, 3), (2304, 5)):
+                g = torch.Generator(device="cuda").manual_seed(L + H)
+                qkv = (torch.randn(L, 3 * H * 128, device="cuda", generator=g) * 1.5).to(dtype)
+                vt = qkv[:, 2 * H * 128:].t().contiguous()
+                for ws in (False, True):
+                    outs = []
+                    for geo in (1, 2):
+                        _Ops.attention_geometry, _Ops.attention_use_workspace = geo, ws
+                        out = torch.empty(L, H * 128, device="cuda", dtype=dtype)
+                        attention_packed(qkv, vt, H, out=out)
+                        outs.append(out.float())
+                    diff = (outs[0] - outs[1]).abs()
+                    assert (diff <= ulp * outs[0].abs() + 1e-6).all(), (dtype, L, H, ws, diff.max().item())
+                    assert (diff != 0).float().mean().item() < 2e-2, (dtype, L, H, ws, (diff != 0).float().mean().item())
+    finally:
+        _Ops.attention_geometry, _Ops.attention_use_workspace = saved
+
+
 def _ref_attention(q, k, v):
     """q, k, v: [L, H, D] 16-bit -> float32 [L, H, D]"""
     qf, kf, vf = (t.float().permute(1, 0, 2) for t in (q, k, v))
@@ -192,14 +232,22 @@ def test_flux_transformer_svdq_attention_vs_sdpa():
     t, gd = torch.tensor([0.7], device="cuda"), torch.tensor([3.5], device="cuda")
     outs = {}
     try:
+        from nunchaku_amd import mode
+
         for impl in ("svdq", "sdpa"):
             FluxAttentionAMD.attention_impl = impl
-            with torch.no_grad():
+            with torch.no_grad(), mode.deterministic_mode():
                 outs[impl] = model(lat, enc, pooled, t, img_ids, txt_ids, gd)[0].float()
     finally:
         FluxAttentionAMD.attention_impl = "svdq"
+    from tests.helpers import psnr_db
+
     rel = ((outs["svdq"] - outs["sdpa"]).norm() / outs["sdpa"].norm()).item()
-    assert torch.isfinite(outs["svdq"]).all() and rel < 5e-2, f"svdq vs sdpa attention: relative L2 {rel:.3g}"
+    psnr = psnr_db(outs["svdq"], outs["sdpa"])
+    print(f"model with svdq vs sdpa attention: PSNR {psnr:.1f} dB rel {rel:.2e}")
+    # two attention kernels (fp32 summation orders differ) in front of W4A4 layers: last-bit differences flip 4-bit codes;
+    # measured on this tiny random-weight model: 39.0 dB / 3.8e-2 (deterministic mode: the low-rank atomics are not the cause)
+    assert torch.isfinite(outs["svdq"]).all() and rel < 5e-2 and psnr > 35.0, f"svdq vs sdpa attention: relative L2 {rel:.3g}, PSNR {psnr:.1f} dB"
 
 
 def test_attention_full_size_properties():
@@ -296,10 +344,14 @@ def test_reference_fp16_attention_operators():
             s1 = proc(single, torch.cat([e, x], 1), image_rotary_emb=rot_all)
     # The outputs pass through the W4A4 output projection: attention results that differ in the last bit (different kernels'
     # summation order) flip a few 4-bit codes, so single elements move by a few per cent of the maximum while the bulk agrees.
+    from tests.helpers import psnr_db
+
     for got, ref in ((a1, a0), (c1, c0), (s1, s0)):
         err = (got.float() - ref.float()).abs().max().item()
         rel = ((got.float() - ref.float()).norm() / ref.float().norm()).item()
-        assert torch.isfinite(got.float()).all() and rel <= 1e-2 and err <= 4e-2 * ref.float().abs().max().item() + 1e-3, (err, rel)
+        psnr = psnr_db(got, ref)
+        print(f"nunchaku-fp16 processor vs SDPA processor: PSNR {psnr:.1f} dB rel {rel:.2e} max err {err:.3e}")
+        assert torch.isfinite(got.float()).all() and rel <= 1e-2 and psnr >= 45.0, (err, rel, psnr)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -91,15 +91,20 @@ def test_flux_transformer_fused_norm_vs_torch_ops():
     txt_ids = torch.zeros(t_txt, 3, device="cuda")
     t, gd = torch.tensor([0.7], device="cuda"), torch.tensor([3.5], device="cuda")
     outs = {}
+    from nunchaku_amd import mode
+    from tests.helpers import psnr_db
+
     try:
         for fused in (True, False):
             FluxTransformerAMD.fused_norm = fused
-            with torch.no_grad():
+            with torch.no_grad(), mode.deterministic_mode():
                 outs[fused] = model(lat, enc, pooled, t, img_ids, txt_ids, gd)[0].float()
     finally:
         FluxTransformerAMD.fused_norm = True
     rel = ((outs[True] - outs[False]).norm() / outs[False].norm()).item()
-    assert torch.isfinite(outs[True]).all() and rel < 5e-2, f"fused vs torch-op AdaLayerNormZero: relative L2 {rel:.3g}"
+    psnr = psnr_db(outs[True], outs[False])
+    print(f"FLUX model fused vs torch-op AdaLayerNormZero / residuals: PSNR {psnr:.1f} dB rel {rel:.2e}")
+    assert torch.isfinite(outs[True]).all() and rel < 3e-2 and psnr > 40.0, f"fused vs torch-op AdaLayerNormZero: relative L2 {rel:.3g}, PSNR {psnr:.1f}"
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

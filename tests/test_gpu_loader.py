@@ -25,12 +25,13 @@ def test_legacy_state_dict_loads_and_reproduces(built_lib):
     img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
     txt_ids = torch.zeros(t_txt, 3, device="cuda")
     t, gd = torch.tensor([0.3], device="cuda"), torch.tensor([3.5], device="cuda")
-    with torch.no_grad():
+    from nunchaku_amd import mode
+
+    with torch.no_grad(), mode.deterministic_mode():  # fixed-point low-rank reductions: identical weights -> identical bits
         a = src(lat, enc, pooled, t, img_ids, txt_ids, gd)
         b = dst(lat, enc, pooled, t, img_ids, txt_ids, gd)
     assert torch.isfinite(a).all()
-    # fp32 atomics in the low-rank reductions make repeated runs differ in the last bits; weights are identical
-    assert (a.float() - b.float()).norm() / a.float().norm() < 2e-2
+    assert torch.equal(a, b), f"loaded model differs from its source: max |d| {(a.float() - b.float()).abs().max().item():.3e}"
     # src has been repacked by its forward pass: its state dict is exported through the inverse permutations, bit for bit
     again = loader.export_legacy_state_dict(src)
     assert set(again) == set(legacy)
@@ -55,17 +56,28 @@ def test_captured_step_replays_like_eager(built_lib):
     img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
     txt_ids = torch.zeros(t_txt, 3, device="cuda")
     gd = torch.tensor([3.5], device="cuda")
+    from nunchaku_amd import mode
+
     fn = lambda lat, t: model(lat, enc, pooled, t, img_ids, txt_ids, gd)
     lat0 = torch.randn(1, side * side, 64, device="cuda", generator=g).bfloat16()
+    with mode.deterministic_mode():  # the captured launches carry the fixed-point accumulator format: replays == eager, bit for bit
+        cap = CapturedStep(fn, [lat0, torch.tensor([0.5], device="cuda")])
+        for seed, tv in ((7, 0.9), (8, 0.2)):
+            lat = torch.randn(1, side * side, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed)).bfloat16()
+            t = torch.tensor([tv], device="cuda")
+            got = cap(lat, t).clone()
+            with torch.no_grad():
+                ref = fn(lat, t)
+            assert torch.isfinite(got).all()
+            assert torch.equal(got, ref), f"replay differs from eager: max |d| {(got.float() - ref.float()).abs().max().item():.3e}"
+    # default mode (fp32 atomics): replays agree with eager to the W4A4 code-flip level
     cap = CapturedStep(fn, [lat0, torch.tensor([0.5], device="cuda")])
-    for seed, tv in ((7, 0.9), (8, 0.2)):
-        lat = torch.randn(1, side * side, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed)).bfloat16()
-        t = torch.tensor([tv], device="cuda")
-        got = cap(lat, t).clone()
-        with torch.no_grad():
-            ref = fn(lat, t)
-        assert torch.isfinite(got).all()
-        assert (got.float() - ref.float()).norm() / ref.float().norm() < 2e-2  # fp32-atomic noise through 4-bit layers
+    got = cap(lat, t).clone()
+    with torch.no_grad():
+        ref = fn(lat, t)
+    from tests.helpers import psnr_db
+
+    assert psnr_db(got, ref) > 45.0, psnr_db(got, ref)
 
 
 def test_pipeline_facing_class_call_contract(built_lib, tmp_path):
@@ -97,13 +109,15 @@ def test_pipeline_facing_class_call_contract(built_lib, tmp_path):
                   pooled_projections=torch.randn(1, 64, device="cuda", generator=g).bfloat16(),
                   encoder_hidden_states=torch.randn(1, t_txt, 128, device="cuda", generator=g).bfloat16(),
                   txt_ids=torch.zeros(t_txt, 3, device="cuda"), img_ids=img_ids, joint_attention_kwargs=None)
-    with torch.no_grad():
+    from nunchaku_amd import mode
+
+    with torch.no_grad(), mode.deterministic_mode():
         noise_pred = model(**kwargs, return_dict=False)[0]  # exactly how FluxPipeline.__call__ uses its transformer
         out = model(**kwargs)
         ref = src(lat, kwargs["encoder_hidden_states"], kwargs["pooled_projections"], kwargs["timestep"], img_ids,
                   kwargs["txt_ids"], kwargs["guidance"]).sample
     assert noise_pred.shape == lat.shape and torch.isfinite(noise_pred.float()).all()
-    assert (out.sample.float() - noise_pred.float()).norm() / noise_pred.float().norm() < 2e-2
-    assert (noise_pred.float() - ref.float()).norm() / ref.float().norm() < 2e-2
+    assert torch.equal(out.sample, noise_pred)
+    assert torch.equal(noise_pred, ref), f"from_pretrained model differs from its source: max |d| {(noise_pred.float() - ref.float()).abs().max().item():.3e}"
     with pytest.raises(NotImplementedError):
         model(**kwargs, controlnet_block_samples=[lat])

@@ -1,0 +1,102 @@
+// What does one more instruction between two MFMAs cost on a gfx950 SIMD that hosts ONE wave?  (geometry-2 attention kernel,
+// DESIGN.md 6b.)  Loop body: 8 x { v_mfma_f32_32x32x16_bf16 (8 independent accumulators) ; N fillers of one kind (independent
+// registers) }, 4 waves per workgroup = one per SIMD, one workgroup per CU.  Prints shader cycles per MFMA (s_memtime) for every
+// (kind, N).   hipcc --offload-arch=gfx950 -O2 -o filler_probe filler_probe.hip && ./filler_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// filler r of a slot works on its own register g<r> (no dependence between the fillers of a slot, nor on the MFMAs)
+#define FILL_fma(r)   "v_fma_f32 %[g" #r "], %[f1], %[f2], %[g" #r "]\n"
+#define FILL_exp(r)   "v_exp_f32 %[g" #r "], %[f1]\n"
+#define FILL_cvt(r)   "v_cvt_pk_bf16_f32 %[g" #r "], %[f1], %[f2]\n"
+#define FILL_dot(r)   "v_dot2c_f32_bf16 %[g" #r "], %[f1], %[f2]\n"
+#define FILL_max3(r)  "v_max3_f32 %[g" #r "], %[f1], %[f2], %[g" #r "]\n"
+#define FILL_add(r)   "v_add_f32 %[g" #r "], %[f1], %[g" #r "]\n"
+#define FILL_perm(r)  "v_permlane32_swap_b32 %[g" #r "], %[h" #r "]\n"
+#define FILL_mov(r)   "v_mov_b32 %[g" #r "], %[f1]\n"
+#define FILL_pkmul(r) "v_pk_mul_f32 %[p0], %[p1], %[p1]\n"
+#define FILL_dsr(r)   "ds_read_b128 %[d0], %[la]\n"
+#define FILL_snop(r)  "s_nop 0\n"
+#define FILL_salu(r)  "s_add_u32 %[s0], %[s0], 1\n"
+#define FILL_dep(r)   "v_fma_f32 %[g0], %[f1], %[f2], %[g0]\n" /* a DEPENDENT chain: every filler on the same register */
+#define FILL_accr(r)  "v_accvgpr_read_b32 %[g" #r "], %[a7]\n"
+
+#define MF(i) "v_mfma_f32_32x32x16_bf16 %[a" #i "], %[x], %[y], %[a" #i "]\n"
+
+#define BODY(F) MF(0) F MF(1) F MF(2) F MF(3) F MF(4) F MF(5) F MF(6) F MF(7) F
+
+#define KERNEL(name, F)                                                                                                        \
+    __global__ __launch_bounds__(256, 1) void name(long long *out, int iters) {                                               \
+        __shared__ v4f lds[1024];                                                                                              \
+        v16f a0 = {}, a1 = {}, a2 = {}, a3 = {}, a4 = {}, a5 = {}, a6 = {}, a7 = {};                                           \
+        v4f x = {1.f, 2.f, 3.f, 4.f}, y = {1.f, 1.f, 1.f, 1.f}, d0 = {};                                                       \
+        float f1 = 0.5f, f2 = 0.25f;                                                                                           \
+        float g0 = threadIdx.x, g1 = 1, g2 = 2, g3 = 3, g4 = 4, g5 = 5, g6 = 6, g7 = 7;                                        \
+        float h0 = 1, h1 = 1, h2 = 2, h3 = 3, h4 = 4, h5 = 5, h6 = 6, h7 = 7;                                                  \
+        double p0 = 0, p1 = 1;                                                                                                 \
+        unsigned la = (threadIdx.x & 63) * 16, s0 = 0;                                                                         \
+        lds[threadIdx.x] = x;                                                                                                  \
+        __syncthreads();                                                                                                       \
+        long long t0 = __builtin_readcyclecounter();                                                                           \
+        for (int i = 0; i < iters; i++)                                                                                        \
+            asm volatile(BODY(F)                                                                                               \
+                         : [a0] "+a"(a0), [a1] "+a"(a1), [a2] "+a"(a2), [a3] "+a"(a3), [a4] "+a"(a4), [a5] "+a"(a5), [a6] "+a"(a6),  \
+                           [a7] "+a"(a7), [d0] "+v"(d0), [p0] "+v"(p0), [s0] "+s"(s0), [g0] "+v"(g0), [g1] "+v"(g1),            \
+                           [g2] "+v"(g2), [g3] "+v"(g3), [g4] "+v"(g4), [g5] "+v"(g5), [g6] "+v"(g6), [g7] "+v"(g7),            \
+                           [h0] "+v"(h0), [h1] "+v"(h1), [h2] "+v"(h2), [h3] "+v"(h3), [h4] "+v"(h4), [h5] "+v"(h5),            \
+                           [h6] "+v"(h6), [h7] "+v"(h7)                                                                        \
+                         : [x] "v"(x), [y] "v"(y), [f1] "v"(f1), [f2] "v"(f2), [la] "v"(la), [p1] "v"(p1) : "scc");                    \
+        asm volatile("s_waitcnt lgkmcnt(0)\ns_nop 15\ns_nop 15" ::: "memory");                                                 \
+        long long t1 = __builtin_readcyclecounter();                                                                           \
+        float acc = a0[0] + a1[0] + a2[0] + a3[0] + a4[0] + a5[0] + a6[0] + a7[0] + g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7 + h0 + h1 + h2 + h3 + h4 + h5 + h6 + h7 + d0[0] + (float)p0 + s0;          \
+        if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;                                                                       \
+        if (acc == 12345.678f) out[0] = 0;                                                                                     \
+    }
+
+#define K1(k) KERNEL(k_##k##_1, FILL_##k(0))
+#define K2(k) KERNEL(k_##k##_2, FILL_##k(0) FILL_##k(1))
+#define K4(k) KERNEL(k_##k##_4, FILL_##k(0) FILL_##k(1) FILL_##k(2) FILL_##k(3))
+#define K5(k) KERNEL(k_##k##_5, FILL_##k(0) FILL_##k(1) FILL_##k(2) FILL_##k(3) FILL_##k(4))
+#define K6(k) KERNEL(k_##k##_6, FILL_##k(0) FILL_##k(1) FILL_##k(2) FILL_##k(3) FILL_##k(4) FILL_##k(5))
+#define K8(k) KERNEL(k_##k##_8, FILL_##k(0) FILL_##k(1) FILL_##k(2) FILL_##k(3) FILL_##k(4) FILL_##k(5) FILL_##k(6) FILL_##k(7))
+#define KALL(k) K1(k) K2(k) K4(k) K5(k) K6(k) K8(k)
+
+KERNEL(k_none, "")
+KALL(fma) KALL(exp) KALL(cvt) KALL(dot) KALL(max3) KALL(add) KALL(perm) KALL(mov) KALL(pkmul) KALL(dsr) KALL(snop) KALL(salu) KALL(dep)
+// mixes as in the attention iteration
+KERNEL(k_mix_a, FILL_fma(0) FILL_fma(1) FILL_exp(2) FILL_exp(3) FILL_cvt(4))
+KERNEL(k_mix_b, FILL_fma(0) FILL_fma(1) FILL_exp(2) FILL_exp(3))
+KERNEL(k_mix_c, FILL_fma(0) FILL_exp(1) FILL_cvt(2) FILL_dot(3))
+KERNEL(k_mix_d, FILL_fma(0) FILL_fma(1) FILL_exp(2) FILL_exp(3) FILL_cvt(4) FILL_dsr(5))
+KERNEL(k_mix_e, FILL_fma(0) FILL_exp(0) FILL_fma(1) FILL_exp(1))   /* exp reads the fma before it */
+KERNEL(k_mix_f, FILL_fma(0) FILL_fma(1) FILL_exp(0) FILL_exp(1))
+
+struct Entry { const char *name; void (*fn)(long long *, int); };
+#define E1(k) {#k "_1", k_##k##_1}, {#k "_2", k_##k##_2}, {#k "_4", k_##k##_4}, {#k "_5", k_##k##_5}, {#k "_6", k_##k##_6}, {#k "_8", k_##k##_8},
+
+int main() {
+    std::vector<Entry> es = {{"none", k_none}, E1(fma) E1(exp) E1(cvt) E1(dot) E1(max3) E1(add) E1(perm) E1(mov) E1(pkmul) E1(dsr) E1(snop) E1(salu) E1(dep)
+                             {"mix_2fma_2exp_cvt", k_mix_a}, {"mix_2fma_2exp", k_mix_b}, {"mix_fma_exp_cvt_dot", k_mix_c},
+                             {"mix_2fma_2exp_cvt_dsr", k_mix_d}, {"mix_fma_exp_fma_exp_dependent", k_mix_e}, {"mix_fma_fma_exp_exp_dependent", k_mix_f}};
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    long long *d;
+    const int G = 256, iters = 2000;
+    hipMalloc(&d, G * sizeof(long long));
+    std::vector<long long> h(G);
+    for (auto &e : es) {
+        printf("%-32s ...\r", e.name);
+        for (int rep = 0; rep < 2; rep++) {
+            hipLaunchKernelGGL(e.fn, dim3(G), dim3(256), 0, 0, d, iters);
+            hipDeviceSynchronize();
+        }
+        hipMemcpy(h.data(), d, G * sizeof(long long), hipMemcpyDeviceToHost);
+        double s = 0;
+        for (auto v : h) s += v;
+        printf("%-32s %7.2f cycles / MFMA   (%s)\n", e.name, s / G / (iters * 8.0), hipGetErrorString(hipGetLastError()));
+    }
+    return 0;
+}

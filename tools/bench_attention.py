@@ -20,12 +20,22 @@ def t(fn, it=20):
 
 fl = 4 * H * L * L * 128
 from nunchaku_amd._C import _Ops, ops
-for rep in range(2):  # same box, interleaved: persistent schedule (workspace) vs plain grid
-    _Ops.attention_use_workspace = False
-    us0 = t(lambda: attention_packed(qkv, vt, H, out=out)); print(f"svdq_attention plain grid  {us0:.1f} us  {fl/us0/1e6:.0f} TFLOP/s")
-    _Ops.attention_use_workspace = True
-    us = t(lambda: attention_packed(qkv, vt, H, out=out)); print(f"svdq_attention persistent  {us:.1f} us  {fl/us/1e6:.0f} TFLOP/s")
+outs, best = {}, {}
+REPS = int(os.environ.get("ATT_REPS", "5"))
+for rep in range(REPS):  # same box, interleaved: both geometries x persistent schedule (workspace) vs plain grid; best of REPS
+    for geo in (1, 2):
+        if geo == 2 and L % 256: continue
+        _Ops.attention_geometry = geo
+        for ws in (False, True):
+            _Ops.attention_use_workspace = ws
+            us = t(lambda: attention_packed(qkv, vt, H, out=out), it=30)
+            best[(geo, ws)] = min(best.get((geo, ws), 1e9), us)
+        outs[geo] = out.clone()
+for (geo, ws), us in sorted(best.items()):
+    print(f"svdq_attention geometry {geo} {'persistent' if ws else 'plain grid'}  {us:.1f} us  {fl/us/1e6:.0f} TFLOP/s  (best of {REPS} x 30 launches)", flush=True)
 ops.attention_workspace_status()
+if 2 in outs: print("geometry 2 vs 1: max |diff|", (outs[2].float() - outs[1].float()).abs().max().item())
+_Ops.attention_geometry = int(os.environ.get("ATT_GEOMETRY", "0")); attention_packed(qkv, vt, H, out=out)
 q, k, v = (qkv[:, i * H * 128:(i + 1) * H * 128].unflatten(1, (H, 128)).permute(1, 0, 2)[None] for i in range(3))
 us2 = t(lambda: F.scaled_dot_product_attention(q, k, v)); print(f"torch sdpa (strided views) {us2:.1f} us  {fl/us2/1e6:.0f} TFLOP/s")
 ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float())[0].permute(1, 0, 2).reshape(L, H * 128)
