@@ -279,8 +279,10 @@ typedef struct svdq_attention_args {
      * V^T columns must be FINITE (0 * NaN is NaN in the matrix unit): zero them.  Output rows of padded queries are unspecified.
      * Role of the reference's padded-row masking (epilogues.cuh:427-550, attention.cuh). */
     int32_t kv_len0, kv_start1, kv_end1;
-    /* workgroup geometry: 0 = automatic; 1 = 8 waves x 32 query rows (two waves per SIMD); 2 = 4 waves x 64 query rows (one wave
-     * per SIMD with the whole register file; needs L % 256 == 0).  Same arithmetic per row: results are bit-identical. */
+    /* workgroup geometry: 0 = automatic (geometry 2 on the plain grid when L % 256 == 0, else geometry 1); 1 = 8 waves x 32 query
+     * rows (two waves per SIMD); 2 = 4 waves x 64 query rows (one wave per SIMD with the whole register file; needs L % 256 == 0).
+     * An explicit geometry uses the persistent schedule when a workspace is given.  Same arithmetic per row (maxima, deferred
+     * rescale, rounded-probability row sums); the two differ in the summation order of the row sums only (<= 1 ulp of the output). */
     int32_t geometry;
 } svdq_attention_args;
 

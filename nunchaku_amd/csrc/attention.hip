@@ -40,6 +40,18 @@
 #ifndef SVDQ_ATTN_STAGE
 #define SVDQ_ATTN_STAGE(statement) statement
 #endif
+// clock / phase stamps of the tools-built probe library (tools/ablate/attn_probe_hooks.inc); nothing in the product build
+#ifdef SVDQ_PROBE
+#include "attn_probe_hooks.inc"
+#else
+#define SVDQ_ATTN_PROBE_PARAMS
+#define SVDQ_ATTN_PROBE_FILL(p)
+#define SVDQ_ATTN_PROBE_BEGIN()
+#define SVDQ_ATTN_PROBE_LOOP_BEGIN()
+#define SVDQ_ATTN_PROBE_LOOP_END(n)
+#define SVDQ_ATTN_PROBE_STAMP(i, j)
+#define SVDQ_ATTN_PROBE_END()
+#endif
 
 namespace svdq {
 
@@ -67,6 +79,7 @@ struct AttnParams {
     // persistent schedule (svdq_attention_args.workspace): arrival counters + error word, then one slab per workgroup
     int *ws_flags;
     float *ws_slabs;
+    SVDQ_ATTN_PROBE_PARAMS
 };
 
 constexpr int ATT_SLAB_O = 8 * 16 * 64 * 4;            // floats: [wave][j][lane][4] image of o
@@ -78,7 +91,6 @@ constexpr int ATT_SPIN_LIMIT = 1 << 22;                // x s_sleep(8) ~ 1 s: a 
 // scale*log2(e) factor): until then P = exp2(s - m_stale) <= 2^8, exact in fp32 and with the same RELATIVE rounding
 // in the 16-bit P fragments; later tiles almost never rescale (64 multiplies + exp per wave-tile saved)
 constexpr float ATT_DEFER_LOG2 = 8.0f;
-constexpr int ATT_DEFAULT_GEOMETRY = 1; // svdq_attention_args.geometry = 0 resolves to this (when L % 256 == 0; otherwise geometry 1)
 
 // The persistent schedule's arithmetic, shared by the kernel and its host replay (svdq_attention_schedule).
 // Workgroup g first takes F = tasks / G WHOLE tasks (task f*G + g: the workgroups of an XCD, numbered contiguously, walk the keys
@@ -542,6 +554,7 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
     lds_u8 *const L8 = (lds_u8 *)lds;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    SVDQ_ATTN_PROBE_BEGIN();
     const int lr = lane & 31, h = lane >> 5;
     for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * NT + tid; i < p.zero_vec; i += (long long)gridDim.x * gridDim.y * NT)
         p.zero_ptr[i] = v4i{0, 0, 0, 0}; // side job: clear the next quantiser's low-rank accumulators
@@ -578,17 +591,18 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
     // The DMA is inline asm on purpose: the compiler orders every later LDS read behind an LDS-DMA builtin with vmcnt(0); here the
     // waits are counted by hand (tile_landed below).  Its own vmcnt bookkeeping stays safe: in-order retirement, extra operations it
     // does not know about can only make its waits longer.
+    auto dma_piece = [&](unsigned lds_at, unsigned voff, const uint8_t *src) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_at), "v"(voff), "s"(src) : "memory", "m0");
+    };
     auto dma_k = [&](int kv0, int slot) {
         const uint8_t *src = kbase + (size_t)kv0 * p.ldk * 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + slot * 2 * ATT_TILE + i * 1024), "v"(kdma[i]), "s"(src) : "memory", "m0");
+        for (int i = 0; i < 4; i++) dma_piece(lds0 + slot * 2 * ATT_TILE + i * 1024, kdma[i], src);
     };
     auto dma_v = [&](int kv0, int slot) {
         const uint8_t *src = vtbase + (size_t)kv0 * 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + slot * 2 * ATT_TILE + ATT_TILE + i * 1024), "v"(vdma[i]), "s"(src) : "memory", "m0");
+        for (int i = 0; i < 4; i++) dma_piece(lds0 + slot * 2 * ATT_TILE + ATT_TILE + i * 1024, vdma[i], src);
     };
     V8 qf[RT][8];
     v16f o[RT][4];
@@ -730,8 +744,12 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
     auto step = [&](auto bufc, auto morec, int j) {
         constexpr int BUF = decltype(bufc)::value;
         constexpr bool MORE = decltype(morec)::value;
-        SVDQ_ATTN_STAGE(if (j + 2 < j_end) dma_k((j + 2) * ATT_KB, BUF);)
-        SVDQ_ATTN_STAGE(if constexpr (MORE) dma_v((j + 1) * ATT_KB, BUF ^ 1);)
+        SVDQ_ATTN_PROBE_STAMP(0, j);
+        // MORE: the 8 DMA pieces are issued from inside the slots (a piece costs ~55 cycles of issue on its own, little in the shadow
+        // of an MFMA) -- unconditionally: past the segment's end K re-fetches its last tile into a buffer nobody reads any more
+        const uint8_t *ksrc = kbase + (size_t)min(j + 2, j_end - 1) * (ATT_KB * 2) * p.ldk;
+        const uint8_t *vsrc = vtbase + (size_t)min(j + 1, j_end - 1) * (ATT_KB * 2);
+        SVDQ_ATTN_PROBE_STAMP(1, j);
         V8 pf[RT][4];
         if constexpr (MORE) {
             // the steady-state iteration, placed slot by slot (tools/gen_attn_step.py -> attention_step64.inc): one MFMA per slot
@@ -746,9 +764,12 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
             for (int rt = 0; rt < RT; rt++) nmc[rt] = m_run[rt] == -INFINITY ? 0.f : -(m_run[rt] * c);
             unsigned px[RT * 4][2], py[RT * 4][2];
 #define A64_SB __builtin_amdgcn_sched_barrier(0);
+#define A64_STAMP(n) SVDQ_ATTN_PROBE_STAMP(2 + (n), j);
 #define A64_KREAD(ds, kt) kw[(ds) * 2 + (kt)] = *(const lds_v4i *)(L8 + (ka[ds] + (KBO + (kt) * 8192)));
 #define A64_VREAD(ks, dt) vw[(ks) * 4 + (dt)] = *(const lds_v4i *)(L8 + (va[ks] + (VBO + (dt) * 4096)));
 #define A64_QK(ds, kt, rt) qk_mfma(std::integral_constant<bool, (ds) == 0>{}, sn[rt][kt], kw[(ds) * 2 + (kt)], qf[rt][ds]);
+#define A64_DMAK(i) SVDQ_ATTN_STAGE(dma_piece(lds0 + BUF * 2 * ATT_TILE + (i) * 1024, kdma[i], ksrc);)
+#define A64_DMAV(i) SVDQ_ATTN_STAGE(dma_piece(lds0 + (BUF ^ 1) * 2 * ATT_TILE + ATT_TILE + (i) * 1024, vdma[i], vsrc);)
 #define A64_PV(ks, dt, rt) o[rt][dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw[(ks) * 4 + (dt)]), pf[rt][ks], o[rt][dt]);
 #define A64_FMA(rt, ks, i) e[(rt) * 4 + (ks)][i] = __builtin_fmaf(sc[rt][(ks) >> 1][8 * ((ks) & 1) + (i)], c, nmc[rt]);
 #define A64_EXP(rt, ks, i) e[(rt) * 4 + (ks)][i] = __builtin_amdgcn_exp2f(e[(rt) * 4 + (ks)][i]);
@@ -768,10 +789,13 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
                           else { constexpr int r_ = 2 * (((i) - 1) >> 1) + 1, kt_ = ((i) - 1) & 1; mloc[rt] = fmaxf(fmaxf(mloc[rt], sn[rt][kt_][r_]), r_ + 1 < 16 ? sn[rt][kt_][r_ + 1] : sn[rt][kt_][r_]); } }
 #include SVDQ_ATTN_STEP_INC
 #undef A64_SB
+#undef A64_STAMP
 #undef A64_KREAD
 #undef A64_VREAD
 #undef A64_QK
 #undef A64_PV
+#undef A64_DMAK
+#undef A64_DMAV
 #undef A64_FMA
 #undef A64_EXP
 #undef A64_CVT
@@ -785,8 +809,10 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
             exp_pack(s[BUF], pf);
             pv(bufc, pf);
         }
+        SVDQ_ATTN_PROBE_STAMP(11, j);
         SVDQ_ATTN_STAGE(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");)
         SVDQ_ATTN_TILE_BARRIER();
+        SVDQ_ATTN_PROBE_STAMP(12, j);
     };
 
     while (true) {
@@ -840,12 +866,14 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
         mask(s[0], j0);
         row_max(s[0]);
         __syncthreads(); // K(j0) has been read by every wave before the first step requests K(j0+2) into its buffer
+        SVDQ_ATTN_PROBE_LOOP_BEGIN();
         for (int j = j0; j < j1 - 2; j += 2) {
             step(std::integral_constant<int, 0>{}, std::true_type{}, j);
             step(std::integral_constant<int, 1>{}, std::true_type{}, j + 1);
         }
         step(std::integral_constant<int, 0>{}, std::true_type{}, j1 - 2);
         step(std::integral_constant<int, 1>{}, std::false_type{}, j1 - 1);
+        SVDQ_ATTN_PROBE_LOOP_END(j1 - j0);
         float l_run[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) l_run[rt] = l2a[rt] + l2b[rt];
@@ -911,6 +939,7 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) finish_rows<DT>(p, o[rt], l_run[rt], q0 + 32 * rt, head, lane);
     } // segments
+    SVDQ_ATTN_PROBE_END();
 }
 
 
@@ -1056,6 +1085,7 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.zero_vec = a->zero_ptr ? a->zero_bytes / 16 : 0;
     p.ws_flags = nullptr;
     p.ws_slabs = nullptr;
+    SVDQ_ATTN_PROBE_FILL(p);
     if (a->workspace) {
         if (((uintptr_t)a->workspace & 15) || a->workspace_bytes < 0) { set_error("svdq_attention: workspace must be 16-byte aligned"); return SVDQ_E_INVALID; }
         if (a->workspace_bytes >= svdq_attention_workspace_bytes()) { // a smaller one is ignored (plain grid), as in svdq_gemm_w4a4
@@ -1070,8 +1100,11 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
         return SVDQ_E_INVALID;
     }
     const int nw = a->L % 256 == 0 ? 8 : 4;
-    const int groups = attention_groups(p);
-    const int geometry = a->geometry ? a->geometry : ATT_DEFAULT_GEOMETRY;
+    // automatic: 4 x 64 on the plain grid when the length allows it (measured at 24 heads x 4608 tokens, same box: 245 us against 282
+    // for 8 x 32 on either schedule; its own persistent schedule 270: the workgroups no longer walk the keys of a head together and
+    // its one-iteration DMA flight is sensitive to the L2 misses that causes); an explicit geometry takes the workspace if given
+    const int geometry = a->geometry ? a->geometry : (a->L % 256 == 0 ? 2 : 1);
+    const int groups = geometry == 2 && a->geometry == 0 ? 0 : attention_groups(p);
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
     if (geometry == 2 && a->L % 256 == 0) { if (a->dtype == SVDQ_FP16) launch_attention64<SVDQ_FP16>(p, groups, st); else launch_attention64<SVDQ_BF16>(p, groups, st); }
     else if (groups > 0) { if (a->dtype == SVDQ_FP16) launch_attention_persistent<SVDQ_FP16>(p, groups, st); else launch_attention_persistent<SVDQ_BF16>(p, groups, st); }

@@ -75,13 +75,52 @@ KERNEL(k_mix_d, FILL_fma(0) FILL_fma(1) FILL_exp(2) FILL_exp(3) FILL_cvt(4) FILL
 KERNEL(k_mix_e, FILL_fma(0) FILL_exp(0) FILL_fma(1) FILL_exp(1))   /* exp reads the fma before it */
 KERNEL(k_mix_f, FILL_fma(0) FILL_fma(1) FILL_exp(0) FILL_exp(1))
 
+
+// the MFMA CONSUMES what a ds_read_b128 delivered: A operand = fragment register r[i], read from LDS `lead` slots before its MFMA
+// (two MFMAs per fragment, as in the attention kernel: reads per MFMA = 0.5), counted lgkmcnt wait in front of the first user
+#define RD(r)  "ds_read_b128 %[r" #r "], %[la]\n"
+#define MU(i, r) "v_mfma_f32_32x32x16_bf16 %[a" #i "], %[r" #r "], %[y], %[a" #i "]\n"
+#define W(n) "s_waitcnt lgkmcnt(" #n ")\n"
+#define KERNEL_USE(name, BODYSTR)                                                                                              \
+    __global__ __launch_bounds__(256, 1) void name(long long *out, int iters) {                                               \
+        __shared__ v4f lds[1024];                                                                                              \
+        v16f a0 = {}, a1 = {}, a2 = {}, a3 = {}, a4 = {}, a5 = {}, a6 = {}, a7 = {};                                           \
+        v4f y = {1.f, 1.f, 1.f, 1.f}, r0 = {}, r1 = {}, r2 = {}, r3 = {};                                                      \
+        float f1 = 0.5f, f2 = 0.25f, g0 = 0, g1 = 1, g2 = 2, g3 = 3;                                                           \
+        unsigned la = (threadIdx.x & 63) * 16;                                                                                 \
+        lds[threadIdx.x] = y;                                                                                                  \
+        __syncthreads();                                                                                                       \
+        long long t0 = __builtin_readcyclecounter();                                                                           \
+        for (int i = 0; i < iters; i++)                                                                                        \
+            asm volatile(BODYSTR                                                                                               \
+                         : [a0] "+a"(a0), [a1] "+a"(a1), [a2] "+a"(a2), [a3] "+a"(a3), [a4] "+a"(a4), [a5] "+a"(a5), [a6] "+a"(a6),  \
+                           [a7] "+a"(a7), [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2), [r3] "+v"(r3), [g0] "+v"(g0), [g1] "+v"(g1),  \
+                           [g2] "+v"(g2), [g3] "+v"(g3)                                                                        \
+                         : [y] "v"(y), [f1] "v"(f1), [f2] "v"(f2), [la] "v"(la) : "scc");                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)\ns_nop 15\ns_nop 15" ::: "memory");                                                 \
+        long long t1 = __builtin_readcyclecounter();                                                                           \
+        float acc = a0[0] + a1[0] + a2[0] + a3[0] + a4[0] + a5[0] + a6[0] + a7[0] + r0[0] + r1[0] + r2[0] + r3[0] + g0 + g1 + g2 + g3; \
+        if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;                                                                       \
+        if (acc == 12345.678f) out[0] = 0;                                                                                     \
+    }
+// fragment ring of 4, a read every second MFMA, issued 4 MFMAs (two reads) before its first user: wait lgkmcnt(1)
+#define V4 FILL_fma(0) FILL_fma(1) FILL_fma(2) FILL_fma(3)
+KERNEL_USE(k_use_lead4, W(1) MU(0, 0) RD(2) MU(1, 0) W(1) MU(2, 1) RD(3) MU(3, 1) W(1) MU(4, 2) RD(0) MU(5, 2) W(1) MU(6, 3) RD(1) MU(7, 3))
+KERNEL_USE(k_use_lead4_valu, W(1) MU(0, 0) RD(2) V4 MU(1, 0) V4 W(1) MU(2, 1) RD(3) V4 MU(3, 1) V4 W(1) MU(4, 2) RD(0) V4 MU(5, 2) V4 W(1) MU(6, 3) RD(1) V4 MU(7, 3) V4)
+// the same reads, but the MFMAs do not use them (operand = a register nothing writes)
+KERNEL_USE(k_nouse_lead4, W(1) MU(0, 0) "ds_read_b128 %[r2], %[la]\n" MU(1, 0) W(1) MU(2, 0) "ds_read_b128 %[r3], %[la]\n" MU(3, 0) W(1) MU(4, 0) "ds_read_b128 %[r2], %[la]\n" MU(5, 0) W(1) MU(6, 0) "ds_read_b128 %[r3], %[la]\n" MU(7, 0))
+// lead 2 (one read ahead): wait lgkmcnt(0)
+KERNEL_USE(k_use_lead2, W(0) MU(0, 0) RD(1) MU(1, 0) W(0) MU(2, 1) RD(2) MU(3, 1) W(0) MU(4, 2) RD(3) MU(5, 2) W(0) MU(6, 3) RD(0) MU(7, 3))
+
 struct Entry { const char *name; void (*fn)(long long *, int); };
 #define E1(k) {#k "_1", k_##k##_1}, {#k "_2", k_##k##_2}, {#k "_4", k_##k##_4}, {#k "_5", k_##k##_5}, {#k "_6", k_##k##_6}, {#k "_8", k_##k##_8},
 
 int main() {
     std::vector<Entry> es = {{"none", k_none}, E1(fma) E1(exp) E1(cvt) E1(dot) E1(max3) E1(add) E1(perm) E1(mov) E1(pkmul) E1(dsr) E1(snop) E1(salu) E1(dep)
                              {"mix_2fma_2exp_cvt", k_mix_a}, {"mix_2fma_2exp", k_mix_b}, {"mix_fma_exp_cvt_dot", k_mix_c},
-                             {"mix_2fma_2exp_cvt_dsr", k_mix_d}, {"mix_fma_exp_fma_exp_dependent", k_mix_e}, {"mix_fma_fma_exp_exp_dependent", k_mix_f}};
+                             {"mix_2fma_2exp_cvt_dsr", k_mix_d}, {"mix_fma_exp_fma_exp_dependent", k_mix_e}, {"mix_fma_fma_exp_exp_dependent", k_mix_f},
+                             {"use_lead4 (MFMA reads ds data)", k_use_lead4}, {"use_lead4 + 4 fma per MFMA", k_use_lead4_valu},
+                             {"nouse_lead4 (same reads, unused)", k_nouse_lead4}, {"use_lead2", k_use_lead2}};
     setvbuf(stdout, nullptr, _IONBF, 0);
     long long *d;
     const int G = 256, iters = 2000;

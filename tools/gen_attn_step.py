@@ -35,7 +35,7 @@ def units(op):
     return UNITS[op.split("(")[0]]
 
 
-def build(lead=4, pre=28, budget=5.25, rm_from=36, drop=0):
+def build(lead=4, pre=28, budget=5.25, rm_from=36, drop=0, stamps=0, dma0=1, dma_units=1.0):
     """drop (timing experiments, wrong results): bit 0 = no exp, bit 1 = no softmax VALU at all, bit 2 = no fragment reads, bit 3 = no row maxima"""
     mf = [("QK", ds, kt, rt) for ds in range(8) for kt in range(2) for rt in range(2)]
     first_pv = {}
@@ -81,11 +81,16 @@ def build(lead=4, pre=28, budget=5.25, rm_from=36, drop=0):
         preamble.append(ex.pop(0))
     fin_slot = {}
     dot_slot = {first_pv[ks] + 7: ks for ks in range(4)}
+    # the 8 LDS-DMA pieces of the next tiles: one per slot, early, so that they have the rest of the iteration to land
+    dma_slot = {dma0 + 2 * i: (f"A64_DMAK({i})" if i < 4 else f"A64_DMAV({i - 4})") for i in range(8)}
     for i in range(n):
         u = reads[i]
         if i in dot_slot:  # this slot is the dots': nothing else beside them
             slots[i].append(f"A64_DOT8({dot_slot[i]})")
             continue
+        if i in dma_slot:
+            slots[i].append(dma_slot[i])
+            u += dma_units
         while ex and u + units(ex[0]) <= budget:
             op = ex.pop(0)
             u += units(op)
@@ -114,10 +119,14 @@ def build(lead=4, pre=28, budget=5.25, rm_from=36, drop=0):
     out = [f"// generated by tools/gen_attn_step.py --lead {lead} --pre {pre} --budget {budget}" + (f" drop={drop} (TIMING ONLY)" if drop else "") + ": do not edit",
            *filter(keep, preamble), "A64_SB"]
     for i, (kind, a, b, rt) in enumerate(mf):
+        if stamps and i % 8 == 0:
+            out.append(f"A64_STAMP({i // 8})")
         call = f"A64_{kind}({a}, {b}, {rt})"
         out.append(call + " " + " ".join(filter(keep, slots[i])) + " A64_SB")
     if tail:
         out.append(" ".join(filter(keep, tail)) + " A64_SB")
+    if stamps:
+        out.append("A64_STAMP(8)")
     return "\n".join(out) + "\n"
 
 
