@@ -538,17 +538,26 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
 // Geometry 2: 4 waves x 64 query rows, ONE wave per SIMD with the whole 512-register file (O: 128 registers, two score
 // sets: 128, Q: 64).  Against the 8 x 32 geometry above a K / V^T fragment read from LDS feeds two MFMAs instead of one,
 // and the instruction stream itself overlaps what the two co-resident waves of a SIMD used to overlap by chance:
-//   iteration j:   exp / pack of S(j)   beside the 32 MFMAs of  S(j+1) = K(j+1) Q^T        (two score sets in registers)
-//                  row maxima of S(j+1) beside the 32 MFMAs of  O += V^T(j) P(j)
-// K tiles are staged two iterations ahead, V^T tiles one: K(j+2) -> the buffer K(j) was read from in iteration j-1,
-// V^T(j+1) -> the buffer of V^T(j-1); the global loads are issued one iteration before their LDS writes (the registers
-// carry them across the barrier), one barrier per tile.  Same arithmetic per row as geometry 1 (per 32-row tile: maxima,
-// deferred rescale, rounded-probability row sums), same task / persistent-schedule / slab definitions (task = 256 rows).
+//   iteration j:   P(j) = exp2(S'(j)) -> 16-bit fragments   beside the 32 MFMAs of  S'(j+1) = K(j+1) Q'^T - mc
+//                  row maxima of S'(j+1)                     beside the 32 MFMAs of  O += V^T(j) P(j)
+// The tile loop is generated assembly with explicit registers (tools/gen_attn_loop.py -> attention_loop64_*.inc; DESIGN.md 6b:
+// what an instruction beside an MFMA costs was measured, the iteration is packed to it slot by slot, and the hazards a compiler
+// would cover are covered by construction); the segment's first and last tile, the schedule, the slabs and the epilogue are C++.
+// Scores are RELATIVE and in log2 units: Q is multiplied by scale * log2(e) when it is loaded (16-bit rounding of the product: the
+// one numerical difference to geometry 1), a score accumulator starts at -mc instead of 0 (mc: the row's reference point, a stale
+// maximum; -inf while the row has seen no finite score -- the start value is 0 then), so P = exp2(s') with no further arithmetic.
+// K / V^T staging: LDS-DMA into two [K | V^T] buffers, K(j+2) where K(j) was read one iteration earlier, V^T(j+1) where V^T(j-1)
+// was.  Same task / persistent-schedule / slab definitions as geometry 1 (task = 256 rows).  No key-padding mask: svdq_attention
+// runs masked launches on geometry 1.
+typedef float v32f __attribute__((ext_vector_type(32)));
+typedef int v32i __attribute__((ext_vector_type(32)));
+
 template <int DT, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p) {
     using V8 = typename Half<DT>::V8;
+    using T = typename Half<DT>::T;
     constexpr int NT = 256, RT = 2;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * ATT_TILE]; // [buf][K | V^T]: K(t) and V^T(t) live in buffer t & 1
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * ATT_TILE]; // [buf][K | V^T]: K(t) and V^T(t) live in buffer (t - j0) & 1
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     typedef __attribute__((address_space(3))) v4i lds_v4i;
     lds_u8 *const L8 = (lds_u8 *)lds;
@@ -570,147 +579,64 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
     const int run_hi = PERSIST && g < sched.Gs ? sched.bound(g + 1) : 0;
 
     // staging: LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = one 1 KiB piece per instruction, written lane-linearly at
-    // M0), no registers, no ds_write; a tile is requested at the top of an iteration and must have landed at its end.  A K piece = 4 key rows, a V^T piece = 8 channel rows; wave w issues pieces
-    // 4w .. 4w+3 of each matrix.  The XOR swizzle of the fragment reads (conflict-free ds_read_b128) is applied on the SOURCE side:
-    // the lane that writes 16-byte position p of a row fetches the chunk p ^ f(row) of that row.
-    unsigned kdma[4], vdma[4];
+    // M0), no registers, no ds_write.  A K piece = 4 key rows, a V^T piece = 8 channel rows; wave w issues pieces 4w .. 4w+3 of each
+    // matrix.  The XOR swizzle of the fragment reads (conflict-free ds_read_b128) is applied on the SOURCE side: the lane that writes
+    // 16-byte position p of a row fetches the chunk p ^ f(row) of that row.
+    v4i kdma, vdma;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int kr = 16 * wave + 4 * i + (lane >> 4), vd = 32 * wave + 8 * i + (lane >> 3);
-        kdma[i] = (unsigned)kr * (unsigned)p.ldk * 2u + (((lane & 15) ^ (kr & 15)) << 4);
-        vdma[i] = (unsigned)vd * (unsigned)p.ldvt * 2u + (((lane & 7) ^ ((vd >> 1) & 7)) << 4);
+        kdma[i] = (int)((unsigned)kr * (unsigned)p.ldk * 2u + (((lane & 15) ^ (kr & 15)) << 4));
+        vdma[i] = (int)((unsigned)vd * (unsigned)p.ldvt * 2u + (((lane & 7) ^ ((vd >> 1) & 7)) << 4));
     }
-    unsigned ka[8], va[4];
+    v8i ka;
+    v4i va;
 #pragma unroll
     for (int ds = 0; ds < 8; ds++) ka[ds] = lr * 256 + (((2 * ds + h) ^ (lr & 15)) << 4);
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) va[ks] = ATT_TILE + lr * 128 + (((2 * ks + h) ^ ((lr >> 1) & 7)) << 4);
-    const unsigned lds0 = (unsigned)(uintptr_t)L8 + __builtin_amdgcn_readfirstlane(wave) * 4096; // this wave's pieces of slot 0's K; V^T: + ATT_TILE
+    const unsigned lds0 = (unsigned)(uintptr_t)L8 + __builtin_amdgcn_readfirstlane(wave) * 4096; // this wave's pieces of buffer 0's K; V^T: + ATT_TILE
 
     const uint8_t *kbase = nullptr, *vtbase = nullptr;
-    // The DMA is inline asm on purpose: the compiler orders every later LDS read behind an LDS-DMA builtin with vmcnt(0); here the
-    // waits are counted by hand (tile_landed below).  Its own vmcnt bookkeeping stays safe: in-order retirement, extra operations it
-    // does not know about can only make its waits longer.
+    // (inline asm: the compiler orders every later LDS read behind an LDS-DMA builtin with vmcnt(0); its own vmcnt bookkeeping stays
+    //  safe -- in-order retirement, extra operations it does not know about can only make its waits longer)
     auto dma_piece = [&](unsigned lds_at, unsigned voff, const uint8_t *src) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_at), "v"(voff), "s"(src) : "memory", "m0");
     };
-    auto dma_k = [&](int kv0, int slot) {
+    auto dma_k = [&](int kv0, int buf) {
         const uint8_t *src = kbase + (size_t)kv0 * p.ldk * 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) dma_piece(lds0 + slot * 2 * ATT_TILE + i * 1024, kdma[i], src);
+        for (int i = 0; i < 4; i++) dma_piece(lds0 + buf * 2 * ATT_TILE + i * 1024, (unsigned)kdma[i], src);
     };
-    auto dma_v = [&](int kv0, int slot) {
+    auto dma_v = [&](int kv0, int buf) {
         const uint8_t *src = vtbase + (size_t)kv0 * 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) dma_piece(lds0 + slot * 2 * ATT_TILE + ATT_TILE + i * 1024, vdma[i], src);
+        for (int i = 0; i < 4; i++) dma_piece(lds0 + buf * 2 * ATT_TILE + ATT_TILE + i * 1024, (unsigned)vdma[i], src);
     };
-    V8 qf[RT][8];
-    v16f o[RT][4];
-    v16f s[2][RT][2]; // two score sets: S(j) being exponentiated, S(j+1) being accumulated
-    float m_run[RT];
-    // row sums over the ROUNDED probabilities (v_dot2c against (1, 1) on the packed fragments the PV MFMA reads), this lane's share
-    // as two chains.  A v_dot2c beside an MFMA waits for the matrix pipe: ~20 cycles for the first one behind an MFMA, 4 for each
-    // further one (profiles/r3_mfma_filler_prices.txt) -- so the 8 of a key step sit together in ONE slot (A64_DOT8), 4 such slots
-    // per tile, instead of 32 slots with one each
-    float l2a[RT], l2b[RT];
-    const float c = p.scale_log2e;
-    int j_end = 0;
 
-    // S^T[k][q] of the K tile in buffer BUF: per d-step two K fragments, each feeding the MFMAs of both row tiles (4 chains).
-    // These MFMAs are inline asm: with 512 registers the compiler selects the AGPR form for every MFMA builtin and then copies the
-    // scores out for the softmax (and the zeros in): 320 v_accvgpr moves per tile.  The asm pins what the design needs -- scores
-    // in arch VGPRs (the VALU reads them), Q in AGPRs (only MFMAs read it); O stays with the builtins (AGPR accumulators).
-    // Hazards the compiler cannot see through asm: MFMA result -> VALU read needs 11 wait states (8-pass MFMA): settle() below.
-    auto qk_mfma = [&](auto firstc, v16f &acc, const v4i &kw, const V8 &q) {
-        if constexpr (decltype(firstc)::value) {
-            if constexpr (DT == SVDQ_BF16) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(kw), "a"(q));
-            else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(kw), "a"(q));
-        } else {
-            if constexpr (DT == SVDQ_BF16) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(kw), "a"(q));
-            else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(kw), "a"(q));
-        }
+    // state, in the shapes the loop's register plan wants (tools/gen_attn_loop.py): a score set = two 32-register halves (row tile rt:
+    // key half kt at [16 kt .. 16 kt + 15]); O as four 32-register pieces ((rt, dt) at O[2 rt + dt / 2][16 (dt & 1) ..]); Q' as two
+    // (fragment ds at [4 ds .. 4 ds + 3]); the accumulator start values (row tile rt at [16 rt ..]); mc; the row sums {l2a0, l2b0, l2a1, l2b1}
+    v32f SA[RT], SB[RT], O[4], MI;
+    v32i Q32[RT];
+    v2f mc;
+    v4f l2;
+    const float c = p.scale_log2e;
+
+    auto qfrag = [&](int rt, int ds) {
+        return __builtin_bit_cast(V8, v4i{Q32[rt][4 * ds], Q32[rt][4 * ds + 1], Q32[rt][4 * ds + 2], Q32[rt][4 * ds + 3]});
     };
-    auto qk = [&](auto bufc, v16f (&sd)[RT][2]) {
-        constexpr int BO = decltype(bufc)::value * 2 * ATT_TILE; // ring slot
+    // P = exp2(s') of one score set -> the 16-bit B fragments of the PV MFMA, and O += V^T P from buffer `buf`; row sums over the
+    // rounded probabilities (the segment's last tile: the loop handles every tile that has a successor)
+    auto last_tile = [&](v32f (&sd)[RT], int buf) {
+        V8 pf[RT][4];
 #pragma unroll
-        for (int ds = 0; ds < 8; ds++)
-#pragma unroll
-            for (int kt = 0; kt < 2; kt++) {
-                const v4i kw = *(const lds_v4i *)(L8 + (ka[ds] + (BO + kt * 8192)));
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-                    if (ds == 0) qk_mfma(std::true_type{}, sd[rt][kt], kw, qf[rt][ds]);
-                    else qk_mfma(std::false_type{}, sd[rt][kt], kw, qf[rt][ds]);
-                }
-            }
-    };
-    // every consumer of a score set sits behind this: >= 24 wait states after the last asm MFMA that wrote it
-    auto settle = [&](v16f (&sd)[RT][2]) {
-        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sd[0][0]), "+v"(sd[0][1]), "+v"(sd[1][0]), "+v"(sd[1][1]));
-    };
-    // key-padding mask of tile j (workgroup-uniform branch: only tiles that contain padding pay)
-    auto mask = [&](v16f (&sd)[RT][2], int j) {
-        if (__builtin_expect(p.kv_len0 > 0, 0)) {
-            const int k0 = j * ATT_KB;
-            const bool all_real = k0 + ATT_KB <= p.kv_len0 || (k0 >= p.kv_start1 && k0 + ATT_KB <= p.kv_end1);
-            if (!all_real) {
-#pragma unroll
-                for (int kt = 0; kt < 2; kt++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int key = k0 + 32 * kt + 8 * (r >> 2) + 4 * h + (r & 3);
-                        const bool real = (key < p.kv_len0) | ((key >= p.kv_start1) & (key < p.kv_end1));
-#pragma unroll
-                        for (int rt = 0; rt < RT; rt++) sd[rt][kt][r] = real ? sd[rt][kt][r] : -INFINITY;
-                    }
-            }
-        }
-    };
-    // exchange the row maxima between the two lanes of a row, then the (deferred) rescale of O and l -- every MFMA of the previous
-    // tile's PV has been issued
-    auto row_max_finish = [&](float (&mloc_)[RT]) {
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            float mloc = mloc_[rt];
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
-            const unsigned mine = sw[0], other = sw[1]; // (scalar copies: bit_cast on a vector element reads element 0 in this clang)
-            mloc = fmaxf(__builtin_bit_cast(float, mine), __builtin_bit_cast(float, other));
-            if (__builtin_amdgcn_ballot_w64((mloc - m_run[rt]) * c > ATT_DEFER_LOG2) != 0) {
-                const float m_new = fmaxf(m_run[rt], mloc);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[rt] - m_new) * c);
-                m_run[rt] = m_new;
-                l2a[rt] *= alpha;
-                l2b[rt] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 4; dt++) o[rt][dt] = o[rt][dt] * alpha;
-            }
-        }
-    };
-    // row maxima of a score set (the prologue's form; the steady-state iteration computes them slice by slice)
-    auto row_max = [&](v16f (&sd)[RT][2]) {
-        float mloc[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            mloc[rt] = fmaxf(sd[rt][0][0], sd[rt][1][0]);
-#pragma unroll
-            for (int r = 1; r < 16; r += 2) {
-                mloc[rt] = fmaxf(fmaxf(mloc[rt], sd[rt][0][r]), r + 1 < 16 ? sd[rt][0][r + 1] : sd[rt][0][r]);
-                mloc[rt] = fmaxf(fmaxf(mloc[rt], sd[rt][1][r]), r + 1 < 16 ? sd[rt][1][r + 1] : sd[rt][1][r]);
-            }
-        }
-        row_max_finish(mloc);
-    };
-    // P = 2^(s c - m c) -> the 16-bit B fragments of the PV MFMA; row sums over the rounded probabilities
-    auto exp_pack = [&](v16f (&sd)[RT][2], V8 (&pf)[RT][4]) {
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            const float nmc = m_run[rt] == -INFINITY ? 0.f : -(m_run[rt] * c);
+        for (int rt = 0; rt < RT; rt++)
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
-                const int kt = ks >> 1, r0 = 8 * (ks & 1);
                 float e[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sd[rt][kt][r0 + i], c, nmc));
+                for (int i = 0; i < 8; i++) e[i] = __builtin_amdgcn_exp2f(sd[rt][16 * (ks >> 1) + 8 * (ks & 1) + i]);
                 unsigned x[2], y[2];
 #pragma unroll
                 for (int d2 = 0; d2 < 2; d2++) {
@@ -721,98 +647,24 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
                     y[d2] = sw[1];
                 }
                 pf[rt][ks] = __builtin_bit_cast(V8, v4i{(int)x[0], (int)x[1], (int)y[0], (int)y[1]});
-                l2a[rt] = sum2<DT>(y[0], sum2<DT>(x[0], l2a[rt]));
-                l2b[rt] = sum2<DT>(y[1], sum2<DT>(x[1], l2b[rt]));
+                l2[2 * rt] = sum2<DT>(y[0], sum2<DT>(x[0], l2[2 * rt]));
+                l2[2 * rt + 1] = sum2<DT>(y[1], sum2<DT>(x[1], l2[2 * rt + 1]));
             }
-        }
-    };
-    // O^T[d][q] += V^T[d][k] P^T[k][q]: per key step four V^T fragments, each feeding both row tiles (8 chains)
-    auto pv = [&](auto bufc, const V8 (&pf)[RT][4]) {
-        constexpr int BO = decltype(bufc)::value * 2 * ATT_TILE;
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++)
+        for (int rt = 0; rt < RT; rt++)
 #pragma unroll
             for (int dt = 0; dt < 4; dt++) {
-                const v4i vw = *(const lds_v4i *)(L8 + (va[ks] + (BO + dt * 4096)));
+                v16f acc;
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) o[rt][dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw), pf[rt][ks], o[rt][dt]);
+                for (int r = 0; r < 16; r++) acc[r] = O[2 * rt + (dt >> 1)][16 * (dt & 1) + r];
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const v4i vw = *(const lds_v4i *)(L8 + ((unsigned)va[ks] + (buf * 2 * ATT_TILE + dt * 4096)));
+                    acc = Half<DT>::mfma32(__builtin_bit_cast(V8, vw), pf[rt][ks], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) O[2 * rt + (dt >> 1)][16 * (dt & 1) + r] = acc[r];
             }
-    };
-    // iteration j (buffer parity BUF = j & 1, relative to the segment's first tile); MORE: tile j+1 exists.  Requested here: K(j+2)
-    // into the buffer K(j) was read from in iteration j-1, V^T(j+1) into the buffer of V^T(j-1); both have landed (this wave's
-    // pieces: vmcnt(0); everybody's: the barrier) when the iteration ends.
-    auto step = [&](auto bufc, auto morec, int j) {
-        constexpr int BUF = decltype(bufc)::value;
-        constexpr bool MORE = decltype(morec)::value;
-        SVDQ_ATTN_PROBE_STAMP(0, j);
-        // MORE: the 8 DMA pieces are issued from inside the slots (a piece costs ~55 cycles of issue on its own, little in the shadow
-        // of an MFMA) -- unconditionally: past the segment's end K re-fetches its last tile into a buffer nobody reads any more
-        const uint8_t *ksrc = kbase + (size_t)min(j + 2, j_end - 1) * (ATT_KB * 2) * p.ldk;
-        const uint8_t *vsrc = vtbase + (size_t)min(j + 1, j_end - 1) * (ATT_KB * 2);
-        SVDQ_ATTN_PROBE_STAMP(1, j);
-        V8 pf[RT][4];
-        if constexpr (MORE) {
-            // the steady-state iteration, placed slot by slot (tools/gen_attn_step.py -> attention_step64.inc): one MFMA per slot
-            // with its share of the exp / pack of S(j), of the fragment reads and of the row maxima of S(j+1); the order in the
-            // source is the order in the binary (sched_barrier between slots)
-            v16f (&sc)[RT][2] = s[BUF];
-            v16f (&sn)[RT][2] = s[BUF ^ 1];
-            constexpr int KBO = (BUF ^ 1) * 2 * ATT_TILE, VBO = BUF * 2 * ATT_TILE;
-            v4i kw[16], vw[16];
-            float nmc[RT], e[RT * 4][8], mloc[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) nmc[rt] = m_run[rt] == -INFINITY ? 0.f : -(m_run[rt] * c);
-            unsigned px[RT * 4][2], py[RT * 4][2];
-#define A64_SB __builtin_amdgcn_sched_barrier(0);
-#define A64_STAMP(n) SVDQ_ATTN_PROBE_STAMP(2 + (n), j);
-#define A64_KREAD(ds, kt) kw[(ds) * 2 + (kt)] = *(const lds_v4i *)(L8 + (ka[ds] + (KBO + (kt) * 8192)));
-#define A64_VREAD(ks, dt) vw[(ks) * 4 + (dt)] = *(const lds_v4i *)(L8 + (va[ks] + (VBO + (dt) * 4096)));
-#define A64_QK(ds, kt, rt) qk_mfma(std::integral_constant<bool, (ds) == 0>{}, sn[rt][kt], kw[(ds) * 2 + (kt)], qf[rt][ds]);
-#define A64_DMAK(i) SVDQ_ATTN_STAGE(dma_piece(lds0 + BUF * 2 * ATT_TILE + (i) * 1024, kdma[i], ksrc);)
-#define A64_DMAV(i) SVDQ_ATTN_STAGE(dma_piece(lds0 + (BUF ^ 1) * 2 * ATT_TILE + ATT_TILE + (i) * 1024, vdma[i], vsrc);)
-#define A64_PV(ks, dt, rt) o[rt][dt] = Half<DT>::mfma32(__builtin_bit_cast(V8, vw[(ks) * 4 + (dt)]), pf[rt][ks], o[rt][dt]);
-#define A64_FMA(rt, ks, i) e[(rt) * 4 + (ks)][i] = __builtin_fmaf(sc[rt][(ks) >> 1][8 * ((ks) & 1) + (i)], c, nmc[rt]);
-#define A64_EXP(rt, ks, i) e[(rt) * 4 + (ks)][i] = __builtin_amdgcn_exp2f(e[(rt) * 4 + (ks)][i]);
-#define A64_CVT(rt, ks, d) { if ((d) < 2) px[(rt) * 4 + (ks)][(d) & 1] = pack2<DT>(e[(rt) * 4 + (ks)][2 * ((d) & 1)], e[(rt) * 4 + (ks)][2 * ((d) & 1) + 1]); \
-                             else py[(rt) * 4 + (ks)][(d) & 1] = pack2<DT>(e[(rt) * 4 + (ks)][4 + 2 * ((d) & 1)], e[(rt) * 4 + (ks)][4 + 2 * ((d) & 1) + 1]); }
-#define A64_DOT8(ks) { _Pragma("unroll") for (int rt_ = 0; rt_ < RT; rt_++) { const v4i w_ = __builtin_bit_cast(v4i, pf[rt_][ks]); \
-                           l2a[rt_] = sum2<DT>((unsigned)w_[2], sum2<DT>((unsigned)w_[0], l2a[rt_])); l2b[rt_] = sum2<DT>((unsigned)w_[3], sum2<DT>((unsigned)w_[1], l2b[rt_])); } \
-                       asm volatile("" : "+v"(l2a[0]), "+v"(l2b[0]), "+v"(l2a[1]), "+v"(l2b[1])); } // (pinned to the slot: machine sinking would move them to the loop's end)
-#define A64_SWAP(rt, ks, d2) { auto sw = __builtin_amdgcn_permlane32_swap(px[(rt) * 4 + (ks)][d2], py[(rt) * 4 + (ks)][d2], false, false); \
-                               px[(rt) * 4 + (ks)][d2] = sw[0]; py[(rt) * 4 + (ks)][d2] = sw[1]; }
-#define A64_FIN(rt, ks) pf[rt][ks] = __builtin_bit_cast(V8, v4i{(int)px[(rt) * 4 + (ks)][0], (int)px[(rt) * 4 + (ks)][1], (int)py[(rt) * 4 + (ks)][0], (int)py[(rt) * 4 + (ks)][1]});
-            // the row maxima of S(j+1) start >= 18 MFMAs (> 500 cycles) after the last asm MFMA that wrote it: the 11 wait states of
-            // that hazard have long passed; the empty asm only orders the reads behind the writes for the compiler.  The mask of a
-            // tile with padding (rare, workgroup-uniform) sits at the same point.
-#define A64_SETTLE asm volatile("" : "+v"(sn[0][0]), "+v"(sn[0][1]), "+v"(sn[1][0]), "+v"(sn[1][1])); mask(sn, j + 1);
-#define A64_RMAX(rt, i) { if ((i) == 0) mloc[rt] = fmaxf(sn[rt][0][0], sn[rt][1][0]); \
-                          else { constexpr int r_ = 2 * (((i) - 1) >> 1) + 1, kt_ = ((i) - 1) & 1; mloc[rt] = fmaxf(fmaxf(mloc[rt], sn[rt][kt_][r_]), r_ + 1 < 16 ? sn[rt][kt_][r_ + 1] : sn[rt][kt_][r_]); } }
-#include SVDQ_ATTN_STEP_INC
-#undef A64_SB
-#undef A64_STAMP
-#undef A64_KREAD
-#undef A64_VREAD
-#undef A64_QK
-#undef A64_PV
-#undef A64_DMAK
-#undef A64_DMAV
-#undef A64_FMA
-#undef A64_EXP
-#undef A64_CVT
-#undef A64_DOT8
-#undef A64_SWAP
-#undef A64_FIN
-#undef A64_SETTLE
-#undef A64_RMAX
-            row_max_finish(mloc);
-        } else {
-            exp_pack(s[BUF], pf);
-            pv(bufc, pf);
-        }
-        SVDQ_ATTN_PROBE_STAMP(11, j);
-        SVDQ_ATTN_STAGE(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");)
-        SVDQ_ATTN_TILE_BARRIER();
-        SVDQ_ATTN_PROBE_STAMP(12, j);
     };
 
     while (true) {
@@ -836,63 +688,111 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
         const int q0 = (task - head * QT) * 256 + wave * 64;
         kbase = (const uint8_t *)(p.k + (size_t)head * p.k_hs);
         vtbase = (const uint8_t *)(p.vt + (size_t)head * p.vt_hs);
+        // prologue: K(j0), V^T(j0) -> buffer 0, K(j0+1) -> buffer 1 (a segment has at least two tiles); every wave passed the barrier
+        // that ends the previous segment: all buffers are free.  Q' meanwhile.
+        dma_k(j0 * ATT_KB, 0);
+        dma_v(j0 * ATT_KB, 0);
+        dma_k((j0 + 1) * ATT_KB, 1);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
             const uint16_t *qrow = p.q + (size_t)(q0 + 32 * rt + lr) * p.ldq + (size_t)head * p.q_hs + 8 * h;
 #pragma unroll
             for (int ds = 0; ds < 8; ds++) {
-                // the fragment is BORN in an AGPR (tied operand: the copy happens here, once per task): every later use is an "a"
-                // operand of an asm MFMA, and a value that lives in arch VGPRs between them is reloaded from scratch per use
-                const V8 qv = *reinterpret_cast<const V8 *>(qrow + 16 * ds);
-                asm volatile("" : "=a"(qf[rt][ds]) : "0"(qv));
+                const V8 qraw = *reinterpret_cast<const V8 *>(qrow + 16 * ds);
+                V8 qv;
+#pragma unroll
+                for (int i = 0; i < 8; i++) qv[i] = f2h<T>(h2f(qraw[i]) * c);
+                const v4i w = __builtin_bit_cast(v4i, qv);
+#pragma unroll
+                for (int k = 0; k < 4; k++) Q32[rt][4 * ds + k] = w[k];
             }
-#pragma unroll
-            for (int dt = 0; dt < 4; dt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[rt][dt][r] = 0.f;
-            m_run[rt] = -INFINITY;
-            l2a[rt] = l2b[rt] = 0.f;
         }
-        j_end = j1;
-        // prologue: K(j0), V^T(j0) -> buffer 0, K(j0+1) -> buffer 1 (a segment has at least two tiles); every wave passed the barrier
-        // that ends the previous segment's last step: all buffers are free
-        dma_k(j0 * ATT_KB, 0);
-        dma_v(j0 * ATT_KB, 0);
-        dma_k((j0 + 1) * ATT_KB, 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 32; r++) O[i][r] = 0.f;
+        l2 = v4f{0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        qk(std::integral_constant<int, 0>{}, s[0]);
-        settle(s[0]);
-        mask(s[0], j0);
-        row_max(s[0]);
-        __syncthreads(); // K(j0) has been read by every wave before the first step requests K(j0+2) into its buffer
-        SVDQ_ATTN_PROBE_LOOP_BEGIN();
-        for (int j = j0; j < j1 - 2; j += 2) {
-            step(std::integral_constant<int, 0>{}, std::true_type{}, j);
-            step(std::integral_constant<int, 1>{}, std::true_type{}, j + 1);
-        }
-        step(std::integral_constant<int, 0>{}, std::true_type{}, j1 - 2);
-        step(std::integral_constant<int, 1>{}, std::false_type{}, j1 - 1);
-        SVDQ_ATTN_PROBE_LOOP_END(j1 - j0);
-        float l_run[RT];
+        // first tile: S'(j0) against the start value 0, then every row takes its own maximum as the reference point
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) l_run[rt] = l2a[rt] + l2b[rt];
+        for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+                v16f acc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+                for (int ds = 0; ds < 8; ds++) {
+                    const v4i kw = *(const lds_v4i *)(L8 + ((unsigned)ka[ds] + kt * 8192));
+                    acc = Half<DT>::mfma32(__builtin_bit_cast(V8, kw), qfrag(rt, ds), acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) SA[rt][16 * kt + r] = acc[r];
+            }
+            float mloc = SA[rt][0];
+#pragma unroll
+            for (int r = 1; r < 32; r++) mloc = fmaxf(mloc, SA[rt][r]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
+            const unsigned mine = sw[0], other = sw[1]; // (scalar copies: bit_cast on a vector element reads element 0 in this clang)
+            mloc = fmaxf(__builtin_bit_cast(float, mine), __builtin_bit_cast(float, other));
+            const bool finite = mloc > -INFINITY;
+            mc[rt] = finite ? mloc : -INFINITY;
+            const float shift = finite ? mloc : 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; r++) SA[rt][r] -= shift;
+#pragma unroll
+            for (int r = 0; r < 16; r++) MI[16 * rt + r] = -shift;
+        }
+        __syncthreads(); // K(j0) has been read by every wave before the loop's first iteration requests K(j0+2) into its buffer
+        SVDQ_ATTN_PROBE_LOOP_BEGIN();
+        {
+            // ---- the tile loop: iterations j0 .. j1 - 2 (generated assembly, every operand pinned to a physical register) ----------
+            unsigned jj = (unsigned)j0;
+            const unsigned jend = (unsigned)j1, kstride = (unsigned)p.ldk * (ATT_KB * 2);
+#define SVDQ_ATTN_LOOP_OPERANDS                                                                                                         \
+            : "+{v[0:31]}"(SA[0]), "+{v[32:63]}"(SA[1]), "+{v[64:95]}"(SB[0]), "+{v[96:127]}"(SB[1]), "+{v[192:223]}"(MI),           \
+              "+{a[0:31]}"(O[0]), "+{a[32:63]}"(O[1]), "+{a[64:95]}"(O[2]), "+{a[96:127]}"(O[3]), "+{v[244:245]}"(mc),               \
+              "+{v[248:251]}"(l2), "+{s46}"(jj)                                                                                        \
+            : "{a[128:159]}"(Q32[0]), "{a[160:191]}"(Q32[1]), "{v[224:231]}"(ka), "{v[232:235]}"(va), "{v[236:239]}"(kdma),          \
+              "{v[240:243]}"(vdma), "{s40}"(lds0), "{s[42:43]}"(kbase), "{s[44:45]}"(vtbase), "{s47}"(jend), "{s48}"(kstride)         \
+            : "memory", "scc", "vcc", "m0", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60",    \
+              "s61", "s62", "s63", "s64", "s65", "s66", "s67", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135",       \
+              "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149",        \
+              "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163",        \
+              "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177",        \
+              "v178", "v179", "v180", "v181", "v182", "v183",                                                                        \
+              "v246", "v247", "v252", "v253", "v254", "v255"
+            if constexpr (DT == SVDQ_BF16) {
+                asm volatile(
+#include "attention_loop64_bf16.inc"
+                    SVDQ_ATTN_LOOP_OPERANDS);
+            } else {
+                asm volatile(
+#include "attention_loop64_fp16.inc"
+                    SVDQ_ATTN_LOOP_OPERANDS);
+            }
+#undef SVDQ_ATTN_LOOP_OPERANDS
+        }
+        last_tile(SB, 1); // a segment has an even number of tiles: its last one sits in score set B / buffer 1
+        __syncthreads();  // the buffers are free for the next segment's prologue
+        SVDQ_ATTN_PROBE_LOOP_END(j1 - j0);
+        float l_run[RT] = {l2[0] + l2[1], l2[2] + l2[3]};
 
         if constexpr (PERSIST) {
             typedef __attribute__((address_space(1))) int gint;
             typedef __attribute__((address_space(1))) v4f gv4f;
             typedef __attribute__((address_space(1))) v2f gv2f;
             gint *flags = (gint *)p.ws_flags;
-            if (j0 > 0) { // not the owner: publish (same slab image as geometry 1, [wave][rt][j][lane])
+#define SVDQ_OREG(rt, j, e) O[2 * (rt) + ((j) >> 3)][16 * (((j) >> 2) & 1) + ((j) & 3) * 4 + (e)] /* register (j = 4 dt + c, e) of row tile rt */
+            if (j0 > 0) { // not the owner: publish (the slab image of geometry 1, [wave][rt][j][lane]; the reference point in log2 units)
                 float *slab = p.ws_slabs + (size_t)g * ATT_SLAB_FLOATS;
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const v4f v = {o[rt][j >> 2][(j & 3) * 4 + 0], o[rt][j >> 2][(j & 3) * 4 + 1], o[rt][j >> 2][(j & 3) * 4 + 2], o[rt][j >> 2][(j & 3) * 4 + 3]};
-                        *(gv4f *)(slab + ((size_t)((wave * RT + rt) * 16 + j) * 64 + lane) * 4) = v;
-                    }
-                    *(gv2f *)(slab + ATT_SLAB_O + (size_t)((wave * RT + rt) * 64 + lane) * 2) = v2f{m_run[rt], l_run[rt]};
+                    for (int j = 0; j < 16; j++)
+                        *(gv4f *)(slab + ((size_t)((wave * RT + rt) * 16 + j) * 64 + lane) * 4) = v4f{SVDQ_OREG(rt, j, 0), SVDQ_OREG(rt, j, 1), SVDQ_OREG(rt, j, 2), SVDQ_OREG(rt, j, 3)};
+                    *(gv2f *)(slab + ATT_SLAB_O + (size_t)((wave * RT + rt) * 64 + lane) * 2) = v2f{mc[rt], l_run[rt]};
                 }
                 const int owner = sched.owner_of(g, tl);
                 __syncthreads();
@@ -922,26 +822,33 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) {
                         const v2f ml = __builtin_nontemporal_load((const gv2f *)(slab + ATT_SLAB_O + (size_t)((wave * RT + rt) * 64 + lane) * 2));
-                        const float m_new = fmaxf(m_run[rt], ml[0]);
-                        const float fa = __builtin_amdgcn_exp2f((m_run[rt] - m_new) * c), fb = __builtin_amdgcn_exp2f((ml[0] - m_new) * c);
+                        const float m_new = fmaxf(mc[rt], ml[0]); // (-inf: that side saw no finite score: weight 0)
+                        const float fa = mc[rt] == m_new ? 1.f : __builtin_amdgcn_exp2f(mc[rt] - m_new), fb = ml[0] == m_new ? 1.f : __builtin_amdgcn_exp2f(ml[0] - m_new);
 #pragma unroll
                         for (int j = 0; j < 16; j++) {
                             const v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)((wave * RT + rt) * 16 + j) * 64 + lane) * 4));
 #pragma unroll
-                            for (int e = 0; e < 4; e++) o[rt][j >> 2][(j & 3) * 4 + e] = o[rt][j >> 2][(j & 3) * 4 + e] * fa + v[e] * fb;
+                            for (int e = 0; e < 4; e++) SVDQ_OREG(rt, j, e) = SVDQ_OREG(rt, j, e) * fa + v[e] * fb;
                         }
                         l_run[rt] = l_run[rt] * fa + ml[1] * fb;
-                        m_run[rt] = m_new;
+                        mc[rt] = m_new;
                     }
                 }
             }
         }
+#undef SVDQ_OREG
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) finish_rows<DT>(p, o[rt], l_run[rt], q0 + 32 * rt, head, lane);
+        for (int rt = 0; rt < RT; rt++) {
+            v16f o4[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o4[dt][r] = O[2 * rt + (dt >> 1)][16 * (dt & 1) + r];
+            finish_rows<DT>(p, o4, l_run[rt], q0 + 32 * rt, head, lane);
+        }
     } // segments
     SVDQ_ATTN_PROBE_END();
 }
-
 
 template <int DT, int NW> static void launch_attention(const AttnParams &p, hipStream_t st) {
     dim3 grid(p.L / (NW * 32), p.H), block(NW * 64);
@@ -1103,7 +1010,7 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     // automatic: 4 x 64 on the plain grid when the length allows it (measured at 24 heads x 4608 tokens, same box: 245 us against 282
     // for 8 x 32 on either schedule; its own persistent schedule 270: the workgroups no longer walk the keys of a head together and
     // its one-iteration DMA flight is sensitive to the L2 misses that causes); an explicit geometry takes the workspace if given
-    const int geometry = a->geometry ? a->geometry : (a->L % 256 == 0 ? 2 : 1);
+    const int geometry = a->kv_len0 > 0 ? 1 : a->geometry ? a->geometry : (a->L % 256 == 0 ? 2 : 1); // (the key mask lives in geometry 1)
     const int groups = geometry == 2 && a->geometry == 0 ? 0 : attention_groups(p);
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
     if (geometry == 2 && a->L % 256 == 0) { if (a->dtype == SVDQ_FP16) launch_attention64<SVDQ_FP16>(p, groups, st); else launch_attention64<SVDQ_BF16>(p, groups, st); }
