@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events in the timed region (their cost: ~0.5 %%)")
     ap.add_argument("--layers", type=int, nargs=2, default=(19, 38), help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--attention-geometry", type=int, default=0, choices=[0, 1, 2],
+                    help="workgroup geometry of the attention kernel (svdq_attention_args.geometry): 0 = the library's choice (4 waves x 64 "
+                         "rows on the prescaled Q the QKV GEMM emits), 1 = 8 waves x 32 rows, 2 = 4 x 64 with its persistent schedule (same-box A/B)")
     ap.add_argument("--geometry", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="workgroup geometry of the W4A4 GEMM (svdq_gemm_args.geometry): 0 = the library's choice, 1 = 256x128 "
                          "tiles / one workgroup per CU, 2 = 128x128 tiles / two per CU out of phase, 3 = 2 without the phase offset")
@@ -153,6 +156,7 @@ def main():
     from nunchaku_amd._C import _Ops
 
     _Ops.gemm_geometry = args.geometry
+    _Ops.attention_geometry = args.attention_geometry
     mode.set_deterministic(args.deterministic)
     rank, local_rank, world = replica.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -291,7 +295,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": workload,
-                "gemm_geometry": args.geometry, "deterministic": args.deterministic,
+                "gemm_geometry": args.geometry, "attention_geometry": args.attention_geometry, "deterministic": args.deterministic,
                 "weights": "uniform-random 4-bit codes (not SVD-residual codes: the clock of a power-limited kernel is data dependent)",
                 "parallelism": f"{world} independent replica(s), one image each; weights broadcast once over RCCL "
                                f"({bcast_bytes / 1e9:.2f} GB)" + ("; step replayed as one HIP graph" if args.graph else ""),

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 16
+#define SVDQ_ABI_VERSION 17
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -206,6 +206,12 @@ typedef struct svdq_gemm_args {
      * depending on the geometry) must become resident while owners wait -- true for a stream that owns the device, not for
      * a CU-masked stream or beside a long-running co-tenant kernel; pass workspace = NULL there. */
     int32_t *status;
+    /* SVDQ_FUSE_RMSNORM_ROPE only (extension): the Q third (columns [0, N/3)) is multiplied by q_scale inside the epilogue, BEFORE
+     * its single rounding to 16-bit (0 = off = 1.0; q_scale = 1.0 is bit-identical to off).  For svdq_attention_args.q_prescaled: the
+     * attention kernel then needs no per-score scaling, and Q carries one rounding as in the reference (scaling an already rounded Q
+     * inside the attention kernel would add a second one). */
+    float q_scale;
+    int32_t reserved2;        /* must be 0 */
 } svdq_gemm_args;
 
 int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
@@ -270,7 +276,8 @@ typedef struct svdq_attention_args {
     void *workspace;
     int64_t workspace_bytes;
     int32_t qlora_act_format; /* SVDQ_LORA_ACT_F32 | SVDQ_LORA_ACT_Q32 (deterministic head sum) */
-    int32_t reserved2;
+    int32_t q_prescaled;      /* non-zero: Q already carries the factor scale * log2(e) (svdq_gemm_args.q_scale of the QKV GEMM that wrote
+                                 it); `scale` is then not applied again.  Either geometry. */
     int32_t *status;          /* optional host-visible status word, as svdq_gemm_args.status */
     /* Key-padding mask (optional; kv_len0 == 0: every one of the L keys is real).  Keys [0, kv_len0) and [kv_start1, kv_end1) are
      * real tokens, all others are padding and get probability 0 -- the token buffers of a pipeline are padded to a multiple of
@@ -279,10 +286,12 @@ typedef struct svdq_attention_args {
      * V^T columns must be FINITE (0 * NaN is NaN in the matrix unit): zero them.  Output rows of padded queries are unspecified.
      * Role of the reference's padded-row masking (epilogues.cuh:427-550, attention.cuh). */
     int32_t kv_len0, kv_start1, kv_end1;
-    /* workgroup geometry: 0 = automatic (geometry 2 on the plain grid when L % 256 == 0, else geometry 1); 1 = 8 waves x 32 query
-     * rows (two waves per SIMD); 2 = 4 waves x 64 query rows (one wave per SIMD with the whole register file; needs L % 256 == 0).
-     * An explicit geometry uses the persistent schedule when a workspace is given.  Same arithmetic per row (maxima, deferred
-     * rescale, rounded-probability row sums); the two differ in the summation order of the row sums only (<= 1 ulp of the output). */
+    /* workgroup geometry: 0 = automatic; 1 = 8 waves x 32 query rows (two waves per SIMD); 2 = 4 waves x 64 query rows (one wave per
+     * SIMD with the whole register file, the tile loop in generated assembly; needs L % 256 == 0 and no key mask -- masked launches run
+     * geometry 1).  Geometry 2 keeps its scores relative and in log2 units, which needs Q multiplied by scale * log2(e): with q_prescaled
+     * the producer has done that (one rounding, as accurate as geometry 1); otherwise the kernel scales the 16-bit Q itself -- a second
+     * rounding, ~2.5x the error of geometry 1 against an fp32 reference.  Hence automatic = geometry 2 (on the plain grid) iff
+     * q_prescaled, L % 256 == 0 and no mask; an explicit geometry uses the persistent schedule when a workspace is given. */
     int32_t geometry;
 } svdq_attention_args;
 

@@ -344,6 +344,7 @@ class _Ops:
         act, wgt, out, qout, ascales, wscales, oscales, poolout, lora_act_in, lora_up, lora_down, lora_act_out,
         norm_q, norm_k, rotary_emb, bias, smooth_factor, out_vk, out_linearattn, act_unsigned, lora_scales,
         fuse_silu, fp4, alpha, wcscales, out_q, out_k, out_v, attn_tokens, out_vt=None, lora_act_zeroed=False, second=None, split_rows=0,
+        q_scale=0.0,
     ):
         """reference: csrc/ops.h:10-81 -> kernels::gemm_w4a4 (zgemm.h:8-36).  The epilogue is inferred
         from which optional tensors are present, exactly as gemm_w4a4_launch_impl.cuh:282-423 does.
@@ -470,6 +471,7 @@ class _Ops:
             if fmt_in not in (torch.float32, torch.int64):
                 raise ValueError("gemm_w4a4: lora_act_in must be float32 (or int64: the deterministic fixed-point format)")
             a.lora_act_format = _lib.LORA_ACT_Q32 if fmt_in == torch.int64 else _lib.LORA_ACT_F32
+        a.q_scale = float(q_scale)  # extension: the Q third times q_scale before its rounding (for attention(q_prescaled=True))
         if out_vt is not None and a.fuse != _lib.FUSE_RMSNORM_ROPE:
             raise ValueError("gemm_w4a4: out_vt needs the RMSNorm+RoPE epilogue (rotary_emb, norm_q, norm_k)")
         if out_vt is not None and out_vt.shape[1] < a.M:
@@ -619,12 +621,14 @@ class _Ops:
         _Ops.attention(q[0].transpose(0, 1), k[0].transpose(0, 1), vt, o[0].view(T, H, 128), scale, kv_valid=kv_valid)
 
     @staticmethod
-    def attention(q, k, vt, out, scale, zero=None, quant=None, kv_valid=None):
+    def attention(q, k, vt, out, scale, zero=None, quant=None, kv_valid=None, q_prescaled=False):
         """Non-causal attention, head_dim 128 (role of the reference's ``ops.attention_fp16``, csrc/ops.h:114-121
         -> attention.cu:11-94).  Strided views, no copies: ``q``/``k``/``out`` are ``[L, H, 128]`` (any token and head
         stride, unit channel stride), ``vt`` is ``[H, 128, L]`` with unit token stride (V transposed, as the QKV
         GEMM's ``out_vt`` writes it).  L must be a multiple of 128 (pad the buffers; ``kv_valid = (n,)`` or ``(n0, start1, end1)``
-        masks the padded keys: keys ``[0, n0)`` and ``[start1, end1)`` are real; padded V^T columns must be finite)."""
+        masks the padded keys: keys ``[0, n0)`` and ``[start1, end1)`` are real; padded V^T columns must be finite).
+        ``q_prescaled``: the producer of ``q`` multiplied it by ``scale * log2(e)`` before rounding (``gemm_w4a4(q_scale=...)``):
+        the kernel then runs its faster geometry without losing accuracy (``svdq_attention_args.geometry``)."""
         lib = _lib.load()
         for name, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
             if name == "out" and t is None and quant is not None:
@@ -659,6 +663,7 @@ class _Ops:
         a.vt_hs, a.ldvt = vt.stride(0), vt.stride(1)
         a.L, a.H, a.head_dim, a.dtype = L, H, D, _DT[q.dtype]
         a.scale = float(scale)
+        a.q_prescaled = 1 if q_prescaled else 0  # Q already carries scale * log2(e) (gemm_w4a4(q_scale=...)): `scale` is not applied again
         if kv_valid is not None:
             kv = tuple(int(v) for v in kv_valid)
             a.kv_len0 = kv[0]

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 16
+ABI_VERSION = 17
 LORA_ACT_F32, LORA_ACT_Q32 = 0, 1
 
 
@@ -55,6 +55,7 @@ class GemmArgs(C.Structure):
         ("wgt2", C.c_void_p), ("wscales2", C.c_void_p), ("bias2", C.c_void_p), ("lora_up2", C.c_void_p),
         ("next_smooth2", C.c_void_p), ("next_lora_down2", C.c_void_p), ("norm_q2", C.c_void_p), ("norm_k2", C.c_void_p),
         ("split_rows", C.c_int32), ("lora_act_format", C.c_int32), ("status", C.c_void_p),
+        ("q_scale", C.c_float), ("reserved2", C.c_int32),
     ]
 
 
@@ -68,7 +69,7 @@ class AttentionArgs(C.Structure):
         ("qact", C.c_void_p), ("qscales", C.c_void_p), ("qlora_act", C.c_void_p), ("qsmooth", C.c_void_p),
         ("qlora_down", C.c_void_p), ("qsmooth2", C.c_void_p), ("qlora_down2", C.c_void_p), ("qR", C.c_int32),
         ("qsplit_rows", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("qlora_act_format", C.c_int32), ("reserved2", C.c_int32), ("status", C.c_void_p),
+        ("qlora_act_format", C.c_int32), ("q_prescaled", C.c_int32), ("status", C.c_void_p),
         ("kv_len0", C.c_int32), ("kv_start1", C.c_int32), ("kv_end1", C.c_int32), ("geometry", C.c_int32),
     ]
 

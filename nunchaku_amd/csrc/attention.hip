@@ -29,16 +29,10 @@
 #include "svdq_common.h"
 #include <type_traits>
 
-// tools/ablate/build_attn.py builds timing variants of geometry 2's iteration (the placement under other generator options; the
-// per-tile barrier / the staging removed: wrong results, timing only) by redefining these three; the product build has no switches
-#ifndef SVDQ_ATTN_STEP_INC
-#define SVDQ_ATTN_STEP_INC "attention_step64.inc"
-#endif
-#ifndef SVDQ_ATTN_TILE_BARRIER
-#define SVDQ_ATTN_TILE_BARRIER() __syncthreads()
-#endif
-#ifndef SVDQ_ATTN_STAGE
-#define SVDQ_ATTN_STAGE(statement) statement
+// tools/ablate/build_attn.py builds timing variants of geometry 2's tile loop (the generator under other options) by redefining these
+#ifndef SVDQ_ATTN_LOOP_INC_BF16
+#define SVDQ_ATTN_LOOP_INC_BF16 "attention_loop64_bf16.inc"
+#define SVDQ_ATTN_LOOP_INC_FP16 "attention_loop64_fp16.inc"
 #endif
 // clock / phase stamps of the tools-built probe library (tools/ablate/attn_probe_hooks.inc); nothing in the product build
 #ifdef SVDQ_PROBE
@@ -49,7 +43,6 @@
 #define SVDQ_ATTN_PROBE_BEGIN()
 #define SVDQ_ATTN_PROBE_LOOP_BEGIN()
 #define SVDQ_ATTN_PROBE_LOOP_END(n)
-#define SVDQ_ATTN_PROBE_STAMP(i, j)
 #define SVDQ_ATTN_PROBE_END()
 #endif
 
@@ -701,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
                 const V8 qraw = *reinterpret_cast<const V8 *>(qrow + 16 * ds);
                 V8 qv;
 #pragma unroll
-                for (int i = 0; i < 8; i++) qv[i] = f2h<T>(h2f(qraw[i]) * c);
+                for (int i = 0; i < 8; i++) qv[i] = c == 1.0f ? qraw[i] : f2h<T>(h2f(qraw[i]) * c); // (c = 1: Q came prescaled, no second rounding)
                 const v4i w = __builtin_bit_cast(v4i, qv);
 #pragma unroll
                 for (int k = 0; k < 4; k++) Q32[rt][4 * ds + k] = w[k];
@@ -765,11 +758,11 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
               "v246", "v247", "v252", "v253", "v254", "v255"
             if constexpr (DT == SVDQ_BF16) {
                 asm volatile(
-#include "attention_loop64_bf16.inc"
+#include SVDQ_ATTN_LOOP_INC_BF16
                     SVDQ_ATTN_LOOP_OPERANDS);
             } else {
                 asm volatile(
-#include "attention_loop64_fp16.inc"
+#include SVDQ_ATTN_LOOP_INC_FP16
                     SVDQ_ATTN_LOOP_OPERANDS);
             }
 #undef SVDQ_ATTN_LOOP_OPERANDS
@@ -980,7 +973,7 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.q = (const uint16_t *)a->q; p.k = (const uint16_t *)a->k; p.vt = (const uint16_t *)a->vt; p.out = (uint16_t *)a->out;
     p.q_hs = a->q_hs; p.k_hs = a->k_hs; p.vt_hs = a->vt_hs; p.o_hs = a->o_hs;
     p.L = a->L; p.H = a->H; p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;
-    p.scale_log2e = a->scale * 1.4426950408889634f;
+    p.scale_log2e = a->q_prescaled ? 1.0f : a->scale * 1.4426950408889634f; // (prescaled: Q carries scale * log2(e), svdq_gemm_args.q_scale)
     p.qact = (uint8_t *)a->qact; p.qscales = (uint16_t *)a->qscales; p.qlora_act = a->qlora_act;
     p.qlora_q32 = a->qlora_act_format == SVDQ_LORA_ACT_Q32;
     p.status = a->status;
@@ -1007,10 +1000,11 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
         return SVDQ_E_INVALID;
     }
     const int nw = a->L % 256 == 0 ? 8 : 4;
-    // automatic: 4 x 64 on the plain grid when the length allows it (measured at 24 heads x 4608 tokens, same box: 245 us against 282
-    // for 8 x 32 on either schedule; its own persistent schedule 270: the workgroups no longer walk the keys of a head together and
-    // its one-iteration DMA flight is sensitive to the L2 misses that causes); an explicit geometry takes the workspace if given
-    const int geometry = a->kv_len0 > 0 ? 1 : a->geometry ? a->geometry : (a->L % 256 == 0 ? 2 : 1); // (the key mask lives in geometry 1)
+    // automatic: geometry 2 on the plain grid when Q comes prescaled, the length allows it and there is no key mask (the mask lives in
+    // geometry 1).  Same box, 24 heads x 4608 tokens: 216 us against 274 for geometry 1 on its better schedule; geometry 2's own
+    // persistent schedule 236.  With a raw Q geometry 2 has to scale the 16-bit values itself (a second rounding, ~2.5x the error against
+    // fp32): only on explicit request.  An explicit geometry takes the workspace if given.
+    const int geometry = a->kv_len0 > 0 ? 1 : a->geometry ? a->geometry : (a->L % 256 == 0 && a->q_prescaled ? 2 : 1);
     const int groups = geometry == 2 && a->geometry == 0 ? 0 : attention_groups(p);
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
     if (geometry == 2 && a->L % 256 == 0) { if (a->dtype == SVDQ_FP16) launch_attention64<SVDQ_FP16>(p, groups, st); else launch_attention64<SVDQ_BF16>(p, groups, st); }

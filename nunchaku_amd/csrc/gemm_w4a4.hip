@@ -124,6 +124,7 @@ struct GemmParams {
     int stagger;             // NW = 4: the second workgroup of a CU starts half a tile late
     int dynamic;             // NW = 4: tiles are drawn from per-XCD queues in the workspace instead of a fixed list per workgroup
     int *status;             // optional host-visible status word (svdq_gemm_args.status)
+    float q_scale;           // RMSNORM_ROPE: factor of the Q third, applied before its rounding to 16-bit (svdq_gemm_args.q_scale; 1 = off)
     int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
     float lora_scales[MAX_LORA_TILES];
     SVDQ_PROBE_PARAMS
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                 for (int mi = 0; mi < 2; mi++) {
                     const int row = wm * 64 + mi * 32 + lr;
                     const float tot = sq[row] + sq[BM + row];
-                    const float coef = 1.0f / sqrtf(tot / 128.0f + 1e-6f);
+                    const float coef = (is_q ? p.q_scale : 1.0f) / sqrtf(tot / 128.0f + 1e-6f); // (q_scale = 1: the same division as without it)
 #pragma unroll
                     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
@@ -1056,6 +1057,10 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     }
     if (a->R > 0 && (!a->lora_act_in || !a->lora_up)) { set_error("svdq_gemm_w4a4: R > 0 needs lora_act_in and lora_up"); return SVDQ_E_INVALID; }
     if (a->dtype != SVDQ_BF16 && a->dtype != SVDQ_FP16) { set_error("svdq_gemm_w4a4: unknown dtype %d", a->dtype); return SVDQ_E_INVALID; }
+    if (a->reserved2 != 0 || !(a->q_scale >= 0.f) || !(a->q_scale < 1e30f) || (a->q_scale != 0.f && a->fuse != SVDQ_FUSE_RMSNORM_ROPE)) {
+        set_error("svdq_gemm_w4a4: q_scale=%g must be finite and >= 0 and needs the RMSNORM_ROPE epilogue; reserved2 must be 0", (double)a->q_scale);
+        return SVDQ_E_INVALID;
+    }
     if (a->variant != 0 || a->reserved != 0) {
         set_error("svdq_gemm_w4a4: variant and reserved must be 0 (timing experiments live in tools/ablate, not in this library)");
         return SVDQ_E_INVALID;
@@ -1149,6 +1154,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.M = a->M; p.M_pad = a->M_pad; p.N = a->N; p.K = a->K; p.R = a->R; p.R2 = a->R2; p.ldo = a->ldo;
     p.lora_fixed = a->lora_act_format;
     p.status = a->status;
+    p.q_scale = a->q_scale == 0.f ? 1.0f : a->q_scale;
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;
     SVDQ_PROBE_FILL(p);
 

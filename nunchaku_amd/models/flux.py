@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops.attention import attention_packed, attention_packed_quantized
+from ..ops.attention import attention_packed, attention_packed_quantized, q_prescale
 from ..ops.elementwise import residual_gate_stats, residual_gate_stats_pair
 from ..ops.gemv import awq_gemv_w4a16_batched
 from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair,
@@ -122,6 +122,7 @@ class FluxAttentionAMD(nn.Module):
         t_txt = encoder_hidden.shape[1] if self.joint else 0
         tokens = t_txt + hidden.shape[1]
         svdq = self._use_svdq(B, tokens)
+        qs = q_prescale(self.head_dim) if svdq else 0.0  # the QKV GEMM emits Q times scale * log2(e): the attention kernel's fast geometry
         qkv = torch.empty(B, tokens, 3 * hd, dtype=hidden.dtype, device=hidden.device)
         vt = torch.empty(hd, tokens, dtype=hidden.dtype, device=hidden.device) if svdq else None
         grouped = False
@@ -131,21 +132,21 @@ class FluxAttentionAMD(nn.Module):
             if self.grouped and B == 1 and len(rotary) > 2:  # one launch for both streams (rows: text, then image)
                 grouped = fused_qkv_norm_rottary_pair(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k,
                                                       hidden, self.to_qkv, self.norm_q, self.norm_k, rotary[2], qkv[0],
-                                                      out_vt=vt, ln_a=ln_ctx, ln_b=ln)
+                                                      out_vt=vt, ln_a=ln_ctx, ln_b=ln, q_scale=qs)
             if not grouped:
                 fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rot_img, output=qkv[0, t_txt:],
-                                       out_vt=vt[:, t_txt:] if svdq else None, ln=ln)
+                                       out_vt=vt[:, t_txt:] if svdq else None, ln=ln, q_scale=qs)
                 fused_qkv_norm_rottary(encoder_hidden, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, rot_txt,
-                                       output=qkv[0, :t_txt], out_vt=vt[:, :t_txt] if svdq else None, ln=ln_ctx)
+                                       output=qkv[0, :t_txt], out_vt=vt[:, :t_txt] if svdq else None, ln=ln_ctx, q_scale=qs)
         else:
             fused_qkv_norm_rottary(hidden, self.to_qkv, self.norm_q, self.norm_k, rotary, output=qkv.view(B * tokens, -1),
-                                   out_vt=vt, ln=ln, quantized=quantized)
+                                   out_vt=vt, ln=ln, quantized=quantized, q_scale=qs)
         pool = None
         if svdq and self.fused_out_quant and B == 1 and (not self.joint or (self.grouped and _pair_compatible(self.to_add_out, self.out_proj))):
             src = ln_ctx if self.joint else ln  # the pool of the stream whose rows come first carries the scratch
             qpool = src[3] if src is not None and len(src) > 3 else None
             qres = attention_packed_quantized(qkv[0], vt, self.heads, self.out_proj, lin_first=self.to_add_out if self.joint else None,
-                                              split_rows=t_txt, pool=qpool)
+                                              split_rows=t_txt, pool=qpool, q_prescaled=True)
             if qres is not None:  # the 16-bit attention output never exists: straight into the output projection(s)
                 if self.joint:
                     ca, a = linear_pair_quantized(*qres, self.to_add_out, self.out_proj, t_txt)
@@ -153,7 +154,7 @@ class FluxAttentionAMD(nn.Module):
                 return self.out_proj.forward_quant(*qres).view(B, tokens, -1)
         if svdq:  # the same launch clears the low-rank accumulators of the output projections' quantisers
             zf = _pad256(hidden.shape[1]) * self.out_proj.rank + (_pad256(t_txt) * self.to_add_out.rank if self.joint else 0)
-            o, pool = attention_packed(qkv[0], vt, self.heads, zero_floats=zf)
+            o, pool = attention_packed(qkv[0], vt, self.heads, zero_floats=zf, q_prescaled=True)
             o = o.unsqueeze(0)
         else:
             q, k, v = qkv.chunk(3, dim=-1)

@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops.attention import attention_packed, attention_packed_quantized
+from ..ops.attention import attention_packed, attention_packed_quantized, q_prescale
 from ..ops.elementwise import residual_gate_stats, residual_gate_stats_pair
 from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair, linear_pair,
                          linear_pair_quantized)
@@ -99,16 +99,17 @@ class NunchakuQwenAttention(nn.Module):
         if self.fused_qkv and B == 1 and self.head_dim == 128 and tokens % 128 == 0:
             qkv = torch.empty(tokens, 3 * hd, dtype=hidden_states.dtype, device=hidden_states.device)
             vt = torch.empty(hd, tokens, dtype=hidden_states.dtype, device=hidden_states.device)
+            qs = q_prescale(self.head_dim)  # Q leaves the QKV GEMM times scale * log2(e): the attention kernel's fast geometry
             done = False
             if t_txt % 256 == 0 and t_img % 256 == 0:  # both streams in one launch (rows: text first)
                 done = fused_qkv_norm_rottary_pair(encoder_hidden_states, self.add_qkv_proj, self.norm_added_q, self.norm_added_k,
-                                                   hidden_states, self.to_qkv, self.norm_q, self.norm_k, packed["all"], qkv, out_vt=vt)
+                                                   hidden_states, self.to_qkv, self.norm_q, self.norm_k, packed["all"], qkv, out_vt=vt, q_scale=qs)
             if not done:
                 fused_qkv_norm_rottary(encoder_hidden_states, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, packed["txt"],
-                                       output=qkv[:t_txt], out_vt=vt[:, :t_txt])
+                                       output=qkv[:t_txt], out_vt=vt[:, :t_txt], q_scale=qs)
                 fused_qkv_norm_rottary(hidden_states, self.to_qkv, self.norm_q, self.norm_k, packed["img"], output=qkv[t_txt:],
-                                       out_vt=vt[:, t_txt:])
-            o = attention_packed(qkv, vt, self.heads).unsqueeze(0)
+                                       out_vt=vt[:, t_txt:], q_scale=qs)
+            o = attention_packed(qkv, vt, self.heads, q_prescaled=True).unsqueeze(0)
         else:
             o = self._reference_ops(hidden_states, encoder_hidden_states, packed)
         if t_txt % 256 == 0 and B == 1:
@@ -126,10 +127,11 @@ class NunchakuQwenAttention(nn.Module):
         qkv = torch.empty(tokens, 3 * hd, dtype=hidden.dtype, device=hidden.device)
         vt = torch.empty(hd, tokens, dtype=hidden.dtype, device=hidden.device)
         ok = fused_qkv_norm_rottary_pair(enc, self.add_qkv_proj, self.norm_added_q, self.norm_added_k, hidden, self.to_qkv, self.norm_q,
-                                         self.norm_k, packed["all"], qkv, out_vt=vt, ln_a=ln_txt, ln_b=ln_img)
+                                         self.norm_k, packed["all"], qkv, out_vt=vt, ln_a=ln_txt, ln_b=ln_img, q_scale=q_prescale(self.head_dim))
         if not ok:
             raise RuntimeError("forward_fused_norm: the two streams' projections cannot share a launch (shapes / ranks differ)")
-        qres = attention_packed_quantized(qkv, vt, self.heads, self.to_out[0], lin_first=self.to_add_out, split_rows=t_txt, pool=ln_txt[3])
+        qres = attention_packed_quantized(qkv, vt, self.heads, self.to_out[0], lin_first=self.to_add_out, split_rows=t_txt, pool=ln_txt[3],
+                                          q_prescaled=True)
         if qres is not None:
             txt, img = linear_pair_quantized(*qres, self.to_add_out, self.to_out[0], t_txt)
             return img, txt

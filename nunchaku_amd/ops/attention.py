@@ -18,8 +18,14 @@ def alloc_qkv(tokens: int, heads: int, dtype: torch.dtype, device, head_dim: int
     return qkv, vt
 
 
+def q_prescale(head_dim: int = 128, scale: float | None = None) -> float:
+    """The factor a QKV GEMM applies to Q (``fused_qkv_norm_rottary(..., q_scale=)``) so that the attention kernel needs no per-score
+    scaling: ``scale * log2(e)``.  Pass ``q_prescaled=True`` to the attention call that reads that buffer."""
+    return (1.0 / math.sqrt(head_dim) if scale is None else scale) * 1.4426950408889634
+
+
 def attention_packed(qkv: torch.Tensor, vt: torch.Tensor, heads: int, out: torch.Tensor | None = None,
-                     scale: float | None = None, zero_floats: int = 0):
+                     scale: float | None = None, zero_floats: int = 0, q_prescaled: bool = False):
     """``softmax(scale * Q K^T) V`` per head, reading Q and K in place from the fused QKV GEMM output
     ``qkv`` [L, 3*H*128] and V from its transposed side output ``vt`` [H*128, L]; returns ``[L, H*128]``
     token-major (the layout the output projection's quantiser reads).  No transposes, no copies.
@@ -35,7 +41,8 @@ def attention_packed(qkv: torch.Tensor, vt: torch.Tensor, heads: int, out: torch
     k = qkv[:, heads * D : 2 * heads * D].unflatten(1, (heads, D))
     zwords = zero_floats * lora_act_words()
     zero = torch.empty((zwords + 3) // 4 * 4, dtype=torch.float32, device=qkv.device) if zero_floats > 0 else None
-    ops.attention(q, k, vt.unflatten(0, (heads, D)), out.unflatten(1, (heads, D)), 1.0 / math.sqrt(D) if scale is None else scale, zero)
+    ops.attention(q, k, vt.unflatten(0, (heads, D)), out.unflatten(1, (heads, D)), 1.0 / math.sqrt(D) if scale is None else scale, zero,
+                  q_prescaled=q_prescaled)
     if zero_floats > 0:
         from .elementwise import ZeroPool
 
@@ -44,7 +51,7 @@ def attention_packed(qkv: torch.Tensor, vt: torch.Tensor, heads: int, out: torch
 
 
 def attention_packed_quantized(qkv: torch.Tensor, vt: torch.Tensor, heads: int, lin, lin_first=None, split_rows: int = 0,
-                               pool=None, scale: float | None = None):
+                               pool=None, scale: float | None = None, q_prescaled: bool = False):
     """Attention whose epilogue emits the quantised input of the output projection ``lin`` directly (codes, scales and
     low-rank down projection: what ``lin.quantize(attention_packed(...))`` would return, without the 16-bit round trip).
     Joint attention: rows ``< split_rows`` belong to ``lin_first`` (text), the rest to ``lin``.  ``pool``: a ZeroPool for
@@ -71,5 +78,5 @@ def attention_packed_quantized(qkv: torch.Tensor, vt: torch.Tensor, heads: int, 
         quant.update(smooth=lin.smooth_factor, lora_down=lin.proj_down)
     q = qkv[:, : heads * D].unflatten(1, (heads, D))
     k = qkv[:, heads * D : 2 * heads * D].unflatten(1, (heads, D))
-    ops.attention(q, k, vt.unflatten(0, (heads, D)), None, 1.0 / math.sqrt(D) if scale is None else scale, None, quant)
+    ops.attention(q, k, vt.unflatten(0, (heads, D)), None, 1.0 / math.sqrt(D) if scale is None else scale, None, quant, q_prescaled=q_prescaled)
     return act, asc, lact

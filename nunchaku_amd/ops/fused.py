@@ -38,11 +38,13 @@ def fused_gelu_mlp(x: torch.Tensor, fc1, fc2, pad_size: int = 256, ln=None, quan
 
 
 def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rotary_emb: torch.Tensor | None = None,
-                           output=None, attn_tokens: int = 0, out_vt: torch.Tensor | None = None, ln=None, quantized=None):
+                           output=None, attn_tokens: int = 0, out_vt: torch.Tensor | None = None, ln=None, quantized=None,
+                           q_scale: float = 0.0):
     """QKV projection with RMSNorm(q), RMSNorm(k) and rotary embedding applied in the GEMM epilogue.
     ``rotary_emb`` is the ``pack_rotemb`` tensor of the reference ([1, M_pad, 128] float32).
     ``out_vt`` ([out_features/3, tokens] view): V is written transposed there for ``ops.attention`` instead of
-    into ``output`` (this library's form of the reference's ``output=(q, k, v)`` packed mode)."""
+    into ``output`` (this library's form of the reference's ``output=(q, k, v)`` packed mode).  ``q_scale``: Q is emitted times this
+    factor (``ops.attention.q_prescale()``) for ``attention_packed(..., q_prescaled=True)``."""
     B, S, C_in = x.shape
     M = B * S
     x2 = x.reshape(M, C_in)
@@ -70,7 +72,7 @@ def fused_qkv_norm_rottary(x: torch.Tensor, proj, norm_q=None, norm_k=None, rota
         act=qx, wgt=proj.qweight, out=output, ascales=ascales, wscales=proj.wscales, lora_act_in=lora_act,
         lora_up=proj.proj_up, bias=proj.bias, fp4=False, alpha=proj.wtscale, wcscales=proj.wcscales,
         norm_q=None if norm_q is None else norm_q.weight, norm_k=None if norm_k is None else norm_k.weight,
-        rotary_emb=rot, out_vt=out_vt, lora_scales=getattr(proj, "lora_scales", None),
+        rotary_emb=rot, out_vt=out_vt, lora_scales=getattr(proj, "lora_scales", None), q_scale=q_scale,
     )
     return output.view(B, S, -1)
 
@@ -167,7 +169,7 @@ def fused_gelu_mlp_pair(xa, fc1a, fc2a, xb, fc1b, fc2b, ln_a=None, ln_b=None):
 
 
 def fused_qkv_norm_rottary_pair(xa, proj_a, nq_a, nk_a, xb, proj_b, nq_b, nk_b, rotary_emb, output, out_vt=None,
-                                ln_a=None, ln_b=None):
+                                ln_a=None, ln_b=None, q_scale: float = 0.0):
     """QKV projections of both streams into ``output`` [Ma + Mb, 3*H*128] (rows: stream a, then stream b) with one
     GEMM launch; ``rotary_emb`` is the packed table of the concatenated token sequence.  Returns False when the
     layers cannot be grouped (nothing has been written)."""
@@ -178,7 +180,7 @@ def fused_qkv_norm_rottary_pair(xa, proj_a, nq_a, nk_a, xb, proj_b, nq_b, nk_b, 
     svdq_gemm_w4a4_cuda(
         act=act, wgt=proj_a.qweight, out=output, ascales=asc, wscales=proj_a.wscales, lora_act_in=lact, lora_up=proj_a.proj_up,
         bias=proj_a.bias, norm_q=nq_a.weight, norm_k=nk_a.weight, rotary_emb=rotary_emb.reshape(-1, rotary_emb.shape[-1]),
-        out_vt=out_vt, lora_scales=getattr(proj_a, "lora_scales", None),
+        out_vt=out_vt, lora_scales=getattr(proj_a, "lora_scales", None), q_scale=q_scale,
         second=_second(proj_b, norm_q=nq_b.weight, norm_k=nk_b.weight), split_rows=Ma)
     return True
 

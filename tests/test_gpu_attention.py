@@ -36,9 +36,9 @@ def _geometry(request):
 
 
 def test_attention_geometries_agree():
-    """Same arithmetic per query row in both geometries (per 32-row tile: maxima, deferred rescale, ascending key tiles, row sums over
-    the ROUNDED probabilities) except the summation order of the row sums (v_dot2c chains in geometry 1, the matrix pipe in
-    geometry 2): outputs agree to one 16-bit ulp, and almost everywhere exactly."""
+    """On a Q that comes prescaled both geometries compute the same thing -- per 32-row tile: maxima, deferred move of the reference
+    point, ascending key tiles, row sums over the ROUNDED probabilities -- in different summation orders (and geometry 2 keeps its
+    scores relative: s' = s - m accumulated, not subtracted afterwards): outputs agree to two 16-bit ulps, mostly exactly."""
     from nunchaku_amd._C import _Ops
     from nunchaku_amd.ops.attention import attention_packed
 
@@ -49,31 +49,73 @@ def test_attention_geometries_agree():
             for L, H in ((256, 2), (1024, 3), (2304, 5)):
                 g = torch.Generator(device="cuda").manual_seed(L + H)
                 qkv = (torch.randn(L, 3 * H * 128, device="cuda", generator=g) * 1.5).to(dtype)
+                qkv, kw, _ = _as_produced_for(2, qkv, H)
                 vt = qkv[:, 2 * H * 128:].t().contiguous()
                 for ws in (False, True):
                     outs = []
                     for geo in (1, 2):
                         _Ops.attention_geometry, _Ops.attention_use_workspace = geo, ws
                         out = torch.empty(L, H * 128, device="cuda", dtype=dtype)
-                        attention_packed(qkv, vt, H, out=out)
+                        attention_packed(qkv, vt, H, out=out, **kw)
                         outs.append(out.float())
                     diff = (outs[0] - outs[1]).abs()
-                    assert (diff <= ulp * outs[0].abs() + 1e-6).all(), (dtype, L, H, ws, diff.max().item())
-                    assert (diff != 0).float().mean().item() < 2e-2, (dtype, L, H, ws, (diff != 0).float().mean().item())
+                    # (an output near zero is a sum of cancelling terms: the error scale is that of the terms, hence the absolute part)
+                    assert (diff <= 2 * ulp * outs[0].abs() + 0.5 * ulp * outs[0].abs().max()).all(), (dtype, L, H, ws, diff.max().item())
+                    assert (diff != 0).float().mean().item() < 0.25, (dtype, L, H, ws, (diff != 0).float().mean().item())
     finally:
         _Ops.attention_geometry, _Ops.attention_use_workspace = saved
 
 
-def _ref_attention(q, k, v):
+def test_geometry_2_on_a_raw_q_is_less_accurate_and_only_runs_on_request():
+    """Without q_prescaled the automatic choice is geometry 1.  Asked for explicitly, geometry 2 scales the 16-bit Q itself (a second
+    rounding): correct, but 2-4x the error of geometry 1 against fp32 on peaky rows -- bounded here, documented in svdq_amd.h."""
+    from nunchaku_amd._C import _Ops
+    from nunchaku_amd.ops.attention import attention_packed
+
+    L, H = 1024, 3
+    saved = _Ops.attention_geometry
+    try:
+        for dtype in (torch.bfloat16, torch.float16):
+            g = torch.Generator(device="cuda").manual_seed(9)
+            qkv = torch.randn(L, 3 * H * 128, device="cuda", generator=g).to(dtype)
+            qkv[: L // 2, : H * 128] *= 4.0
+            q, k, v = (qkv[:, i * H * 128:(i + 1) * H * 128].unflatten(1, (H, 128)) for i in range(3))
+            vt = v.permute(1, 2, 0).contiguous().view(H * 128, L)
+            ref = _ref_attention(q, k, v).reshape(L, H * 128)
+            errs = {}
+            for geo in (0, 1, 2):
+                _Ops.attention_geometry = geo
+                errs[geo] = (attention_packed(qkv, vt, H).float() - ref).abs().max().item()
+            assert errs[0] == errs[1], "automatic geometry on a raw Q must be geometry 1"
+            assert errs[2] <= 5.0 * errs[1] + 1e-6 and errs[2] <= 8 * (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * ref.abs().max().item(), errs
+    finally:
+        _Ops.attention_geometry = saved
+
+
+def _ref_attention(q, k, v, scale=None):
     """q, k, v: [L, H, D] 16-bit -> float32 [L, H, D]"""
     qf, kf, vf = (t.float().permute(1, 0, 2) for t in (q, k, v))
-    s = qf @ kf.transpose(1, 2) / math.sqrt(q.shape[-1])
+    s = qf @ kf.transpose(1, 2) * (1.0 / math.sqrt(q.shape[-1]) if scale is None else scale)
     return (torch.softmax(s, dim=-1) @ vf).permute(1, 0, 2)
+
+
+def _as_produced_for(geometry, qkv, H):
+    """Geometry 2 is built for a Q its PRODUCER multiplied by scale * log2(e) before the rounding to 16-bit (svdq_gemm_args.q_scale;
+    ops.attention(q_prescaled=True)): the tests hand it such a Q -- the given one times that factor, rounded once -- and compare with a
+    reference over the SAME 16-bit values, whose softmax scale is then ln 2.  Geometry 1 takes the buffer as it is.
+    -> (qkv the kernel reads, keyword arguments of attention_packed, softmax scale of the reference)"""
+    if geometry != 2:
+        return qkv, {}, 1.0 / math.sqrt(128)
+    from nunchaku_amd.ops.attention import q_prescale
+
+    pre = qkv.clone()
+    pre[:, : H * 128] = (qkv[:, : H * 128].float() * q_prescale(128)).to(qkv.dtype)
+    return pre, {"q_prescaled": True}, math.log(2.0)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("L,H", [(128, 1), (384, 3), (1152, 2), (256, 2), (1024, 3)])  # L % 256 == 0: pipelined kernel
-def test_attention_matches_fp32_reference(dtype, L, H):
+def test_attention_matches_fp32_reference(dtype, L, H, _geometry):
     from nunchaku_amd.ops.attention import attention_packed
 
     td = TORCH_DT[dtype]
@@ -81,12 +123,13 @@ def test_attention_matches_fp32_reference(dtype, L, H):
     qkv = torch.randn(L, 3 * H * 128, device="cuda", generator=g).to(td)
     # peaky rows too: scale some queries so the softmax is far from uniform
     qkv[: L // 2, : H * 128] *= 4.0
+    qkv, kw, scale = _as_produced_for(_geometry, qkv, H)
     q, k, v = (qkv[:, i * H * 128:(i + 1) * H * 128].unflatten(1, (H, 128)) for i in range(3))
     vt = v.permute(1, 2, 0).contiguous().view(H * 128, L)
-    out = attention_packed(qkv, vt, H)
-    ref = _ref_attention(q, k, v).reshape(L, H * 128)
+    out = attention_packed(qkv, vt, H, **kw)
+    ref = _ref_attention(q, k, v, scale).reshape(L, H * 128)
     err = (out.float() - ref).abs().max().item()
-    sd = torch.nn.functional.scaled_dot_product_attention(q.permute(1, 0, 2)[None], k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None])
+    sd = torch.nn.functional.scaled_dot_product_attention(q.permute(1, 0, 2)[None], k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None], scale=scale)
     err_sdpa = (sd[0].permute(1, 0, 2).reshape(L, H * 128).float() - ref).abs().max().item()
     tol = 3 * (2.0 ** -8 if dtype == "bf16" else 2.0 ** -11) * ref.abs().max().item()
     assert err <= tol, f"attention error {err:.3g} > {tol:.3g}"
@@ -95,7 +138,7 @@ def test_attention_matches_fp32_reference(dtype, L, H):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("L,H", [(256, 3), (1024, 3), (512, 130), (4608, 24)])
-def test_attention_persistent_schedule_matches_plain_grid(dtype, L, H):
+def test_attention_persistent_schedule_matches_plain_grid(dtype, L, H, _geometry):
     """With a workspace the launch is persistent (one workgroup per CU, tasks split along the keys, partial (O, m, l) merged
     by the task's owner: 2 workgroups per task at (256, 3), 8 at (1024, 3), the FLUX.1 case last).  Same result as the
     plain grid up to fp32 summation order, bit-reproducible from launch to launch, counters left at zero."""
@@ -108,13 +151,14 @@ def test_attention_persistent_schedule_matches_plain_grid(dtype, L, H):
     g = torch.Generator(device="cuda").manual_seed(L * 7 + H)
     qkv = torch.randn(L, 3 * H * 128, device="cuda", generator=g).to(td)
     qkv[: L // 2, : H * 128] *= 4.0
+    qkv, kw, scale = _as_produced_for(_geometry, qkv, H)
     vt = qkv[:, 2 * H * 128:].t().contiguous()
     try:
         _Ops.attention_use_workspace = False
-        plain = attention_packed(qkv, vt, H)
+        plain = attention_packed(qkv, vt, H, **kw)
     finally:
         _Ops.attention_use_workspace = True
-    runs = [attention_packed(qkv, vt, H) for _ in range(3)]
+    runs = [attention_packed(qkv, vt, H, **kw) for _ in range(3)]
     ops.attention_workspace_status()
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
     ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11
@@ -122,13 +166,13 @@ def test_attention_persistent_schedule_matches_plain_grid(dtype, L, H):
     assert diff <= 2 * ulp * plain.float().abs().max().item(), f"persistent vs plain grid: {diff:.3g}"
     if L * H <= 70000:
         q, k, v = (qkv[:, i * H * 128:(i + 1) * H * 128].unflatten(1, (H, 128)) for i in range(3))
-        ref = _ref_attention(q, k, v).reshape(L, H * 128)
+        ref = _ref_attention(q, k, v, scale).reshape(L, H * 128)
         assert (runs[0].float() - ref).abs().max().item() <= 3 * ulp * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("L,H", [(256, 2), (1024, 3), (1152, 2)])
-def test_attention_matches_its_tile_by_tile_restatement(dtype, L, H):
+def test_attention_matches_its_tile_by_tile_restatement(dtype, L, H, _geometry):
     """oracle.attention_tiled follows the kernel's arithmetic tile by tile (deferred rescale per 32-row wave block, probabilities
     rounded to 16 bits, row sums over the ROUNDED probabilities): the kernel -- plain grid (L = 1152: the 4-wave kernel) and
     persistent schedule with its split tasks (the others) -- must agree to about one unit in the last place of the 16-bit output.
@@ -140,16 +184,17 @@ def test_attention_matches_its_tile_by_tile_restatement(dtype, L, H):
     g = torch.Generator(device="cuda").manual_seed(17 * L + H)
     qkv = torch.randn(L, 3 * H * 128, device="cuda", generator=g).to(td)
     qkv[: L // 2, : H * 128] *= 4.0  # peaky rows: the deferred rescale and the dominated-row case both occur
+    qkv, kw, scale = _as_produced_for(_geometry, qkv, H)  # (geometry 2: the restatement sees the same prescaled Q, scale ln 2 -> c = 1)
     vt = qkv[:, 2 * H * 128:].t().contiguous()
-    out = f32(attention_packed(qkv, vt, H)).reshape(L, H, 128)
+    out = f32(attention_packed(qkv, vt, H, **kw)).reshape(L, H, 128)
     x = f32(qkv).reshape(L, 3, H, 128)
     ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11
     worst, off = 0.0, 0.0
     for h in range(H):
-        ref = O.attention_tiled(x[:, 0, h], x[:, 1, h], x[:, 2, h], 1.0 / math.sqrt(128), dtype)
+        ref = O.attention_tiled(x[:, 0, h], x[:, 1, h], x[:, 2, h], scale, dtype)
         # the error scale of a sum of rounded terms is ulp * sum p |v| (the same weights applied to |V|), not ulp * |result|:
         # an output near zero is a sum of cancelling terms
-        cond = O.attention_tiled(x[:, 0, h], x[:, 1, h], np.abs(x[:, 2, h]), 1.0 / math.sqrt(128), dtype)
+        cond = O.attention_tiled(x[:, 0, h], x[:, 1, h], np.abs(x[:, 2, h]), scale, dtype)
         err = np.abs(out[:, h] - ref) / cond
         worst = max(worst, float(err.max()))
         off = max(off, float((err > 1.0 * ulp).mean()))
@@ -210,6 +255,62 @@ def test_qkv_gemm_transposed_v_output(dtype, M):
     assert torch.equal(vt[:, off:off + M], full[:, 2 * N // 3:].t())
     assert (out[:, 2 * N // 3:] == sentinel).all()
     assert (vt[:, :off] == sentinel).all() and (vt[:, off + M:] == sentinel).all()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_qkv_gemm_q_scale_scales_q_before_its_rounding(dtype):
+    """svdq_gemm_args.q_scale (RMSNorm+RoPE epilogue): the Q third is the plain epilogue's Q times the factor with ONE rounding -- at most one
+    16-bit ulp from (rounded Q) x factor, and strictly closer to it on average than a second rounding would be; K and V are untouched; a
+    factor of 1 is bit-identical to none.  Then the consumer: attention(q_prescaled) on that buffer against attention on the plain one."""
+    from nunchaku_amd._C import _Ops
+    from nunchaku_amd.ops.attention import attention_packed, q_prescale
+    from nunchaku_amd.ops.fused import fused_qkv_norm_rottary
+    from tests.test_gpu_parity import _gemm_inputs
+
+    M, K, H = 512, 256, 2
+    N = 3 * H * 128
+    Lyr, x = _gemm_inputs(M, K, N, 32, dtype, seed=31)
+    rng = np.random.default_rng(32)
+    ang = rng.uniform(0, 6.28, (M, 64)).astype(np.float32)
+    packed = torch.from_numpy(O.pack_rotemb_ref(np.stack([np.sin(ang), np.cos(ang)], axis=-1).astype(np.float32))).cuda().view(1, M, 128)
+    mod = make_module(Lyr, dtype)
+
+    class W:
+        def __init__(self):
+            self.weight = torch.ones(128, device="cuda", dtype=TORCH_DT[dtype])
+
+    xin = t16(x, dtype).view(1, M, K)
+    td = TORCH_DT[dtype]
+    c = q_prescale(128)
+    outs = {}
+    for qs in (0.0, 1.0, c):
+        out = torch.empty(M, N, device="cuda", dtype=td)
+        vt = torch.empty(H * 128, M, device="cuda", dtype=td)
+        fused_qkv_norm_rottary(xin, mod, W(), W(), packed, output=out, out_vt=vt, q_scale=qs)
+        outs[qs] = (out, vt)
+    plain, one, scaled = outs[0.0][0], outs[1.0][0], outs[c][0]
+    assert torch.equal(plain[:, : 2 * H * 128], one[:, : 2 * H * 128]) and torch.equal(outs[0.0][1], outs[1.0][1])
+    assert torch.equal(plain[:, H * 128: 2 * H * 128], scaled[:, H * 128: 2 * H * 128]) and torch.equal(outs[0.0][1], outs[c][1])
+    q0, q1 = plain[:, : H * 128].float(), scaled[:, : H * 128].float()
+    ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11
+    assert ((q1 - q0 * c).abs() <= 2.02 * ulp * (q0 * c).abs() + 1e-7).all()       # two roundings apart at most from (rounded q) x c ...
+    twice = (q0 * c).to(td).float()                                                 # ... and not simply that value rounded again
+    assert (q1 != twice).float().mean().item() > 0.05
+    saved = _Ops.attention_geometry
+    try:
+        _Ops.attention_geometry = 0  # automatic: geometry 1 on the plain buffer, geometry 2 on the prescaled one
+        a_plain = attention_packed(plain, outs[0.0][1], H).float()
+        a_pre = attention_packed(scaled, outs[c][1], H, q_prescaled=True).float()
+    finally:
+        _Ops.attention_geometry = saved
+    q, k = (plain[:, i * H * 128:(i + 1) * H * 128].unflatten(1, (H, 128)) for i in range(2))
+    v = outs[0.0][1].t().unflatten(1, (H, 128))  # (with out_vt the V third of `out` is not written)
+    ref = _ref_attention(q, k, v).reshape(M, H * 128)
+    ref_pre = _ref_attention(scaled[:, : H * 128].unflatten(1, (H, 128)), k, v, math.log(2.0)).reshape(M, H * 128)  # over the values the kernel read
+    e_plain, e_pre = (a_plain - ref).abs().max().item(), (a_pre - ref_pre).abs().max().item()
+    assert e_pre <= 3 * ulp * ref.abs().max().item() and e_pre <= 2.0 * e_plain + 1e-6, (e_plain, e_pre)
+    # and the two pipelines agree with each other to the rounding of Q (different 16-bit inputs: not a kernel property, a sanity bound)
+    assert (a_pre - a_plain).abs().max().item() <= 16 * ulp * ref.abs().max().item()
 
 
 def test_flux_transformer_svdq_attention_vs_sdpa():
@@ -314,7 +415,7 @@ def test_attention_fused_output_quantiser(dtype, joint):
     assert (got[2] - ref_la).abs().max() <= 2e-3 * ref_la.abs().max() + 1e-5
 
 
-def test_reference_fp16_attention_operators():
+def test_reference_fp16_attention_operators(_geometry):
     """The reference's "nunchaku-fp16" attention surface (attention_processors/flux.py:114-237, csrc/ops.h:114-121):
     fused_qkv_norm_rottary(..., output=(q, k, v), attn_tokens=) + _C.ops.attention_fp16, through the nunchaku shim,
     against the SDPA processor on the same module."""
@@ -351,7 +452,8 @@ def test_reference_fp16_attention_operators():
         rel = ((got.float() - ref.float()).norm() / ref.float().norm()).item()
         psnr = psnr_db(got, ref)
         print(f"nunchaku-fp16 processor vs SDPA processor: PSNR {psnr:.1f} dB rel {rel:.2e} max err {err:.3e}")
-        assert torch.isfinite(got.float()).all() and rel <= 1e-2 and psnr >= 45.0, (err, rel, psnr)
+        # (the processors hand a RAW Q to attention_fp16: under the 4x64 fixture that is geometry 2's explicit raw-Q path, a second rounding of Q)
+        assert torch.isfinite(got.float()).all() and rel <= (2e-2 if _geometry == 2 else 1e-2) and psnr >= 45.0, (err, rel, psnr)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

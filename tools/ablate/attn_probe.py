@@ -1,6 +1,6 @@
-"""Read the clock / phase stamps of a probe build of the attention kernel (tools/ablate/build_attn.py probe,stamps=1[,...]).
+"""Read the clock / phase stamps of a probe build of the attention kernel (tools/ablate/build_attn.py probe[,...]).
 
-    SVDQ_LIB=$PWD/tools/ablate/libsvdq_amd_attn_probe_stamps1.so PYTHONPATH=$PWD python tools/ablate/attn_probe.py
+    SVDQ_LIB=$PWD/tools/ablate/libsvdq_amd_attn_probe.so PYTHONPATH=$PWD python tools/ablate/attn_probe.py
 """
 import ctypes, json, os, sys, torch
 import nunchaku_amd._lib as _L
@@ -30,13 +30,9 @@ for ws in (False, True):
     e0.record(); attention_packed(qkv, vt, H, out=out); e1.record(); torch.cuda.synchronize()
     c = clk.view(-1, 4).cpu()
     c = c[c[:, 0] > 0].double()
-    t = trace.cpu().tolist()
     rec = {"schedule": "persistent" if ws else "plain grid", "us": round(e0.elapsed_time(e1) * 1e3, 1), "workgroups": len(c),
            "clock_GHz": round(float((c[:, 0] / c[:, 1]).mean()) * 0.1, 3),
            "cycles_per_tile_in_loop": round(float(c[:, 2].sum() / c[:, 3].sum()), 1),
            "loop_share_of_kernel_cycles": round(float(c[:, 2].sum() / c[:, 0].sum()), 3),
-           "kernel_cycles_min_mean_max": [int(c[:, 0].min()), int(c[:, 0].mean()), int(c[:, 0].max())],
-           "one_iteration_stamps": {"dma_requests": t[1] - t[0], "preamble": t[2] - t[1],
-                                    "slots_by_8": [t[3 + n] - t[2 + n] for n in range(8)], "tail_to_barrier": t[11] - t[10],
-                                    "vmcnt_and_barrier": t[12] - t[11], "whole": t[12] - t[0]} if t[12] else None}
+           "kernel_cycles_min_mean_max": [int(c[:, 0].min()), int(c[:, 0].mean()), int(c[:, 0].max())]}
     print(json.dumps(rec), flush=True)
