@@ -112,6 +112,77 @@ KERNEL_USE(k_nouse_lead4, W(1) MU(0, 0) "ds_read_b128 %[r2], %[la]\n" MU(1, 0) W
 // lead 2 (one read ahead): wait lgkmcnt(0)
 KERNEL_USE(k_use_lead2, W(0) MU(0, 0) RD(1) MU(1, 0) W(0) MU(2, 1) RD(2) MU(3, 1) W(0) MU(4, 2) RD(3) MU(5, 2) W(0) MU(6, 3) RD(0) MU(7, 3))
 
+// ---- the same with TWO waves per SIMD (512-thread workgroup: the GEMM's regime): the partner wave's fillers can use the shadow too
+#undef KERNEL
+#define KERNEL(name, F)                                                                                                        \
+    __global__ __launch_bounds__(512, 2) void name(long long *out, int iters) {                                               \
+        __shared__ v4f lds[1024];                                                                                              \
+        v16f a0 = {}, a1 = {}, a2 = {}, a3 = {}, a4 = {}, a5 = {}, a6 = {}, a7 = {};                                           \
+        v4f x = {1.f, 2.f, 3.f, 4.f}, y = {1.f, 1.f, 1.f, 1.f}, d0 = {};                                                       \
+        float f1 = 0.5f, f2 = 0.25f;                                                                                           \
+        float g0 = threadIdx.x, g1 = 1, g2 = 2, g3 = 3, g4 = 4, g5 = 5, g6 = 6, g7 = 7;                                        \
+        float h0 = 1, h1 = 1, h2 = 2, h3 = 3, h4 = 4, h5 = 5, h6 = 6, h7 = 7;                                                  \
+        double p0 = 0, p1 = 1;                                                                                                 \
+        unsigned la = (threadIdx.x & 63) * 16, s0 = 0;                                                                         \
+        lds[threadIdx.x & 1023] = x;                                                                                           \
+        __syncthreads();                                                                                                       \
+        long long t0 = __builtin_readcyclecounter();                                                                           \
+        for (int i = 0; i < iters; i++)                                                                                        \
+            asm volatile(BODY(F)                                                                                               \
+                         : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6),  \
+                           [a7] "+v"(a7), [d0] "+v"(d0), [p0] "+v"(p0), [s0] "+s"(s0), [g0] "+v"(g0), [g1] "+v"(g1),            \
+                           [g2] "+v"(g2), [g3] "+v"(g3), [g4] "+v"(g4), [g5] "+v"(g5), [g6] "+v"(g6), [g7] "+v"(g7),            \
+                           [h0] "+v"(h0), [h1] "+v"(h1), [h2] "+v"(h2), [h3] "+v"(h3), [h4] "+v"(h4), [h5] "+v"(h5),            \
+                           [h6] "+v"(h6), [h7] "+v"(h7)                                                                        \
+                         : [x] "v"(x), [y] "v"(y), [f1] "v"(f1), [f2] "v"(f2), [la] "v"(la), [p1] "v"(p1) : "scc");            \
+        asm volatile("s_waitcnt lgkmcnt(0)\ns_nop 15\ns_nop 15" ::: "memory");                                                 \
+        long long t1 = __builtin_readcyclecounter();                                                                           \
+        float acc = a0[0] + a1[0] + a2[0] + a3[0] + a4[0] + a5[0] + a6[0] + a7[0] + g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7 + h0 + h1 + h2 + h3 + h4 + h5 + h6 + h7 + d0[0] + (float)p0 + s0; \
+        if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;                                                                       \
+        if (acc == 12345.678f) out[0] = 0;                                                                                     \
+    }
+KERNEL(w2_none, "")
+KERNEL(w2_fma_2, FILL_fma(0) FILL_fma(1))
+KERNEL(w2_fma_4, FILL_fma(0) FILL_fma(1) FILL_fma(2) FILL_fma(3))
+KERNEL(w2_fma_6, FILL_fma(0) FILL_fma(1) FILL_fma(2) FILL_fma(3) FILL_fma(4) FILL_fma(5))
+KERNEL(w2_fma_8, FILL_fma(0) FILL_fma(1) FILL_fma(2) FILL_fma(3) FILL_fma(4) FILL_fma(5) FILL_fma(6) FILL_fma(7))
+KERNEL(w2_fma_8_dsr, FILL_fma(0) FILL_fma(1) FILL_fma(2) FILL_fma(3) FILL_fma(4) FILL_fma(5) FILL_fma(6) FILL_fma(7) FILL_dsr(0))
+KERNEL(w2_fma_8_2dsr_salu, FILL_fma(0) FILL_fma(1) FILL_fma(2) FILL_fma(3) FILL_dsr(0) FILL_fma(4) FILL_fma(5) FILL_fma(6) FILL_fma(7) FILL_dsr(0) FILL_salu(0))
+
+// ---- the GEMM's own arithmetic, registers only, two waves per SIMD: per 32x32x64 tile-group one FP6 product MFMA (v_mfma_scale_f32_32x32x64_f8f6f4,
+//      fp6 x fp6), one 16-bit scale-tile MFMA and 16 v_fmac (acc += P * S) -- wall-clock rate at the chip's power limit, no memory at all
+typedef int v6i_ __attribute__((ext_vector_type(6)));
+#define TG(P, S, PN, SN) \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 %[" #PN "], %[w6], %[a6], 0, %[mx], %[mx] op_sel_hi:[0,0,0] cbsz:2 blgp:2\n" \
+    "v_fmac_f32 %[c0], %[f1], %[f2]\n v_fmac_f32 %[c1], %[f1], %[f2]\n v_fmac_f32 %[c2], %[f1], %[f2]\n v_fmac_f32 %[c3], %[f1], %[f2]\n" \
+    "v_fmac_f32 %[c4], %[f1], %[f2]\n v_fmac_f32 %[c5], %[f1], %[f2]\n v_fmac_f32 %[c6], %[f1], %[f2]\n v_fmac_f32 %[c7], %[f1], %[f2]\n" \
+    "v_mfma_f32_32x32x16_bf16 %[" #SN "], %[x], %[y], 0\n" \
+    "v_fmac_f32 %[c0], %[f1], %[f2]\n v_fmac_f32 %[c1], %[f1], %[f2]\n v_fmac_f32 %[c2], %[f1], %[f2]\n v_fmac_f32 %[c3], %[f1], %[f2]\n" \
+    "v_fmac_f32 %[c4], %[f1], %[f2]\n v_fmac_f32 %[c5], %[f1], %[f2]\n v_fmac_f32 %[c6], %[f1], %[f2]\n v_fmac_f32 %[c7], %[f1], %[f2]\n"
+#define TG_NOFMA(PN, SN) \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 %[" #PN "], %[w6], %[a6], 0, %[mx], %[mx] op_sel_hi:[0,0,0] cbsz:2 blgp:2\n" \
+    "v_mfma_f32_32x32x16_bf16 %[" #SN "], %[x], %[y], 0\n"
+#define GEMM_KERNEL(name, BODYSTR)                                                                                            \
+    __global__ __launch_bounds__(512, 2) void name(long long *out, int iters) {                                               \
+        v16f p0 = {}, p1 = {}, s0 = {}, s1 = {};                                                                               \
+        v4f x = {1.f, 2.f, 3.f, 4.f}, y = {1.f, 1.f, 1.f, 1.f};                                                                \
+        v6i_ w6 = {0x11111111, 0x22222222, 0x12121212, 0x21212121, 0x11221122, 0x22112211}, a6 = w6;                           \
+        int mx = 0x7f7f7f7f;                                                                                                   \
+        float c0 = threadIdx.x, c1 = 1, c2 = 2, c3 = 3, c4 = 4, c5 = 5, c6 = 6, c7 = 7, f1 = 1.0001f, f2 = 0.5f;  /* (the fmac sources are plain registers: round 2 measured the same time with the MFMA results as sources) */ \
+        long long t0 = __builtin_readcyclecounter();                                                                           \
+        for (int i = 0; i < iters; i++)                                                                                        \
+            asm volatile(BODYSTR                                                                                               \
+                         : [p0] "+v"(p0), [p1] "+v"(p1), [s0] "+v"(s0), [s1] "+v"(s1), [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2),  \
+                           [c3] "+v"(c3), [c4] "+v"(c4), [c5] "+v"(c5), [c6] "+v"(c6), [c7] "+v"(c7)                          \
+                         : [x] "v"(x), [y] "v"(y), [w6] "v"(w6), [a6] "v"(a6), [mx] "v"(mx), [f1] "v"(f1), [f2] "v"(f2));              \
+        long long t1 = __builtin_readcyclecounter();                                                                           \
+        float acc = p0[0] + p1[0] + s0[0] + s1[0] + c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;                                     \
+        if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;                                                                       \
+        if (acc == 12345.678f) out[0] = 0;                                                                                     \
+    }
+GEMM_KERNEL(g_full, TG(p0, s0, p1, s1) TG(p1, s1, p0, s0) TG(p0, s0, p1, s1) TG(p1, s1, p0, s0))
+GEMM_KERNEL(g_mfma_only, TG_NOFMA(p1, s1) TG_NOFMA(p0, s0) TG_NOFMA(p1, s1) TG_NOFMA(p0, s0))
+
 struct Entry { const char *name; void (*fn)(long long *, int); };
 #define E1(k) {#k "_1", k_##k##_1}, {#k "_2", k_##k##_2}, {#k "_4", k_##k##_4}, {#k "_5", k_##k##_5}, {#k "_6", k_##k##_6}, {#k "_8", k_##k##_8},
 
@@ -121,6 +192,8 @@ int main() {
                              {"mix_2fma_2exp_cvt_dsr", k_mix_d}, {"mix_fma_exp_fma_exp_dependent", k_mix_e}, {"mix_fma_fma_exp_exp_dependent", k_mix_f},
                              {"use_lead4 (MFMA reads ds data)", k_use_lead4}, {"use_lead4 + 4 fma per MFMA", k_use_lead4_valu},
                              {"nouse_lead4 (same reads, unused)", k_nouse_lead4}, {"use_lead2", k_use_lead2}};
+    std::vector<Entry> es2 = {{"2 waves/SIMD: none", w2_none}, {"2 waves/SIMD: fma_2", w2_fma_2}, {"2 waves/SIMD: fma_4", w2_fma_4}, {"2 waves/SIMD: fma_6", w2_fma_6},
+                              {"2 waves/SIMD: fma_8", w2_fma_8}, {"2 waves/SIMD: fma_8 + ds_read", w2_fma_8_dsr}, {"2 waves/SIMD: fma_8 + 2 ds_read + salu", w2_fma_8_2dsr_salu}};
     setvbuf(stdout, nullptr, _IONBF, 0);
     long long *d;
     const int G = 256, iters = 2000;
@@ -136,6 +209,47 @@ int main() {
         double s = 0;
         for (auto v : h) s += v;
         printf("%-32s %7.2f cycles / MFMA   (%s)\n", e.name, s / G / (iters * 8.0), hipGetErrorString(hipGetLastError()));
+    }
+    for (auto &e : es2) {  // 512 threads: the cycles are per MFMA of ONE wave; the SIMD retires two of them in that time
+        hipEvent_t ev0, ev1;
+        hipEventCreate(&ev0); hipEventCreate(&ev1);
+        float ms = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            hipEventRecord(ev0, 0);
+            hipLaunchKernelGGL(e.fn, dim3(G), dim3(512), 0, 0, d, iters * 10);
+            hipEventRecord(ev1, 0);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, ev0, ev1);
+        }
+        printf("%-40s wall %.3f ms for %d x 8 waves x %d MFMAs = %.0f TFLOP/s\n", e.name, ms, G, iters * 10 * 8, (double)G * 8 * iters * 10 * 8 * 32768 / (ms * 1e-3) / 1e12);
+        for (int rep = 0; rep < 2; rep++) {
+            hipLaunchKernelGGL(e.fn, dim3(G), dim3(512), 0, 0, d, iters);
+            hipDeviceSynchronize();
+        }
+        hipMemcpy(h.data(), d, G * sizeof(long long), hipMemcpyDeviceToHost);
+        double s = 0;
+        for (auto v : h) s += v;
+        printf("%-40s %7.2f cycles / MFMA of one wave = %6.2f per MFMA of the SIMD   (%s)\n", e.name, s / G / (iters * 8.0), s / G / (iters * 16.0), hipGetErrorString(hipGetLastError()));
+    }
+    struct { const char *name; void (*fn)(long long *, int); } gs[] = {{"GEMM arithmetic: P + S + 16 v_fmac per tile-group", g_full}, {"GEMM arithmetic: P + S only", g_mfma_only}};
+    for (auto &e : gs) {
+        hipEvent_t ev0, ev1;
+        hipEventCreate(&ev0); hipEventCreate(&ev1);
+        float ms = 0;
+        const int it = iters * 5;
+        for (int rep = 0; rep < 2; rep++) {
+            hipEventRecord(ev0, 0);
+            hipLaunchKernelGGL(e.fn, dim3(G), dim3(512), 0, 0, d, it);
+            hipEventRecord(ev1, 0);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, ev0, ev1);
+        }
+        hipMemcpy(h.data(), d, G * sizeof(long long), hipMemcpyDeviceToHost);
+        double s = 0;
+        for (auto v : h) s += v;
+        const double tg = (double)G * 8 * it * 4;  // tile-groups (32 x 32 x 64) of the launch
+        printf("%-52s %6.1f cycles per tile-group of one wave, wall %.3f ms = %.0f TOP/s (2 x 32 x 32 x 64 per tile-group), clock %.2f GHz  (%s)\n", e.name,
+               s / G / (it * 4.0), ms, tg * 2 * 32 * 32 * 64 / (ms * 1e-3) / 1e12, s / G / (ms * 1e-3) / 1e9, hipGetErrorString(hipGetLastError()));
     }
     return 0;
 }
