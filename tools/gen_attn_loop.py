@@ -68,12 +68,13 @@ def ar(a, n=1):
 class Body:
     """One iteration for buffer parity `buf`: score set (buf ? B : A) is exponentiated, the other one accumulated."""
 
-    def __init__(self, dt, buf, tag, lead=4, budget=5.0, rm_from=36, dma0=1):
+    def __init__(self, dt, buf, tag, lead=4, budget=5.0, rm_from=36, dma0=1, drop=0):
         self.dt, self.buf, self.tag = dt, buf, tag
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.lines = []
         self.reads = []      # fragment ids in issue order
         self.lead, self.budget, self.rm_from, self.dma0 = lead, budget, rm_from, dma0
+        self.drop = drop  # timing experiments (wrong results): 1 = no vmcnt wait at the end of an iteration, 2 = no barrier, 4 = no DMA
 
     def e(self, s):
         self.lines.append(s)
@@ -138,6 +139,8 @@ class Body:
             self.e(f"v_max3_f32 {vr(MLOC + rt)}, {vr(MLOC + rt)}, {vr(sn(kt) + r)}, {vr(sn(kt) + (r + 1 if r + 1 < 16 else r))}")
 
     def op_dma(self, i):
+        if self.drop & 4:
+            return
         # K(j+2) -> K half of buffer `buf` (K(j) was read from it one iteration ago), V^T(j+1) -> V half of the other buffer.
         # hazard: SALU write of M0 -> LDS-DMA needs one wait state
         if i < 4:
@@ -299,8 +302,10 @@ class Body:
             emit(op)
         for rt in range(2):
             self.finish(rt)
-        e("s_waitcnt vmcnt(0)")      # this wave's DMA pieces have landed ...
-        e("s_barrier")               # ... and everybody's; every read of this iteration's buffers is done
+        if not self.drop & 1:
+            e("s_waitcnt vmcnt(0)")      # this wave's DMA pieces have landed ...
+        if not self.drop & 2:
+            e("s_barrier")               # ... and everybody's; every read of this iteration's buffers is done
         e("s_add_u32 s46, s46, 1")
         return self.lines
 
