@@ -1,6 +1,8 @@
 """Quantiser kernel time (library profiler: HIP events around the launch) at FLUX shapes, plain and with the fused LN."""
 import os, sys, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nunchaku_amd._lib as _L0
+_L0._LIB_PATH = os.environ.get("SVDQ_LIB", _L0._LIB_PATH)  # same-box A/B against another build of the library (tools only)
 from tools.bench_kernels import rand_layer
 from nunchaku_amd import _lib
 from nunchaku_amd.ops.elementwise import residual_gate_stats
