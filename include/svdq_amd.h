@@ -296,7 +296,8 @@ typedef struct svdq_attention_args {
 } svdq_attention_args;
 
 int svdq_attention(const svdq_attention_args *args, void *stream);
-/* size of the persistent-schedule workspace for the current device (1023 arrival counters + 1 error word + one fp32 slab per CU) */
+/* size of the persistent-schedule workspace for the current device (1023 arrival counters + 1 error word + two fp32 slabs per CU: the part a
+ * contributor publishes and, for geometry 2, the part the owner of a split task parks while it runs its whole tasks) */
 int64_t svdq_attention_workspace_bytes(void);
 /* Synchronises `stream`, then returns SVDQ_E_HIP (and clears the flag) if a launch that used `workspace` timed out waiting
  * for partial results; SVDQ_OK otherwise.  Test / debugging aid. */

@@ -660,9 +660,20 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
             }
     };
 
+    // Persistent schedule, geometry 2's order: the remainder run FIRST, whole tasks afterwards.  Every split segment publishes -- a
+    // contributor to its slab (as in geometry 1), the owner of a split task (the segment with the task's first tiles) to its stash --
+    // and nobody waits: the owner folds the parts together after its whole tasks, when the contributors' slabs are long since written.
+    // (Geometry 1 runs whole tasks first and its owners wait with their registers full; the schedule arithmetic is the same.)
+    int own_tl = -1; // the split task this workgroup owns (at most one: a run is shorter than a task)
     while (true) {
         int task, j0, j1, tl = -1;
-        if (whole_left > 0) {
+        if (PERSIST && pos < run_hi) {
+            tl = pos / ntiles;
+            j0 = pos - tl * ntiles;
+            j1 = min(ntiles, j0 + (run_hi - pos));
+            pos += j1 - j0;
+            task = sched.F * G + tl;
+        } else if (whole_left > 0) {
             if constexpr (PERSIST) task = (sched.F - whole_left) * G + g;
             else {
                 const int b = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, N = (int)(gridDim.x * gridDim.y);
@@ -670,12 +681,6 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
             }
             j0 = 0; j1 = ntiles;
             whole_left--;
-        } else if (pos < run_hi) {
-            tl = pos / ntiles;
-            j0 = pos - tl * ntiles;
-            j1 = min(ntiles, j0 + (run_hi - pos));
-            pos += j1 - j0;
-            task = sched.F * G + tl;
         } else break;
         const int head = task / QT;
         const int q0 = (task - head * QT) * 256 + wave * 64;
@@ -773,13 +778,13 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
         float l_run[RT] = {l2[0] + l2[1], l2[2] + l2[3]};
 
         if constexpr (PERSIST) {
-            typedef __attribute__((address_space(1))) int gint;
-            typedef __attribute__((address_space(1))) v4f gv4f;
-            typedef __attribute__((address_space(1))) v2f gv2f;
-            gint *flags = (gint *)p.ws_flags;
+            if (tl >= 0 && (j0 > 0 || j1 < ntiles)) { // a part of a split task: publish the un-normalised state, no epilogue here
+                typedef __attribute__((address_space(1))) int gint;
+                typedef __attribute__((address_space(1))) v4f gv4f;
+                typedef __attribute__((address_space(1))) v2f gv2f;
+                // contributor: slab g (the slab image of geometry 1, [wave][rt][j][lane]; the reference point in log2 units); owner: stash G + g
+                float *slab = p.ws_slabs + (size_t)(j0 > 0 ? g : G + g) * ATT_SLAB_FLOATS;
 #define SVDQ_OREG(rt, j, e) O[2 * (rt) + ((j) >> 3)][16 * (((j) >> 2) & 1) + ((j) & 3) * 4 + (e)] /* register (j = 4 dt + c, e) of row tile rt */
-            if (j0 > 0) { // not the owner: publish (the slab image of geometry 1, [wave][rt][j][lane]; the reference point in log2 units)
-                float *slab = p.ws_slabs + (size_t)g * ATT_SLAB_FLOATS;
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
@@ -787,49 +792,19 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
                         *(gv4f *)(slab + ((size_t)((wave * RT + rt) * 16 + j) * 64 + lane) * 4) = v4f{SVDQ_OREG(rt, j, 0), SVDQ_OREG(rt, j, 1), SVDQ_OREG(rt, j, 2), SVDQ_OREG(rt, j, 3)};
                     *(gv2f *)(slab + ATT_SLAB_O + (size_t)((wave * RT + rt) * 64 + lane) * 2) = v2f{mc[rt], l_run[rt]};
                 }
-                const int owner = sched.owner_of(g, tl);
-                __syncthreads();
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(flags + owner, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+#undef SVDQ_OREG
+                if (j0 > 0) {
+                    const int owner = sched.owner_of(g, tl);
+                    __syncthreads();
+                    if (tid == 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_fetch_add((gint *)p.ws_flags + owner, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else own_tl = tl; // (its own later loads of the stash are ordered behind these stores: same wave, same addresses)
                 continue;
             }
-            if (j1 < ntiles) { // owner of a split task: fold in the other segments, ascending workgroup order
-                const int last = sched.last_contributor(g, tl);
-                if (tid == 0) {
-                    int spins = 0; // bounded wait, as in geometry 1
-                    while (__hip_atomic_load(flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < last - g && ++spins < ATT_SPIN_LIMIT)
-                        __builtin_amdgcn_s_sleep(8);
-                    if (spins >= ATT_SPIN_LIMIT) {
-                        __hip_atomic_store(flags + ATT_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (p.status) __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                    __hip_atomic_store(flags + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                __syncthreads();
-                for (int q = g + 1; q <= last; q++) {
-                    const float *slab = p.ws_slabs + (size_t)q * ATT_SLAB_FLOATS;
-#pragma unroll
-                    for (int rt = 0; rt < RT; rt++) {
-                        const v2f ml = __builtin_nontemporal_load((const gv2f *)(slab + ATT_SLAB_O + (size_t)((wave * RT + rt) * 64 + lane) * 2));
-                        const float m_new = fmaxf(mc[rt], ml[0]); // (-inf: that side saw no finite score: weight 0)
-                        const float fa = mc[rt] == m_new ? 1.f : __builtin_amdgcn_exp2f(mc[rt] - m_new), fb = ml[0] == m_new ? 1.f : __builtin_amdgcn_exp2f(ml[0] - m_new);
-#pragma unroll
-                        for (int j = 0; j < 16; j++) {
-                            const v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)((wave * RT + rt) * 16 + j) * 64 + lane) * 4));
-#pragma unroll
-                            for (int e = 0; e < 4; e++) SVDQ_OREG(rt, j, e) = SVDQ_OREG(rt, j, e) * fa + v[e] * fb;
-                        }
-                        l_run[rt] = l_run[rt] * fa + ml[1] * fb;
-                        mc[rt] = m_new;
-                    }
-                }
-            }
         }
-#undef SVDQ_OREG
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
             v16f o4[4];
@@ -840,6 +815,52 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
             finish_rows<DT>(p, o4, l_run[rt], q0 + 32 * rt, head, lane);
         }
     } // segments
+    if constexpr (PERSIST) {
+        if (own_tl >= 0) { // ---- the split task this workgroup owns: its own stash + the contributors' slabs, ascending workgroup order, then the epilogue
+            typedef __attribute__((address_space(1))) int gint;
+            typedef __attribute__((address_space(1))) v4f gv4f;
+            typedef __attribute__((address_space(1))) v2f gv2f;
+            gint *flags = (gint *)p.ws_flags;
+            const int task = sched.F * G + own_tl, head = task / QT, q0 = (task - head * QT) * 256 + wave * 64;
+            const int last = sched.last_contributor(g, own_tl);
+            if (tid == 0) {
+                int spins = 0; // bounded wait, as in geometry 1 (here the arrivals are normally long since complete)
+                while (__hip_atomic_load(flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < last - g && ++spins < ATT_SPIN_LIMIT)
+                    __builtin_amdgcn_s_sleep(8);
+                if (spins >= ATT_SPIN_LIMIT) {
+                    __hip_atomic_store(flags + ATT_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p.status) __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __hip_atomic_store(flags + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                v16f o4[4];
+                float mrun = -INFINITY, lrun = 0.f;
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o4[dt][r] = 0.f;
+                for (int q = g; q <= last; q++) { // q = g: the owner's own stash
+                    const float *slab = p.ws_slabs + (size_t)(q == g ? G + g : q) * ATT_SLAB_FLOATS;
+                    const v2f ml = __builtin_nontemporal_load((const gv2f *)(slab + ATT_SLAB_O + (size_t)((wave * RT + rt) * 64 + lane) * 2));
+                    const float m_new = fmaxf(mrun, ml[0]); // reference points in log2 units (-inf: that part saw no finite score: weight 0)
+                    const float fa = mrun == m_new ? 1.f : __builtin_amdgcn_exp2f(mrun - m_new), fb = ml[0] == m_new ? 1.f : __builtin_amdgcn_exp2f(ml[0] - m_new);
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)((wave * RT + rt) * 16 + j) * 64 + lane) * 4));
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o4[j >> 2][(j & 3) * 4 + e] = o4[j >> 2][(j & 3) * 4 + e] * fa + v[e] * fb;
+                    }
+                    lrun = lrun * fa + ml[1] * fb;
+                    mrun = m_new;
+                }
+                finish_rows<DT>(p, o4, lrun, q0 + 32 * rt, head, lane);
+            }
+        }
+    }
     SVDQ_ATTN_PROBE_END();
 }
 
@@ -884,7 +905,8 @@ static int attention_groups_for(int L, int H, int cus) {
 
 using namespace svdq;
 
-extern "C" int64_t svdq_attention_workspace_bytes(void) { return ATT_WS_HEADER + (int64_t)attention_cus() * ATT_SLAB_FLOATS * 4; }
+// header + two slabs per workgroup of the persistent schedule: the one a contributor publishes, and (geometry 2) the stash an owner parks its own part in
+extern "C" int64_t svdq_attention_workspace_bytes(void) { return ATT_WS_HEADER + 2 * (int64_t)attention_cus() * ATT_SLAB_FLOATS * 4; }
 
 extern "C" int svdq_attention_workspace_status(void *workspace, void *stream) {
     if (!workspace) { set_error("svdq_attention_workspace_status: workspace is NULL"); return SVDQ_E_INVALID; }
