@@ -10,8 +10,9 @@
 //          all: with svdq_attention_args.qact the epilogue emits that quantiser's result itself (a wave's 32 rows x 128
 //          channels of one head are one F6 chunk in the register layout it holds)
 //
-// Kernel: workgroup = 8 waves = 256 query rows of one head (4 waves / 128 rows when L % 256 != 0), wave =
-// 32 query rows;
+// Two workgroup geometries (svdq_attention_args.geometry).  Geometry 1, described here: workgroup = 8 waves = 256 query rows of
+// one head (4 waves / 128 rows when L % 256 != 0), wave = 32 query rows.  Geometry 2 (attention_kernel64 below: 4 waves x 64 rows, one wave per
+// SIMD, the tile loop in generated assembly) shares the layouts, the task definition, the slabs and the epilogue;
 // KV tiles of 64 keys, double-buffered in LDS with XOR-swizzled 16-byte pieces (conflict-free ds_read_b128);
 // the score MFMA is issued swapped (S^T = K Q^T) so a lane holds 32 of the 64 scores of ONE query row: the
 // online softmax is lane-local plus one lane^32 exchange; P is packed to 16-bit with v_cvt_pk + one
