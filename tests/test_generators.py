@@ -98,3 +98,130 @@ def test_attention_loop_plan_is_complete_and_ordered():
         assert max(vregs) <= 255
         aregs = {r for a, b in re.findall(r"a\[(\d+):(\d+)\]", text) for r in range(int(a), int(b) + 1)} | {int(x) for x in re.findall(r"\ba(\d+)\b", text)}
         assert max(aregs) <= 191
+
+
+def _regs(tok):
+    """registers named by one operand token: ('v', n) / ('a', n) / ('s', n)"""
+    out = []
+    m = re.fullmatch(r"-?([vas])\[(\d+):(\d+)\]", tok)
+    if m:
+        return [(m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1)]
+    m = re.fullmatch(r"-?([vas])(\d+)", tok)
+    if m:
+        return [(m.group(1), int(m.group(2)))]
+    if tok in ("vcc", "m0", "exec"):
+        return [(tok, 0)]
+    return out
+
+
+def test_attention_loop_hazards_are_covered_by_construction():
+    """Static walk over the generated assembly (straight-line order; the rare rescale blocks are part of it): the wait states a compiler's
+    hazard recogniser would insert are there.  Checked: >= 2 wait states between a VALU write and a v_permlane32_swap that reads it; >= 1
+    between an M0 write and the LDS-DMA that uses it; >= 1 between a v_exp_f32 and the instruction that reads its result; an MFMA result in
+    VGPRs is not read by a VALU instruction before 12 wait states or two further MFMAs have passed; an AGPR tile an MFMA wrote is not
+    read by v_accvgpr_read before 18 wait states; every ds_read result is covered by a counted s_waitcnt before its first reader."""
+    import gen_attn_loop as GA
+
+    for dt in ("bf16", "fp16"):
+        lines, _ = GA.build(dt)
+        last_valu, last_exp, last_mfma_v, last_mfma_a, last_m0 = {}, {}, {}, {}, None  # register -> (wait-state clock, mfma count) of its last writer
+        pending_ds = {}  # VGPR -> index of the ds_read that will write it (cleared by a wait that covers it)
+        ds_order = []
+        clock, mfmas = 0, 0
+        for ln in lines:
+            if not ln or ln.startswith((";", ".")) or ln.endswith(":"):
+                continue
+            op, _, rest = ln.partition(" ")
+            toks = [t.strip() for t in rest.split(",")] if rest else []
+            if op == "s_nop":
+                clock += int(toks[0]) + 1
+                continue
+            if op == "s_waitcnt":
+                m = re.search(r"lgkmcnt\((\d+)\)", rest)
+                if m:
+                    keep = int(m.group(1))
+                    done = ds_order[: len(ds_order) - keep] if keep else ds_order[:]
+                    for regs in done:
+                        for r in regs:
+                            pending_ds.pop(r, None)
+                    ds_order = ds_order[len(ds_order) - keep:] if keep else []
+                clock += 1
+                continue
+            if op.startswith("s_") and op not in ("s_add_u32", "s_mov_b32"):
+                clock += 1
+                if op in ("s_barrier", "s_branch") or op.startswith("s_cbranch"):
+                    clock += 4
+                continue
+            dst = _regs(toks[0]) if toks else []
+            srcs = [r for t in toks[1:] for r in _regs(t.split(" ")[0])]
+            if op.startswith("v_permlane32_swap"):
+                srcs = srcs + dst  # reads and writes both operands
+            if op in ("v_fmac_f32",) or op.startswith("v_dot2c") or op.startswith("v_mfma") and False:
+                srcs = srcs + dst
+            # ---- checks on the readers
+            for r in srcs:
+                assert r not in pending_ds, f"{ln}: reads {r} before the ds_read that loads it is waited for"
+            if op.startswith("v_permlane32_swap"):
+                for r in srcs:
+                    if r in last_valu:
+                        assert clock - last_valu[r] >= 2, f"{ln}: {r} written {clock - last_valu[r]} wait states earlier"
+            if op.startswith("global_load_lds"):
+                assert last_m0 is not None and clock - last_m0 >= 1, ln
+            is_mfma = op.startswith("v_mfma")
+            is_valu = op.startswith("v_") and not is_mfma
+            if is_valu:
+                for r in srcs:
+                    if r in last_exp:
+                        assert clock - last_exp[r] >= 1, f"{ln}: reads the v_exp result {r} in the next issue slot"
+                    if r[0] == "v" and r in last_mfma_v:
+                        c0, m0_ = last_mfma_v[r]
+                        assert clock - c0 >= 12 or mfmas - m0_ >= 2, f"{ln}: reads the MFMA result {r} too early"
+            if op == "v_accvgpr_read_b32":
+                for r in srcs:
+                    if r in last_mfma_a:
+                        assert clock - last_mfma_a[r][0] >= 18 or mfmas - last_mfma_a[r][1] >= 3, f"{ln}: reads {r} too early behind the MFMA that wrote it"
+            # ---- bookkeeping on the writers
+            clock += 1
+            if op == "s_add_u32" and toks and toks[0] == "m0":
+                last_m0 = clock
+                continue
+            if op.startswith("ds_read"):
+                ds_order.append(dst)
+                for r in dst:
+                    pending_ds[r] = True
+                continue
+            if is_mfma:
+                mfmas += 1
+                for r in dst:
+                    (last_mfma_v if r[0] == "v" else last_mfma_a)[r] = (clock, mfmas)
+                    last_valu.pop(r, None)
+                continue
+            if is_valu:
+                for r in dst + (srcs if op.startswith("v_permlane32_swap") else []):
+                    last_valu[r] = clock
+                    last_exp.pop(r, None)
+                    last_mfma_v.pop(r, None)
+                if op.startswith("v_exp_f32"):
+                    for r in dst:
+                        last_exp[r] = clock
+
+
+def test_the_hazard_walk_notices_missing_wait_states():
+    """The checker above is not vacuous: strip the generator's own wait states / counted waits and it objects."""
+    import gen_attn_loop as GA
+
+    orig = GA.build
+    try:
+        for strip in ("s_nop 1", "s_nop 0", "s_waitcnt lgkmcnt(1)"):
+            def stripped(dt, _strip=strip, **kw):
+                lines, bodies = orig(dt, **kw)
+                return [ln for ln in lines if ln != _strip], bodies
+
+            GA.build = stripped
+            try:
+                test_attention_loop_hazards_are_covered_by_construction()
+            except AssertionError:
+                continue
+            raise AssertionError(f"removing every '{strip}' went unnoticed")
+    finally:
+        GA.build = orig
