@@ -263,6 +263,12 @@ def main():
     step(total - 1, latents)
     torch.cuda.synchronize()
     n_a, ms_a, flops_a = prof(2)
+    # ... and the AWQ GEMV's (the modulation projections: one batched launch per step) from a third
+    lib.svdq_prof_select(1 << 3)
+    lib.svdq_prof_reset()
+    step(total - 1, latents)
+    torch.cuda.synchronize()
+    n_v, ms_v, bytes_v = prof(3)
     lib.svdq_prof_enable(0)
     lib.svdq_prof_select(0xFFFFFFFF)
 
@@ -323,6 +329,8 @@ def main():
                 "attention": {"launches": n_a, "ms_per_step": ms_a, "measured_on": "one extra untimed step",
                               "TFLOPs": flops_a / (ms_a * 1e-3) / 1e12 if ms_a > 0 else 0.0, "bound": "mfma",
                               "frac_bf16": (flops_a / (ms_a * 1e-3) / 1e12 / BF16_PEAK_TFLOPS) if ms_a > 0 else 0.0},
+                "gemv_awq": {"launches": n_v, "ms_per_step": ms_v, "measured_on": "one extra untimed step",
+                             "GBps": bytes_v / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0, "bound": "hbm by bytes, VALU in practice"},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -67,21 +67,53 @@ def test_gemv_awq_op_surface_and_errors():
         ops.gemv_awq(x.repeat(5, 1)[:9], kern, t16(s, "bf16"), t16(z, "bf16"), 9, 64, 128, 64)
 
 
-def test_gemv_awq_batched_matches_single_launches():
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemv_awq_batched_matches_single_launches(dtype):
     from nunchaku_amd.models.linear import AWQW4A16Linear
     from nunchaku_amd.ops.gemv import awq_gemv_w4a16_batched
 
     K = 256
     layers = []
     for i, (N, chunks) in enumerate([(768, 6), (384, 3), (64, 1), (1536, 6)] * 21):  # 84 layers: two launches
-        q, s, z, bias = _layer(N, K, "bf16", seed=100 + i % 4)
-        lin = AWQW4A16Linear(K, N, device="cuda")
-        lin.load_state_dict({"qweight": torch.from_numpy(O.pack_awq_w4_ref(q)), "wscales": t16(s, "bf16"), "wzeros": t16(z, "bf16"),
-                             "bias": t16(bias, "bf16")})
+        q, s, z, bias = _layer(N, K, dtype, seed=100 + i % 4)
+        lin = AWQW4A16Linear(K, N, torch_dtype=TORCH_DT[dtype], device="cuda")
+        lin.load_state_dict({"qweight": torch.from_numpy(O.pack_awq_w4_ref(q)), "wscales": t16(s, dtype), "wzeros": t16(z, dtype),
+                             "bias": t16(bias, dtype)})
         lin.out_chunks = chunks
         layers.append(lin)
-    x = t16(np.random.default_rng(1).standard_normal((1, K)).astype(np.float32), "bf16")
+    x = t16(np.random.default_rng(1).standard_normal((1, K)).astype(np.float32), dtype)
     outs = awq_gemv_w4a16_batched(x, layers)
     assert len(outs) == len(layers)
     for lin, o in list(zip(layers, outs))[::7]:
         assert torch.equal(o, lin(x))
+
+
+def test_gemv_awq_fp16_packed_path_keeps_the_rounding_points_at_the_edges():
+    """M = 1, fp16 runs on the packed 16-bit pipe (v_pk_fma_f16 / v_pk_mul_f16).  Scales and activations chosen so that
+    dequantised weights and products land in fp16's subnormal range and next to its overflow threshold: the per-element
+    roundings (gemv_awq.cu:192-236) must still be the oracle's."""
+    from nunchaku_amd.models.linear import AWQW4A16Linear
+
+    N, K = 64, 256
+    rng = np.random.default_rng(11)
+    q = rng.integers(0, 16, size=(N, K)).astype(np.uint8)
+    s = np.empty((K // 64, N), np.float32)
+    s[0], s[1], s[2], s[3] = 2.0 ** -12, 2.0 ** -20, 0.37, 6.0
+    s = O.round16(s * (1 + rng.random((K // 64, N)).astype(np.float32) * 0.3), "fp16")
+    z = O.round16(-7.5 * s * (1 + 0.1 * rng.standard_normal((K // 64, N)).astype(np.float32)), "fp16")
+    lin = AWQW4A16Linear(K, N, bias=False, torch_dtype=torch.float16, device="cuda")
+    lin.load_state_dict({"qweight": torch.from_numpy(O.pack_awq_w4_ref(q)), "wscales": t16(s, "fp16"), "wzeros": t16(z, "fp16")},
+                        strict=False)
+    x = rng.standard_normal((1, K)).astype(np.float32)
+    x[:, 0:64] *= 2.0 ** -6     # products around 2^-18 .. 2^-15: subnormal fp16
+    x[:, 64:128] *= 2.0 ** -3   # products around 2^-24: the last subnormal steps, or zero
+    x[:, 200] = 500.0           # |w| up to ~60: one product per row of up to ~3e4 (fp16 spacing 16-32 there), sums in fp32
+    small = x.copy()
+    small[:, 128:] = 0.0        # outputs of ~2^-13: made of subnormal weights and subnormal products only
+    for xv in (O.round16(small, "fp16"), O.round16(x, "fp16")):
+        got = f32(lin(t16(xv, "fp16")))
+        ref = O.awq_gemv_w4a16(xv, q, s, z, "fp16")
+        assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+        assert (got != ref).mean() <= 0.05
+        ulp = np.maximum(np.abs(ref) * 2.0 ** -10, 2.0 ** -24)  # one fp16 step at ref (2^-24 in the subnormal range)
+        assert (np.abs(got - ref) <= ulp).all(), "gemv_awq fp16 edges: more than one 16-bit step from the oracle"

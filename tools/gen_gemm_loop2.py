@@ -100,6 +100,20 @@ class Gen:
         return HI_L[kind], (stage - 2) * self.geo.stage
 
     def frag_reads(self, buf, grp, stage):
+        """the 12 LDS reads of one group's fragments and scales.  Timing-only options (garbage results): "rd20u" drops the
+        group-1 halves of plane 1 (what a merged 16-byte read of plane 1 would save: 4 of 24 reads per K-step), "rd18u" also one
+        weight-scale read per group (what packed weight-scale pairs would save), "rd0" every read but one."""
+        out = self._frag_reads(buf, grp, stage)
+        if "rd0" in self.opts:
+            return out[:1]
+        if "rd20u" in self.opts or "rd18u" in self.opts:
+            out = [ln for ln in out if not (grp == 1 and ln.startswith("ds_read_b64"))]
+        if "rd18u" in self.opts:
+            k = [i for i, ln in enumerate(out) if ln.startswith("ds_read_u16")][1]
+            out = out[:k] + out[k + 1:]
+        return out
+
+    def _frag_reads(self, buf, grp, stage):
         out = []
         for kind, roff in ((1, 0), (0, 12)):  # W fragments first (v1's order), then A
             base, imm = self.lds(kind, stage)
