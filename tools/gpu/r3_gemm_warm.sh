@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 3: L2 warm-up of a tile's epilogue operands from inside the main loop (generator option "pf") vs the same sources without it:
-# launch times (three interleaved repetitions) and workgroup 0's phase stamps.  usage: tools/gpu/r3_gemm_warm.sh <outdir-name>
+# launch times (three interleaved repetitions) and workgroup 0's phase stamps.  (Record of a finished experiment: the option and its
+# kernel-side plumbing were removed after it showed no effect -- commit 42bb9bd's parent tree has them; profiles/r3_gemm_epilogue_warmup_ab.txt.)  usage: tools/gpu/r3_gemm_warm.sh <outdir-name>
 O=gpurun_out/$1; mkdir -p $O
 P=tools/ablate/gemm_probe
 {
