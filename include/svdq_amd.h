@@ -99,7 +99,9 @@ typedef struct svdq_quantize_args {
     int32_t R;             /* multiple of 16 (0 = no low-rank branch)                         */
     int32_t ldx;           /* row stride of x in elements (>= K, multiple of 4)               */
     int32_t dtype;         /* SVDQ_BF16 | SVDQ_FP16                                           */
-    int32_t fuse_glu;      /* must be 0 (SVDQ_E_UNSUPPORTED otherwise; not on the FLUX path)  */
+    int32_t fuse_glu;      /* non-zero: x holds rows of 2K interleaved (value, gate) pairs (ldx >= 2K, a multiple of 8; x 16-byte
+                              aligned) and the op quantises round16(value * round16(silu(gate))) -- the reference's
+                              load_act_to_fpsum<fuse_glu> (gemm_base.cuh:606-633).  Not with ln_stats or x2.               */
     int32_t fp4;           /* must be 0 (NVFP4 is Blackwell-only)                             */
     /* Optional fused AdaLayerNormZero front end (extension; all three or none).  The quantiser then reads
      *   x' = round16(round16(round16((x - mean) * rstd) * mod_scale) + mod_shift)

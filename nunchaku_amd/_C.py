@@ -296,6 +296,10 @@ class _Ops:
         if input.stride(-1) != 1:
             input = input.contiguous()
         M, K = input.shape
+        if fuse_glu:  # rows of (value, gate) pairs: the quantised width is half the input's (launch_impl.cuh:463)
+            if K % 2 or ln_stats is not None or second is not None:
+                raise ValueError("quantize_w4a4_act_fuse_lora: fuse_glu needs an even input width and does not combine with ln_stats / second")
+            K //= 2
         M_pad = output.numel() // output.shape[-1]
         R = 0 if lora_down is None else lora_down.shape[-1]
         image = _fp6_image(output, M_pad, K, True, "quantize_w4a4_act_fuse_lora")

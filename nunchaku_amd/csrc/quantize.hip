@@ -31,7 +31,10 @@ struct QuantSecond {
     int M, ldx, split_rows; // M: valid rows of the second stream; x == nullptr: off
 };
 
-template <int DT, int RT32 /* 32-rank tiles held in registers */, int OCC /* workgroups per CU the register budget allows */>
+// GLU = svdq_quantize_args.fuse_glu (reference load_act_to_fpsum<fuse_glu>, gemm_base.cuh:606-633): the input row holds 2K values,
+// (value, gate) pairs, and the kernel quantises  x[k] = round16(value[k] * round16(silu(gate[k])))  -- silu in fp32 (gemm_utils.cuh:
+// 323-327: x * sigmoid(x) with ex2.approx / rcp.approx; here the hardware exp2 and rcp), the product as a 16-bit multiply.
+template <int DT, int RT32 /* 32-rank tiles held in registers */, int OCC /* workgroups per CU the register budget allows */, bool GLU = false>
 __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<DT>::T *__restrict__ x,
                                                        const typename Half<DT>::T *__restrict__ smooth,
                                                        const typename Half<DT>::T *__restrict__ lora_down, // [R][K]
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
 #pragma unroll
         for (int j = 0; j < 16; j++) accL[i][j] = 0.f;
 
-    const T *xrow = x + (size_t)row * ldx;
+    const T *xrow = x + (size_t)row * ldx; // (GLU: ldx counts the 2K raw columns)
     // fused AdaLayerNormZero front end: per-row statistics of the LayerNorm this projection follows
     float ln_mean = 0.f, ln_rstd = 0.f;
     if (ln_stats && valid) {
@@ -86,13 +89,19 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
         //      latency-bound otherwise: two dependent round trips per chunk): activations, smoothing factors
         //      and the first 32 ranks of lora_down for both groups
         u16x4 xv[2][8], sv[2][8], bv[2][4][2], msv[2][8], mhv[2][8];
+        u16x8 graw[GLU ? 2 : 1][GLU ? 8 : 1];
 #pragma unroll
         for (int grp = 0; grp < 2; grp++) {
             const int kbase = kp * 128 + grp * 64 + 4 * h; // + 32t + 8c + e
 #pragma unroll
             for (int tc = 0; tc < 8; tc++) {
-                if (valid) xv[grp][tc] = *reinterpret_cast<const u16x4 *>(xrow + kbase + 8 * tc);
-                else xv[grp][tc] = u16x4{0, 0, 0, 0};
+                if constexpr (GLU) { // 4 (value, gate) pairs = 16 bytes; combined below, once every load is in flight
+                    if (valid) graw[grp][tc] = *reinterpret_cast<const u16x8 *>(xrow + 2 * (kbase + 8 * tc));
+                    else graw[grp][tc] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                } else {
+                    if (valid) xv[grp][tc] = *reinterpret_cast<const u16x4 *>(xrow + kbase + 8 * tc);
+                    else xv[grp][tc] = u16x4{0, 0, 0, 0};
+                }
                 if (smooth) sv[grp][tc] = *reinterpret_cast<const u16x4 *>(smooth + kbase + 8 * tc);
             }
             if (ln_stats) { // modulation vectors of this group: requested with everything else, consumed below
@@ -115,6 +124,18 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
                     }
                 }
             }
+        }
+        if constexpr (GLU) { // x <- round16(value * round16(gate * sigmoid(gate))); padded rows: 0 * silu(0) = 0
+#pragma unroll
+            for (int grp = 0; grp < 2; grp++)
+#pragma unroll
+                for (int tc = 0; tc < 8; tc++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float v = h2f(hfrom<T>(graw[grp][tc][2 * e])), g = h2f(hfrom<T>(graw[grp][tc][2 * e + 1]));
+                        const float sg = round16<T>(g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g)));
+                        xv[grp][tc][e] = hbits(f2h<T>(v * sg));
+                    }
         }
         if (ln_stats) { // x <- round16(round16(round16((x - mean) * rstd) * scale) + shift); padded rows stay 0
 #pragma unroll
@@ -542,7 +563,7 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     dim3 grid(tiles * slices), block(256);
     const int rt32 = (a->R + 31) / 32;
     QuantSecond s2{a->x2, a->smooth2, a->lora_down2, a->mod_scale2, a->mod_shift2, a->ln_stats2, a->M2, a->ldx2, a->split_rows};
-    if (rt32 <= 1 && cpw == 4 && (long long)a->M_pad * (a->ldx > a->ldx2 ? a->ldx : a->ldx2) * 2 < 0x7fffffffLL) {
+    if (!a->fuse_glu && rt32 <= 1 && cpw == 4 && (long long)a->M_pad * (a->ldx > a->ldx2 ? a->ldx : a->ldx2) * 2 < 0x7fffffffLL) {
         // fast path: one chunk per wave, 4 waves = 4 neighbouring chunks of one row tile (same grid as the general kernel at cpw = 4)
         QuantParams qp{a->x, a->smooth, a->lora_down, a->mod_scale, a->mod_shift, a->ln_stats, (uint8_t *)a->act, a->ascales, a->lora_act,
                        a->M, a->K, a->R, a->ldx, atomics, s2};
@@ -555,16 +576,18 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
         }
         return hip_check(hipGetLastError(), "svdq_quantize_w4a4_act_fuse_lora launch");
     }
-#define SVDQ_LAUNCH_Q(RT)                                                                                            \
-    hipLaunchKernelGGL((quantize_kernel<DT, RT, 1>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,          \
+#define SVDQ_LAUNCH_QG(RT, GLU)                                                                                      \
+    hipLaunchKernelGGL((quantize_kernel<DT, RT, 1, GLU>), grid, block, 0, st, (const T *)a->x, (const T *)a->smooth,     \
                        (const T *)a->lora_down, (uint8_t *)a->act, (T *)a->ascales, a->lora_act, a->M, a->K, a->R,    \
                        a->ldx, cpw, atomics, a->ln_stats, (const T *)a->mod_scale, (const T *)a->mod_shift, s2)
+#define SVDQ_LAUNCH_Q(RT) do { if (a->fuse_glu) SVDQ_LAUNCH_QG(RT, true); else SVDQ_LAUNCH_QG(RT, false); } while (0)
     if (rt32 == 0) SVDQ_LAUNCH_Q(0);
     else if (rt32 <= 1) SVDQ_LAUNCH_Q(1);
     else if (rt32 <= 2) SVDQ_LAUNCH_Q(2);
     else if (rt32 <= 4) SVDQ_LAUNCH_Q(4);
     else SVDQ_LAUNCH_Q(8);
 #undef SVDQ_LAUNCH_Q
+#undef SVDQ_LAUNCH_QG
     return hip_check(hipGetLastError(), "svdq_quantize_w4a4_act_fuse_lora launch");
 }
 
@@ -575,7 +598,7 @@ using namespace svdq;
 extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, void *stream) {
     if (!a) { set_error("svdq_quantize: args is NULL"); return SVDQ_E_INVALID; }
     if (a->fp4) { set_error("svdq_quantize: fp4 (NVFP4) is not supported on gfx950"); return SVDQ_E_UNSUPPORTED; }
-    if (a->fuse_glu) { set_error("svdq_quantize: fuse_glu is not supported"); return SVDQ_E_UNSUPPORTED; }
+    if (a->fuse_glu && (a->ln_stats || a->x2)) { set_error("svdq_quantize: fuse_glu does not combine with the LayerNorm front end or a grouped launch"); return SVDQ_E_INVALID; }
     if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_quantize: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
     if (a->lora_act_format == SVDQ_LORA_ACT_Q32 && ((uintptr_t)a->lora_act & 7)) { set_error("svdq_quantize: a Q31.32 lora_act must be 8-byte aligned"); return SVDQ_E_INVALID; }
     if (!a->x || !a->act || !a->ascales) { set_error("svdq_quantize: x, act and ascales are required"); return SVDQ_E_INVALID; }
@@ -585,6 +608,10 @@ extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, voi
     }
     if (a->K <= 0 || a->K % 128) { set_error("svdq_quantize: K=%d must be a positive multiple of 128", a->K); return SVDQ_E_INVALID; }
     if (a->ldx < a->K || a->ldx % 4) { set_error("svdq_quantize: ldx=%d must be >= K and a multiple of 4", a->ldx); return SVDQ_E_INVALID; }
+    if (a->fuse_glu && (a->ldx < 2 * a->K || a->ldx % 8 || ((uintptr_t)a->x & 15))) {
+        set_error("svdq_quantize: fuse_glu reads rows of 2K (value, gate) pairs: ldx=%d must be >= 2K and a multiple of 8, x 16-byte aligned", a->ldx);
+        return SVDQ_E_INVALID;
+    }
     if (a->R < 0 || a->R % 16 || a->R > 256) { set_error("svdq_quantize: R=%d must be a multiple of 16 in [0, 256]", a->R); return SVDQ_E_INVALID; }
     if (a->R > 0 && (!a->lora_down || !a->lora_act)) { set_error("svdq_quantize: R > 0 needs lora_down and lora_act"); return SVDQ_E_INVALID; }
     if (((uintptr_t)a->act) & 15) { set_error("svdq_quantize: act must be 16-byte aligned"); return SVDQ_E_INVALID; }
@@ -623,7 +650,7 @@ extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, voi
     }
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes: x in, codes + scales + lora_act out, lora_down in (once)
-    const double bytes = (double)(a->M + (a->x2 ? a->M2 : 0)) * a->K * 2 + (double)a->M_pad * a->K * 3 / 4 + (double)a->M_pad * (a->K / 64) * 2 +
+    const double bytes = (double)(a->M + (a->x2 ? a->M2 : 0)) * a->K * (a->fuse_glu ? 4 : 2) + (double)a->M_pad * a->K * 3 / 4 + (double)a->M_pad * (a->K / 64) * 2 +
                          (double)a->M_pad * a->R * 4 + (double)a->K * a->R * 2;
     const int prof = prof_begin(1, bytes, st);
     int rc = a->dtype == SVDQ_BF16 ? launch_quantize<SVDQ_BF16>(a, st) : launch_quantize<SVDQ_FP16>(a, st);

@@ -24,7 +24,8 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     lora_act_zeroed: bool = False,
     second: dict | None = None,
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """4-bit quantisation of ``input`` [M, K] plus the low-rank down projection.
+    """4-bit quantisation of ``input`` [M, K] (``fuse_glu``: [M, 2K] interleaved (value, gate) pairs, quantised as
+    ``value * silu(gate)``) plus the low-rank down projection.
 
     Returns ``(output [M_pad, 3K/4] uint8, oscales [K/64, M_pad], lora_act_out [M_pad, R] float32)``
     with ``M_pad = ceil(M / pad_size) * pad_size``.  ``output`` and ``oscales`` are opaque (the FP6
@@ -36,6 +37,8 @@ def svdq_quantize_w4a4_act_fuse_lora_cuda(
     if fp4:
         raise NotImplementedError("NVFP4 is not available on MI355X")
     M, K = input.shape
+    if fuse_glu:  # [M, 2K] (value, gate) pairs -> K quantised channels (the reference's wrapper sizes its buffers from the
+        K //= 2   # input width and can only be called with caller-sized ones in this mode, launch_impl.cuh:463-467)
     R = lora_down.shape[1]
     M_pad = ceil_divide(M, pad_size) * pad_size
     dev = input.device

@@ -317,6 +317,15 @@ def lora_down_project(x16: np.ndarray, lora_down: np.ndarray) -> np.ndarray:
     return (x16.astype(np.float64) @ lora_down.astype(np.float64)).astype(F32)
 
 
+def glu_pairs(x2: np.ndarray, dtype: str) -> np.ndarray:
+    """load_act_to_fpsum<fuse_glu = true> (gemm_base.cuh:606-633): the row holds (value, gate) pairs;
+    out[k] = value[k] * silu(gate[k]) with silu(T) = (T)(float(g) * sigmoid(float(g))) rounded to 16 bits
+    (gemm_utils.cuh:323-327) and the product a 16-bit multiply (one more rounding).  [M, 2K] -> [M, K]."""
+    v, g = x2[:, 0::2].astype(F32), x2[:, 1::2]
+    sg = round16(silu(g), dtype)
+    return round16((v.astype(np.float64) * sg.astype(np.float64)).astype(F32), dtype)
+
+
 def quantize_w4a4_act_fuse_lora(
     x: np.ndarray,
     smooth: np.ndarray | None,
@@ -328,7 +337,7 @@ def quantize_w4a4_act_fuse_lora(
     """kernels::quantize_w4a4_act_fuse_lora  (gemm_w4a4.cuh:1097-1184; launch
     gemm_w4a4_launch_impl.cuh:451-521; caller Linear.cpp:444-502, ops/quantize.py:11-81).
 
-    x         : [M, K] 16-bit input (float32 carrier)
+    x         : [M, K] 16-bit input (float32 carrier); with ``fuse_glu`` [M, 2K] interleaved (value, gate) pairs
     smooth    : [K] 16-bit smoothing factor (logical order) or None
     lora_down : [K, R] 16-bit LOGICAL down projection (x @ lora_down) or None
 
@@ -339,9 +348,9 @@ def quantize_w4a4_act_fuse_lora(
     then :func:`quantize_rows` (signed).
     Returns (codes int8 [M_pad, K], ascales [K/64, M_pad], lora_act f32 [M_pad, R]).
     """
-    M, K = x.shape
     if fuse_glu:
-        raise NotImplementedError("fuse_glu is not on the FLUX path (SURVEY.md §8a)")
+        x = glu_pairs(x, dtype)
+    M, K = x.shape
     M_pad = ceil_div(M, pad_size) * pad_size
     xp = np.zeros((M_pad, K), dtype=F32)
     xp[:M] = x

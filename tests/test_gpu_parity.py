@@ -81,6 +81,42 @@ def test_quantize_bit_exact(dtype, M, K, R):
     assert np.all(np.abs(la2.cpu().numpy() - la_ref) <= bound)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,K,R", [(256, 256, 32), (77, 384, 16), (513, 1024, 48)])
+def test_quantize_fuse_glu(dtype, M, K, R):
+    """fuse_glu (load_act_to_fpsum<true>, gemm_base.cuh:606-633): the input holds (value, gate) pairs and the op quantises
+    round16(value * round16(silu(gate))).  silu runs on the hardware exp2 / rcp (the reference: ex2.approx / rcp.approx) against
+    the oracle's exact one: an input element may land one 16-bit step away in a few cases per thousand, so -- unlike the plain
+    quantiser -- codes are held to +-1 on <= 1 % of the elements and scales to one 16-bit step on <= 2 % of the groups."""
+    from nunchaku_amd import layout
+    from nunchaku_amd.ops.quantize import svdq_quantize_w4a4_act_fuse_lora_cuda
+
+    L = O.make_svdq_layer(K, 128, R, seed=M + 1, dtype=dtype, cheap=True)
+    rng = np.random.default_rng(M)
+    x2 = O.round16(rng.standard_normal((M, 2 * K)).astype(np.float32) * 1.5, dtype)
+    mod = make_module(L, dtype)
+    qx, asc, la = svdq_quantize_w4a4_act_fuse_lora_cuda(t16(x2, dtype), lora_down=mod.proj_down, smooth=mod.smooth_factor, fuse_glu=True)
+    q_ref, asc_ref, la_ref = O.quantize_w4a4_act_fuse_lora(x2, L["smooth"], L["proj_down"], dtype, fuse_glu=True)
+    M_pad = q_ref.shape[0]
+    assert qx.shape == (M_pad, K * 3 // 4) and asc.shape == (K // 64, M_pad) and la.shape == (M_pad, R)
+    codes = layout.unpack_act(qx, K).cpu().numpy().astype(np.int32)
+    diff = np.abs(codes - q_ref)
+    assert diff.max() <= 1 and (diff != 0).mean() <= 0.01, f"{(diff != 0).sum()} of {diff.size} codes differ (max {diff.max()})"
+    sc = f32(layout.unpack_scales(asc, M_pad))
+    step = np.abs(asc_ref) * (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10) + 1e-30
+    assert np.all(np.abs(sc - asc_ref) <= step) and (sc != asc_ref).mean() <= 0.02
+    assert not codes[M:].any() and not sc[:, M:].any()  # padded rows: 0 * silu(0)
+    g = O.glu_pairs(x2, dtype)
+    # fp32 summation order + up to four inputs of a row one 16-bit step (<= 2^-7 | 2^-10 relative) off, each worth at most max_k |g_k d_kr|
+    big = np.max(np.abs(g)[:, :, None] * np.abs(L["proj_down"])[None, :, :], axis=1)
+    bound = 2e-5 * (np.abs(g) @ np.abs(L["proj_down"])) + 1e-6 + 4 * (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10) * big
+    err = np.abs(la.cpu().numpy()[:M] - la_ref[:M])
+    assert np.all(err <= bound), f"lora_act: worst err / bound = {(err / bound).max():.2f}"
+    # the same call through the C ABI's validation: the pair rows must be 16-byte aligned and 2K wide
+    with pytest.raises((ValueError, RuntimeError)):
+        svdq_quantize_w4a4_act_fuse_lora_cuda(t16(x2, dtype)[:, 1:-1], lora_down=mod.proj_down, smooth=mod.smooth_factor, fuse_glu=True)
+
+
 def test_quantize_strided_input_and_zero_rows():
     from nunchaku_amd import layout
 

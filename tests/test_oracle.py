@@ -92,3 +92,20 @@ def test_fused_mlp_tracks_dense():
     h = O.gelu_tanh(x @ fc1["dense"].T + fc1["bias"])
     ref = h @ fc2["dense"].T + fc2["bias"]
     assert np.linalg.norm(o - ref) / np.linalg.norm(ref) < 0.5  # two stacked 4-bit layers, random weights
+
+
+def test_quantize_fuse_glu_is_the_plain_quantiser_on_the_gated_input():
+    """fuse_glu only changes what is read (gemm_base.cuh:606-633): value * silu(gate), two 16-bit roundings."""
+    rng = np.random.default_rng(3)
+    M, K = 40, 128
+    L = O.make_svdq_layer(K, 128, 16, seed=2, cheap=True)
+    x2 = O.round16(rng.standard_normal((M, 2 * K)).astype(np.float32), "bf16")
+    g = O.glu_pairs(x2, "bf16")
+    assert g.shape == (M, K)
+    v, gate = x2[:, 0::2].astype(np.float64), x2[:, 1::2].astype(np.float64)
+    exact = v * gate / (1.0 + np.exp(-gate))
+    assert np.all(np.abs(g - exact) <= 2.0 ** -7 * np.abs(exact) + 1e-30)  # two roundings of 2^-9 each
+    assert np.array_equal(O.round16(g, "bf16"), g)
+    a = O.quantize_w4a4_act_fuse_lora(x2, L["smooth"], L["proj_down"], "bf16", fuse_glu=True)
+    b = O.quantize_w4a4_act_fuse_lora(g, L["smooth"], L["proj_down"], "bf16")
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
