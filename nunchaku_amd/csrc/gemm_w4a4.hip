@@ -29,6 +29,7 @@
 //     and the low-rank up projection (a 16-bit MFMA issued straight onto the fp32 accumulators) are
 //     added before the single rounding to 16-bit that precedes the activation epilogues.
 #include "svdq_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 // Clock / phase stamps of the tools-built probe library (tools/ablate/build.py compiles this file with -DSVDQ_PROBE and
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
 #pragma unroll
                     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                        for (int r = 0; r < 16; r++) s += acc[ni][mi][r] * acc[ni][mi][r];
+                        for (int r = 0; r < 16; r++) s = __builtin_fmaf(acc[ni][mi][r], acc[ni][mi][r], s); // (fused, as nvcc contracts the reference's)
                     s += __shfl_xor(s, 32);
                     if (h == 0) sq[wn * BM + wm * 64 + mi * 32 + lr] = s;
                 }
@@ -668,10 +669,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                             float v1 = acc[ni][mi][c * 4 + 1] * (coef * h2f(hfrom<T>(wv[1])));
                             float v2 = acc[ni][mi][c * 4 + 2] * (coef * h2f(hfrom<T>(wv[2])));
                             float v3 = acc[ni][mi][c * 4 + 3] * (coef * h2f(hfrom<T>(wv[3])));
-                            acc[ni][mi][c * 4 + 0] = round16<T>(v0 * sc0.y - v1 * sc0.x);
-                            acc[ni][mi][c * 4 + 1] = round16<T>(v0 * sc0.x + v1 * sc0.y);
-                            acc[ni][mi][c * 4 + 2] = round16<T>(v2 * sc1.y - v3 * sc1.x);
-                            acc[ni][mi][c * 4 + 3] = round16<T>(v2 * sc1.x + v3 * sc1.y);
+                            // (one multiply + one fused multiply-add per output; the rounding to 16 bits is the store's own
+                            //  conversion below -- nothing else reads these values: 96 VALU instructions per tile less)
+                            acc[ni][mi][c * 4 + 0] = __builtin_fmaf(v0, sc0.y, -(v1 * sc0.x));
+                            acc[ni][mi][c * 4 + 1] = __builtin_fmaf(v0, sc0.x, v1 * sc0.y);
+                            acc[ni][mi][c * 4 + 2] = __builtin_fmaf(v2, sc1.y, -(v3 * sc1.x));
+                            acc[ni][mi][c * 4 + 3] = __builtin_fmaf(v2, sc1.x, v3 * sc1.y);
                         }
                 }
             }
@@ -820,25 +823,29 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             // (one DPP quad_perm) and every lane stores one dword = (m even, m odd) of one channel.
             const int nv0 = nw0 - 2 * (p.N / 3);
             const int odd = lr & 1;
+            auto store_vt = [&](auto full) { // full: every row of the tile is a real row (block-uniform): no per-lane predicates
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                const int m_base = (mw0 + mi * 32 + lr) & ~1;
-                uint16_t *vcol = (uint16_t *)p.out_vt + m_base;
+                for (int mi = 0; mi < 2; mi++) {
+                    const int m_base = (mw0 + mi * 32 + lr) & ~1;
+                    uint16_t *vcol = (uint16_t *)p.out_vt + m_base;
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
+                    for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        float v0 = acc[ni][mi][r], v1 = acc[ni][mi][r + 1];
-                        if constexpr (DT == SVDQ_FP16) { v0 = fminf(fmaxf(v0, -65504.f), 65504.f); v1 = fminf(fmaxf(v1, -65504.f), 65504.f); }
-                        const unsigned own = (unsigned)hbits(f2h<T>(v0)) | ((unsigned)hbits(f2h<T>(v1)) << 16);
-                        const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, true); // lane ^ 1
-                        const unsigned val = odd ? ((oth >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (oth << 16));
-                        const int n = nv0 + ni * 32 + (r >> 2) * 8 + h * 4 + (r & 3) + odd;
-                        uint16_t *dst = vcol + (size_t)n * p.ldvt;
-                        if (m_base + 1 < p.M) *reinterpret_cast<unsigned *>(dst) = val;
-                        else if (m_base < p.M) *dst = (uint16_t)val;
-                    }
-            }
+                        for (int r = 0; r < 16; r += 2) {
+                            float v0 = acc[ni][mi][r], v1 = acc[ni][mi][r + 1];
+                            if constexpr (DT == SVDQ_FP16) { v0 = fminf(fmaxf(v0, -65504.f), 65504.f); v1 = fminf(fmaxf(v1, -65504.f), 65504.f); }
+                            const unsigned own = (unsigned)hbits(f2h<T>(v0)) | ((unsigned)hbits(f2h<T>(v1)) << 16);
+                            const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, true); // lane ^ 1
+                            const unsigned val = odd ? ((oth >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (oth << 16));
+                            const int n = nv0 + ni * 32 + (r >> 2) * 8 + h * 4 + (r & 3) + odd;
+                            uint16_t *dst = vcol + (size_t)n * p.ldvt;
+                            if (decltype(full)::value || m_base + 1 < p.M) *reinterpret_cast<unsigned *>(dst) = val;
+                            else if (m_base < p.M) *dst = (uint16_t)val;
+                        }
+                }
+            };
+            if (m0 + BM <= p.M) store_vt(std::true_type{});
+            else store_vt(std::false_type{});
         } else
         if constexpr (FUSE != SVDQ_FUSE_GELU_QUANT) {
 #pragma unroll

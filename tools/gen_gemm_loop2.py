@@ -362,6 +362,11 @@ class Gen:
         ool = []
         for ph in range(nph):
             top = self.new_label(f"top{ph}_")
+            # "al6" / "al8" / "al12": the ring's first body (the target of the back branch, once per NSTAGE K-steps) starts on a
+            # 64 / 256 / 4096-byte boundary -- takes the loop's position in the instruction stream out of the compiler's hands
+            for o in self.opts:
+                if o.startswith("al") and o[2:].isdigit():
+                    e(f".p2align {int(o[2:])}")
             e(f"{top}:")
             for j in range(self.geo.nstage):
                 # the body's own entry label sits behind a phase-1 body's deferred-issue block: alias it
