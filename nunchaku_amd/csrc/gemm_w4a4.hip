@@ -496,15 +496,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         unsigned lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const unsigned lr_e = lane_e & 31, h_e = lane_e >> 5;
-        u16x4 bv[2][4] = {}; // (zero-initialised: conditionally loaded values must not look loop-carried to the register allocator)
+        // The bias rides on the matrix pipe as well: D[n][m] += bias[n] * 1 is an MFMA whose weight-side operand holds bias[n] in ONE
+        // k-slot and whose activation-side operand holds 1.0 there (exact: one non-zero product per output).  Column tile ni uses
+        // k-slot 0 of the lanes of half ni, so that the wave needs ONE coalesced 16-bit load (lane (lr, h) <- bias[nw0 + 32 h + lr])
+        // where the C-layout add needed eight 8-byte loads, 32 conversions and 64 v_add per wave and tile.
+        unsigned bias_bits = 0; // (zero-initialised: conditionally loaded values must not look loop-carried to the register allocator)
         const char *b_base = (const char *)(bm >= split_bm ? p.bias2 : p.bias);
-        const unsigned b_off = (unsigned)(nw0 + h_e * 4) * 2u;
-        if (use_bias) {
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) bv[ni][c] = *reinterpret_cast<const u16x4 *>(b_base + b_off + (ni * 32 + c * 8) * 2);
-        }
+        const unsigned b_off = (unsigned)(nw0 + h_e * 4) * 2u; // (the fused epilogues' per-column vectors, C layout)
+        if (use_bias) bias_bits = *reinterpret_cast<const uint16_t *>(b_base + (unsigned)(nw0 + h_e * 32 + lr_e) * 2u);
         const char *la_base = (const char *)p.lora_act_in;
         const char *lu_base = (const char *)(bm >= split_bm ? p.lora_up2 : p.lora_up);
         // lora_act_in: fp32 [M_pad][R], or (LAQ) Q31.32 fixed point in int64 [M_pad][R] -- the order-independent accumulation
@@ -527,16 +526,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         auto lora_mfma = [&](int rc, const LaRegs &t, const V8 (&u)[2]) {
             const float sc = p.lora_scales[rc >> 4];
             V8 la[2];
+            auto convert = [&](auto unit) { // unit: the scale of these 16 ranks is 1 (the default; block-uniform): v * 1 = v, no multiply
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
+                for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    // element j of the lane's 8 ranks: fp32 as stored, or Q31.32 (low word, high word) -> fp32
-                    float v;
-                    if constexpr (LAQ) v = q32_to_float(t.q[mi][j >> 1][2 * (j & 1)], t.q[mi][j >> 1][2 * (j & 1) + 1]);
-                    else { const int w = t.q[mi][j >> 2][j & 3]; v = __builtin_bit_cast(float, w); }
-                    la[mi][j] = f2h<T>(v * sc);
-                }
+                    for (int j = 0; j < 8; j++) {
+                        // element j of the lane's 8 ranks: fp32 as stored, or Q31.32 (low word, high word) -> fp32
+                        float v;
+                        if constexpr (LAQ) v = q32_to_float(t.q[mi][j >> 1][2 * (j & 1)], t.q[mi][j >> 1][2 * (j & 1) + 1]);
+                        else { const int w = t.q[mi][j >> 2][j & 3]; v = __builtin_bit_cast(float, w); }
+                        la[mi][j] = f2h<T>(decltype(unit)::value ? v : v * sc);
+                    }
+            };
+            if (sc == 1.0f) convert(std::true_type{});
+            else convert(std::false_type{});
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
@@ -569,13 +572,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         }
         if (use_bias) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++)
+            for (int ni = 0; ni < 2; ni++) {
+                V8 bw, one;
 #pragma unroll
-                for (int c = 0; c < 4; c++)
+                for (int j = 0; j < 8; j++) { bw[j] = (T)0.f; one[j] = (T)0.f; }
+                bw[0] = hfrom<T>((uint16_t)(h_e == (unsigned)ni ? bias_bits : 0u));
+                one[0] = h_e == (unsigned)ni ? (T)1.0f : (T)0.f;
 #pragma unroll
-                    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                        for (int e = 0; e < 4; e++) acc[ni][mi][c * 4 + e] += h2f(hfrom<T>(bv[ni][c][e]));
+                for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(bw, one, acc[ni][mi]);
+            }
         }
         if (Rr > 0) lora_mfma(0, x0, u0);
         if (Rr > 16) {
