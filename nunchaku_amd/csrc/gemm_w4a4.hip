@@ -21,7 +21,7 @@
 //     64 x 64 = 2 x 2 MFMA tiles; two waves per SIMD so that one wave's fma stream overlaps the
 //     other's MFMAs (a single wave issues one VALU op per ~8 cycles on gfx950).
 //   * K-step = 128 channels (two groups).  Operands go HBM -> LDS by DMA (global_load_lds, 16 B per
-//     lane = one 1 KiB plane of an F6 chunk per wave instruction), 4-stage ring (NSTAGE).
+//     lane = one 1 KiB plane of an F6 chunk per wave instruction), 3-stage ring (NSTAGE).
 //   * the MFMA is issued "transposed" (weights = A operand, activations = B) so that in the C layout
 //     a lane owns ONE output row m and 16 columns n = 32*tile + 8c + 4*(lane>>5) + e: 8-byte output
 //     stores, RoPE pairs and the next layer's FP6 lane record are lane-local.
@@ -70,7 +70,7 @@ constexpr int WS_BYTES = 1024;                 // 512 used
 constexpr int MAX_LORA_TILES = 16;             // R <= 256
 
 // Workgroup geometry (tools/gen_gemm_loop2.py: class Geometry -- keep in step).
-//   NW = 8: 512 threads, tile 256 x 128, ONE workgroup per CU (157 KiB of LDS), 4-stage ring.
+//   NW = 8: 512 threads, tile 256 x 128, ONE workgroup per CU (156 KiB of LDS), 3-stage ring + the tile's staged epilogue operands.
 //   NW = 4: 256 threads, tile 128 x 128, TWO workgroups per CU (80 KiB of LDS each), 3-stage ring: the two workgroups
 //           run half a tile out of phase, so one's epilogue (matrix pipe idle: 15-30 % of a K = 3072 tile) and its
 //           K-step barrier stalls sit under the other's main loop.
@@ -78,12 +78,18 @@ constexpr int MAX_LORA_TILES = 16;             // R <= 256
 template <int NW> struct Geo {
     static constexpr int BM = 32 * NW;
     static constexpr int THREADS = 64 * NW;
-    static constexpr int NSTAGE = NW == 8 ? 4 : 3;
+    static constexpr int NSTAGE = 3; // (NW = 8 ran a ring of four until the end of round 3: measured equal, bit-identical; the stage now holds STG_BYTES)
     static constexpr int A_BYTES = (BM / 32) * F6_CHUNK;
     static constexpr int STAGE_BYTES = A_BYTES + W_BYTES + AS_BYTES + WS_BYTES; // 38912 | 26624
     static constexpr int EPI_BYTES = 2 * BM * 4;   // epilogue scratch behind the ring (row sums of the RMSNorm epilogue: [2][BM] fp32)
     static constexpr int MAIL_BYTES = 16;          // one word: the tile id a workgroup's thread 0 drew from the dynamic queue
-    static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + EPI_BYTES + MAIL_BYTES; // 157712 | 80912 (two of them: 158 of 160 KiB)
+    // NW = 8: the tile's epilogue operands, staged by the main loop's prologue (tools/gen_gemm_loop2.py stage_epilogue_operands()) and
+    // read by the epilogue from LDS instead of from memory: lora_act_in [BM][32] fp32 (16-byte chunk c of row r at position c ^ (r & 7)),
+    // lora_up [128][32] 16-bit (linear), bias [128] 16-bit
+    static constexpr int STG_OFF = NSTAGE * STAGE_BYTES + EPI_BYTES + MAIL_BYTES;
+    static constexpr int STG_LU = 32768, STG_BIAS = 40960;
+    static constexpr int STG_BYTES = NW == 8 ? STG_BIAS + 256 : 0;
+    static constexpr int LDS_BYTES = STG_OFF + STG_BYTES; // 160016 | 80912 (two of them: 158 of 160 KiB)
     static constexpr int WG_PER_CU = NW == 8 ? 1 : 2;
 };
 // workspace header: 2048 int32 words.  Words [0, 1023): per-remainder-tile arrival counters of the stream-K split (at most
@@ -126,6 +132,7 @@ struct GemmParams {
     int dynamic;             // NW = 4: tiles are drawn from per-XCD queues in the workspace instead of a fixed list per workgroup
     int *status;             // optional host-visible status word (svdq_gemm_args.status)
     float q_scale;           // RMSNORM_ROPE: factor of the Q third, applied before its rounding to 16-bit (svdq_gemm_args.q_scale; 1 = off)
+    int stage_lora;          // NW = 8: rank 32, fp32 lora_act_in, 16-byte aligned operands: the loop stages lora_act_in / lora_up of a tile in LDS
     int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
     float lora_scales[MAX_LORA_TILES];
     SVDQ_PROBE_PARAMS
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         }
 
         SVDQ_PROBE_STAMP(0);
+        bool stg_counted = false;
         {
             // ---- hand-scheduled main loop (generated inline asm, every operand pinned to a physical register;
             //      DESIGN.md "Main loop"; tools/gen_gemm_loop2.py) ---------------------------------------------
@@ -374,11 +382,36 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             };
             v4i rA = srd(pA), rX1 = srd(pX1), rX2 = srd(pX2);
             const unsigned phaseB = wv >= NW / 2 ? 1u : 0u; // generator option "dph" only
+            // NW = 8: the loop's prologue stages this tile's epilogue operands in LDS (Geo::STG_OFF) when this segment ends the tile,
+            // i.e. runs its epilogue: bit 0 = lora_act_in (this wave's rows 32 w .. 32 w + 31: 4 KiB) + lora_up (its rows 16 w ..: 1 KiB)
+            // -- rank 32, fp32 accumulators, 16-byte aligned (p.stage_lora) --, bit 1 = bias (wave 0: 256 B); bits 8..10 = wave
+            unsigned stg_flags = 0;
+            const char *stg_la = (const char *)p.wgt, *stg_lu = stg_la, *stg_b = stg_la;
+            if (NW == 8 && kp1 == KP) {
+                if (!LAQ && p.stage_lora) {
+                    stg_flags |= 1u;
+                    stg_la = (const char *)p.lora_act_in + ((size_t)m0 + 32 * wv) * 128;
+                    stg_lu = (const char *)(bm >= split_bm ? p.lora_up2 : p.lora_up) + ((size_t)n0 + 16 * wv) * 64;
+                }
+                if (p.bias) {
+                    stg_flags |= 2u;
+                    stg_b = (const char *)(bm >= split_bm ? p.bias2 : p.bias) + (size_t)n0 * 2;
+                }
+                stg_flags |= (unsigned)wv << 8;
+            }
+            // DMAs this loop call issues behind the staging ones (5 per K-step while step < tot - NSTAGE): with 15 or more of them the
+            // epilogue's "s_waitcnt vmcnt(15)" proves the staged operands landed (vmcnt retires in order) without waiting for the next
+            // tile's prefetch; a shorter call simply drains
+            const int stg_issues = min((int)kp_s, (int)(kp_s + ncnt) - NSTAGE);
+            stg_counted = stg_issues >= 3;
+            const unsigned stg_lds = lds_base + G_::STG_OFF;
+            const unsigned long long stg_la_u = (unsigned long long)stg_la, stg_lu_u = (unsigned long long)stg_lu, stg_b_u = (unsigned long long)stg_b;
 #define SVDQ_LOOP2_OPERANDS                                                                                             \
                 : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
                   "+{s[72:75]}"(rA), "+{s[76:79]}"(rX1), "+{s[80:83]}"(rX2)                                                      \
                 : "{v210}"(in_la), "{v211}"(in_lw), "{v212}"(in_lsa), "{v213}"(in_lsw), "{v214}"(offA), "{v215}"(offX1),         \
                   "{v216}"(offX2), "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX2v), "{s52}"(phaseB),         \
+                  "{s51}"(stg_flags), "{s54}"(stg_lds), "{s[88:89]}"(stg_la_u), "{s[90:91]}"(stg_lu_u), "{s[92:93]}"(stg_b_u),                  \
                   "{s58}"(ring),                                                                                                   \
                   "{s59}"(npre), "{s60}"(ncnt), "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed)            \
                 : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", "s84", "s85", "s86", "s87", SVDQ_LOOP_CLOBBER_V
@@ -406,7 +439,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             // The loop returns with the next segment's first K-steps still in flight (no vmcnt drain: their latency
             // overlaps the epilogue's own loads).  An epilogue that waits on a global load of its own -- younger than
             // those DMAs, vmcnt retires in order -- proves them landed; otherwise the next prologue waits itself.
-            landed = ((p.bias || p.R > 0) && kp1 == KP) ? npre : 0;
+            // (NW = 8: the epilogue starts with s_waitcnt vmcnt(0) + a barrier before it reads the staged operands)
+            landed = ((NW == 8 || p.bias || p.R > 0) && kp1 == KP) ? npre : 0;
             pA = nA; pX1 = nX1; pX2 = nX2; // the next segment's bases (set by stream_ptrs above)
         }
         SVDQ_PROBE_STAMP(1);
@@ -500,10 +534,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         // k-slot and whose activation-side operand holds 1.0 there (exact: one non-zero product per output).  Column tile ni uses
         // k-slot 0 of the lanes of half ni, so that the wave needs ONE coalesced 16-bit load (lane (lr, h) <- bias[nw0 + 32 h + lr])
         // where the C-layout add needed eight 8-byte loads, 32 conversions and 64 v_add per wave and tile.
+        // NW = 8: bias, lora_act_in and lora_up of the tile were staged in LDS by the main loop's prologue (Geo::STG_OFF) and landed under
+        // the loop: the first phase of the epilogue reads LDS instead of waiting on ~13 global loads per wave with the matrix pipe idle.
+        typedef __attribute__((address_space(3))) const uint8_t lds_cbytes;
+        lds_cbytes *stg = (lds_cbytes *)((lds_void *)lds) + G_::STG_OFF;
+        bool staged_l = false; // block-uniform
+        if constexpr (NW == 8) {
+            staged_l = !LAQ && p.stage_lora;
+            if (stg_counted) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads(); // every wave's pieces are in LDS
+        }
         unsigned bias_bits = 0; // (zero-initialised: conditionally loaded values must not look loop-carried to the register allocator)
         const char *b_base = (const char *)(bm >= split_bm ? p.bias2 : p.bias);
         const unsigned b_off = (unsigned)(nw0 + h_e * 4) * 2u; // (the fused epilogues' per-column vectors, C layout)
-        if (use_bias) bias_bits = *reinterpret_cast<const uint16_t *>(b_base + (unsigned)(nw0 + h_e * 32 + lr_e) * 2u);
+        if (use_bias) {
+            if constexpr (NW == 8) bias_bits = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t *>(stg + G_::STG_BIAS + (unsigned)(wn * 64 + h_e * 32 + lr_e) * 2u);
+            else bias_bits = *reinterpret_cast<const uint16_t *>(b_base + (unsigned)(nw0 + h_e * 32 + lr_e) * 2u);
+        }
         const char *la_base = (const char *)p.lora_act_in;
         const char *lu_base = (const char *)(bm >= split_bm ? p.lora_up2 : p.lora_up);
         // lora_act_in: fp32 [M_pad][R], or (LAQ) Q31.32 fixed point in int64 [M_pad][R] -- the order-independent accumulation
@@ -522,6 +570,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         auto load_lu = [&](int rc, V8 (&u)[2]) {
 #pragma unroll
             for (int ni = 0; ni < 2; ni++) u[ni] = *reinterpret_cast<const V8 *>(lu_base + (lu_off + ni * lu_ni + rc * 2));
+        };
+        // the same operands from the staging region (rank 32, fp32): row r of the tile holds 16-byte chunk c (ranks 4c .. 4c + 3) at
+        // position c ^ (r & 7); the lane's 8 ranks rc + 8h .. are chunks rc / 4 + 2h and the next one
+        auto staged_la = [&](int rc, LaRegs &t) {
+            if constexpr (!LAQ) {
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const unsigned row = (unsigned)(wm * 64 + mi * 32) + lr_e, c = (unsigned)(rc / 4 + j) + 2u * h_e;
+                        t.q[mi][j] = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>(stg + row * 128u + ((c ^ (lr_e & 7u)) * 16u));
+                    }
+            }
+        };
+        auto staged_lu = [&](int rc, V8 (&u)[2]) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+                u[ni] = *reinterpret_cast<__attribute__((address_space(3))) const V8 *>(stg + G_::STG_LU + ((unsigned)(wn * 64 + ni * 32) + lr_e) * 64u + (unsigned)rc * 2u + h_e * 16u);
         };
         auto lora_mfma = [&](int rc, const LaRegs &t, const V8 (&u)[2]) {
             const float sc = p.lora_scales[rc >> 4];
@@ -547,8 +613,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         };
         LaRegs x0 = {}, x1 = {};
         V8 u0[2] = {}, u1[2] = {};
-        if (Rr > 0) { load_la(0, x0); load_lu(0, u0); }
-        if (Rr > 16) { if constexpr (!LAQ) load_la(16, x1); load_lu(16, u1); } // (LAQ: twice the registers per value -- ranks 16..31 follow the first MFMA)
+        if (staged_l) { staged_la(0, x0); staged_lu(0, u0); staged_la(16, x1); staged_lu(16, u1); }
+        else {
+            if (Rr > 0) { load_la(0, x0); load_lu(0, u0); }
+            if (Rr > 16) { if constexpr (!LAQ) load_la(16, x1); load_lu(16, u1); } // (LAQ: twice the registers per value -- ranks 16..31 follow the first MFMA)
+        }
         // GELU_QUANT: the next layer's smoothing factors and the first 32 ranks of its low-rank down projection ride on the
         // same round trip (they are consumed ~2000 instructions later, behind the GELU and the requantisation)
         u16x4 nsv[2][4] = {}, ldw[2][2][2] = {};
@@ -592,6 +661,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             load_lu(rc, u0);
             lora_mfma(rc, x0, u0);
         }
+        // NW = 8: nothing of this epilogue has gone to memory yet -- whatever is outstanding is the next tile's prefetch (and a fused
+        // epilogue's own parameter loads): waiting here proves the prefetch landed (`landed` above) so that the next loop call need not
+        // drain this epilogue's stores
+        // (GELU_QUANT has loads of its own in flight since the top of the epilogue -- the next layer's smoothing factors and low-rank
+        //  down rows -- and waits for them further down: that wait is the proof, as it always was for this epilogue)
+        if constexpr (NW == 8 && FUSE != SVDQ_FUSE_GELU_QUANT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SVDQ_PROBE_STAMP(2);
 
         // the single rounding to the 16-bit model dtype (the reference's tile is 16-bit from here on).  With the default
@@ -1168,6 +1243,9 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.workspace_bytes = a->workspace_bytes;
     p.M = a->M; p.M_pad = a->M_pad; p.N = a->N; p.K = a->K; p.R = a->R; p.R2 = a->R2; p.ldo = a->ldo;
     p.lora_fixed = a->lora_act_format;
+    // the 256 x 128 geometry stages a tile's low-rank operands in LDS when they are whole 1 KiB pieces: rank 32, fp32, 16-byte aligned
+    p.stage_lora = a->R == 32 && a->lora_act_format == SVDQ_LORA_ACT_F32 && a->lora_act_in && a->lora_up &&
+                   (((uintptr_t)a->lora_act_in | (uintptr_t)a->lora_up | (uintptr_t)a->lora_up2) & 15) == 0;
     p.status = a->status;
     p.q_scale = a->q_scale == 0.f ? 1.0f : a->q_scale;
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;

@@ -9,7 +9,7 @@ two waves retires ~1 instruction per 4.5 cycles whatever the mix, MFMA and VALU 
 86 per 32x32x64 tile-group, one wave or two), and every DMA / LDS / scalar instruction of the memory side adds its ~4.5
 cycles on top (compute alone 86, whole loop 129 cycles per tile-group).  v1 spends ~230 instructions per wave and K-step,
 144 of them arithmetic.  v2 removes bookkeeping, not work:
-  * the 4-stage LDS ring is unrolled: one copy of the K-step body per stage, every LDS address is base + immediate
+  * the LDS ring (4 stages then, 3 now) is unrolled: one copy of the K-step body per stage, every LDS address is base + immediate
     (no per-step v_mov / v_add / s_cselect stage rotation);
   * operand streams are MUBUF LDS-DMA (buffer_load_dwordx4 ... lds) with the K-step offset in ONE shared soffset SGPR per
     stream class: 2 scalar adds per K-step instead of 6 add/addc, segment switch = 3 s_mov_b64 out of line;
@@ -36,18 +36,21 @@ CHUNK, PLANE = 3072, 1024
 
 
 class Geometry:
-    """Workgroup geometry of the loop.  nw = 8: 512 threads, tile 256 x 128, one workgroup per CU, 4-stage ring, 5 DMA
+    """Workgroup geometry of the loop.  nw = 8: 512 threads, tile 256 x 128, one workgroup per CU, 3-stage ring (+ the staged epilogue operands), 5 DMA
     instructions per wave and K-step (three A planes, one W plane, one W plane / scale image / repeat).  nw = 4: 256 threads,
     tile 128 x 128, TWO workgroups per CU (80 KiB of LDS each), 3-stage ring, 7 DMA instructions per wave and K-step (the
     three planes of A chunk `wave`, the three planes of W chunk `wave`, one scale image / repeat).  The wave tile (64 x 64),
     the register plan and the arithmetic are the same."""
 
-    def __init__(self, nw):
+    def __init__(self, nw, nstage=None):
         assert nw in (4, 8)
         self.nw = nw
         self.a_bytes = nw * CHUNK
         self.stage = self.a_bytes + 4 * CHUNK + 1024 + 1024
-        self.nstage = 4 if nw == 8 else 3
+        # nw = 8: a ring of three since the end of round 3 (measured equal to four, bit-identical: profiles/r3_gemm_ring3.txt); the
+        # freed stage holds the tile's epilogue operands (lora_act_in 32 KB, lora_up 8 KB, bias 256 B), staged by the loop's prologue
+        self.nstage = nstage or 3
+        self.staging = nw == 8
         self.x1_planes = 1 if nw == 8 else 3
         self.dma_per_step = 3 + self.x1_planes + 1
 
@@ -67,6 +70,10 @@ S_NA, S_NX1, S_NX2 = 62, 64, 66
 SRD_A, SRD_X1, SRD_X2 = 72, 76, 80
 S_KOFF, S_KOFF2, S_DSTEP, S_STG = 84, 85, 86, 87
 S_PHASE = 52  # in ("dph" builds): 1 for waves 4..7
+# staging of the epilogue operands (nw = 8): in: s51 flags (bit 0: low-rank operands, bit 1: bias; bits 8..10: wave), s54 LDS address of the
+# staging region, s[88:89] this wave's 4 KiB of lora_act_in, s[90:91] its 1 KiB of lora_up, s[92:93] the tile's 256 bytes of bias
+S_STGF, S_STGB, S_SLA, S_SLU, S_SB = 51, 54, 88, 90, 92
+STG_LU, STG_BIAS = 32768, 40960   # offsets inside the staging region (lora_act_in at 0)
 
 
 def vr(a, n=1):
@@ -80,8 +87,8 @@ def sr(a, n=1):
 class Gen:
     def __init__(self, smfma, opts="", nw=8):
         self.smfma = smfma
-        self.geo = Geometry(nw)
         self.opts = set(o for o in opts.split("+") if o)
+        self.geo = Geometry(nw, 4 if "st4" in self.opts else None)  # "st4": the former ring of four (nw = 8; timing only: the kernel's LDS map assumes three)
         self.lines = []
         self.label = 0
 
@@ -175,6 +182,56 @@ class Gen:
             f"{ld} {vr(OFF_X2)}, {sr(SRD_X2, 4)}, {sr(S_KOFF2)} offen lds",
             f"s_add_u32 {sr(S_KOFF2)}, {sr(S_KOFF2)}, {sr(S_IX2)}",
         ]
+
+    def stage_epilogue_operands(self):
+        """nw = 8, behind the entry barrier (every wave has left the previous tile's epilogue): this wave's share of the tile's
+        epilogue operands goes to the staging region by LDS-DMA and lands under the main loop -- 4 pieces of 1 KiB of lora_act_in
+        (rows 32 w .. 32 w + 31 of the tile, fp32 [row][32 ranks] = 128 B per row; lane i of a piece fetches 16-byte chunk
+        (i & 7) ^ ((i >> 3) & 7) of row i >> 3, i.e. the LDS image holds chunk c of row r at position c ^ (r & 7): the epilogue's
+        16-byte reads of one chunk over 32 rows then spread over the banks), 1 piece of lora_up (rows 16 w .. 16 w + 15, linear)
+        and, wave 0, the bias (4 bytes per lane).  The DMAs are older than every DMA of the loop: its vmcnt waits only get stricter."""
+        if not self.geo.staging:
+            return []
+        Lno, Lnob = self.new_label("nostg"), self.new_label("nostgb")
+        t0, t1, t2 = 64, 65, 66   # P buffer registers: free until the first MFMA
+        out = [
+            f"s_bitcmp1_b32 {sr(S_STGF)}, 0",
+            f"s_cbranch_scc0 {Lno}",
+            f"s_bfe_u32 {sr(S_TMP)}, {sr(S_STGF)}, 0x30008",                 # wave
+            f"v_lshrrev_b32 {vr(t0)}, 7, {vr(OFF_A)}",                        # row in piece = lane >> 3   (OFF_A = 16 * lane)
+            f"v_bfe_u32 {vr(t1)}, {vr(OFF_A)}, 4, 3",                         # chunk position = lane & 7
+            f"v_and_b32 {vr(t2)}, 7, {vr(t0)}",
+            f"v_xor_b32 {vr(t1)}, {vr(t1)}, {vr(t2)}",                        # chunk fetched
+            f"v_lshlrev_b32 {vr(t1)}, 4, {vr(t1)}",
+            f"v_lshl_or_b32 {vr(t0)}, {vr(t0)}, 7, {vr(t1)}",                 # byte offset inside the 1 KiB piece
+            f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 10",                       # wave * 1024
+            f"s_add_u32 m0, {sr(S_STGB)}, {sr(S_TMP)}",
+            f"s_add_u32 m0, m0, {STG_LU}",
+            "s_nop 0",
+            f"global_load_lds_dwordx4 {vr(OFF_A)}, {sr(S_SLU, 2)}",
+            f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 2",                        # wave * 4096
+            f"s_add_u32 m0, {sr(S_STGB)}, {sr(S_TMP)}",
+        ]
+        # (no instruction offsets: an LDS-DMA's immediate offset moves the memory AND the LDS address; one address register per piece)
+        out += [f"v_add_u32 {vr(t0 + 2 + i)}, {0x400 * i}, {vr(t0)}" for i in range(1, 4)]
+        for i in range(4):
+            out += ["s_nop 0", f"global_load_lds_dwordx4 {vr(t0 + 2 + i if i else t0)}, {sr(S_SLA, 2)}"]
+            if i < 3:
+                out.append("s_add_u32 m0, m0, 1024")
+        out += [
+            f"{Lno}:",
+            f"s_bitcmp1_b32 {sr(S_STGF)}, 1",
+            f"s_cbranch_scc0 {Lnob}",
+            f"s_bfe_u32 {sr(S_TMP)}, {sr(S_STGF)}, 0x30008",
+            f"s_cmp_eq_u32 {sr(S_TMP)}, 0",
+            f"s_cbranch_scc0 {Lnob}",
+            f"v_lshrrev_b32 {vr(t0 + 6)}, 2, {vr(OFF_A)}",                    # 4 * lane (a register no DMA above has used as its address)
+            f"s_add_u32 m0, {sr(S_STGB)}, {STG_BIAS}",
+            "s_nop 0",
+            f"global_load_lds_dword {vr(t0 + 6)}, {sr(S_SB, 2)}",
+            f"{Lnob}:",
+        ]
+        return out
 
     def switch_segment(self):
         """DMA cursor moves to the first K-step of the next segment"""
@@ -338,6 +395,8 @@ class Gen:
         e("s_waitcnt vmcnt(0)")
         e(f"{Lpw}:")
         e("s_barrier")
+        for ln in self.stage_epilogue_operands():
+            e(ln)
         # enter the unrolled ring at this segment's stage
         entry = [self.new_label(f"in{j}_") for j in range(self.geo.nstage)]
         for j in range(1, self.geo.nstage):
