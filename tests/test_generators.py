@@ -225,3 +225,46 @@ def test_the_hazard_walk_notices_missing_wait_states():
             raise AssertionError(f"removing every '{strip}' went unnoticed")
     finally:
         GA.build = orig
+
+
+def test_gemm_loop_lds_dma_discipline():
+    """Static walk over the generated GEMM loops (the staging block of the 256 x 128 geometry went wrong exactly here once):
+    every LDS-DMA instruction is preceded -- since the last M0 write -- by at least one other instruction (the M0 -> LDS-DMA wait
+    state); LDS-DMA in the global form carries no instruction offset (it would move the memory AND the LDS address); no LDS-DMA's
+    address register is written again before the next one issues from a different register; the staging block exists for nw = 8
+    only, sits directly behind the entry barrier, and moves 4 pieces of lora_act_in + 1 of lora_up + the bias per wave into
+    [0, 32 KiB) / [32 KiB, 40 KiB) / 40 KiB of the staging region."""
+    import gen_gemm_loop2 as G2
+
+    for nw in (8, 4):
+        g = G2.Gen("v_mfma_f32_32x32x16_bf16", "", nw)
+        lines = [ln for ln in g.build() if not ln.startswith(";")]
+        since_m0 = None  # instructions since the last M0 write (None: M0 not written yet)
+        for ln in lines:
+            op = ln.split()[0]
+            if op.endswith(":"):
+                continue
+            is_dma = (op.startswith("buffer_load") and ln.rstrip().endswith(" lds")) or op.startswith("global_load_lds")
+            if is_dma:
+                assert since_m0 is not None and since_m0 >= 1, f"nw={nw}: LDS-DMA right behind its M0 write: {ln}"
+                if op.startswith("global_load_lds"):
+                    assert "offset:" not in ln, f"nw={nw}: {ln}"
+            if re.search(r"\bm0\b", ln.split(",")[0]) and op.startswith("s_"):
+                since_m0 = 0
+            elif since_m0 is not None:
+                since_m0 += 1
+        stg = [i for i, ln in enumerate(lines) if ln.startswith("global_load_lds")]
+        if nw == 4:
+            assert not stg
+            continue
+        assert len(stg) == 6
+        bar = max(i for i, ln in enumerate(lines[:stg[0]]) if ln == "s_barrier")
+        assert not any(ln.startswith(("buffer_load", "ds_read", "v_mfma")) for ln in lines[bar + 1:stg[0]])  # nothing of the loop in between
+        regs = [lines[i].split()[1].rstrip(",") for i in stg]
+        assert len(set(regs[1:5])) == 4 and regs[0] == f"v{G2.OFF_A}"  # lora_up: 16 * lane; lora_act_in: one address register per piece
+        block = lines[bar + 1:stg[-1] + 1]
+        for i, r in zip(stg, regs):  # no write to an address register behind an LDS-DMA that read it
+            assert not any(re.match(rf"v_\w+ {r},", ln) for ln in lines[i + 1:stg[-1] + 1]), (r, lines[i])
+        assert sum(1 for ln in block if ln == "s_add_u32 m0, m0, 1024") == 3
+        assert f"s_add_u32 m0, m0, {G2.STG_LU}" in block and f"s_add_u32 m0, s{G2.S_STGB}, {G2.STG_BIAS}" in block
+        assert g.geo.nstage == 3 and g.geo.stage * 3 + 2 * 256 * 4 + 16 + G2.STG_BIAS + 256 <= 160 * 1024  # the kernel's LDS map (Geo<8>)
