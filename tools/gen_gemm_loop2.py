@@ -14,7 +14,7 @@ cycles on top (compute alone 86, whole loop 129 cycles per tile-group).  v1 spen
   * operand streams are MUBUF LDS-DMA (buffer_load_dwordx4 ... lds) with the K-step offset in ONE shared soffset SGPR per
     stream class: 2 scalar adds per K-step instead of 6 add/addc, segment switch = 3 s_mov_b64 out of line;
   * every wave issues exactly 5 DMA instructions per K-step (waves 6, 7 repeat their W plane), so the wait for "my DMAs of
-    K-step s+1 have landed" is the constant s_waitcnt vmcnt(10) -- no counting ladder, no taken branch on the hot path;
+    K-step s+1 have landed" is the constant s_waitcnt vmcnt(5 * (stages - 2)) -- no counting ladder, no taken branch on the hot path;
     the DMA-less last K-steps of a workgroup's last segment take an out-of-line path with vmcnt(0);
   * loop control: 3 + 4 scalar instructions per K-step, all branches not taken in steady state.
 
