@@ -82,6 +82,13 @@ def test_validation_errors_are_returned_not_aborted(built_lib):
     assert b"M_pad" in lib.svdq_last_error()
     a.M_pad, a.fp4 = 256, 1
     assert lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), None) == 2  # unsupported
+    # fuse_glu reads rows of 2K (value, gate) pairs and does not combine with the LayerNorm front end
+    a.fp4, a.fuse_glu = 0, 1
+    assert lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), None) == 1  # ldx = 128 < 2K
+    assert b"fuse_glu" in lib.svdq_last_error() and b"2K" in lib.svdq_last_error()
+    a.ldx, a.ln_stats, a.mod_scale, a.mod_shift = 256, 16, 16, 16
+    assert lib.svdq_quantize_w4a4_act_fuse_lora(C.byref(a), None) == 1
+    assert b"fuse_glu" in lib.svdq_last_error()
     g = _lib.GemmArgs()
     g.act, g.wgt, g.ascales, g.wscales = 16, 16, 16, 16
     g.M, g.M_pad, g.N, g.K = 256, 256, 100, 128
