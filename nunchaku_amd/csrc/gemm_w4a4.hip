@@ -45,6 +45,7 @@
 #define SVDQ_PROBE_END()
 #define SVDQ_PROBE_FILL(p)
 #define SVDQ_PROBE_GRID(g, tiles, slots) (g)
+#define SVDQ_PROBE_OFF(bit) false
 #endif
 
 // generated main loops (tools/gen_gemm_loop2.py); the probe build substitutes option variants
@@ -822,7 +823,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                 for (int i = 0; i < 6; i++) rec[i] = (uint32_t)pk[i];
                 const int m_abs = mw0 + mi * 32 + lr;
                 uint8_t *dst = p.qout + ((size_t)(m_abs >> 5) * KP2 + (g2 >> 1)) * F6_CHUNK + (size_t)lane * 16;
-                if ((g2 & 1) == 0) {
+                if (SVDQ_PROBE_OFF(2)) {
+                } else if ((g2 & 1) == 0) {
                     *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
                     *reinterpret_cast<uint2 *>(dst + F6_PLANE) = make_uint2(rec[4], rec[5]);
                 } else {
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.  With
             // the activations as the A operand the result tile has the RANK along the lanes, so every fp32
             // atomic instruction hits two 128-byte lines instead of 64 different ones.
-            if (p.R2 > 0) {
+            if (p.R2 > 0 && !SVDQ_PROBE_OFF(4)) {
                 const T *ld = (const T *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
                 for (int t2 = 0; t2 < p.R2; t2 += 32) {
                     v16f d[2];
@@ -876,7 +878,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) {
                         const size_t at = (size_t)(mw0 + mi * 32 + h * 4) * p.R2 + t2 + lr;
-                        if (live && LAQ) {
+                        if (SVDQ_PROBE_OFF(1)) {
+                            asm volatile("" :: "v"(d[mi]));
+                        } else if (live && LAQ) {
                             // deterministic mode: Q31.32 fixed point, 64-bit INTEGER atomics -- the sum does not depend on the order
                             long long *dst = (long long *)p.lora_act_out + at;
 #pragma unroll

@@ -3,6 +3,8 @@
 // registers) }, 4 waves per workgroup = one per SIMD, one workgroup per CU.  Prints shader cycles per MFMA (s_memtime) for every
 // (kind, N).   hipcc --offload-arch=gfx950 -O2 -o filler_probe filler_probe.hip && ./filler_probe
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <cstdlib>
 #include <cstdio>
 #include <vector>
 
@@ -186,7 +188,37 @@ GEMM_KERNEL(g_mfma_only, TG_NOFMA(p1, s1) TG_NOFMA(p0, s0) TG_NOFMA(p1, s1) TG_N
 struct Entry { const char *name; void (*fn)(long long *, int); };
 #define E1(k) {#k "_1", k_##k##_1}, {#k "_2", k_##k##_2}, {#k "_4", k_##k##_4}, {#k "_5", k_##k##_5}, {#k "_6", k_##k##_6}, {#k "_8", k_##k##_8},
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc >= 3 && !strcmp(argv[1], "sustain")) {
+        // filler_probe sustain <seconds> [mfma|gemm]: keep the chip on the pure-MFMA loop (two waves per SIMD) or on the GEMM's arithmetic for that long
+        // (rocm-smi clock / power sampling from outside) and print the in-kernel counter rate against the wall clock
+        const double secs = atof(argv[2]);
+        const bool gemm = argc >= 4 && !strcmp(argv[3], "gemm");
+        long long *d;
+        hipMalloc(&d, 256 * sizeof(long long));
+        hipEvent_t ev0, ev1;
+        hipEventCreate(&ev0); hipEventCreate(&ev1);
+        const int it = 20000;
+        double total = 0;
+        float ms = 0;
+        while (total < secs * 1e3) {
+            hipEventRecord(ev0, 0);
+            if (gemm) hipLaunchKernelGGL(g_full, dim3(256), dim3(512), 0, 0, d, it);
+            else hipLaunchKernelGGL(w2_none, dim3(256), dim3(512), 0, 0, d, it);
+            hipEventRecord(ev1, 0);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, ev0, ev1);
+            total += ms;
+        }
+        std::vector<long long> h(256);
+        hipMemcpy(h.data(), d, 256 * sizeof(long long), hipMemcpyDeviceToHost);
+        double s = 0;
+        for (auto v : h) s += v;
+        const double mfma_per_simd = gemm ? (double)it * 4 * 2 * 2 : (double)it * 8 * 2;  // both waves of a SIMD
+        printf("{\"sustain\":\"%s\",\"launch_ms\":%.3f,\"s_memtime_GHz\":%.3f,\"ns_per_simd_mfma\":%.3f,\"GHz_if_32_cycles_per_mfma\":%.3f}\n", gemm ? "gemm arithmetic" : "pure mfma",
+               ms, s / 256 / (ms * 1e-3) / 1e9, ms * 1e6 / mfma_per_simd, 32.0 * mfma_per_simd / (ms * 1e6));
+        return 0;
+    }
     std::vector<Entry> es = {{"none", k_none}, E1(fma) E1(exp) E1(cvt) E1(dot) E1(max3) E1(add) E1(perm) E1(mov) E1(pkmul) E1(dsr) E1(snop) E1(salu) E1(dep)
                              {"mix_2fma_2exp_cvt", k_mix_a}, {"mix_2fma_2exp", k_mix_b}, {"mix_fma_exp_cvt_dot", k_mix_c},
                              {"mix_2fma_2exp_cvt_dsr", k_mix_d}, {"mix_fma_exp_fma_exp_dependent", k_mix_e}, {"mix_fma_fma_exp_exp_dependent", k_mix_f},
