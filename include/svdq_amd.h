@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 17
+#define SVDQ_ABI_VERSION 18
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -226,7 +226,11 @@ int svdq_gemm_workspace_status(void *workspace, void *stream);
  * `cap` records of 6 int32 {position, tile, kp0, kp1, partial slot or -1, contributors the owner waits for}
  * and returns the number of segments, or -1 for invalid shapes. */
 int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t *out, int32_t cap);
-/* the same for an explicit geometry (1 or 2, see svdq_gemm_args.geometry); svdq_gemm_schedule is geometry 1 */
+/* the same for an explicit geometry (1 or 2, see svdq_gemm_args.geometry); svdq_gemm_schedule is geometry 1.
+ * geometry 3 replays the ROW-RUN schedule a GELU_QUANT launch of geometry 1 takes when it has a next-layer low-rank branch of rank <= 32, no K
+ * split and at least two tiles per workgroup (every workgroup walks one run of consecutive column tiles of one row block, so that the next
+ * layer's low-rank down projection is accumulated inside the workgroup and written once per run): tile ids are row-major there
+ * (tile = row_block * (N / 128) + column_tile); -1 when such a launch would take the plain schedule. */
 int svdq_gemm_schedule_ex(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t geometry,
                           int32_t *out, int32_t cap);
 
@@ -422,6 +426,10 @@ int svdq_prof_reset(void);
  * queue serialisation per launch, so bench.py brackets only the kernel its roofline line is about. */
 int svdq_prof_select(uint32_t class_mask);
 int svdq_prof_read(int32_t kernel_class, int64_t *launches, double *total_ms, double *total_work);
+/* Sub-classes (ABI 18): a gemm_w4a4 launch is recorded under its epilogue variant.  svdq_prof_read(0, ...) still sums every GEMM launch;
+ * svdq_prof_read(SVDQ_PROF_GEMM_VARIANT(fuse), ...) returns the launches of one epilogue (SVDQ_FUSE_NONE / _SILU / _GELU_QUANT / _RMSNORM_ROPE),
+ * so that a bench line can show which variant moved. */
+#define SVDQ_PROF_GEMM_VARIANT(fuse) (0 | (((fuse) + 1) << 8))
 
 /* thread-local message of the last failing call on this thread ("" if none) */
 const char *svdq_last_error(void);

@@ -134,6 +134,8 @@ struct GemmParams {
     int *status;             // optional host-visible status word (svdq_gemm_args.status)
     float q_scale;           // RMSNORM_ROPE: factor of the Q third, applied before its rounding to 16-bit (svdq_gemm_args.q_scale; 1 = off)
     int stage_lora;          // NW = 8: rank 32, fp32 lora_act_in, 16-byte aligned operands: the loop stages lora_act_in / lora_up of a tile in LDS
+    int rowrun;              // NW = 8, GELU_QUANT: run length of the row-run schedule (GemmSchedule::init_runs; 0 = the plain schedule): the next layer's
+                             // low-rank down projection accumulates in LDS over a workgroup's run of column tiles, one flush of atomics per run
     int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
     float lora_scales[MAX_LORA_TILES];
     SVDQ_PROBE_PARAMS
@@ -152,8 +154,10 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x));
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q31.32 (deterministic mode) */>
+template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q31.32 (deterministic mode) */,
+          bool CARRY = false /* GELU_QUANT, NW = 8, fp32 lora_act_out of rank <= 32: the next layer's low-rank down projection accumulates in LDS */>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams p) {
+    static_assert(!CARRY || (NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ), "the low-rank-down carry lives in the 256 x 128 geometry's staging region");
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     using G_ = Geo<NW>;
@@ -175,7 +179,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
     // 1024 x 1024 patch of the output that shares its activation and weight panels in that XCD's L2.
     const int G = gridDim.x;
     const int pos = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    // row runs (GELU_QUANT, NW = 8): tile ids are row-major and a workgroup walks one run of consecutive column tiles
+    const int rowrun = CARRY ? p.rowrun : 0;
     auto tile_coords = [&](int t, int &bm, int &bn) {
+        if (CARRY && rowrun > 0) { bm = t / TN; bn = t - bm * TN; return; }
         const int strip = t / (8 * TM);
         const int w = min(8, TN - 8 * strip);
         const int r = t - strip * 8 * TM;
@@ -240,7 +247,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
     constexpr long long SLAB_BYTES = (long long)BM * BN * 4;
     const bool ws_ok = p.workspace != nullptr && p.workspace_bytes >= SK_HEADER_BYTES + 2LL * G * SLAB_BYTES;
     GemmSchedule sched;
-    sched.init(NT, KP, G, ws_ok ? p.sk_gs : 0, pos);
+    if (CARRY && rowrun > 0) sched.init_runs(TM, TN, KP, rowrun, pos);
+    else sched.init(NT, KP, G, ws_ok ? p.sk_gs : 0, pos);
     const bool sk = sched.gs > 0;
     const int F = sched.F;
     typedef GemmSegment Seg;
@@ -308,6 +316,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                 for (int i = 0; i < KP; i += 8) __builtin_amdgcn_s_sleep(127); // ~ KP x 1000 cycles = half a tile's loop
             }
         }
+    }
+
+    // the workgroup's low-rank-down carry (CARRY kernels): [BM rows][32 ranks] fp32 in the lora_act_in slot of the staging region -- the loop
+    // stages lora_up and bias only (stg_flags bit 2) and the epilogue loads its lora_act_in rows from memory.  The column waves of a tile add
+    // their partial sums here; the carry goes to lora_act_out when the workgroup leaves the row block: with the row-run schedule once per run.
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float *carry = (lds_float *)((lds_void *)lds) + G_::STG_OFF / 4;
+    bool carry_dirty = false; // block-uniform
+    if constexpr (CARRY) {
+        typedef __attribute__((address_space(3))) v4f lds_v4f;
+        const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < BM * 32 / 4 / (64 * NW); i++) ((lds_v4f *)carry)[i * 64 * NW + tid] = z4;
+        __syncthreads();
     }
 
     unsigned ring = 0, npre = 0, landed = 0;
@@ -390,7 +412,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             const char *stg_la = (const char *)p.wgt, *stg_lu = stg_la, *stg_b = stg_la;
             if (NW == 8 && kp1 == KP) {
                 if (!LAQ && p.stage_lora) {
-                    stg_flags |= 1u;
+                    stg_flags |= CARRY ? 5u : 1u;
                     stg_la = (const char *)p.lora_act_in + ((size_t)m0 + 32 * wv) * 128;
                     stg_lu = (const char *)(bm >= split_bm ? p.lora_up2 : p.lora_up) + ((size_t)n0 + 16 * wv) * 64;
                 }
@@ -614,7 +636,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         };
         LaRegs x0 = {}, x1 = {};
         V8 u0[2] = {}, u1[2] = {};
-        if (staged_l) { staged_la(0, x0); staged_lu(0, u0); staged_la(16, x1); staged_lu(16, u1); }
+        if (staged_l) {
+            if constexpr (CARRY) { load_la(0, x0); load_la(16, x1); }  // (the region's lora_act_in slot holds the carry)
+            else { staged_la(0, x0); staged_la(16, x1); }
+            staged_lu(0, u0); staged_lu(16, u1);
+        }
         else {
             if (Rr > 0) { load_la(0, x0); load_lu(0, u0); }
             if (Rr > 16) { if constexpr (!LAQ) load_la(16, x1); load_lu(16, u1); } // (LAQ: twice the registers per value -- ranks 16..31 follow the first MFMA)
@@ -844,7 +870,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             // atomic instruction hits two 128-byte lines instead of 64 different ones.
             if (p.R2 > 0 && !SVDQ_PROBE_OFF(4)) {
                 const T *ld = (const T *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
-                for (int t2 = 0; t2 < p.R2; t2 += 32) {
+                for (int t2 = 0; t2 < (CARRY ? 32 : p.R2); t2 += 32) { // (CARRY: rank <= 32, one pass)
                     v16f d[2];
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) d[mi] = zero16;
@@ -856,7 +882,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                             V8 wv;
                             if (live) {
                                 u16x4 w0 = ldw[ni][q][0], w1 = ldw[ni][q][1]; // ranks 0..31: requested at the top of the epilogue
-                                if (t2 > 0) {
+                                if (!CARRY && t2 > 0) {
                                     const T *src = ld + (size_t)(t2 + lr) * p.N + nw0 + ni * 32 + q * 16 + h * 4;
                                     w0 = *reinterpret_cast<const u16x4 *>(src);
                                     w1 = *reinterpret_cast<const u16x4 *>(src + 8);
@@ -880,6 +906,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                         const size_t at = (size_t)(mw0 + mi * 32 + h * 4) * p.R2 + t2 + lr;
                         if (SVDQ_PROBE_OFF(1)) {
                             asm volatile("" :: "v"(d[mi]));
+                        } else if constexpr (CARRY) {
+                            // into the workgroup's carry: below, both row tiles at once (the two column waves of a row block take turns)
                         } else if (live && LAQ) {
                             // deterministic mode: Q31.32 fixed point, 64-bit INTEGER atomics -- the sum does not depend on the order
                             long long *dst = (long long *)p.lora_act_out + at;
@@ -890,6 +918,37 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                             float *dst = (float *)p.lora_act_out + at;
 #pragma unroll
                             for (int i = 0; i < 16; i++) unsafeAtomicAdd(dst + (size_t)((i & 3) + 8 * (i >> 2)) * p.R2, d[mi][i]);
+                        }
+                    }
+                    if constexpr (CARRY) {
+                        if (!SVDQ_PROBE_OFF(1)) {
+                            // carry layout [row / 4][rank][row % 4] fp32: a lane's registers 4 g .. 4 g + 3 (rows 8 g + 4 h + 0..3 of its row tile, rank lr)
+                            // are 16 contiguous bytes -- plain 16-byte reads and writes, no LDS atomics (ds_add_f32 runs at ~1 lane per clock:
+                            // measured 21 k cycles per tile for these 32 instructions per wave, profiles/r4_gemm_rowrun.txt).  The two column waves
+                            // of a row block add to the same words: wave column 0 first, a barrier, then wave column 1.
+                            typedef __attribute__((address_space(3))) v4f lds_v4f;
+                            lds_v4f *c4 = (lds_v4f *)carry + ((unsigned)(wm * 16) + h_e) * 32u + lr_e; // + (mi * 8 + 2 g) * 32
+                            carry_dirty = true;
+#pragma unroll
+                            for (int turn = 0; turn < 2; turn++) {
+                                if (wn == turn && live) {
+                                    v4f old[2][4];
+#pragma unroll
+                                    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                                        for (int g = 0; g < 4; g++) old[mi][g] = c4[(mi * 8 + 2 * g) * 32];
+#pragma unroll
+                                    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                                        for (int g = 0; g < 4; g++) {
+                                            v4f v = old[mi][g];
+#pragma unroll
+                                            for (int e = 0; e < 4; e++) v[e] += d[mi][4 * g + e];
+                                            c4[(mi * 8 + 2 * g) * 32] = v;
+                                        }
+                                }
+                                if (turn == 0) __syncthreads();
+                            }
                         }
                     }
                 }
@@ -968,6 +1027,31 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         }
         } // FUSE != GELU_QUANT
         } // run_epilogue
+        if (CARRY && carry_dirty && (!have_next || nbm != bm)) {
+            // the workgroup leaves the row block: the carry goes to lora_act_out -- 16 atomic instructions per wave where every TILE used to
+            // issue 32 per wave; with the row-run schedule once per run of column tiles -- and is cleared for the next row block
+            carry_dirty = false;
+            __syncthreads();
+            // (the thread id passes through an empty asm statement: otherwise the 16 addresses are hoisted above the main loop and spilled)
+            unsigned tid_e = tid;
+            asm volatile("" : "+v"(tid_e));
+            // float4 t + 512 j of the carry = rank t & 31 of the four rows 4 ((t >> 5) + 16 j) + 0..3
+            typedef __attribute__((address_space(3))) v4f lds_v4f;
+            const unsigned rank = tid_e & 31u, rg0 = tid_e >> 5;
+            float *dst = (float *)p.lora_act_out + ((size_t)m0 + 4 * rg0) * p.R2 + rank;
+            lds_v4f *src = (lds_v4f *)carry + tid_e;
+            const bool live = (int)rank < p.R2;
+            const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < BM * 32 / 4 / (64 * NW); j++) {
+                const v4f v = src[j * (64 * NW)];
+                src[j * (64 * NW)] = z4;
+                if (live) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) unsafeAtomicAdd(dst + (size_t)(j * (64 * NW / 32) * 4 + e) * p.R2, v[e]);
+                }
+            }
+        }
         SVDQ_PROBE_STAMP(5);
         if (dyn) dq_pending = have_next ? share(dq_drawn) : -1;
         SVDQ_PROBE_NEXT_SEGMENT();
@@ -1042,6 +1126,12 @@ static int pick_geometry(const svdq_gemm_args *a, bool with_ws) {
     return (use1 < 0.9 && tiles2 >= 4 * cus) ? 2 : 1;
 }
 
+// Row runs (GELU_QUANT on 256 x 128 tiles with a next-layer low-rank branch of rank <= 32 and no K split): worth it from two tiles per
+// workgroup (profiles/r4_gemm_rowrun.txt: the per-tile atomics of the low-rank down projection cost 12 % of the fc1 launch)
+static bool rowrun_applies(int M_pad, int N, int R2, int sk_gs, int slots) {
+    return R2 > 0 && R2 <= 32 && sk_gs == 0 && (M_pad / 256) * (N / BN) >= 2 * slots;
+}
+
 template <int DT, int FUSE, int NW, bool LAQ>
 static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
     using G_ = Geo<NW>;
@@ -1052,6 +1142,22 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
     p.dynamic = NW == 4 && p.dynamic && with_ws && tiles > slots && p.sk_gs == 0;
     int g = persistent_grid(tiles, p.sk_gs, slots);
     if (p.dynamic) g = slots; // every CU hosts two workgroups; the queue balances them
+    p.rowrun = 0;
+    // the low-rank-down carry (and, from two tiles per workgroup, the row-run schedule that makes it pay): GELU_QUANT on 256 x 128 tiles with an fp32
+    // next-layer low-rank branch of rank <= 32
+    constexpr bool CAN_CARRY = NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ;
+    if constexpr (CAN_CARRY) {
+        if (p.R2 > 0 && p.R2 <= 32) {
+            if (rowrun_applies(p.M_pad, p.N, p.R2, p.sk_gs, slots)) {
+                const int TM = p.M_pad / G_::BM, TN = p.N / BN;
+                p.rowrun = GemmSchedule::run_length(TM, TN, slots);
+                g = (TM * ((TN + p.rowrun - 1) / p.rowrun) + 7) / 8 * 8; // a multiple of 8: the XCD-aware numbering keeps consecutive runs on one XCD
+            }
+            dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
+            hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true>), grid, block, 0, st, p);
+            return;
+        }
+    }
     dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
     hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ>), grid, block, 0, st, p);
 }
@@ -1103,9 +1209,28 @@ extern "C" int svdq_gemm_workspace_status(void *workspace, void *stream) {
 // {position, tile, kp0, kp1, slot-or-minus-one, contributors} and return the number of segments (or -1).
 extern "C" int svdq_gemm_schedule_ex(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t geometry,
                                      int32_t *out, int32_t cap) {
-    if (geometry != 1 && geometry != 2) return -1;
-    const int bm = geometry == 1 ? 256 : 128, slots = geometry == 1 ? cus : 2 * cus;
+    if (geometry != 1 && geometry != 2 && geometry != 3) return -1;
+    const int bm = geometry == 2 ? 128 : 256, slots = geometry == 2 ? 2 * cus : cus;
     if (M_pad <= 0 || N <= 0 || K <= 0 || M_pad % 256 || N % BN || K % 128 || cus <= 0) return -1;
+    if (geometry == 3) {
+        // the row-run schedule of a GELU_QUANT launch (256 x 128 tiles): tile ids are ROW-MAJOR (tile = bm * TN + bn); -1 when the launch
+        // would take the plain schedule (fewer than two tiles per workgroup)
+        const int TM = M_pad / 256, TN = N / BN;
+        if (!rowrun_applies(M_pad, N, 32, 0, cus)) return -1;
+        const int rl = GemmSchedule::run_length(TM, TN, cus);
+        const int G = (TM * ((TN + rl - 1) / rl) + 7) / 8 * 8;
+        int n = 0;
+        for (int pos = 0; pos < G; pos++) {
+            GemmSchedule sc;
+            sc.init_runs(TM, TN, K / 128, rl, pos);
+            GemmSegment sg;
+            while (sc.next(sg)) {
+                if (out && n < cap) { int32_t *r = out + 6 * n; r[0] = pos; r[1] = sg.tile; r[2] = sg.kp0; r[3] = sg.kp1; r[4] = -1; r[5] = 0; }
+                n++;
+            }
+        }
+        return n;
+    }
     const int tiles = (M_pad / bm) * (N / BN), KP = K / 128;
     const int gs = with_workspace ? streamk_groups_for(tiles, KP, slots) : 0;
     const int G = persistent_grid(tiles, gs, slots);
@@ -1260,7 +1385,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.dynamic = geo == 2 || geo == 4;
     p.stagger = geo == 4 || geo == 5;
     hipStream_t st = (hipStream_t)stream;
-    const int prof = prof_begin(0, 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
+    const int prof = prof_begin(SVDQ_PROF_GEMM_VARIANT(a->fuse), 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
     if (geo == 1) {
         if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, 8>(p, a->fuse, with_ws, st);
         else launch_fuse<SVDQ_FP16, 8>(p, a->fuse, with_ws, st);

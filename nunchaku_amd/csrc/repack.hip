@@ -21,7 +21,7 @@ static bool g_prof_on = false;
 static uint32_t g_prof_mask = 0xffffffffu; // kernel classes that are bracketed (svdq_prof_select)
 
 int prof_begin(int cls, double work, hipStream_t st) {
-    if (!g_prof_on || !((g_prof_mask >> cls) & 1u)) return -1;
+    if (!g_prof_on || !((g_prof_mask >> (cls & 0xff)) & 1u)) return -1; // (bits 8.. of cls: sub-class, e.g. the GEMM's epilogue variant)
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return -1;
     int i = (int)g_prof_used++;
@@ -366,7 +366,7 @@ int svdq_prof_read(int32_t kernel_class, int64_t *launches, double *total_ms, do
     double ms = 0, work = 0;
     for (size_t i = 0; i < g_prof_used; i++) {
         ProfRec &r = g_prof_pool[i];
-        if (r.cls != kernel_class) continue;
+        if (kernel_class < 256 ? (r.cls & 0xff) != kernel_class : r.cls != kernel_class) continue; // a class with all its sub-classes, or one sub-class
         if (hipEventSynchronize(r.e1) != hipSuccess) { set_error("svdq_prof_read: hipEventSynchronize failed"); return SVDQ_E_HIP; }
         float t = 0;
         if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) { set_error("svdq_prof_read: hipEventElapsedTime failed"); return SVDQ_E_HIP; }

@@ -153,13 +153,34 @@ __host__ __device__ __forceinline__ int f6_dec(unsigned c, int is_unsigned) {
 // SEGMENT FIRST (the head of a tile somebody else owns is published before our own owner duty can wait).
 // The segment with kp1 == KP owns its tile: it collects the fp32 partials of the `contributors()` other
 // segments and runs the epilogue.
+//
+// Row runs (init_runs; the GELU_QUANT launch of the 256 x 128 geometry): position `pos` walks ONE run of up to RL
+// consecutive column tiles of one row block -- tile ids are row-major here (tile = bm * TN + bn) -- so that the next layer's low-rank
+// down projection of its tiles accumulates inside the workgroup and goes to memory once per run instead of once per tile.
 struct GemmSegment { int tile, kp0, kp1; long long u0; };
 struct GemmSchedule {
     int NT, KP, G, gs, pos, F, R;
     long long RU, su, su_end, su_begin;
     int it_full;
+    int run_t, run_end; // row runs: the next tile of this position's run and its end (run_end < 0: not in run mode)
+    // run length for a launch of TM x TN tiles on `slots` workgroup slots: as many rounds as the plain schedule needs, longer if the
+    // runs would not fit the slots; runs per row = ceil(TN / RL), grid = TM * runs per row
+    static __host__ __device__ int run_length(int TM, int TN, int slots) {
+        int rl = (TM * TN + slots - 1) / slots;
+        if (rl < 1) rl = 1;
+        while (rl < TN && TM * ((TN + rl - 1) / rl) > slots) rl++;
+        return rl;
+    }
+    __host__ __device__ void init_runs(int TM, int TN, int KP_, int RL, int pos_) {
+        NT = TM * TN; KP = KP_; G = 0; gs = 0; pos = pos_; F = 0; R = 0; RU = su = su_end = su_begin = 0; it_full = 0;
+        const int rpr = (TN + RL - 1) / RL, run = pos_;
+        if (run >= TM * rpr) { run_t = run_end = 0; return; }
+        const int bm = run / rpr, c = run - bm * rpr;
+        run_t = bm * TN + c * RL;
+        run_end = bm * TN + (c * RL + RL < TN ? c * RL + RL : TN);
+    }
     __host__ __device__ void init(int NT_, int KP_, int G_, int gs_, int pos_) {
-        NT = NT_; KP = KP_; G = G_; pos = pos_;
+        NT = NT_; KP = KP_; G = G_; pos = pos_; run_t = 0; run_end = -1;
         F = NT / G; R = NT - F * G;
         gs = (R > 0 && gs_ >= R && gs_ <= G) ? gs_ : 0;
         RU = (long long)R * KP;
@@ -170,6 +191,10 @@ struct GemmSchedule {
     __host__ __device__ long long ubound(int q) const { return (long long)q * RU / gs; }             // first K-step of position q
     __host__ __device__ int pos_of(long long u) const { return (int)(((u + 1) * gs - 1) / RU); }     // position holding K-step u
     __host__ __device__ bool next(GemmSegment &sg) {
+        if (run_end >= 0) {
+            if (run_t < run_end) { sg = GemmSegment{run_t, 0, KP, 0}; run_t++; return true; }
+            return false;
+        }
         if (it_full < F) { sg = GemmSegment{it_full * G + pos, 0, KP, 0}; it_full++; return true; }
         if (!gs) {
             if (it_full == F && pos < R) { sg = GemmSegment{F * G + pos, 0, KP, 0}; it_full++; return true; }

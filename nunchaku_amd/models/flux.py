@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops.attention import attention_packed, attention_packed_quantized, q_prescale
+from ..ops.attention import attention_packed, attention_packed_quantized, kv_valid_ranges, q_prescale
 from ..ops.elementwise import residual_gate_stats, residual_gate_stats_pair
 from ..ops.gemv import awq_gemv_w4a16_batched
 from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair,
@@ -106,6 +106,9 @@ class FluxAttentionAMD(nn.Module):
     grouped = True  # plain class attribute (set False for A/B runs); nothing is read from the environment
     # True: the attention epilogue emits the output projection's quantised activation (svdq_attention_args.qact)
     fused_out_quant = True
+    # True: the engine pads both token streams to 256 rows so that every token count runs the fused path (False: A/B -- token counts that
+    # are not a multiple of 128 then take torch's SDPA)
+    padded_tokens = True
 
     @property
     def out_proj(self) -> SVDQW4A4Linear:
@@ -114,9 +117,10 @@ class FluxAttentionAMD(nn.Module):
     def _use_svdq(self, B, tokens):
         return self.attention_impl == "svdq" and B == 1 and self.head_dim == 128 and tokens % 128 == 0
 
-    def forward(self, hidden, encoder_hidden=None, rotary=None, ln=None, ln_ctx=None, quantized=None):
+    def forward(self, hidden, encoder_hidden=None, rotary=None, ln=None, ln_ctx=None, quantized=None, kv_valid=None):
         """``ln`` / ``ln_ctx`` = (stats, scale, shift): the inputs are the UN-normalised streams and the
-        AdaLayerNormZero front end runs inside the QKV projections' quantiser."""
+        AdaLayerNormZero front end runs inside the QKV projections' quantiser.  ``kv_valid``: the real key rows when the
+        streams are padded to 256 rows (the engine pads every token count onto this path; ``ops.attention.kv_valid_ranges``)."""
         B = hidden.shape[0]
         hd = self.heads * self.head_dim
         t_txt = encoder_hidden.shape[1] if self.joint else 0
@@ -146,7 +150,7 @@ class FluxAttentionAMD(nn.Module):
             src = ln_ctx if self.joint else ln  # the pool of the stream whose rows come first carries the scratch
             qpool = src[3] if src is not None and len(src) > 3 else None
             qres = attention_packed_quantized(qkv[0], vt, self.heads, self.out_proj, lin_first=self.to_add_out if self.joint else None,
-                                              split_rows=t_txt, pool=qpool, q_prescaled=True)
+                                              split_rows=t_txt, pool=qpool, q_prescaled=True, kv_valid=kv_valid)
             if qres is not None:  # the 16-bit attention output never exists: straight into the output projection(s)
                 if self.joint:
                     ca, a = linear_pair_quantized(*qres, self.to_add_out, self.out_proj, t_txt)
@@ -154,7 +158,7 @@ class FluxAttentionAMD(nn.Module):
                 return self.out_proj.forward_quant(*qres).view(B, tokens, -1)
         if svdq:  # the same launch clears the low-rank accumulators of the output projections' quantisers
             zf = _pad256(hidden.shape[1]) * self.out_proj.rank + (_pad256(t_txt) * self.to_add_out.rank if self.joint else 0)
-            o, pool = attention_packed(qkv[0], vt, self.heads, zero_floats=zf, q_prescaled=True)
+            o, pool = attention_packed(qkv[0], vt, self.heads, zero_floats=zf, q_prescaled=True, kv_valid=kv_valid)
             o = o.unsqueeze(0)
         else:
             q, k, v = qkv.chunk(3, dim=-1)
@@ -239,7 +243,7 @@ class FluxJointBlockAMD(nn.Module):
         # already carries the +1 of the scale
         return F.layer_norm(x, (x.shape[-1],), eps=1e-6) * scale[:, None] + shift[:, None]
 
-    def forward(self, hidden, encoder_hidden, temb_act, rotary, stats=None, mods=None):
+    def forward(self, hidden, encoder_hidden, temb_act, rotary, stats=None, mods=None, kv_valid=None):
         """``mods`` = (mod, mod_context) outputs computed ahead of the block (one batched GEMV launch per step).
         ``stats`` = (image-stream, text-stream) LayerNorm statistics of the inputs: the fused path -- LayerNorm and
         modulation inside the quantisers, gated residual + next statistics in one element-wise pass (B == 1).
@@ -252,7 +256,7 @@ class FluxJointBlockAMD(nn.Module):
             c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c
             n_h = self._ln_mod(hidden, scale_msa, shift_msa)
             n_e = self._ln_mod(encoder_hidden, c_scale_msa, c_shift_msa)
-            a, ca = self.attn(n_h, n_e, rotary)
+            a, ca = self.attn(n_h, n_e, rotary, kv_valid=kv_valid)
             hidden = hidden + gate_msa[:, None] * a  # transformer_flux_v2.py:230-251, op for op
             n_h = self._ln_mod(hidden, scale_mlp, shift_mlp)
             hidden = hidden + gate_mlp[:, None] * self.ff(n_h)
@@ -267,7 +271,7 @@ class FluxJointBlockAMD(nn.Module):
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = m_out.view(6, -1)
         c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c_out.view(6, -1)
         a, ca = self.attn(hidden, encoder_hidden, rotary, ln=(h_stats, scale_msa, shift_msa, h_pool),
-                          ln_ctx=(e_stats, c_scale_msa, c_shift_msa, e_pool))
+                          ln_ctx=(e_stats, c_scale_msa, c_shift_msa, e_pool), kv_valid=kv_valid)
         mp_h, mp_e = _pad256(hidden.shape[1]), _pad256(encoder_hidden.shape[1])
         r_mlp = self.ff.fc1.rank + self.ff.fc2.rank          # fc1's quantiser + the GELU epilogue's accumulator for fc2
         r_mlp_c = self.ff_context.fc1.rank + self.ff_context.fc2.rank
@@ -307,12 +311,12 @@ class FluxSingleBlockAMD(nn.Module):
     def mod(self) -> AWQW4A16Linear:
         return self.norm.linear
 
-    def forward(self, hidden, temb_act, rotary, stats=None, mods=None):
+    def forward(self, hidden, temb_act, rotary, stats=None, mods=None, kv_valid=None):
         if stats is None:
             shift, scale, gate = self.mod(temb_act).view(temb_act.shape[0], 3, -1).permute(1, 0, 2)
             n = F.layer_norm(hidden, (hidden.shape[-1],), eps=1e-6) * scale[:, None] + shift[:, None]
             mlp = fused_gelu_mlp(n, self.mlp_fc1, self.mlp_fc2)
-            att = self.attn(n, rotary=rotary)
+            att = self.attn(n, rotary=rotary, kv_valid=kv_valid)
             out = hidden + gate[:, None] * (att + mlp)  # transformer_flux_v2.py:332-335
             if out.dtype == torch.float16:
                 out = out.clip(-65504, 65504)
@@ -323,7 +327,7 @@ class FluxSingleBlockAMD(nn.Module):
         both = quantize_two(hidden, self.mlp_fc1, self.attn.to_qkv, ln=ln) if FluxAttentionAMD.grouped else None
         q_mlp, q_qkv = both if both is not None else (None, None)  # one quantiser launch for the two projections
         mlp = fused_gelu_mlp(hidden, self.mlp_fc1, self.mlp_fc2, ln=ln, quantized=q_mlp)
-        att = self.attn(hidden, rotary=rotary, ln=ln, quantized=q_qkv)
+        att = self.attn(hidden, rotary=rotary, ln=ln, quantized=q_qkv, kv_valid=kv_valid)
         # hidden + gate * (att + mlp), the next block's statistics and its three low-rank accumulators, one pass
         hidden, st, pool = residual_gate_stats(hidden, att, gate, b=mlp, zero_floats=_pad256(hidden.shape[1]) * (
             self.mlp_fc1.rank + self.mlp_fc2.rank + self.attn.to_qkv.rank + self.attn.out_proj.rank), clamp_fp16=True)
@@ -468,10 +472,13 @@ class FluxEngineMixin:
         return self
 
     def engine_forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
-                       guidance=None):
+                       guidance=None, controlnet_block_samples=None, controlnet_single_block_samples=None, controlnet_blocks_repeat=False):
         """hidden_states [1, T_img, 64]; encoder_hidden_states [1, T_txt, 4096]; pooled [1, 768];
         timestep/guidance [1]; img_ids [T_img, 3]; txt_ids [T_txt, 3]  ->  [1, T_img, 64]
-        (transformer_flux_v2.py:430-561; batch 1 -- the fused QKV epilogue takes one rotary table)."""
+        (transformer_flux_v2.py:430-561; batch 1 -- the fused QKV epilogue takes one rotary table).
+        ``controlnet_block_samples`` / ``controlnet_single_block_samples``: lists of ``[1, T_img, dim]`` residuals added to the image
+        stream behind the joint / single blocks with diffusers' indexing (``FluxTransformer2DModel.forward``: sample
+        ``i // ceil(blocks / samples)``, or ``i % samples`` with ``controlnet_blocks_repeat``)."""
         dt = self.dtype_
         if hidden_states.shape[0] > 1:
             # The fused QKV epilogue takes ONE rotary table and the operand buffers of a launch belong to one sample
@@ -479,8 +486,11 @@ class FluxEngineMixin:
             # is a loop over samples here -- the data-parallel unit of this library is the replica, not the batch axis.
             def per(t, i):
                 return t[i:i + 1] if t is not None and t.dim() > 0 and t.shape[0] == hidden_states.shape[0] else t
+            def per_list(ts, i):
+                return None if ts is None else [per(t, i) for t in ts]
             return torch.cat([self.engine_forward(hidden_states[i:i + 1], encoder_hidden_states[i:i + 1], pooled_projections[i:i + 1],
-                                           per(timestep, i), img_ids, txt_ids, per(guidance, i))
+                                           per(timestep, i), img_ids, txt_ids, per(guidance, i), per_list(controlnet_block_samples, i),
+                                           per_list(controlnet_single_block_samples, i), controlnet_blocks_repeat)
                               for i in range(hidden_states.shape[0])], dim=0)
         hidden = self.x_embedder(hidden_states)
         # diffusers casts timestep / guidance to the model dtype BEFORE the x1000 (transformer_flux.py: timestep.to(dtype) * 1000)
@@ -493,9 +503,24 @@ class FluxEngineMixin:
 
         t_txt, t_img = enc.shape[1], hidden.shape[1]
         rot = flux_pos_embed(torch.cat([txt_ids, img_ids], dim=0), self.axes)  # [1, T, 64, 1, 2]
-        rot_txt = pack_rotemb(pad_tensor(rot[:, :t_txt], 256, 1))
-        rot_img = pack_rotemb(pad_tensor(rot[:, t_txt:], 256, 1))
-        rot_all = pack_rotemb(pad_tensor(rot, 256, 1))
+        rot_t, rot_i = pad_tensor(rot[:, :t_txt], 256, 1), pad_tensor(rot[:, t_txt:], 256, 1)
+        rot_txt, rot_img = pack_rotemb(rot_t), pack_rotemb(rot_i)
+        # EVERY token count runs the hot path (the reference pads any M to 256 rows, Linear.cpp:445-446, and masks the padded K rows of its
+        # attention, epilogues.cuh:427-550): both streams are padded to 256 rows with zero tokens right behind the embedders -- the joint
+        # sequence is [text | pad | image | pad], every stream starts on a 256-row boundary as the grouped launches need -- every launch of
+        # the step sees the shapes the parity suite and the bench exercise, the attention kernel masks the padded keys (kv_valid), and the
+        # real image rows are sliced out at the end.  A padded row is a token nobody attends to: it stays finite and touches no real row.
+        p_txt, p_img = rot_t.shape[1], rot_i.shape[1]
+        kv_valid = None
+        attn0 = (self.blocks[0] if len(self.blocks) else self.single_blocks[0]).attn
+        if FluxAttentionAMD.padded_tokens and attn0.attention_impl == "svdq" and attn0.head_dim == 128:
+            kv_valid = kv_valid_ranges(t_txt, t_img)
+        if kv_valid is not None:
+            enc, hidden = F.pad(enc, (0, 0, 0, p_txt - t_txt)), F.pad(hidden, (0, 0, 0, p_img - t_img))
+            rot_all = pack_rotemb(torch.cat([rot_t, rot_i], dim=1))
+        else:
+            p_txt = t_txt
+            rot_all = pack_rotemb(pad_tensor(rot, 256, 1))
 
         fused = self.fused_norm and hidden.shape[0] == 1
         stats = ((residual_gate_stats(hidden)[1], None), (residual_gate_stats(enc)[1], None)) if fused else None
@@ -503,14 +528,33 @@ class FluxEngineMixin:
         mods = awq_gemv_w4a16_batched(temb_act, [m for b in self.blocks for m in (b.mod, b.mod_context)] +
                                       [b.mod for b in self.single_blocks]) if fused and self.batched_mods else None
         nj = len(self.blocks)
+
+        def control(samples, i, n_blocks):
+            """diffusers' choice of the ControlNet residual behind block i, as a [1, rows of the (padded) image stream, dim] tensor"""
+            n = len(samples)
+            smp = samples[i % n] if controlnet_blocks_repeat else samples[i // -(-n_blocks // n)]
+            return F.pad(smp.to(hidden.dtype), (0, 0, 0, hidden.shape[1] - smp.shape[1])) if smp.shape[1] != hidden.shape[1] else smp.to(hidden.dtype)
+
         for i, blk in enumerate(self.blocks):
             enc, hidden, stats = blk(hidden, enc, temb_act, (rot_img, rot_txt, rot_all), stats,
-                                     mods=(mods[2 * i], mods[2 * i + 1]) if mods is not None else None)
+                                     mods=(mods[2 * i], mods[2 * i + 1]) if mods is not None else None, kv_valid=kv_valid)
+            if controlnet_block_samples is not None:
+                # hidden_states + sample (one 16-bit add); the fused path needs the LayerNorm statistics of the sum: the same pass
+                hidden, h_stats = residual_gate_stats(hidden, control(controlnet_block_samples, i, nj), want_stats=fused)
+                if fused:
+                    stats = ((h_stats, stats[0][1]), stats[1])
+        t_pad = enc.shape[1]
         hidden = torch.cat([enc, hidden], dim=1)
         stats = (torch.cat([stats[1][0], stats[0][0]], dim=0), None) if fused else None  # [txt; img] row order
         for i, blk in enumerate(self.single_blocks):
-            hidden, stats = blk(hidden, temb_act, rot_all, stats, mods=mods[2 * nj + i] if mods is not None else None)
-        hidden = hidden[:, t_txt:]
+            hidden, stats = blk(hidden, temb_act, rot_all, stats, mods=mods[2 * nj + i] if mods is not None else None, kv_valid=kv_valid)
+            if controlnet_single_block_samples is not None:
+                img_rows = hidden[:, t_pad:]
+                smp = control(controlnet_single_block_samples, i, len(self.single_blocks))
+                _, i_stats = residual_gate_stats(img_rows, F.pad(smp, (0, 0, 0, img_rows.shape[1] - smp.shape[1])), want_stats=fused)
+                if fused:
+                    stats[0][t_pad:] = i_stats
+        hidden = hidden[:, p_txt:p_txt + t_img]
         scale, shift = self.norm_out_mod(temb_act).chunk(2, dim=-1)  # AdaLayerNormContinuous
         hidden = F.layer_norm(hidden, (self.dim,), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]
         return self.proj_out(hidden)

@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops.attention import attention_packed, attention_packed_quantized, q_prescale
+from ..ops.attention import attention_packed, attention_packed_quantized, kv_valid_ranges, q_prescale
 from ..ops.elementwise import residual_gate_stats, residual_gate_stats_pair
 from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rottary, fused_qkv_norm_rottary_pair, linear_pair,
                          linear_pair_quantized)
@@ -86,7 +86,7 @@ class NunchakuQwenAttention(nn.Module):
         self.added_kv_proj_dim = dim
 
     def forward(self, hidden_states, encoder_hidden_states, encoder_hidden_states_mask=None, attention_mask=None,
-                image_rotary_emb=None, **kwargs):
+                image_rotary_emb=None, kv_valid=None, **kwargs):
         """-> (image stream output, text stream output), as the reference's processor returns them.
         ``image_rotary_emb`` = (img_freqs, txt_freqs) complex ``[T, 64]`` (diffusers ``QwenEmbedRope``) or, precomputed
         once per forward by the model, the packed real tables of :func:`pack_qwen_rotary`."""
@@ -109,15 +109,17 @@ class NunchakuQwenAttention(nn.Module):
                                        output=qkv[:t_txt], out_vt=vt[:, :t_txt], q_scale=qs)
                 fused_qkv_norm_rottary(hidden_states, self.to_qkv, self.norm_q, self.norm_k, packed["img"], output=qkv[t_txt:],
                                        out_vt=vt[:, t_txt:], q_scale=qs)
-            o = attention_packed(qkv, vt, self.heads, q_prescaled=True).unsqueeze(0)
+            o = attention_packed(qkv, vt, self.heads, q_prescaled=True, kv_valid=kv_valid).unsqueeze(0)
         else:
+            if kv_valid is not None:
+                raise RuntimeError("NunchakuQwenAttention: padded token streams need the fused QKV path (fused_qkv, batch 1, head_dim 128)")
             o = self._reference_ops(hidden_states, encoder_hidden_states, packed)
         if t_txt % 256 == 0 and B == 1:
             txt, img = linear_pair(o[:, :t_txt], self.to_add_out, o[:, t_txt:], self.to_out[0])
             return img, txt
         return self.to_out[0](o[:, t_txt:]), self.to_add_out(o[:, :t_txt])
 
-    def forward_fused_norm(self, hidden, enc, packed, ln_img, ln_txt):
+    def forward_fused_norm(self, hidden, enc, packed, ln_img, ln_txt, kv_valid=None):
         """The block's fused path (``NunchakuQwenImageTransformerBlock.forward_fused``): ``hidden`` / ``enc`` are the UN-normalised
         streams, LayerNorm + modulation run inside the QKV quantiser (``ln_* = (stats, scale incl. +1, shift, ZeroPool)``), both
         streams share every launch, the attention epilogue emits the output projections' quantised input.  B = 1, token counts
@@ -131,11 +133,13 @@ class NunchakuQwenAttention(nn.Module):
         if not ok:
             raise RuntimeError("forward_fused_norm: the two streams' projections cannot share a launch (shapes / ranks differ)")
         qres = attention_packed_quantized(qkv, vt, self.heads, self.to_out[0], lin_first=self.to_add_out, split_rows=t_txt, pool=ln_txt[3],
-                                          q_prescaled=True)
+                                          q_prescaled=True, kv_valid=kv_valid)
         if qres is not None:
             txt, img = linear_pair_quantized(*qres, self.to_add_out, self.to_out[0], t_txt)
             return img, txt
-        o = attention_packed(qkv, vt, self.heads).unsqueeze(0)
+        # (rank > 32 -- e.g. the r128 checkpoints -- or a runtime LoRA on the output projections: the attention epilogue cannot emit their quantised
+        #  input; Q left the QKV GEMM prescaled all the same)
+        o = attention_packed(qkv, vt, self.heads, q_prescaled=True, kv_valid=kv_valid).unsqueeze(0)
         txt, img = linear_pair(o[:, :t_txt], self.to_add_out, o[:, t_txt:], self.to_out[0])
         return img, txt
 
@@ -177,7 +181,9 @@ def pack_qwen_rotary(img_freqs: torch.Tensor, txt_freqs: torch.Tensor) -> dict:
         return pack_rotemb(pad_tensor(sin_cos, 256, 1))
 
     ic, tc = cs(img_freqs), cs(txt_freqs)
-    return {"img": packed(ic), "txt": packed(tc), "all": packed(torch.cat([tc, ic], dim=0)), "img_cs": ic, "txt_cs": tc}
+    # "all": the joint [text | image] sequence with EVERY stream on a 256-row boundary (zero entries for the padding rows in between)
+    tc_pad = F.pad(tc, (0, 0, 0, 0, 0, -tc.shape[0] % 256))
+    return {"img": packed(ic), "txt": packed(tc), "all": packed(torch.cat([tc_pad, ic], dim=0)), "img_cs": ic, "txt_cs": tc}
 
 
 def qwen_rope_freqs(img_shape: tuple[int, int, int], txt_len: int, axes_dim=(16, 56, 56), theta: float = 10000.0,
@@ -245,7 +251,7 @@ class NunchakuQwenImageTransformerBlock(nn.Module):
             outs.append(m)
         return outs
 
-    def forward_fused(self, hidden, enc, temb_act, packed_rot, stats, mods=None):
+    def forward_fused(self, hidden, enc, temb_act, packed_rot, stats, mods=None, kv_valid=None):
         """The block on this library's fused passes (B = 1, token counts multiples of 256): LayerNorm + modulation inside the
         quantisers, gated residual + the next LayerNorm's statistics in one element-wise pass per stage (both streams per launch),
         grouped GEMM launches, attention-side quantiser.  Same 16-bit rounding points as :meth:`forward`'s torch ops (the fused
@@ -254,7 +260,8 @@ class NunchakuQwenImageTransformerBlock(nn.Module):
         (e_stats, pool), h_stats = stats
         im, tm = mods if mods is not None else self.modulation(temb_act)
         att = self.attn
-        img_a, txt_a = att.forward_fused_norm(hidden, enc, packed_rot, ln_img=(h_stats, im[1], im[0]), ln_txt=(e_stats, tm[1], tm[0], pool))
+        img_a, txt_a = att.forward_fused_norm(hidden, enc, packed_rot, ln_img=(h_stats, im[1], im[0]), ln_txt=(e_stats, tm[1], tm[0], pool),
+                                              kv_valid=kv_valid)
         mp = _pad256(hidden.shape[1]) + _pad256(enc.shape[1])
         r_mlp = self.img_mlp.net[0].proj.rank + self.img_mlp.net[2].rank
         enc, e_stats, hidden, h_stats, pool = residual_gate_stats_pair(enc, txt_a, tm[2], hidden, img_a, im[2], zero_floats=mp * r_mlp)
@@ -266,7 +273,7 @@ class NunchakuQwenImageTransformerBlock(nn.Module):
         return enc, hidden, ((e_stats, pool), h_stats)
 
     def forward(self, hidden_states, encoder_hidden_states, encoder_hidden_states_mask=None, temb=None, image_rotary_emb=None,
-                joint_attention_kwargs=None):
+                joint_attention_kwargs=None, kv_valid=None):
         B = temb.shape[0]
         # nunchaku's modulation weights are stored channel-interleaved: [B, dim * 6] -> [B, 6 * dim] (:236-243)
         img_mod = self.img_mod(temb).view(B, -1, 6).transpose(1, 2).reshape(B, -1)
@@ -276,7 +283,7 @@ class NunchakuQwenImageTransformerBlock(nn.Module):
         img_x, img_gate1 = self._modulate(self.img_norm1(hidden_states), img_mod1)
         txt_x, txt_gate1 = self._modulate(self.txt_norm1(encoder_hidden_states), txt_mod1)
         img_attn, txt_attn = self.attn(hidden_states=img_x, encoder_hidden_states=txt_x, encoder_hidden_states_mask=encoder_hidden_states_mask,
-                                       image_rotary_emb=image_rotary_emb, **(joint_attention_kwargs or {}))
+                                       image_rotary_emb=image_rotary_emb, kv_valid=kv_valid, **(joint_attention_kwargs or {}))
         hidden_states = hidden_states + img_gate1 * img_attn
         encoder_hidden_states = encoder_hidden_states + txt_gate1 * txt_attn
         img_x2, img_gate2 = self._modulate(self.img_norm2(hidden_states), img_mod2)
@@ -329,6 +336,8 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
     fused_norm = True
     # True: all modulation GEMVs of a step in one batched launch (resident models only)
     batched_mods = True
+    # True: both token streams are padded to 256 rows inside forward(), so that every token count runs the fused path (False: A/B)
+    padded_tokens = True
 
     def __init__(self, num_layers: int = 60, num_attention_heads: int = 24, attention_head_dim: int = 128, in_channels: int = 64,
                  out_channels: int = 16, joint_attention_dim: int = 3584, patch_size: int = 2, axes_dims_rope=(16, 56, 56),
@@ -473,7 +482,7 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
         hidden = self.img_in(hidden_states)
         enc = self.txt_in(self.txt_norm(encoder_hidden_states))
         temb = self.time_text_embed(timestep.to(dt), dt)
-        t_txt = enc.shape[1]
+        t_txt, t_img = enc.shape[1], hidden.shape[1]
         shape = img_shapes[0] if img_shapes else (1, int(math.isqrt(hidden.shape[1])), int(math.isqrt(hidden.shape[1])))
         if isinstance(shape, (list, tuple)) and isinstance(shape[0], (list, tuple)):
             shape = shape[0]
@@ -481,8 +490,16 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
         compute_stream = torch.cuda.current_stream()
         if self.offload:
             self.offload_manager.initialize(compute_stream)
-        fused = (self.fused_norm and hidden.shape[0] == 1 and t_txt % 256 == 0 and hidden.shape[1] % 256 == 0 and NunchakuQwenAttention.fused_qkv
-                 and not attention_kwargs and encoder_hidden_states_mask is None)
+        # EVERY token count runs the hot path (the reference pads any M to 256 rows, Linear.cpp:445-446; its own quality gate is 1664 x 928 =
+        # 6032 image tokens, tests/v1/qwenimage/test_qwenimage.py:21,118, and a prompt's text length is arbitrary): both streams are padded to
+        # 256 rows with zero tokens behind the embedders, the attention kernel masks the padded keys (kv_valid), the real image rows are
+        # sliced out at the end.  `encoder_hidden_states_mask` is accepted and ignored, as the reference's processor ignores it
+        # (attention_processors/qwenimage.py: the batch-1 pipeline passes an all-ones mask).
+        hot = hidden.shape[0] == 1 and NunchakuQwenAttention.fused_qkv and self.transformer_blocks[0].attn.head_dim == 128 and not attention_kwargs
+        kv_valid = kv_valid_ranges(t_txt, t_img) if hot and self.padded_tokens else None
+        if kv_valid is not None:
+            enc, hidden = F.pad(enc, (0, 0, 0, -t_txt % 256)), F.pad(hidden, (0, 0, 0, -t_img % 256))
+        fused = self.fused_norm and hot and enc.shape[1] % 256 == 0 and hidden.shape[1] % 256 == 0
         stats = mods = temb_act = None
         if fused:
             temb_act = F.silu(temb)  # img_mod[0] / txt_mod[0] of every block: the same SiLU of the same embedding
@@ -502,12 +519,13 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
             if self.offload:
                 block = self.offload_manager.get_block(i)
             if fused:
-                enc, hidden, stats = block.forward_fused(hidden, enc, temb_act, rot, stats, mods=None if mods is None else mods[i])
+                enc, hidden, stats = block.forward_fused(hidden, enc, temb_act, rot, stats, mods=None if mods is None else mods[i], kv_valid=kv_valid)
             else:
                 enc, hidden = block(hidden_states=hidden, encoder_hidden_states=enc, encoder_hidden_states_mask=encoder_hidden_states_mask,
-                                    temb=temb, image_rotary_emb=rot, joint_attention_kwargs=attention_kwargs)
+                                    temb=temb, image_rotary_emb=rot, joint_attention_kwargs=attention_kwargs, kv_valid=kv_valid)
             if self.offload:
                 self.offload_manager.step(compute_stream)
+        hidden = hidden[:, :t_img]
         scale, shift = self.norm_out["linear"](F.silu(temb)).chunk(2, dim=-1)  # AdaLayerNormContinuous
         hidden = F.layer_norm(hidden, (self.inner_dim,), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]
         out = self.proj_out(hidden)

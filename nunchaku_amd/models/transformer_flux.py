@@ -170,15 +170,16 @@ class NunchakuFluxTransformer2DModelV2(_Base, FluxEngineMixin, NunchakuModelLoad
                 controlnet_blocks_repeat: bool = False):
         """The ``FluxPipeline`` call (reference :430-561): ``timestep`` arrives divided by 1000, ids as [T, 3] (a leading
         batch axis, deprecated in diffusers, is dropped as the reference does :505-517)."""
-        if controlnet_block_samples is not None or controlnet_single_block_samples is not None:
-            raise NotImplementedError("ControlNet residuals are out of scope (SURVEY.md section 8)")
         if txt_ids is not None and txt_ids.ndim == 3:
             txt_ids = txt_ids[0]
         if img_ids is not None and img_ids.ndim == 3:
             img_ids = img_ids[0]
         if self.guidance_embed is not None and guidance is None:
             raise ValueError("this checkpoint has guidance embeddings: pass guidance")
-        out = self.engine_forward(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance)
+        # ControlNet residuals: per-block additions to the image stream with diffusers' indexing (the reference's V2 forward raises here,
+        # transformer_flux_v2.py:537-552; its legacy model and diffusers' FluxTransformer2DModel accept them)
+        out = self.engine_forward(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance,
+                                  controlnet_block_samples, controlnet_single_block_samples, controlnet_blocks_repeat)
         return Transformer2DModelOutput(sample=out) if return_dict else (out,)
 
 

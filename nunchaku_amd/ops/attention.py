@@ -24,13 +24,29 @@ def q_prescale(head_dim: int = 128, scale: float | None = None) -> float:
     return (1.0 / math.sqrt(head_dim) if scale is None else scale) * 1.4426950408889634
 
 
+def kv_valid_ranges(t_first: int, t_second: int = 0, pad: int = 256):
+    """Key ranges of a [first | second] token sequence whose streams are each padded to ``pad`` rows (what the grouped launches need: every
+    stream starts on a 256-row boundary): ``None`` when nothing is padded, ``(n,)`` when only the tail is, ``(n0, start1, end1)`` when the
+    padding of the first stream sits in the middle -- the forms ``ops.attention(kv_valid=...)`` takes."""
+    p_first = (t_first + pad - 1) // pad * pad
+    p_second = (t_second + pad - 1) // pad * pad
+    if p_first == t_first and p_second == t_second:
+        return None
+    if t_second == 0:
+        return (t_first,)
+    if p_first == t_first:
+        return (t_first + t_second,)
+    return (t_first, p_first, p_first + t_second)
+
+
 def attention_packed(qkv: torch.Tensor, vt: torch.Tensor, heads: int, out: torch.Tensor | None = None,
-                     scale: float | None = None, zero_floats: int = 0, q_prescaled: bool = False):
+                     scale: float | None = None, zero_floats: int = 0, q_prescaled: bool = False, kv_valid=None):
     """``softmax(scale * Q K^T) V`` per head, reading Q and K in place from the fused QKV GEMM output
     ``qkv`` [L, 3*H*128] and V from its transposed side output ``vt`` [H*128, L]; returns ``[L, H*128]``
     token-major (the layout the output projection's quantiser reads).  No transposes, no copies.
     ``zero_floats`` > 0: also returns a ``ZeroPool`` of that many fp32 zeros cleared by the same launch (the low-rank
-    accumulators of the output projections' quantisers): ``(out, pool)``."""
+    accumulators of the output projections' quantisers): ``(out, pool)``.  ``kv_valid``: the real key rows of a padded buffer
+    (:func:`kv_valid_ranges`); the other keys get probability 0."""
     L, three_hd = qkv.shape
     D = three_hd // (3 * heads)
     if three_hd != 3 * heads * D or tuple(vt.shape) != (heads * D, L):
@@ -42,7 +58,7 @@ def attention_packed(qkv: torch.Tensor, vt: torch.Tensor, heads: int, out: torch
     zwords = zero_floats * lora_act_words()
     zero = torch.empty((zwords + 3) // 4 * 4, dtype=torch.float32, device=qkv.device) if zero_floats > 0 else None
     ops.attention(q, k, vt.unflatten(0, (heads, D)), out.unflatten(1, (heads, D)), 1.0 / math.sqrt(D) if scale is None else scale, zero,
-                  q_prescaled=q_prescaled)
+                  q_prescaled=q_prescaled, kv_valid=kv_valid)
     if zero_floats > 0:
         from .elementwise import ZeroPool
 
@@ -51,7 +67,7 @@ def attention_packed(qkv: torch.Tensor, vt: torch.Tensor, heads: int, out: torch
 
 
 def attention_packed_quantized(qkv: torch.Tensor, vt: torch.Tensor, heads: int, lin, lin_first=None, split_rows: int = 0,
-                               pool=None, scale: float | None = None, q_prescaled: bool = False):
+                               pool=None, scale: float | None = None, q_prescaled: bool = False, kv_valid=None):
     """Attention whose epilogue emits the quantised input of the output projection ``lin`` directly (codes, scales and
     low-rank down projection: what ``lin.quantize(attention_packed(...))`` would return, without the 16-bit round trip).
     Joint attention: rows ``< split_rows`` belong to ``lin_first`` (text), the rest to ``lin``.  ``pool``: a ZeroPool for
@@ -78,5 +94,6 @@ def attention_packed_quantized(qkv: torch.Tensor, vt: torch.Tensor, heads: int, 
         quant.update(smooth=lin.smooth_factor, lora_down=lin.proj_down)
     q = qkv[:, : heads * D].unflatten(1, (heads, D))
     k = qkv[:, heads * D : 2 * heads * D].unflatten(1, (heads, D))
-    ops.attention(q, k, vt.unflatten(0, (heads, D)), None, 1.0 / math.sqrt(D) if scale is None else scale, None, quant, q_prescaled=q_prescaled)
+    ops.attention(q, k, vt.unflatten(0, (heads, D)), None, 1.0 / math.sqrt(D) if scale is None else scale, None, quant, q_prescaled=q_prescaled,
+                  kv_valid=kv_valid)
     return act, asc, lact

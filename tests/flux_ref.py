@@ -57,7 +57,9 @@ class Ref:
         o = torch.softmax(q @ k.transpose(1, 2) / 128 ** 0.5, dim=-1) @ v
         return r16(o.transpose(0, 1).reshape(T, heads * 128))
 
-    def forward(self, lat, enc, pooled, t, img_ids, txt_ids, g):
+    def forward(self, lat, enc, pooled, t, img_ids, txt_ids, g, control=None, control_single=None):
+        """``control`` / ``control_single``: one ControlNet residual [T_img, dim] added to the image stream behind the joint / the single
+        block (diffusers' FluxTransformer2DModel.forward: a 16-bit add)"""
         from nunchaku_amd.models.flux import timestep_embedding
         from nunchaku_amd.models.embeddings import flux_pos_embed
         m = self.m
@@ -83,6 +85,8 @@ class Ref:
         hidden = r16(hidden + r16(mm[5][None] * self.mlp("transformer_blocks.0.ff.net.0.proj", "transformer_blocks.0.ff.net.2", self.ln_mod(hidden, mm[4], mm[3]))))
         e = r16(e + r16(cc[2][None] * ca))
         e = r16(e + r16(cc[5][None] * self.mlp("transformer_blocks.0.ff_context.net.0.proj", "transformer_blocks.0.ff_context.net.2", self.ln_mod(e, cc[4], cc[3]))))
+        if control is not None:
+            hidden = r16(hidden + control)
         x = torch.cat([e, hidden])
         s = m.single_blocks[0]
         sm = self.awq("single_transformer_blocks.0.norm.linear", ta).view(-1, 3).T
@@ -91,6 +95,8 @@ class Ref:
         att = self.svdq("single_transformer_blocks.0.attn.to_out",
                         self.attend(self.qkv("single_transformer_blocks.0.attn.to_qkv", n, s.attn.norm_q.weight, s.attn.norm_k.weight, rot), s.attn.heads))
         x = r16(x + r16(sm[2][None] * r16(att + mlp)))[tt:]
+        if control_single is not None:
+            x = r16(x + control_single)
         sc, sh = self.lin(m.norm_out_mod, ta).chunk(2, dim=-1)
         x = r16(r16(F.layer_norm(x, (x.shape[-1],), eps=1e-6)) * r16(1 + sc) + sh)
         return self.lin(m.proj_out, x)
@@ -131,14 +137,16 @@ def fill_model_(model, seed: int = 0, realistic: bool = False, rank: int = 32, l
     return layers
 
 
-def synthetic_inputs(side: int, t_txt: int, joint_dim: int, pooled_dim: int, seed: int = 1):
+def synthetic_inputs(side, t_txt: int, joint_dim: int, pooled_dim: int, seed: int = 1):
+    """``side``: the latent grid, an int (square) or (height, width) in 2 x 2 patches -- e.g. (58, 104) for 1664 x 928 pixels"""
+    h, w = (side, side) if isinstance(side, int) else side
     g = torch.Generator().manual_seed(seed)
-    lat = r16(torch.randn(side * side, 64, generator=g))
+    lat = r16(torch.randn(h * w, 64, generator=g))
     enc = r16(torch.randn(t_txt, joint_dim, generator=g))
     pooled = r16(torch.randn(1, pooled_dim, generator=g))
-    img_ids = torch.zeros(side * side, 3)
-    img_ids[:, 1] = torch.arange(side).repeat_interleave(side)
-    img_ids[:, 2] = torch.arange(side).repeat(side)
+    img_ids = torch.zeros(h * w, 3)
+    img_ids[:, 1] = torch.arange(h).repeat_interleave(w)
+    img_ids[:, 2] = torch.arange(w).repeat(h)
     return lat, enc, pooled, img_ids, torch.zeros(t_txt, 3)
 
 

@@ -100,15 +100,17 @@ class BlockTwin:
         return enc, hidden
 
 
-def _block_inputs(dim, t_img, t_txt, seed=1):
+def _block_inputs(dim, t_img, t_txt, seed=1, grid=None):
     from nunchaku_amd.models.qwenimage import qwen_rope_freqs
 
     g = torch.Generator().manual_seed(seed)
     side = int(t_img ** 0.5)
+    grid = grid or (side, side)
+    assert grid[0] * grid[1] == t_img
     hidden = r16(torch.randn(t_img, dim, generator=g))
     enc = r16(torch.randn(t_txt, dim, generator=g))
     temb = r16(torch.randn(1, dim, generator=g))
-    img_f, txt_f = qwen_rope_freqs((1, side, side), t_txt)
+    img_f, txt_f = qwen_rope_freqs((1, grid[0], grid[1]), t_txt)
     return hidden, enc, temb, img_f, txt_f
 
 
@@ -276,3 +278,83 @@ def test_qwen_rope_tables():
     assert torch.allclose(img[8 * 16, 8:36], torch.ones(28, dtype=torch.complex64), atol=1e-6)  # height position 0
     p = pack_qwen_rotary(img, txt)
     assert p["img"].shape == (1, 256, 128) and p["txt"].shape == (1, 256, 128) and p["all"].shape == (1, 512, 128)
+
+
+def _attention_launches(fn):
+    import ctypes as C
+
+    from nunchaku_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.svdq_prof_select(1 << 2), "svdq_prof_select")
+    _lib.check(lib.svdq_prof_enable(256), "svdq_prof_enable")
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        n, ms, work = C.c_int64(0), C.c_double(0), C.c_double(0)
+        _lib.check(lib.svdq_prof_read(2, C.byref(n), C.byref(ms), C.byref(work)), "svdq_prof_read")
+    finally:
+        lib.svdq_prof_enable(0)
+        lib.svdq_prof_select(0xFFFFFFFF)
+    return out, n.value
+
+
+# the reference's own Qwen-Image quality gate runs 1664 x 928 (tests/v1/qwenimage/test_qwenimage.py:21,118): a 58 x 104 grid of
+# 2 x 2 latent patches = 6032 image tokens, and a prompt's text length is arbitrary.  The block on padded streams ([text | pad | image | pad],
+# padded keys masked by the attention kernel) against the twin of the reference's op sequence at the natural sizes.
+@pytest.mark.parametrize("grid,t_txt", [((58, 104), 37), ((13, 20), 300)], ids=["1664x928", "320x208"])
+def test_qwen_block_on_padded_streams_matches_the_reference_op_sequence(grid, t_txt):
+    from nunchaku_amd.models.qwenimage import NunchakuQwenImageTransformerBlock, pack_qwen_rotary
+    from nunchaku_amd.ops.attention import kv_valid_ranges
+
+    dim, t_img = 256, grid[0] * grid[1]
+    block = NunchakuQwenImageTransformerBlock(dim, 2, 128, device="cuda").eval()
+    layers = _fill(block, seed=4)
+    hidden, enc, temb, img_f, txt_f = _block_inputs(dim, t_img, t_txt, seed=2, grid=grid)
+    cs = lambda f: torch.stack([f.real.float(), f.imag.float()], dim=-1)
+    kv = kv_valid_ranges(t_txt, t_img)
+    assert kv is not None and len(kv) == 3  # padding in the middle of the joint sequence
+    pad = lambda x: F.pad(x.cuda().bfloat16(), (0, 0, 0, -x.shape[0] % 256))[None]
+    with torch.no_grad():
+        e_ref, h_ref = BlockTwin(block, layers).forward(hidden, enc, temb, cs(img_f), cs(txt_f))
+        (e, h), launches = _attention_launches(lambda: block(pad(hidden), pad(enc), None, temb.cuda().bfloat16(),
+                                                             pack_qwen_rotary(img_f.cuda(), txt_f.cuda()), kv_valid=kv))
+    assert launches == 1, "the block did not run svdq_attention"
+    for name, got, ref in (("text", e[0, :t_txt].float().cpu(), e_ref), ("image", h[0, :t_img].float().cpu(), h_ref)):
+        psnr, rel = psnr_rel(got, ref)
+        print(f"qwen block {grid} + {t_txt} tokens, padded streams, {name}: PSNR {psnr:.1f} dB rel {rel:.2e}")
+        assert torch.isfinite(got).all() and psnr > 45.0 and rel < 2e-2, (name, psnr, rel)
+    assert torch.isfinite(e).all() and torch.isfinite(h).all()  # the padded rows stay finite (they are V^T columns of the next block)
+
+
+@pytest.mark.parametrize("rank", [32, 64], ids=["r32", "r64"])
+def test_qwen_model_odd_token_counts_run_the_fused_path(rank):
+    """The model pads both streams itself and keeps the fused path -- with the pipeline's real call signature (an all-ones
+    ``encoder_hidden_states_mask``, ignored as the reference's processor ignores it) -- against the reference's torch-op block sequence with no
+    padding anywhere.  rank 64: the attention epilogue cannot emit the output projections' quantised input (rank > 32), the fallback attention
+    call reads the PRESCALED Q (it used to apply the softmax scale twice)."""
+    from nunchaku_amd import mode
+    from nunchaku_amd.models.qwenimage import NunchakuQwenAttention, NunchakuQwenImageTransformer2DModel
+
+    layers, grid, t_txt = 2, (13, 20), 37
+    model = NunchakuQwenImageTransformer2DModel(num_layers=layers, num_attention_heads=2, attention_head_dim=128, in_channels=64, out_channels=16,
+                                                joint_attention_dim=128, rank=rank, device="cuda").init_synthetic_(seed=7).eval()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    lat = torch.randn(1, grid[0] * grid[1], 64, device="cuda", generator=g).bfloat16()
+    enc = torch.randn(1, t_txt, 128, device="cuda", generator=g).bfloat16()
+    mask = torch.ones(1, t_txt, dtype=torch.long, device="cuda")
+    t = torch.tensor([0.3], device="cuda")
+    call = lambda: model(lat, enc, mask, t, [(1, grid[0], grid[1])], txt_seq_lens=[t_txt]).sample.float()
+    with torch.no_grad(), mode.deterministic_mode():
+        hot, launches = _attention_launches(call)
+        assert launches == layers, f"{launches} svdq_attention launches for {layers} blocks"
+        assert torch.equal(hot, call())
+        NunchakuQwenImageTransformer2DModel.padded_tokens, NunchakuQwenAttention.fused_qkv = False, False
+        try:
+            plain, launches = _attention_launches(call)
+        finally:
+            NunchakuQwenImageTransformer2DModel.padded_tokens, NunchakuQwenAttention.fused_qkv = True, True
+        assert launches == 0
+    assert hot.shape == plain.shape == (1, grid[0] * grid[1], 64) and torch.isfinite(hot).all()
+    psnr, rel = psnr_rel(hot.cpu(), plain.cpu())
+    print(f"qwen model rank {rank}, {grid} + {t_txt} tokens: padded fused path vs unpadded torch-op blocks {psnr:.1f} dB rel {rel:.2e}")
+    assert psnr > 40.0 and rel < 3e-2, (psnr, rel)

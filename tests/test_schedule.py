@@ -85,7 +85,7 @@ def test_launches_without_stream_k_run_whole_rounds_on_fewer_workgroups():
 def test_invalid_shapes_are_rejected():
     lib = _lib.load()
     assert lib.svdq_gemm_schedule(100, 128, 128, 256, 0, None, 0) == -1
-    assert lib.svdq_gemm_schedule_ex(256, 128, 128, 256, 0, 3, None, 0) == -1  # the replay knows geometries 1 and 2
+    assert lib.svdq_gemm_schedule_ex(256, 128, 128, 256, 0, 6, None, 0) == -1  # the replay knows geometries 1, 2 and 3 (row runs)
     assert lib.svdq_gemm_schedule(256, 128, 64, 256, 0, None, 0) == -1
 
 
@@ -154,3 +154,33 @@ def test_attention_schedule_plain_grid_cases_and_errors(built_lib):
     assert lib.svdq_attention_schedule(384, 4, 256, None, 0) == 0    # L % 256 != 0: the 4-wave kernel
     assert lib.svdq_attention_schedule(200, 4, 256, None, 0) == -1
     assert lib.svdq_attention_schedule(256, 0, 256, None, 0) == -1
+
+
+# row runs: the schedule of a GELU_QUANT launch with a next-layer low-rank branch (gemm_w4a4.hip "row runs", GemmSchedule::init_runs)
+@pytest.mark.parametrize("M_pad,N", [(4608, 12288), (4096, 12288), (1536, 12288), (4608, 3072), (2560, 1152), (9216, 12288)])
+@pytest.mark.parametrize("cus", [256, 64, 24, 8])
+def test_row_runs_cover_every_tile_once_and_stay_inside_a_row_block(M_pad, N, cus):
+    lib = _lib.load()
+    TM, TN = M_pad // 256, N // 128
+    n = lib.svdq_gemm_schedule_ex(M_pad, N, 3072, cus, 1, 3, None, 0)
+    if TM * TN < 2 * cus:
+        assert n == -1  # fewer than two tiles per workgroup: the plain schedule
+        return
+    seg = schedule(M_pad, N, 3072, cus, 1, geometry=3)
+    assert len(seg) == TM * TN and sorted(seg[:, 1].tolist()) == list(range(TM * TN))  # every tile once, whole (no K split)
+    assert (seg[:, 2] == 0).all() and (seg[:, 3] == 3072 // 128).all()
+    grid = seg[:, 0].max() + 1
+    assert grid <= max(cus, TM)  # (more row blocks than slots: one whole-row run per row block, the surplus workgroups queue)
+    longest = 0
+    for pos in range(grid):
+        t = seg[seg[:, 0] == pos][:, 1]
+        if len(t) == 0:
+            continue
+        assert (np.diff(t) == 1).all()                 # consecutive column tiles ...
+        assert t[0] // TN == t[-1] // TN               # ... of ONE row block (row-major tile ids)
+        longest = max(longest, len(t))
+    # no more rounds than the plain schedule needs when the runs fit the slots
+    rounds = -(-TM * TN // cus)
+    assert longest >= min(rounds, TN)
+    if rounds <= TN and TM * -(-TN // rounds) <= cus:
+        assert longest == rounds

@@ -1,8 +1,12 @@
 """bench.py against another build of the library (SVDQ_LIB=path; tools only: the product loads nunchaku_amd/csrc/libsvdq_amd.so):
-same-box A/B of the whole denoise step.  Arguments are bench.py's."""
-import os, sys
+same-box A/B of the whole denoise step.  Arguments are bench.py's.  An older build is accepted when its argument structs are the
+current ones (ABI 17 -> 18 only added profiler sub-classes): the binding's ABI check is pointed at the library's own number."""
+import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nunchaku_amd._lib as _L
 _L._LIB_PATH = os.path.abspath(os.environ.get("SVDQ_LIB", _L._LIB_PATH))
+_v = ctypes.CDLL(_L._LIB_PATH).svdq_abi_version()
+if _v in (17, 18):
+    _L.ABI_VERSION = _v
 import bench
 bench.main()

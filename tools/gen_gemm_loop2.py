@@ -70,7 +70,7 @@ S_NA, S_NX1, S_NX2 = 62, 64, 66
 SRD_A, SRD_X1, SRD_X2 = 72, 76, 80
 S_KOFF, S_KOFF2, S_DSTEP, S_STG = 84, 85, 86, 87
 S_PHASE = 52  # in ("dph" builds): 1 for waves 4..7
-# staging of the epilogue operands (nw = 8): in: s51 flags (bit 0: low-rank operands, bit 1: bias; bits 8..10: wave), s54 LDS address of the
+# staging of the epilogue operands (nw = 8): in: s51 flags (bit 0: low-rank operands, bit 1: bias, bit 2: of the low-rank operands only lora_up; bits 8..10: wave), s54 LDS address of the
 # staging region, s[88:89] this wave's 4 KiB of lora_act_in, s[90:91] its 1 KiB of lora_up, s[92:93] the tile's 256 bytes of bias
 S_STGF, S_STGB, S_SLA, S_SLU, S_SB = 51, 54, 88, 90, 92
 STG_LU, STG_BIAS = 32768, 40960   # offsets inside the staging region (lora_act_in at 0)
@@ -209,6 +209,8 @@ class Gen:
             f"s_add_u32 m0, m0, {STG_LU}",
             "s_nop 0",
             f"global_load_lds_dwordx4 {vr(OFF_A)}, {sr(S_SLU, 2)}",
+            f"s_bitcmp1_b32 {sr(S_STGF)}, 2",                                 # bit 2: lora_up only (the lora_act_in slot of the region holds the
+            f"s_cbranch_scc1 {Lno}",                                          #        workgroup's low-rank-down carry: gemm_w4a4.hip "row runs")
             f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 2",                        # wave * 4096
             f"s_add_u32 m0, {sr(S_STGB)}, {sr(S_TMP)}",
         ]
