@@ -48,26 +48,87 @@ FLUX_STEP_GOP = 59.5e3 + 0.83e3
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_profile_bench.sh), FETCH_SIZE doubled as
 # MI355X_MICROARCH.md prescribes for gfx950.  PMC counters cannot be read from inside the timed run: the line carries the
 # COMMITTED measurement of the same command and says so ("traffic_source"); null when the profile file is absent.
-TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r3_bench_gemm_hbm_counters.json", "r2_bench_gemm_hbm_counters.json")]
-MFMA_PROFILE = os.path.join(ROOT, "profiles", "r3_bench_gemm_mfma_util.json")
+# Both files carry "csrc_sha16": the hash of the kernel sources they were measured on (kernel_sources_sha16 below, stamped by
+# tools/gpu/r4_profile_bench.sh); a line printed from a tree whose kernels changed since says "stale": true next to the number.
+TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r4_bench_gemm_hbm_counters.json", "r3_bench_gemm_hbm_counters.json")]
+MFMA_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r4_bench_gemm_mfma_util.json", "r3_bench_gemm_mfma_util.json")]
+
+
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources of the library: nunchaku_amd/csrc/*.{hip,h,inc} in name order"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "nunchaku_amd", "csrc", "*"))):
+        if path.endswith((".hip", ".h", ".inc")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def committed_traffic():
+    """-> (bytes per launch, file, measured on these kernel sources?)"""
     for path in TRAFFIC_PROFILES:
         try:
             d = json.load(open(path))
-            return (2 * d["FETCH_SIZE"]["avg_per_dispatch_KB"] + d["WRITE_SIZE"]["avg_per_dispatch_KB"]) * 1024, os.path.relpath(path, ROOT)
+            return ((2 * d["FETCH_SIZE"]["avg_per_dispatch_KB"] + d["WRITE_SIZE"]["avg_per_dispatch_KB"]) * 1024, os.path.relpath(path, ROOT),
+                    d.get("csrc_sha16") == kernel_sources_sha16())
         except Exception:
             continue
-    return None, None
+    return None, None, False
 
 
 def committed_mfma_util():
-    """SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES over the gemm_w4a4 dispatches of this command (tools/gpu/r3_profile_bench.sh)."""
-    try:
-        return json.load(open(MFMA_PROFILE))
-    except Exception:
-        return None
+    """SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE over the gemm_w4a4 dispatches of this command (tools/gpu/r4_profile_bench.sh), with the
+    staleness stamp"""
+    for path in MFMA_PROFILES:
+        try:
+            d = json.load(open(path))
+            d["file"] = os.path.relpath(path, ROOT)
+            d["stale"] = d.get("csrc_sha16") != kernel_sources_sha16()
+            return d
+        except Exception:
+            continue
+    return None
+
+
+class ClockSampler:
+    """The shader clock during the timed region: the `*` line of the device's pp_dpm_sclk (what `rocm-smi --showclocks` prints), read every
+    50 ms by a thread.  profiles/r4_clock_instrument.txt: this reading agrees with GRBM_GUI_ACTIVE / dispatch duration within 1 % for the GEMM
+    launches (s_memtime does not: it undercounts in issue-sparse kernels)."""
+
+    def __init__(self, device_index: int):
+        import glob
+        import threading
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = cards[device_index] if device_index < len(cards) else None
+        self.samples, self._stop, self._thread = [], threading.Event(), None
+        if self.path:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        while not self._stop.is_set():
+            try:
+                m = re.search(r"(\d+)Mhz\s*\*", open(self.path).read())
+                if m:
+                    self.samples.append(int(m.group(1)))
+            except Exception:
+                pass
+            self._stop.wait(0.05)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+
+    def stop(self):
+        """median GHz of the samples (None when the file is not readable)"""
+        if not self._thread:
+            return None
+        self._stop.set()
+        self._thread.join()
+        xs = sorted(self.samples)
+        return xs[len(xs) // 2] / 1e3 if xs else None
 
 
 def cpu_baseline(max_seconds: float = 30.0):
@@ -121,7 +182,10 @@ def main():
                     help="qwen1024 only: layer-wise host offload with N blocks resident on the GPU (0 = everything resident)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
                     help="torch.distributed backend for --gpus > 1 (default: nccl = RCCL; gloo lets several ranks share one GPU: smoke tests)")
-    ap.add_argument("--resolution", type=int, default=None)
+    ap.add_argument("--resolution", type=int, nargs="+", default=None, metavar="PIXELS",
+                    help="image size: one number (square) or WIDTH HEIGHT, multiples of 16 -- e.g. 1664 928, the reference's Qwen-Image quality "
+                         "gate (tests/v1/qwenimage/test_qwenimage.py:21): token counts that are not a multiple of 256 run the same fused path "
+                         "on padded streams")
     ap.add_argument("--txt-tokens", type=int, default=512)
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events in the timed region (their cost: ~0.5 %%)")
     ap.add_argument("--layers", type=int, nargs=2, default=(19, 38), help=argparse.SUPPRESS)  # debugging only
@@ -145,7 +209,11 @@ def main():
     if qwen and "--steps" not in " ".join(sys.argv):
         args.steps, args.warmup = 10, 2
     if args.resolution is None:
-        args.resolution = 512 if schnell else 1024
+        args.resolution = [512 if schnell else 1024]
+    if len(args.resolution) > 2 or any(r <= 0 or r % 16 for r in args.resolution):
+        ap.error("--resolution takes one or two positive multiples of 16")
+    width, height = args.resolution[0], args.resolution[-1]
+    res_name = f"{width}x{height}"
     if schnell and "--steps" not in " ".join(sys.argv):
         args.steps, args.warmup = 4 * 10, 4  # ten 4-step images back to back
 
@@ -183,24 +251,26 @@ def main():
         model.set_offload(True, num_blocks_on_gpu=args.offload)
 
     # ---- one independent image per rank ------------------------------------------------------
-    side = args.resolution // 16
-    t_img, t_txt = side * side, args.txt_tokens
+    gh, gw = height // 16, width // 16   # the grid of 2 x 2 latent patches
+    t_img, t_txt = gh * gw, args.txt_tokens
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     latents = torch.randn(1, t_img, 64, generator=g, device=dev, dtype=torch.bfloat16)
     enc = torch.randn(1, t_txt, 3584 if qwen else 4096, generator=g, device=dev, dtype=torch.bfloat16)
     pooled = torch.randn(1, 768, generator=g, device=dev, dtype=torch.bfloat16)
     img_ids = torch.zeros(t_img, 3, device=dev)
-    img_ids[:, 1] = torch.arange(side, device=dev).repeat_interleave(side)
-    img_ids[:, 2] = torch.arange(side, device=dev).repeat(side)
+    img_ids[:, 1] = torch.arange(gh, device=dev).repeat_interleave(gw)
+    img_ids[:, 2] = torch.arange(gw, device=dev).repeat(gh)
     txt_ids = torch.zeros(t_txt, 3, device=dev)
     guidance = None if schnell else torch.full((1,), 3.5, device=dev)
+    txt_mask = torch.ones(1, t_txt, dtype=torch.long, device=dev)
     total = args.steps + args.warmup
     sigmas = torch.linspace(1.0, 0.0, total + 1, device=dev)
 
     def step(i, lat):
         with torch.no_grad():
             if qwen:
-                v = model(lat, enc, None, sigmas[i].reshape(1), [(1, side, side)], return_dict=False)[0]
+                # the pipeline's call: an all-ones text mask and the text lengths ride along (the reference's processor ignores the mask)
+                v = model(lat, enc, txt_mask, sigmas[i].reshape(1), [(1, gh, gw)], txt_seq_lens=[t_txt], return_dict=False)[0]
             else:
                 v = model(lat, enc, pooled, sigmas[i].reshape(1), img_ids, txt_ids, guidance)
             return lat + (sigmas[i + 1] - sigmas[i]).to(v.dtype) * v  # Euler / flow-matching update
@@ -227,15 +297,20 @@ def main():
     if not args.no_prof and not args.graph:
         _lib.check(lib.svdq_prof_select(1 << 0), "svdq_prof_select")
         _lib.check(lib.svdq_prof_enable(max(1, 2 * n_gemm * (args.steps + 1) + 64)), "svdq_prof_enable")
+    clock = ClockSampler(local_rank)
     replica.barrier()
     torch.cuda.synchronize()
+    clock.start()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         latents = step(i, latents)
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0          # this replica's own time for its K steps (before it waits for the others)
     replica.barrier()
     elapsed = time.perf_counter() - t0
+    clock_ghz = clock.stop()
     elapsed = replica.max_over_ranks(elapsed, dev)
+    own_max, own_min = replica.max_over_ranks(own, dev), -replica.max_over_ranks(-own, dev)
     finite = bool(torch.isfinite(latents.float()).all())
 
     def prof(cls):
@@ -251,6 +326,13 @@ def main():
         torch.cuda.synchronize()
     n_g, ms_g, ops_g = prof(0)
     prof_steps = 1 if args.graph else args.steps
+    per_variant = {}
+    for name, fuse in (("default", 0), ("silu", 1), ("gelu_quant", 2), ("rmsnorm_rope", 3)):
+        n_v_, ms_v_, ops_v_ = prof(0 | ((fuse + 1) << 8))  # SVDQ_PROF_GEMM_VARIANT(fuse), include/svdq_amd.h
+        if n_v_:
+            tops = ops_v_ / (ms_v_ * 1e-3) / 1e12
+            per_variant[name] = {"launches_per_step": n_v_ / prof_steps, "avg_launch_us": ms_v_ * 1e3 / n_v_, "ms_per_step": ms_v_ / prof_steps,
+                                 "TOPs": tops, "frac": tops / INT8_PEAK_TOPS}
     # the quantiser's numbers come from ONE extra, untimed step bracketed on its class only
     lib.svdq_prof_select(1 << 1)
     lib.svdq_prof_reset()
@@ -274,20 +356,20 @@ def main():
 
     if rank == 0:
         achieved = ops_g / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
-        traffic, traffic_file = committed_traffic()
+        traffic, traffic_file, traffic_fresh = committed_traffic()
         if qwen:
-            workload = (f"Qwen-Image-shaped transformer step, {args.resolution}x{args.resolution} ({t_img} image + {t_txt} text tokens), bs=1 "
+            workload = (f"Qwen-Image-shaped transformer step, {res_name} ({t_img} image + {t_txt} text tokens), bs=1 "
                         f"per GPU, {len(model.transformer_blocks)} dual-stream blocks, int4 rank-32, random-init weights, " +
                         (f"layer-wise host offload with {args.offload} blocks resident ({model.offload_manager.host_bytes_per_block() / 1e6:.0f} MB "
                          f"per block over PCIe)" if args.offload else "all blocks resident"))
         else:
-            workload = (f"FLUX.1-{'schnell' if schnell else 'dev'}-shaped transformer step, {args.resolution}x{args.resolution} "
+            workload = (f"FLUX.1-{'schnell' if schnell else 'dev'}-shaped transformer step, {res_name} "
                         f"({t_img} image + {t_txt} text tokens), bs=1 per GPU, {args.layers[0]} joint + "
                         f"{args.layers[1]} single blocks, guidance embedding {'off' if schnell else 'on'}, int4 rank-32, random-init weights")
         line = {
-            "metric": ("denoise steps/sec Qwen-Image 1024^2 bs=1 (4-bit SVDQuant W4A4 + rank-32)" if qwen else
-                       "denoise steps/sec FLUX.1-schnell 512^2 bs=1 (4-bit SVDQuant W4A4 + rank-32)" if schnell else
-                       "denoise steps/sec FLUX.1-dev 1024^2 bs=1 (4-bit SVDQuant W4A4 + rank-32)"),
+            "metric": (f"denoise steps/sec Qwen-Image {res_name} bs=1 (4-bit SVDQuant W4A4 + rank-32)" if qwen else
+                       f"denoise steps/sec FLUX.1-schnell {res_name} bs=1 (4-bit SVDQuant W4A4 + rank-32)" if schnell else
+                       f"denoise steps/sec FLUX.1-dev {res_name} bs=1 (4-bit SVDQuant W4A4 + rank-32)").replace("1024x1024", "1024^2").replace("512x512", "512^2"),
             "value": world * args.steps / elapsed,
             "unit": "steps/s",
             "n_gpus": world,
@@ -296,6 +378,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
+            # aggregate steps/s (value) and the slowest / fastest replica's own rate over its K steps
+            "per_replica": {"min_steps_per_s": args.steps / own_max, "max_steps_per_s": args.steps / own_min},
             "vs_baseline": None,
             "dtype": "int4 codes as FP6 (e2m3) operands of the MX-scaled MFMA (exact), fp32 accumulate, bf16 I/O",
             "data": "synthetic",
@@ -319,7 +403,12 @@ def main():
                 "traffic": traffic,
                 "traffic_source": f"committed: {traffic_file} (rocprofv3 PMC passes of this command: "
                                   "2*FETCH_SIZE + WRITE_SIZE per gemm_w4a4 dispatch); not measured in this run",
+                "traffic_stale": not traffic_fresh,   # true: the kernel sources changed since that file was measured
                 "mfma_util": committed_mfma_util(),
+                # shader clock during the timed region (pp_dpm_sclk sampled every 50 ms on rank 0): the chip runs these kernels at its power
+                # limit; profiles/r4_clock_instrument.txt ties this reading to GRBM_GUI_ACTIVE / dispatch duration
+                "effective_clock_ghz": clock_ghz,
+                "per_variant": per_variant,
                 "launches": n_g,
                 "avg_launch_us": ms_g * 1e3 / max(n_g, 1),
                 "gemm_ms_per_step": ms_g / prof_steps,

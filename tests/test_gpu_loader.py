@@ -119,5 +119,8 @@ def test_pipeline_facing_class_call_contract(built_lib, tmp_path):
     assert noise_pred.shape == lat.shape and torch.isfinite(noise_pred.float()).all()
     assert torch.equal(out.sample, noise_pred)
     assert torch.equal(noise_pred, ref), f"from_pretrained model differs from its source: max |d| {(noise_pred.float() - ref.float()).abs().max().item():.3e}"
-    with pytest.raises(NotImplementedError):
-        model(**kwargs, controlnet_block_samples=[lat])
+    # ControlNet residuals are part of the call contract (round 4; parity: tests/test_flux_block_parity.py): [1, T_img, hidden] per sample
+    hidden = model.x_embedder.out_features
+    ctrl = [torch.full((1, lat.shape[1], hidden), 0.25, dtype=lat.dtype, device=lat.device)]
+    with_ctrl = model(**kwargs, controlnet_block_samples=ctrl, controlnet_single_block_samples=ctrl).sample
+    assert with_ctrl.shape == noise_pred.shape and torch.isfinite(with_ctrl.float()).all() and not torch.equal(with_ctrl, noise_pred)
