@@ -122,5 +122,6 @@ def test_pipeline_facing_class_call_contract(built_lib, tmp_path):
     # ControlNet residuals are part of the call contract (round 4; parity: tests/test_flux_block_parity.py): [1, T_img, hidden] per sample
     hidden = model.x_embedder.out_features
     ctrl = [torch.full((1, lat.shape[1], hidden), 0.25, dtype=lat.dtype, device=lat.device)]
-    with_ctrl = model(**kwargs, controlnet_block_samples=ctrl, controlnet_single_block_samples=ctrl).sample
+    with torch.no_grad():
+        with_ctrl = model(**kwargs, controlnet_block_samples=ctrl, controlnet_single_block_samples=ctrl).sample
     assert with_ctrl.shape == noise_pred.shape and torch.isfinite(with_ctrl.float()).all() and not torch.equal(with_ctrl, noise_pred)
