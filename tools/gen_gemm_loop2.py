@@ -167,19 +167,23 @@ class Gen:
         def m0(dst):
             return f"s_add_u32 m0, {sr(dst)}, {stage_imm}" if stage_imm is not None else f"s_add_u32 m0, {sr(dst)}, {sr(S_STG)}"
         ld = "buffer_load_dwordx4"
+        # cache-policy options (same results, timing / traffic experiments: profiles/r4_gemm_nt_streams.txt): "nta" / "ntw" mark the activation
+        # stream / the weight-side streams non-temporal (streamed once through the L2: the other operand's panels are what a later tile re-reads)
+        nta = " nt" if "nta" in self.opts else ""
+        ntw = " nt" if "ntw" in self.opts else ""
         return [
             m0(S_DA),
             f"s_add_u32 {sr(S_DSTEP)}, {sr(S_DSTEP)}, 1",
-            f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen lds",
-            f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen offset:{PLANE} lds",
-            f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen offset:{2 * PLANE} lds",
+            f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen{nta} lds",
+            f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen offset:{PLANE}{nta} lds",
+            f"{ld} {vr(OFF_A)}, {sr(SRD_A, 4)}, {sr(S_KOFF)} offen offset:{2 * PLANE}{nta} lds",
             m0(S_DX1),
             "s_nop 0",
-        ] + [f"{ld} {vr(OFF_X1)}, {sr(SRD_X1, 4)}, {sr(S_KOFF)} offen" + (f" offset:{pl * PLANE}" if pl else "") + " lds"
+        ] + [f"{ld} {vr(OFF_X1)}, {sr(SRD_X1, 4)}, {sr(S_KOFF)} offen" + (f" offset:{pl * PLANE}" if pl else "") + f"{ntw} lds"
              for pl in range(self.geo.x1_planes)] + [
             m0(S_DX2),
             f"s_add_u32 {sr(S_KOFF)}, {sr(S_KOFF)}, {CHUNK}",
-            f"{ld} {vr(OFF_X2)}, {sr(SRD_X2, 4)}, {sr(S_KOFF2)} offen lds",
+            f"{ld} {vr(OFF_X2)}, {sr(SRD_X2, 4)}, {sr(S_KOFF2)} offen{ntw} lds",
             f"s_add_u32 {sr(S_KOFF2)}, {sr(S_KOFF2)}, {sr(S_IX2)}",
         ]
 
