@@ -705,7 +705,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(acc[ni][mi][r]);
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2_t t = round16_pair<T>(acc[ni][mi][r], acc[ni][mi][r + 1]);
+                        acc[ni][mi][r] = t[0];
+                        acc[ni][mi][r + 1] = t[1];
+                    }
         }
 
         if constexpr (FUSE == SVDQ_FUSE_SILU) {
@@ -794,14 +798,19 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[ni][mi][r] = round16<T>(gelu_tanh_f(acc[ni][mi][r]));
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2_t t = round16_pair<T>(gelu_tanh_f(acc[ni][mi][r]), gelu_tanh_f(acc[ni][mi][r + 1]));
+                        acc[ni][mi][r] = t[0];
+                        acc[ni][mi][r + 1] = t[1];
+                    }
 
             // EpilogueQuantize<false, unsigned> (gemm_w4a4.cuh:930-1043): 16-bit add of the shift,
             // fp32 divide by the next layer's smooth factor -> 16-bit, per (row, 64 columns) absmax,
             // scale = amax/15, unsigned 4-bit codes.  The wave's 64 columns are exactly one group of the
             // next GEMM and the lane's 32 values (j = 16*ni + r) are exactly its F6 lane record.
             const int KP2 = p.N / 128;
-            const int g2 = nw0 / GROUP;
+            const int g2 = n0 / GROUP + (wv & 1); // (= nw0 / GROUP, from the SCALAR wave index: its parity selects the record halves below with a scalar
+                                                  //  branch -- derived from the lane id the compiler predicates both arms: 6 stores per row tile for 2)
             // 1 / smooth of this lane's 32 columns.  The reference divides with __fdividef (gemm_w4a4.cuh:990-993,
             // gemm_utils.cuh:329-344: an approximate reciprocal times the numerator); so does this epilogue
             // (the stand-alone quantiser keeps the exactly rounded division).
@@ -821,11 +830,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        float sh = round16<T>(acc[ni][mi][r] + 0.171875f);
-                        float v = round16<T>(sh * smr[ni][r]);
-                        xh[ni * 16 + r] = v;
-                        amax = fmaxf(amax, fabsf(v));
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2_t sh = round16_pair<T>(acc[ni][mi][r] + 0.171875f, acc[ni][mi][r + 1] + 0.171875f);
+                        const f32x2_t v = round16_pair<T>(sh[0] * smr[ni][r], sh[1] * smr[ni][r + 1]);
+                        xh[ni * 16 + r] = v[0];
+                        xh[ni * 16 + r + 1] = v[1];
+                        amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
                     }
                 amax = fmaxf(amax, __shfl_xor(amax, 32));
                 const float scale = amax * (1.0f / 15.0f);
@@ -847,17 +857,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                 uint32_t rec[6];
 #pragma unroll
                 for (int i = 0; i < 6; i++) rec[i] = (uint32_t)pk[i];
-                const int m_abs = mw0 + mi * 32 + lr;
-                uint8_t *dst = p.qout + ((size_t)(m_abs >> 5) * KP2 + (g2 >> 1)) * F6_CHUNK + (size_t)lane * 16;
-                if (SVDQ_PROBE_OFF(2)) {
-                } else if ((g2 & 1) == 0) {
-                    *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-                    *reinterpret_cast<uint2 *>(dst + F6_PLANE) = make_uint2(rec[4], rec[5]);
-                } else {
-                    *reinterpret_cast<uint2 *>(dst + F6_PLANE + 8) = make_uint2(rec[0], rec[1]);
-                    *reinterpret_cast<uint4 *>(dst + 2 * F6_PLANE) = make_uint4(rec[2], rec[3], rec[4], rec[5]);
+                // Uniform base (from the SCALAR wave index) + one 32-bit lane offset: the stores take the saddr form, no 64-bit address arithmetic
+                // per lane.  The group's parity (= the wave column) decides which 24 bytes of the 48-byte lane record this wave owns: even ->
+                // plane 0 [0, 16) + plane 1 [0, 8); odd -> plane 1 [8, 16) + plane 2 [0, 16).  ONE 16-byte and ONE 8-byte store either way, operands
+                // selected (written as two branch arms the compiler tail-merges them into five narrow stores).
+                const unsigned rt_s = (unsigned)(m0 + (wv >> 1) * 64 + mi * 32) >> 5;
+                uint8_t *dst = p.qout + ((size_t)rt_s * KP2 + (g2 >> 1)) * F6_CHUNK;
+                const bool odd = (g2 & 1) != 0;  // scalar
+                if (!SVDQ_PROBE_OFF(2)) {
+                    const uint4 w16 = odd ? make_uint4(rec[2], rec[3], rec[4], rec[5]) : make_uint4(rec[0], rec[1], rec[2], rec[3]);
+                    const uint2 w8 = odd ? make_uint2(rec[0], rec[1]) : make_uint2(rec[4], rec[5]);
+                    *reinterpret_cast<uint4 *>(dst + (odd ? 2 * F6_PLANE : 0) + lane_e * 16u) = w16;
+                    *reinterpret_cast<uint2 *>(dst + F6_PLANE + (odd ? 8 : 0) + lane_e * 16u) = w8;
                 }
-                if (h == 0) ((T *)p.oscales)[simg_index(m_abs, g2, KP2)] = f2h<T>(scale);
+                // simg_index(m_abs, g2, KP2): the row tile's 32 scales of this group are 64 contiguous bytes
+                if (h_e == 0) ((T *)p.oscales + (((size_t)rt_s * KP2 + (g2 >> 1)) * 2 + (g2 & 1)) * 32)[lr_e] = f2h<T>(scale);
             }
             SVDQ_PROBE_STAMP(3);
             // EpilogueLoraDown for the NEXT layer on the GELU output, before shift/smooth

@@ -75,6 +75,19 @@ template <typename T> __device__ __forceinline__ T hfrom(unsigned short b) { ret
 // round a float to the 16-bit type and come back (the reference keeps its tile in 16-bit between
 // epilogue stages; this reproduces those rounding points)
 template <typename T> __device__ __forceinline__ float round16(float v) { return (float)(T)v; }
+// the same for two values at once.  bf16: ONE v_cvt_pk_bf16_f32 (RNE, both values) + a shift and a mask to come back -- 3 instructions where two
+// round16 cost 4.  fp16 keeps the scalar form on purpose: the backend folds an fp32 operation and the conversion that follows it into one
+// v_fma_mix*_f16 (one rounding, as the oracle's _round16_fma models it); an explicit packed convert would round the fp32 result a second time.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ f32x2_t round16_pair(float a, float b) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, _Float16)) {
+        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+        return (f32x2_t){__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+    } else {
+        return (f32x2_t){round16<T>(a), round16<T>(b)};
+    }
+}
 
 // a / b rounded to nearest for normal-range operands: two Newton steps on the hardware reciprocal rb ~ 1/b
 // (the quotient of the v_div_scale / v_div_fmas / v_div_fixup sequence without its ~7 scaling instructions;
