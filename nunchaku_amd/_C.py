@@ -41,10 +41,11 @@ class _Workspace:
     """Scratch of one (device, stream, kind): the device buffer + a pinned, device-visible int32 status word the kernels
     raise when a waiting workgroup gives up (svdq_gemm_args.status): polled WITHOUT synchronising before every launch."""
 
-    __slots__ = ("buf", "status")
+    __slots__ = ("buf", "status", "captured")
 
     def __init__(self, buf, status):
         self.buf, self.status = buf, status
+        self.captured = False  # its pointer is baked into a captured HIP graph: never evicted (a replay would use freed memory)
 
     def check(self, what: str):
         if self.status is not None and int(self.status[0]) != 0:  # a plain host read of pinned memory
@@ -59,6 +60,7 @@ class _Workspace:
 
 _status_pool = None  # pinned int32 words handed to the workspaces (allocated once, outside any stream capture)
 _status_used = 0
+_status_free: list = []  # words of evicted workspaces, handed out again
 
 
 def _status_word():
@@ -69,6 +71,10 @@ def _status_word():
         if torch.cuda.is_current_stream_capturing():
             return None
         _status_pool = torch.zeros(256, dtype=torch.int32).pin_memory()
+    if _status_free:
+        w = _status_free.pop()
+        w.zero_()
+        return w
     if _status_used >= _status_pool.numel():
         return None
     w = _status_pool[_status_used:_status_used + 1]
@@ -102,16 +108,24 @@ def _workspace(device: torch.device, kind: str = "gemm") -> _Workspace:
             buf = torch.zeros(int(size), dtype=torch.uint8, device=device)
         ws = _Workspace(buf, _status_word())
         _workspaces[key] = ws
-        same_kind = [k for k in _workspaces if k[2] == kind]
+        # least recently used entries beyond the limit go -- except workspaces a captured graph points at
+        same_kind = [k for k in _workspaces if k[2] == kind and not _workspaces[k].captured]
         for k in same_kind[:max(0, len(same_kind) - _WORKSPACE_LIMIT)]:
-            del _workspaces[k]  # the tensor is freed by the caching allocator once queued work on it has finished
+            old = _workspaces.pop(k)  # the tensor is freed by the caching allocator once queued work on it has finished
+            if old.status is not None:
+                _status_free.append(old.status)
     else:
         _workspaces.move_to_end(key)
+    if torch.cuda.is_current_stream_capturing():
+        ws.captured = True
     return ws
 
 
 def release_workspaces() -> None:
-    """Drop every cached workspace (e.g. after a pool of temporary streams has been destroyed)."""
+    """Drop every cached workspace (e.g. after a pool of temporary streams has been destroyed; graphs captured with them must be gone too)."""
+    for ws in _workspaces.values():
+        if ws.status is not None:
+            _status_free.append(ws.status)
     _workspaces.clear()
 
 
@@ -499,7 +513,9 @@ class _Ops:
                 oq[0][:, M:].zero_()
             base_tokens = ok.stride(1) // 128 if ok.stride(1) % 128 == 0 else T_pad
             row0 = (ok.storage_offset() // 128) % max(base_tokens, 1)
-            rows = dict(_packed_rows.get(ok) or {})
+            # this write covers rows [row0, row0 + T_pad) of the buffer: segments an earlier use of the same storage left inside that range
+            # (another text / image split) are gone with it
+            rows = {r0: v for r0, v in (_packed_rows.get(ok) or {}).items() if r0 + v[1] <= row0 or r0 >= row0 + T_pad}
             rows[row0] = (M, T_pad)
             _packed_rows.put(ok, rows)
 

@@ -494,6 +494,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                 }
                 __syncthreads();
                 if (tid == 0) {
+                    // (round 4: write-through `sc1` / `sc0 sc1` stores + vmcnt(0) instead of the release fence -- MI355X_MICROARCH.md "publish-large" --
+                    //  were tried here: 1-2 % faster, and the owner read stale slab lines in every run; profiles/r4_gemm_streamk_publish.txt)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_fetch_add(flags + trel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -245,6 +245,10 @@ class SVDQW4A4Linear(nn.Module):
         widening the low-rank branch to rank ``R + r`` -- the mechanism of the reference's ``update_lora_params`` /
         ``set_lora_strength`` (transformer_flux.py:783-855: concatenate along the rank axis, per-16-rank scales).
         The 4-bit weights are untouched; ``strength`` can be changed later with :meth:`set_lora_strength` for free."""
+        if getattr(self, "_offloaded", False):
+            raise RuntimeError("set_lora: this layer belongs to a block that lives in host memory (CPUOffloadManager): its device slots are sized "
+                               "for the checkpoint's rank.  Attach the LoRA before set_offload(True) is NOT supported either -- merge it into the "
+                               "checkpoint, or keep the block resident (num_blocks_on_gpu)")
         self._ensure_layout()
         self.reset_lora()
         r, K = down.shape

@@ -117,7 +117,14 @@ class CPUOffloadManager:
         for m in block.modules():
             if not isinstance(m, SVDQW4A4Linear):
                 continue
-            m.reset_lora()  # a runtime LoRA is not part of the host image
+            if m._base_lowrank is not None:
+                # a runtime LoRA is not part of the host image (its rank changes the shapes of proj_down / proj_up, which the device slots are
+                # sized for): it is dropped HERE, loudly; attach LoRAs to resident blocks, or merge them before set_offload(True)
+                import warnings
+                warnings.warn("CPUOffloadManager: the runtime LoRA attached to an offloaded SVDQW4A4Linear is removed (set_lora / "
+                              "update_lora_params do not reach offloaded blocks)", RuntimeWarning, stacklevel=3)
+            m.reset_lora()
+            m._offloaded = True  # set_lora on this layer raises until restore(): the device slots are sized for the checkpoint's rank
             if "qweight" in m._amd_names:
                 m.qweight.data = layout.unrepack_qweight(m.qweight.data)
                 m._amd_names.discard("qweight")
@@ -221,6 +228,9 @@ class CPUOffloadManager:
             blk = self.blocks[i]
             for _, _, t in _named_tensors(blk):
                 t.data = t.data.to(device, copy=True)
+            for m in blk.modules():
+                if isinstance(m, SVDQW4A4Linear):
+                    m._offloaded = False
         self._images.clear()
         self._slots = []
         self._entries = None

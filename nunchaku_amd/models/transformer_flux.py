@@ -103,16 +103,31 @@ class NunchakuModelLoaderMixin:
 
 
 _Base = _DiffusersFlux if HAVE_DIFFUSERS else nn.Module
+_UNSET = object()  # "this configuration key was not passed by keyword"
 
 
 class NunchakuFluxTransformer2DModelV2(_Base, FluxEngineMixin, NunchakuModelLoaderMixin):
     """``FluxPipeline``'s ``transformer`` on the MI355X SVDQuant path.  ``NunchakuFluxTransformer2DModelV2(config_dict)``
     builds an uninitialised model (synthetic weights: ``init_synthetic_``); ``from_pretrained`` loads a checkpoint."""
 
-    def __init__(self, config: dict | None = None, rank: int = 32, torch_dtype: torch.dtype = torch.bfloat16, device="cuda", **diffusers_kwargs):
+    def __init__(self, config: dict | None = None, rank: int = 32, torch_dtype: torch.dtype = torch.bfloat16, device="cuda", *,
+                 patch_size=_UNSET, in_channels=_UNSET, out_channels=_UNSET, num_layers=_UNSET, num_single_layers=_UNSET,
+                 attention_head_dim=_UNSET, num_attention_heads=_UNSET, joint_attention_dim=_UNSET, pooled_projection_dim=_UNSET,
+                 guidance_embeds=_UNSET, axes_dims_rope=_UNSET, **diffusers_kwargs):
+        """``NunchakuFluxTransformer2DModelV2(config_dict, device=...)`` builds a complete (uninitialised) model.  The diffusers
+        configuration keys are ALSO named parameters: ``ConfigMixin.from_config`` -> ``extract_init_dict`` passes only the keys it finds in
+        ``__init__``'s signature, so a checkpoint's ``num_layers`` / ``guidance_embeds`` ... reach the skeleton that ``_build_model`` makes
+        on the meta device (with a bare ``**kwargs`` they were dropped and a default-size model was built).  Called that way --
+        configuration by keyword, no ``config`` dict -- the constructor only makes the skeleton; ``from_pretrained`` patches it."""
+        named = dict(patch_size=patch_size, in_channels=in_channels, out_channels=out_channels, num_layers=num_layers,
+                     num_single_layers=num_single_layers, attention_head_dim=attention_head_dim, num_attention_heads=num_attention_heads,
+                     joint_attention_dim=joint_attention_dim, pooled_projection_dim=pooled_projection_dim, guidance_embeds=guidance_embeds,
+                     axes_dims_rope=axes_dims_rope)
+        by_keyword = {k: v for k, v in named.items() if v is not _UNSET}
+        by_keyword.update(diffusers_kwargs)
         cfg = dict(_DEFAULT_CONFIG)
         cfg.update(config or {})
-        cfg.update(diffusers_kwargs)
+        cfg.update(by_keyword)
         if HAVE_DIFFUSERS:
             # diffusers' own constructor builds the full-size bf16 module tree: only ever on the meta device (from_config under
             # torch.device("meta") in _build_model, or here); _patch_model then materialises this package's modules
@@ -121,7 +136,7 @@ class NunchakuFluxTransformer2DModelV2(_Base, FluxEngineMixin, NunchakuModelLoad
         else:
             nn.Module.__init__(self)
             self.config = SimpleNamespace(**cfg)
-        if config is not None or not HAVE_DIFFUSERS or diffusers_kwargs == {}:
+        if config is not None or not HAVE_DIFFUSERS or not by_keyword:
             self._patch_model(rank=rank, torch_dtype=torch_dtype, device=device)
 
     def _patch_model(self, rank: int = 32, torch_dtype: torch.dtype = torch.bfloat16, device="cuda", **kwargs):

@@ -40,7 +40,11 @@ class FluxTransformer2DModel(nn.Module):
 
     @classmethod
     def from_config(cls, config):
-        return cls(**config)
+        # as diffusers' ConfigMixin.extract_init_dict: ONLY the keys named in cls.__init__'s signature reach the constructor (a bare
+        # **kwargs receives nothing) -- the subclass must name the configuration keys it wants to see
+        import inspect
+        expected = set(inspect.signature(cls.__init__).parameters) - {"self", "kwargs"}
+        return cls(**{k: v for k, v in config.items() if k in expected})
 
     @property
     def dtype(self):

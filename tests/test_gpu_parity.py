@@ -188,18 +188,21 @@ def test_linear_no_bias_and_lora_scales():
     assert_close_16(f32(out), ref, "bf16", "lora_scales")
 
 
-def test_silu_epilogue():
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_silu_epilogue(dtype):
     from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
 
-    L, x = _gemm_inputs(256, 256, 128, 32, "bf16", seed=4)
-    mod = make_module(L, "bf16")
-    qx, asc, la = mod.quantize(t16(x, "bf16"))
-    out = torch.empty(256, 128, dtype=torch.bfloat16, device="cuda")
+    L, x = _gemm_inputs(256, 256, 128, 32, dtype, seed=4)
+    mod = make_module(L, dtype)
+    qx, asc, la = mod.quantize(t16(x, dtype))
+    from tests.helpers import TORCH_DT
+
+    out = torch.empty(256, 128, dtype=TORCH_DT[dtype], device="cuda")
     svdq_gemm_w4a4_cuda(act=qx, wgt=mod.qweight, out=out, ascales=asc, wscales=mod.wscales, lora_act_in=la,
                         lora_up=mod.proj_up, bias=mod.bias, fuse_silu=True)
-    ref = O.svdq_linear(x, L, "bf16", "fp32", fuse="silu")["out"]
-    assert_close_16(f32(out), ref, "bf16", "silu", max_bad_frac=2e-3, ulps=1.0)
-    assert_close_16(f32(out), ref, "bf16", "silu(2ulp)", ulps=2.0)
+    ref = O.svdq_linear(x, L, dtype, "fp32", fuse="silu")["out"]
+    assert_close_16(f32(out), ref, dtype, "silu", max_bad_frac=2e-3, ulps=1.0)
+    assert_close_16(f32(out), ref, dtype, "silu(2ulp)", ulps=2.0)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
