@@ -45,3 +45,14 @@ def test_bench_two_ranks_on_one_gpu(config):
     # whole-job value: all ranks' steps over the max-over-ranks time
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2.0) < 1e-6
     assert d["cpu_baseline"] is None and d["roofline"]["launches"] > 0
+    # round 4: per-replica rates, the roofline split per epilogue variant, staleness stamps of the committed PMC numbers
+    pr = d["per_replica"]
+    assert 0 < pr["min_steps_per_s"] <= pr["max_steps_per_s"] and d["value"] <= 2 * pr["max_steps_per_s"] * 1.0001
+    rf = d["roofline"]
+    assert isinstance(rf["traffic_stale"], bool) and (rf["mfma_util"] is None or isinstance(rf["mfma_util"]["stale"], bool))
+    assert rf["effective_clock_ghz"] is None or 0.3 < rf["effective_clock_ghz"] < 3.0
+    pv = rf["per_variant"]
+    assert {"default", "gelu_quant", "rmsnorm_rope"} <= set(pv), pv.keys()
+    assert abs(sum(v["launches_per_step"] for v in pv.values()) * d["steps"] - rf["launches"]) < 1e-6
+    assert all(v["avg_launch_us"] > 0 and 0 < v["frac"] < 1 for v in pv.values())
+    assert abs(sum(v["ms_per_step"] for v in pv.values()) - rf["gemm_ms_per_step"]) < 1e-3 * max(1.0, rf["gemm_ms_per_step"])

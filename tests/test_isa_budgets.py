@@ -1,0 +1,66 @@
+"""Static instruction budgets of the GEMM epilogues, read from the built library's gfx950 code objects (tools/isa_stats.py, llvm-objdump).
+
+VERDICT r3 #1(ii): "a per-output VALU budget for every epilogue, checked in static counts".  What round 4 measured (profiles/r4_gemm_rowrun.txt): on this
+kernel a vector-memory instruction costs the CU's one address unit ~16 cycles whatever its width, and an edit of the epilogue source can multiply their
+number without changing a result -- the GELU_QUANT epilogue's two 24-byte code stores had been compiled into FIVE narrow stores per row tile (8 % of the
+fc1 launch).  So the budgets below are upper bounds on (a) the VALU instructions behind the generated main loop -- every epilogue path, the stream-K
+code and the schedule bookkeeping of the kernel, a static count: per 64 outputs of a lane -- and (b) the vector-memory instruction mix of the paths that
+run every tile.  They are regression guards, set ~5 % above the committed build."""
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs llvm-objdump")
+
+
+@pytest.fixture(scope="module")
+def stats(built_lib):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("isa_stats", os.path.join(ROOT, "tools", "isa_stats.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from nunchaku_amd import _lib
+
+    return mod.gemm_stats(mod.disassemble(_lib.lib_path()))
+
+
+# (fuse, carry) of the kernels the FLUX / Qwen-Image step launches on 256 x 128 tiles, bf16 and fp16, fp32 low-rank accumulators
+BUDGET_VALU = {  # static VALU instructions behind the main loop (64 outputs per lane)
+    (0, 0): 900,    # default: bias + low-rank up on the matrix pipe, 16-bit conversion, 8 x 16-byte stores (+ stream-K publish / collect)
+    (2, 1): 2320,   # GELU -> requantise -> next low-rank down into the workgroup's carry
+    (3, 0): 2320,   # RMSNorm + RoPE (+ the V^T store path of the V third)
+}
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["bf16", "fp16"])
+def test_epilogue_valu_budgets(stats, dt):
+    for (fuse, carry), budget in BUDGET_VALU.items():
+        r = stats[(dt, fuse, 8, 0, carry)]
+        valu = r["post_loop"].get("valu", 0)
+        slack = 1.12 if dt == 1 else 1.0  # fp16 adds the +-65504 clamps and scalar conversions
+        assert valu <= budget * slack, f"dtype {dt} fuse {fuse} carry {carry}: {valu} VALU instructions behind the loop (budget {budget * slack:.0f})"
+
+
+def test_gelu_quant_carry_kernel_memory_instructions(stats):
+    for dt in (0, 1):
+        r = stats[(dt, 2, 8, 0, 1)]
+        h = r["histogram"]
+        # the carry is plain LDS reads / writes: no LDS float atomics (measured ~1 lane per clock) and no compare-and-swap loops
+        assert r["lds_atomics"] == 0 and r["lds_cas"] == 0
+        # per row tile ONE 16-byte and ONE 8-byte code store + one 2-byte scale store: no dwordx3 / stray dword stores from tail-merged branch arms
+        assert h.get("global_store_dwordx3", 0) == 0
+        assert h.get("global_store_dword", 0) <= 4, h   # (the stream-K status / error words)
+        assert h.get("global_store_short", 0) == 2
+        # the low-rank-down partial sums leave the workgroup once per row block: 16 atomic instructions (+ the stream-K arrival counter)
+        assert r["global_atomics"] <= 17
+        assert r["scratch"] <= 6, "spills in the GELU_QUANT epilogue (an address computation hoisted above the main loop's asm block?)"
+
+
+def test_no_kernel_of_the_step_spills_badly(stats):
+    for key, r in stats.items():
+        dt, fuse, nw, laq, carry = key
+        if laq == 0 and fuse in (0, 3):
+            assert r["scratch"] == 0, f"{key}: {r['scratch']} scratch instructions"
