@@ -48,7 +48,7 @@ tm=tg=0
 for v in sorted(set(k for c in sq for k in sq[c])):
     g=lambda c: sum(sq[c][v])/max(len(sq[c][v]),1) if sq.get(c,{}).get(v) else None
     m,gr,us=g('SQ_VALU_MFMA_BUSY_CYCLES'),g('GRBM_GUI_ACTIVE'),g('us')
-    rec={'dispatches_per_step':len(sq.get('GRBM_GUI_ACTIVE',{}).get(v,[])), 'avg_us_under_pmc':us}
+    rec={'dispatches_in_the_command (1 warm-up + 1 timed + 3 instrumented steps)':len(sq.get('GRBM_GUI_ACTIVE',{}).get(v,[])), 'avg_us_under_pmc':us}
     if m and gr:
         rec.update(mfma_busy_cycles_per_simd=m/1024, gui_active_cycles_per_xcd=gr/8, mfma_util=(m/1024)/(gr/8))
         tm+=sum(sq['SQ_VALU_MFMA_BUSY_CYCLES'][v])/1024; tg+=sum(sq['GRBM_GUI_ACTIVE'][v])/8
