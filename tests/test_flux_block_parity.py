@@ -88,7 +88,7 @@ def test_odd_token_counts_run_the_hot_path_and_match_the_oracle(grid, t_txt):
     assert got.shape == ref.shape == (grid[0] * grid[1], 64) and torch.isfinite(got).all()
     psnr, rel = psnr_rel(got, ref)
     print(f"{grid} + {t_txt} tokens: PSNR {psnr:.1f} dB, relative L2 error {rel:.3e}")
-    assert psnr > 50.0 and rel < 1.5e-2
+    assert psnr > 50.0 and rel < 1.5e-2  # measured 54.0 - 58.6 dB (the aligned case: 56.3)
 
 
 def test_padded_path_equals_unpadded_torch_op_path_rows():
@@ -110,7 +110,7 @@ def test_padded_path_equals_unpadded_torch_op_path_rows():
     assert launches == 0  # the A/B arm: SDPA
     psnr, rel = psnr_rel(a.cpu(), b.cpu())
     print(f"padded hot path vs unpadded torch ops: {psnr:.1f} dB")
-    assert psnr > 45.0
+    assert psnr > 48.0  # measured 54.5 dB
 
 
 @pytest.mark.parametrize("grid,t_txt", [(16, 128), ((13, 20), 77)], ids=["aligned", "padded"])

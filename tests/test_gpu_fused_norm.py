@@ -104,7 +104,10 @@ def test_flux_transformer_fused_norm_vs_torch_ops():
     rel = ((outs[True] - outs[False]).norm() / outs[False].norm()).item()
     psnr = psnr_db(outs[True], outs[False])
     print(f"FLUX model fused vs torch-op AdaLayerNormZero / residuals: PSNR {psnr:.1f} dB rel {rel:.2e}")
-    assert torch.isfinite(outs[True]).all() and rel < 3e-2 and psnr > 40.0, f"fused vs torch-op AdaLayerNormZero: relative L2 {rel:.3g}, PSNR {psnr:.1f}"
+    # deterministic mode (fixed-point low-rank sums): measured 48.2 dB / 1.3 % on this 1 + 2 block model with uniform-random 4-bit weights -- the two op
+    # sequences share every 16-bit rounding point, what remains are +-1 flips of 4-bit activation codes where a low-rank partial sum is split
+    # differently (DESIGN.md section 7 "chaotic in the last bit"); the gate sits 3 dB below (round 3: 40 dB / 3 %)
+    assert torch.isfinite(outs[True]).all() and rel < 2e-2 and psnr > 45.0, f"fused vs torch-op AdaLayerNormZero: relative L2 {rel:.3g}, PSNR {psnr:.1f}"
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

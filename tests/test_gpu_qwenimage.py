@@ -138,11 +138,12 @@ def test_qwen_block_matches_the_reference_op_sequence(t_txt):
         for name, got, ref in (("text", e, e_ref), ("image", h, h_ref)):
             psnr, rel = psnr_rel(got, ref)
             print(f"qwen block fused={fused} {name}: PSNR {psnr:.1f} dB rel {rel:.2e}")
-            assert torch.isfinite(got).all() and psnr > 45.0 and rel < 2e-2, (fused, name, psnr, rel)
+            # measured 67.9 - 71.3 dB / 0.13 - 0.18 % (round 4); round 3 gated at 45 dB / 2 %
+            assert torch.isfinite(got).all() and psnr > 60.0 and rel < 6e-3, (fused, name, psnr, rel)
     # the fused path (QKV epilogue + svdq attention, grouped when t_txt % 256 == 0) against the reference-op path on the GPU
     for i in range(2):
         psnr, _ = psnr_rel(outs[True][i], outs[False][i])
-        assert psnr > 45.0
+        assert psnr > 55.0, psnr
 
 
 def _small_model(layers=4):
@@ -265,7 +266,9 @@ def test_qwen_model_fused_passes_match_the_torch_op_blocks(dtype):
     assert torch.equal(per_block, outs[True]), "batched modulation GEMVs differ from the per-block ones"
     psnr, rel = psnr_rel(outs[True], outs[False])
     print(f"qwen model fused vs torch-op blocks ({dtype}): PSNR {psnr:.1f} dB rel {rel:.2e}")
-    assert torch.isfinite(outs[True]).all() and psnr > 40.0 and rel < 3e-2, (psnr, rel)
+    # deterministic mode: measured 52.0 dB (bf16) / 48.5 dB (fp16) on this 3-block model with uniform-random weights (the code-flip floor, see
+    # tests/test_gpu_fused_norm.py); round 3 gated at 40 dB / 3 %
+    assert torch.isfinite(outs[True]).all() and psnr > 45.0 and rel < 2.5e-2, (psnr, rel)
 
 
 def test_qwen_rope_tables():
@@ -322,7 +325,7 @@ def test_qwen_block_on_padded_streams_matches_the_reference_op_sequence(grid, t_
     for name, got, ref in (("text", e[0, :t_txt].float().cpu(), e_ref), ("image", h[0, :t_img].float().cpu(), h_ref)):
         psnr, rel = psnr_rel(got, ref)
         print(f"qwen block {grid} + {t_txt} tokens, padded streams, {name}: PSNR {psnr:.1f} dB rel {rel:.2e}")
-        assert torch.isfinite(got).all() and psnr > 45.0 and rel < 2e-2, (name, psnr, rel)
+        assert torch.isfinite(got).all() and psnr > 58.0 and rel < 6e-3, (name, psnr, rel)  # measured 64.7 - 68.6 dB
     assert torch.isfinite(e).all() and torch.isfinite(h).all()  # the padded rows stay finite (they are V^T columns of the next block)
 
 
@@ -357,4 +360,4 @@ def test_qwen_model_odd_token_counts_run_the_fused_path(rank):
     assert hot.shape == plain.shape == (1, grid[0] * grid[1], 64) and torch.isfinite(hot).all()
     psnr, rel = psnr_rel(hot.cpu(), plain.cpu())
     print(f"qwen model rank {rank}, {grid} + {t_txt} tokens: padded fused path vs unpadded torch-op blocks {psnr:.1f} dB rel {rel:.2e}")
-    assert psnr > 40.0 and rel < 3e-2, (psnr, rel)
+    assert psnr > 42.0 and rel < 3e-2, (psnr, rel)  # measured 45.9 - 46.1 dB: two op sequences on uniform-random weights (code-flip floor)
