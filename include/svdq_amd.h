@@ -313,6 +313,11 @@ int svdq_attention_workspace_status(void *workspace, void *stream);
  * task), last contributing workgroup or -1 (no other contributor)}; returns the number of segments, 0 when the problem runs
  * on the plain grid (L % 256 != 0 or whole rounds of tasks), -1 on bad arguments.  No GPU needed. */
 int svdq_attention_schedule(int32_t L, int32_t H, int32_t cus, int32_t *out, int32_t cap);
+/* Which kernel a launch with these arguments would take (host only; pointers are not looked at): out[0] = workgroup geometry (1 / 2), out[1] = 1 when
+ * the key mask runs on geometry 2 (round 4: q_prescaled or an explicit geometry 2, L % 256 == 0, a run of at least two fully real 64-key tiles),
+ * out[2], out[3] = the main segment [j0, j1) of fully real tiles its assembly loop walks -- the remaining tiles that hold a real key run as C++ "extra"
+ * tiles that continue the softmax state, tiles without a real key are skipped. */
+int svdq_attention_plan(const svdq_attention_args *args, int32_t out[4]);
 
 /* ------------------------------------------------------------------------------------------
  * Gated residual + LayerNorm statistics (extension; the element-wise glue between the operators of a block,

@@ -68,6 +68,7 @@ struct AttnParams {
     int qlora_q32;     // qlora_act holds Q31.32 fixed point (order-independent integer atomics over the heads)
     int *status;       // optional host-visible status word (svdq_attention_args.status)
     int kv_len0, kv_start1, kv_end1; // key mask: keys [0, kv_len0) and [kv_start1, kv_end1) are real, the rest padding (kv_len0 == 0: no mask)
+    int mask_j0, mask_j1;            // geometry 2 with a key mask: the main segment [mask_j0, mask_j1) of fully real tiles (even count) the assembly loop runs
     const uint16_t *qsmooth, *qlora_down, *qsmooth2, *qlora_down2;
     int qR, qsplit_rows;
     // persistent schedule (svdq_attention_args.workspace): arrival counters + error word, then one slab per workgroup
@@ -541,13 +542,19 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attention_kernel(const AttnPa
 // one numerical difference to geometry 1), a score accumulator starts at -mc instead of 0 (mc: the row's reference point, a stale
 // maximum; -inf while the row has seen no finite score -- the start value is 0 then), so P = exp2(s') with no further arithmetic.
 // K / V^T staging: LDS-DMA into two [K | V^T] buffers, K(j+2) where K(j) was read one iteration earlier, V^T(j+1) where V^T(j-1)
-// was.  Same task / persistent-schedule / slab definitions as geometry 1 (task = 256 rows).  No key-padding mask: svdq_attention
-// runs masked launches on geometry 1.
+// was.  Same task / persistent-schedule / slab definitions as geometry 1 (task = 256 rows).  Key-padding mask: the MASK instantiation below
+// (plain grid); masked launches that do not qualify run geometry 1.
 typedef float v32f __attribute__((ext_vector_type(32)));
 typedef int v32i __attribute__((ext_vector_type(32)));
 
-template <int DT, bool PERSIST>
+// MASK (round 4; plain grid only): a key-padding mask.  The assembly loop runs an EVEN number of FULL tiles and cannot mask a score, so a masked
+// launch splits every task: the main segment = the longest run of fully real tiles, cut to an even count, through the loop as always; every other
+// tile that holds a real key -- the odd one of that run, the partially padded tiles at the end of a key range, the tiles of the other range -- is an
+// "extra" tile in C++ that CONTINUES the state (scores against the current reference point, padded keys at -inf, the reference point moved when a row
+// outgrows it); tiles without a real key are never touched.
+template <int DT, bool PERSIST, bool MASK = false>
 __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p) {
+    static_assert(!(PERSIST && MASK), "the key mask runs on the plain grid");
     using V8 = typename Half<DT>::V8;
     using T = typename Half<DT>::T;
     constexpr int NT = 256, RT = 2;
@@ -681,6 +688,7 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
                 task = N % 8 == 0 ? (b % 8) * (N / 8) + b / 8 : b;
             }
             j0 = 0; j1 = ntiles;
+            if constexpr (MASK) { j0 = p.mask_j0; j1 = p.mask_j1; } // the main segment (host: attention_mask_segment)
             whole_left--;
         } else break;
         const int head = task / QT;
@@ -775,6 +783,65 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
         }
         last_tile(SB, 1); // a segment has an even number of tiles: its last one sits in score set B / buffer 1
         __syncthreads();  // the buffers are free for the next segment's prologue
+        if constexpr (MASK) {
+            // branch-free on purpose: written with short-circuit || / && this clang if-converts the select into AGPR writes under a partial exec mask
+            // and loses the scores of range-B keys (round 4: a padded tile at the end of the second range came out wrong on a few rows)
+            const unsigned b_len = (unsigned)(p.kv_end1 - p.kv_start1);
+            auto real_key = [&](int key) { return (int)(key < p.kv_len0) | (int)((unsigned)(key - p.kv_start1) < b_len); };
+            for (int t = 0; t < ntiles; t++) {
+                const int k0 = t * ATT_KB;
+                if ((t >= j0 && t < j1) || !(k0 < p.kv_len0 || (k0 + ATT_KB > p.kv_start1 && k0 < p.kv_end1))) continue; // done by the loop / no real key
+                // ---- an extra tile: K(t), V^T(t) -> buffer 0; S' = K Q'^T against the current start values; padded keys -> -inf; rows that outgrew
+                //      their reference point (or see their first finite score) move it: O, l and the start values follow; then exp / PV as a last tile
+                dma_k(k0, 0);
+                dma_v(k0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const bool all_real = k0 + ATT_KB <= p.kv_len0 || (k0 >= p.kv_start1 && k0 + ATT_KB <= p.kv_end1);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+                    for (int kt = 0; kt < 2; kt++) {
+                        v16f acc;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[r] = MI[16 * rt + r];
+#pragma unroll
+                        for (int ds = 0; ds < 8; ds++) {
+                            const v4i kw = *(const lds_v4i *)(L8 + ((unsigned)ka[ds] + kt * 8192));
+                            acc = Half<DT>::mfma32(__builtin_bit_cast(V8, kw), qfrag(rt, ds), acc);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int key = k0 + 32 * kt + 8 * (r >> 2) + 4 * h + (r & 3); // C layout of S^T: row (key) = 8 (r / 4) + 4 h + r % 4
+                            SA[rt][16 * kt + r] = ((int)all_real | real_key(key)) ? acc[r] : -INFINITY;
+                        }
+                    }
+                    float mloc = SA[rt][0];
+#pragma unroll
+                    for (int r = 1; r < 32; r++) mloc = fmaxf(mloc, SA[rt][r]);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
+                    const unsigned mine = sw[0], other = sw[1];
+                    mloc = fmaxf(__builtin_bit_cast(float, mine), __builtin_bit_cast(float, other)); // the row's largest score RELATIVE to its reference point
+                    const bool fresh = !(mc[rt] > -INFINITY);           // the row has seen no finite score yet (its start value is 0)
+                    const bool move = mloc > -INFINITY && (fresh || mloc > ATT_DEFER_LOG2);
+                    if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                        const float d = move ? mloc : 0.f;               // shift of this row's reference point
+                        const float f = !move ? 1.f : fresh ? 0.f : __builtin_amdgcn_exp2f(-d); // (fresh: O and l are still zero)
+                        mc[rt] = move ? (fresh ? mloc : mc[rt] + d) : mc[rt];
+#pragma unroll
+                        for (int r = 0; r < 32; r++) SA[rt][r] -= d;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) MI[16 * rt + r] = move ? -mc[rt] : MI[16 * rt + r];
+#pragma unroll
+                        for (int r = 0; r < 32; r++) { O[2 * rt][r] *= f; O[2 * rt + 1][r] *= f; }
+                        l2[2 * rt] *= f;
+                        l2[2 * rt + 1] *= f;
+                    }
+                }
+                last_tile(SA, 0);
+                __syncthreads();
+            }
+        }
         SVDQ_ATTN_PROBE_LOOP_END(j1 - j0);
         float l_run[RT] = {l2[0] + l2[1], l2[2] + l2[3]};
 
@@ -873,8 +940,26 @@ template <int DT> static void launch_attention_persistent(const AttnParams &p, i
     hipLaunchKernelGGL((attention_kernel<DT, 8, true>), dim3(groups), dim3(512), 0, st, p);
 }
 template <int DT> static void launch_attention64(const AttnParams &p, int groups, hipStream_t st) {
-    if (groups > 0) hipLaunchKernelGGL((attention_kernel64<DT, true>), dim3(groups), dim3(256), 0, st, p);
+    if (p.kv_len0 > 0) hipLaunchKernelGGL((attention_kernel64<DT, false, true>), dim3(p.L / 256, p.H), dim3(256), 0, st, p);
+    else if (groups > 0) hipLaunchKernelGGL((attention_kernel64<DT, true>), dim3(groups), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attention_kernel64<DT, false>), dim3(p.L / 256, p.H), dim3(256), 0, st, p);
+}
+// Geometry 2 under a key mask: the longest run of fully real 64-key tiles, cut to an even count (what the assembly loop runs); false when no run has two
+static bool attention_mask_segment(const svdq_attention_args *a, int &j0, int &j1) {
+    int a0 = 0, a1 = a->kv_len0 / ATT_KB;
+    int b0 = (a->kv_start1 + ATT_KB - 1) / ATT_KB, b1 = a->kv_end1 / ATT_KB;
+    if (a->kv_end1 <= a->kv_start1 || b1 < b0) b0 = b1 = 0;
+    if (b1 - b0 > a1 - a0) { a0 = b0; a1 = b1; }
+    const int n = (a1 - a0) & ~1;
+    if (n < 2) return false;
+    j0 = a0;
+    j1 = a0 + n;
+    return true;
+}
+
+static bool attention_masked_geometry2(const svdq_attention_args *a, int &j0, int &j1) {
+    j0 = j1 = 0;
+    return a->kv_len0 > 0 && a->geometry != 1 && a->L % 256 == 0 && (a->q_prescaled || a->geometry == 2) && attention_mask_segment(a, j0, j1);
 }
 
 // workgroups of the persistent schedule: one per CU (64 KiB of LDS and 8 waves of ~230 VGPRs: exactly one is resident per CU)
@@ -956,6 +1041,21 @@ extern "C" int svdq_attention_schedule(int32_t L, int32_t H, int32_t cus, int32_
     return n;
 }
 
+// Which kernel a launch with these arguments would take (host only, nothing is launched): out[0] = workgroup geometry (1 / 2), out[1] = 1 when the
+// key mask runs on geometry 2, out[2], out[3] = the main segment [j0, j1) of fully real 64-key tiles its assembly loop walks (the other tiles that
+// hold a real key are C++ "extra" tiles).  Pointers are not looked at.
+extern "C" int svdq_attention_plan(const svdq_attention_args *a, int32_t *out) {
+    if (!a || !out) { set_error("svdq_attention_plan: args and out are required"); return SVDQ_E_INVALID; }
+    if (a->L <= 0 || a->L % 128) { set_error("svdq_attention_plan: L=%d must be a positive multiple of 128", a->L); return SVDQ_E_INVALID; }
+    int j0 = 0, j1 = 0;
+    const bool mask2 = attention_masked_geometry2(a, j0, j1);
+    out[0] = a->kv_len0 > 0 ? (mask2 ? 2 : 1) : a->geometry ? a->geometry : (a->L % 256 == 0 && a->q_prescaled ? 2 : 1);
+    out[1] = mask2 ? 1 : 0;
+    out[2] = j0;
+    out[3] = j1;
+    return SVDQ_OK;
+}
+
 extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     if (!a) { set_error("svdq_attention: args is NULL"); return SVDQ_E_INVALID; }
     if (!a->q || !a->k || !a->vt || (!a->out && !a->qact)) { set_error("svdq_attention: q, k, vt and out (or qact) are required"); return SVDQ_E_INVALID; }
@@ -1027,8 +1127,11 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     // geometry 1).  Same box, 24 heads x 4608 tokens: 216 us against 274 for geometry 1 on its better schedule; geometry 2's own
     // persistent schedule 236.  With a raw Q geometry 2 has to scale the 16-bit values itself (a second rounding, ~2.5x the error against
     // fp32): only on explicit request.  An explicit geometry takes the workspace if given.
-    const int geometry = a->kv_len0 > 0 ? 1 : a->geometry ? a->geometry : (a->L % 256 == 0 && a->q_prescaled ? 2 : 1);
-    const int groups = geometry == 2 && a->geometry == 0 ? 0 : attention_groups(p);
+    // (round 4: a masked launch takes geometry 2 as well -- plain grid, the padded / odd tiles as C++ "extra" tiles behind the assembly loop,
+    //  attention_kernel64<.., MASK> -- when the same conditions hold and some run of fully real tiles has at least two)
+    const bool mask2 = attention_masked_geometry2(a, p.mask_j0, p.mask_j1);
+    const int geometry = a->kv_len0 > 0 ? (mask2 ? 2 : 1) : a->geometry ? a->geometry : (a->L % 256 == 0 && a->q_prescaled ? 2 : 1);
+    const int groups = geometry == 2 && (a->geometry == 0 || mask2) ? 0 : attention_groups(p);
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
     if (geometry == 2 && a->L % 256 == 0) { if (a->dtype == SVDQ_FP16) launch_attention64<SVDQ_FP16>(p, groups, st); else launch_attention64<SVDQ_BF16>(p, groups, st); }
     else if (groups > 0) { if (a->dtype == SVDQ_FP16) launch_attention_persistent<SVDQ_FP16>(p, groups, st); else launch_attention_persistent<SVDQ_BF16>(p, groups, st); }

@@ -502,25 +502,33 @@ class FluxEngineMixin:
         enc = self.context_embedder(encoder_hidden_states)
 
         t_txt, t_img = enc.shape[1], hidden.shape[1]
-        rot = flux_pos_embed(torch.cat([txt_ids, img_ids], dim=0), self.axes)  # [1, T, 64, 1, 2]
-        rot_t, rot_i = pad_tensor(rot[:, :t_txt], 256, 1), pad_tensor(rot[:, t_txt:], 256, 1)
-        rot_txt, rot_img = pack_rotemb(rot_t), pack_rotemb(rot_i)
+        attn0 = (self.blocks[0] if len(self.blocks) else self.single_blocks[0]).attn
+        pad_streams = FluxAttentionAMD.padded_tokens and attn0.attention_impl == "svdq" and attn0.head_dim == 128
+        # the rotary tables depend on the position ids only: a denoise loop passes the same two tensor OBJECTS every step -- built once and kept
+        # (one entry; the cache holds the id tensors themselves, so "the same object, unmodified" cannot be a recycled address)
+        key = (txt_ids._version, img_ids._version, pad_streams)
+        cached = getattr(self, "_rot_cache", None)
+        if cached is not None and cached[0] is txt_ids and cached[1] is img_ids and cached[2] == key:
+            rot_txt, rot_img, rot_all, p_txt, p_img = cached[3]
+        else:
+            rot = flux_pos_embed(torch.cat([txt_ids, img_ids], dim=0), self.axes)  # [1, T, 64, 1, 2]
+            rot_t, rot_i = pad_tensor(rot[:, :t_txt], 256, 1), pad_tensor(rot[:, t_txt:], 256, 1)
+            rot_txt, rot_img = pack_rotemb(rot_t), pack_rotemb(rot_i)
+            p_txt, p_img = rot_t.shape[1], rot_i.shape[1]
+            # joint table: every stream on a 256-row boundary when the streams are padded (below), the plain concatenation otherwise
+            rot_all = pack_rotemb(torch.cat([rot_t, rot_i], dim=1)) if pad_streams and kv_valid_ranges(t_txt, t_img) is not None \
+                else pack_rotemb(pad_tensor(rot, 256, 1))
+            self._rot_cache = (txt_ids, img_ids, key, (rot_txt, rot_img, rot_all, p_txt, p_img))
         # EVERY token count runs the hot path (the reference pads any M to 256 rows, Linear.cpp:445-446, and masks the padded K rows of its
         # attention, epilogues.cuh:427-550): both streams are padded to 256 rows with zero tokens right behind the embedders -- the joint
         # sequence is [text | pad | image | pad], every stream starts on a 256-row boundary as the grouped launches need -- every launch of
         # the step sees the shapes the parity suite and the bench exercise, the attention kernel masks the padded keys (kv_valid), and the
         # real image rows are sliced out at the end.  A padded row is a token nobody attends to: it stays finite and touches no real row.
-        p_txt, p_img = rot_t.shape[1], rot_i.shape[1]
-        kv_valid = None
-        attn0 = (self.blocks[0] if len(self.blocks) else self.single_blocks[0]).attn
-        if FluxAttentionAMD.padded_tokens and attn0.attention_impl == "svdq" and attn0.head_dim == 128:
-            kv_valid = kv_valid_ranges(t_txt, t_img)
+        kv_valid = kv_valid_ranges(t_txt, t_img) if pad_streams else None
         if kv_valid is not None:
             enc, hidden = F.pad(enc, (0, 0, 0, p_txt - t_txt)), F.pad(hidden, (0, 0, 0, p_img - t_img))
-            rot_all = pack_rotemb(torch.cat([rot_t, rot_i], dim=1))
         else:
             p_txt = t_txt
-            rot_all = pack_rotemb(pad_tensor(rot, 256, 1))
 
         fused = self.fused_norm and hidden.shape[0] == 1
         stats = ((residual_gate_stats(hidden)[1], None), (residual_gate_stats(enc)[1], None)) if fused else None

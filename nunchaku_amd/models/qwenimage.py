@@ -486,7 +486,14 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
         shape = img_shapes[0] if img_shapes else (1, int(math.isqrt(hidden.shape[1])), int(math.isqrt(hidden.shape[1])))
         if isinstance(shape, (list, tuple)) and isinstance(shape[0], (list, tuple)):
             shape = shape[0]
-        rot = pack_qwen_rotary(*qwen_rope_freqs(tuple(shape), t_txt, self.axes, device=hidden.device))
+        # the rotary tables depend on the grid, the text length and the device only: built once per (shape, length) and kept (one entry)
+        rkey = (tuple(shape), t_txt, str(hidden.device))
+        cached = getattr(self, "_rot_cache", None)
+        if cached is not None and cached[0] == rkey:
+            rot = cached[1]
+        else:
+            rot = pack_qwen_rotary(*qwen_rope_freqs(tuple(shape), t_txt, self.axes, device=hidden.device))
+            self._rot_cache = (rkey, rot)
         compute_stream = torch.cuda.current_stream()
         if self.offload:
             self.offload_manager.initialize(compute_stream)

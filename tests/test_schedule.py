@@ -184,3 +184,33 @@ def test_row_runs_cover_every_tile_once_and_stay_inside_a_row_block(M_pad, N, cu
     assert longest >= min(rounds, TN)
     if rounds <= TN and TM * -(-TN // rounds) <= cus:
         assert longest == rounds
+
+
+# svdq_attention_plan: which kernel a (masked) attention launch takes -- host only
+def _attn_plan(L, valid=None, q_prescaled=1, geometry=0):
+    lib = _lib.load()
+    a = _lib.AttentionArgs()
+    a.L, a.H, a.head_dim, a.q_prescaled, a.geometry = L, 24, 128, q_prescaled, geometry
+    if valid:
+        a.kv_len0 = valid[0]
+        if len(valid) == 3:
+            a.kv_start1, a.kv_end1 = valid[1], valid[2]
+    out = (C.c_int32 * 4)()
+    assert lib.svdq_attention_plan(C.byref(a), out) == 0
+    return list(out)
+
+
+def test_attention_plan_puts_masked_launches_on_the_fast_geometry(built_lib):
+    assert _attn_plan(4608) == [2, 0, 0, 0]                      # the headline shape: geometry 2, no mask
+    assert _attn_plan(4608, q_prescaled=0) == [1, 0, 0, 0]       # a raw Q: geometry 1 (a second rounding of Q otherwise)
+    # FLUX 1360 x 768: 512 + 4080 tokens, padding at the end: 71 full tiles -> the loop runs 70, tiles 70 (full) and 71 (48 real keys) are extras
+    assert _attn_plan(4608, (4592,)) == [2, 1, 0, 70]
+    # Qwen-Image 1664 x 928 with a 37-token prompt: [37 | pad to 256 | 6032 | pad to 6400]: the image run [4, 98) is the main segment, the
+    # text tile 0 and the image's last tile 98 (16 real keys) are extras, tiles 1..3 and 99 are never touched
+    assert _attn_plan(6400, (37, 256, 6288)) == [2, 1, 4, 98]
+    assert _attn_plan(512, (300, 384, 500)) == [2, 1, 0, 4]
+    assert _attn_plan(512, (64, 256, 257)) == [1, 0, 0, 0]       # no run of two full tiles: geometry 1
+    assert _attn_plan(4608, (4592,), q_prescaled=0) == [1, 0, 0, 0]
+    assert _attn_plan(4608, (4592,), q_prescaled=0, geometry=2) == [2, 1, 0, 70]   # explicit geometry 2 scales Q itself
+    assert _attn_plan(4608, (4592,), geometry=1) == [1, 0, 0, 0]
+    assert _attn_plan(384, (300,)) == [1, 0, 0, 0]               # L % 256 != 0: the 4-wave variant of geometry 1
