@@ -986,10 +986,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             const int nv0 = nw0 - 2 * (p.N / 3);
             const int odd = lr & 1;
             auto store_vt = [&](auto full) { // full: every row of the tile is a real row (block-uniform): no per-lane predicates
+                // address = uniform part (tile origin + the store's channel: scalar arithmetic) + ONE 32-bit lane offset per row tile (the lane's token
+                // pair and its channel inside the 8-channel piece): the 32 stores of a wave take the saddr form, no 64-bit address arithmetic per store
+                const char *vt_tile = (const char *)p.out_vt + ((size_t)(n0 - 2 * (p.N / 3) + (wv & 1) * 64) * p.ldvt + (size_t)(m0 + (wv >> 1) * 64)) * 2;
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++) {
                     const int m_base = (mw0 + mi * 32 + lr) & ~1;
-                    uint16_t *vcol = (uint16_t *)p.out_vt + m_base;
+                    const unsigned lane_off = ((h_e * 4u + (lr_e & 1u)) * (unsigned)p.ldvt + (unsigned)(mi * 32) + (lr_e & ~1u)) * 2u;
 #pragma unroll
                     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
@@ -999,10 +1002,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                             const unsigned own = (unsigned)hbits(f2h<T>(v0)) | ((unsigned)hbits(f2h<T>(v1)) << 16);
                             const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, true); // lane ^ 1
                             const unsigned val = odd ? ((oth >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (oth << 16));
-                            const int n = nv0 + ni * 32 + (r >> 2) * 8 + h * 4 + (r & 3) + odd;
-                            uint16_t *dst = vcol + (size_t)n * p.ldvt;
+                            // channel n = nv0 + 32 ni + 8 (r >> 2) + 4 h + (r & 3) + odd: the h / odd part sits in lane_off
+                            char *dst = const_cast<char *>(vt_tile) + (size_t)(ni * 32 + (r >> 2) * 8 + (r & 3)) * p.ldvt * 2 + lane_off;
                             if (decltype(full)::value || m_base + 1 < p.M) *reinterpret_cast<unsigned *>(dst) = val;
-                            else if (m_base < p.M) *dst = (uint16_t)val;
+                            else if (m_base < p.M) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)val;
                         }
                 }
             };

@@ -237,6 +237,42 @@ def test_qkv_rmsnorm_rope(dtype, M, K, H):
     assert_close_16(got[:, : 2 * N // 3], ref[:, : 2 * N // 3], dtype, "QK", max_bad_frac=2e-3, ulps=2.0)
 
 
+@pytest.mark.parametrize("r2", [16, 32, 48], ids=["next-rank-16", "next-rank-32", "next-rank-48"])
+def test_gelu_quant_next_low_rank_down_by_rank(r2):
+    """The GELU_QUANT epilogue's low-rank down projection for the NEXT layer at ranks on both sides of the carry kernel's limit (round 4: rank <= 32
+    accumulates in the workgroup's LDS carry -- rank 16 with half the lanes idle --, rank 48 keeps the per-tile atomics over two passes of 32 ranks):
+    codes, scales and lora_act_out against the oracle, several column tiles per row block so that the carry really sums."""
+    from nunchaku_amd import layout
+    from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
+
+    dtype, M, C, Hd = "bf16", 300, 256, 1024
+    fc1 = O.make_svdq_layer(C, Hd, 32, seed=31, dtype=dtype, cheap=True)
+    fc2 = O.make_svdq_layer(Hd, C, r2, seed=32, dtype=dtype, cheap=True)
+    x = O.make_activations(M, C, seed=33, dtype=dtype)
+    m1, m2 = make_module(fc1, dtype), make_module(fc2, dtype, act_unsigned=True)
+    qx, asc, la = m1.quantize(t16(x, dtype))
+    M_pad = qx.shape[0]
+    qh = torch.empty(layout.act_image_shape(M_pad, Hd), dtype=torch.uint8, device="cuda")
+    sh = torch.empty(Hd // 64, M_pad, dtype=TORCH_DT[dtype], device="cuda")
+    lh = torch.full((M_pad, r2), 3.0, dtype=torch.float32, device="cuda")  # must be zeroed by the op
+    m2._ensure_layout()
+    svdq_gemm_w4a4_cuda(act=qx, wgt=m1.qweight, qout=qh, ascales=asc, wscales=m1.wscales, oscales=sh, lora_act_in=la, lora_up=m1.proj_up,
+                        lora_down=m2.proj_down, lora_act_out=lh, bias=m1.bias, smooth_factor=m2.smooth_factor)
+    q, a, l_ = O.quantize_w4a4_act_fuse_lora(x, fc1["smooth"], fc1["proj_down"], dtype)
+    r = O.gemm_w4a4(q, a, fc1["qweight"], fc1["wscales"], dtype=dtype, bias=fc1["bias"], lora_act_in=l_, lora_up=fc1["proj_up"], fuse="gelu_quant",
+                    next_smooth=fc2["smooth"], next_lora_down=fc2["proj_down"])
+    codes = layout.unpack_act(qh, Hd, unsigned=True).cpu().numpy()[:M]
+    diff = np.abs(codes.astype(int) - r["qout"][:M].astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 5e-3
+    la_ref = r["lora_act_out"][:M]
+    got = lh.cpu().numpy()
+    assert got.shape[1] == r2 and np.abs(got[:M] - la_ref).max() <= 2e-3 * np.abs(la_ref).max() + 1e-4
+    # twice: the carry must have been left clean by the first launch (same buffer, cleared by the op)
+    svdq_gemm_w4a4_cuda(act=qx, wgt=m1.qweight, qout=qh, ascales=asc, wscales=m1.wscales, oscales=sh, lora_act_in=la, lora_up=m1.proj_up,
+                        lora_down=m2.proj_down, lora_act_out=lh, bias=m1.bias, smooth_factor=m2.smooth_factor)
+    assert np.abs(lh.cpu().numpy()[:M] - la_ref).max() <= 2e-3 * np.abs(la_ref).max() + 1e-4
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_fused_gelu_mlp(dtype):
     from nunchaku_amd import layout
