@@ -122,13 +122,14 @@ class ClockSampler:
             self._thread.start()
 
     def stop(self):
-        """median GHz of the samples (None when the file is not readable)"""
+        """median GHz of the samples; None when the file is not readable or the timed region was shorter than three samples (the first
+        sample of a short region can still show the idle clock)"""
         if not self._thread:
             return None
         self._stop.set()
         self._thread.join()
         xs = sorted(self.samples)
-        return xs[len(xs) // 2] / 1e3 if xs else None
+        return xs[len(xs) // 2] / 1e3 if len(xs) >= 3 else None
 
 
 def cpu_baseline(max_seconds: float = 30.0):

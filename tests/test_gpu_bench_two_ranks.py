@@ -50,7 +50,7 @@ def test_bench_two_ranks_on_one_gpu(config):
     assert 0 < pr["min_steps_per_s"] <= pr["max_steps_per_s"] and d["value"] <= 2 * pr["max_steps_per_s"] * 1.0001
     rf = d["roofline"]
     assert isinstance(rf["traffic_stale"], bool) and (rf["mfma_util"] is None or isinstance(rf["mfma_util"]["stale"], bool))
-    assert rf["effective_clock_ghz"] is None or 0.3 < rf["effective_clock_ghz"] < 3.0
+    assert rf["effective_clock_ghz"] is None or 0.05 < rf["effective_clock_ghz"] < 3.0
     pv = rf["per_variant"]
     assert {"default", "gelu_quant", "rmsnorm_rope"} <= set(pv), pv.keys()
     assert abs(sum(v["launches_per_step"] for v in pv.values()) * d["steps"] - rf["launches"]) < 1e-6

@@ -5,8 +5,12 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nunchaku_amd._lib as _L
 _L._LIB_PATH = os.path.abspath(os.environ.get("SVDQ_LIB", _L._LIB_PATH))
-_v = ctypes.CDLL(_L._LIB_PATH).svdq_abi_version()
+_so = ctypes.CDLL(_L._LIB_PATH)
+_v = _so.svdq_abi_version()
 if _v in (17, 18):
     _L.ABI_VERSION = _v
+for _name in list(_L.EXPORTS):  # entry points an older build does not have (host-side queries added later) are simply not bound
+    if not hasattr(_so, _name):
+        del _L.EXPORTS[_name]
 import bench
 bench.main()
