@@ -100,11 +100,32 @@ class ClockSampler:
     def __init__(self, device_index: int):
         import glob
         import threading
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.path = cards[device_index] if device_index < len(cards) else None
+        self.path = None
+        # the sysfs card of THIS HIP device: matched by PCI address (a box shows every card of the node, the process sees one of them as device 0)
+        bdf = self._pci_address(device_index)
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            if bdf and os.path.basename(os.path.realpath(os.path.dirname(f))).lower() == bdf:
+                self.path = f
         self.samples, self._stop, self._thread = [], threading.Event(), None
         if self.path:
             self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _pci_address(device_index: int):
+        """'0000:bb:dd.f' of a HIP device (hipDeviceGetPCIBusId), or None"""
+        import ctypes
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0 and buf.value:
+                return buf.value.decode().strip().lower()
+        except Exception:
+            pass
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            return "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            return None
 
     def _run(self):
         import re
@@ -188,6 +209,9 @@ def main():
                          "gate (tests/v1/qwenimage/test_qwenimage.py:21): token counts that are not a multiple of 256 run the same fused path "
                          "on padded streams")
     ap.add_argument("--txt-tokens", type=int, default=512)
+    ap.add_argument("--weight-codes", choices=["uniform", "residual"], default="uniform",
+                    help="distribution of the random 4-bit weight codes: uniform, or that of a quantised Gaussian residual (SURVEY 8d's synthetic layers); "
+                         "both kernels of the step run at the chip's power limit, where the clock depends on the data")
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events in the timed region (their cost: ~0.5 %%)")
     ap.add_argument("--layers", type=int, nargs=2, default=(19, 38), help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,7 +269,7 @@ def main():
     else:
         model = FluxTransformerAMD(num_layers=args.layers[0], num_single_layers=args.layers[1], guidance_embeds=not schnell, device=dev)
     if rank == 0:
-        model.init_synthetic_(seed=0)
+        model.init_synthetic_(seed=0, codes=args.weight_codes)
     bcast_bytes = replica.broadcast_module_(model, src=0)
     model.eval()
     if qwen and args.offload:
@@ -387,7 +411,8 @@ def main():
             "config": {
                 "workload": workload,
                 "gemm_geometry": args.geometry, "attention_geometry": args.attention_geometry, "deterministic": args.deterministic,
-                "weights": "uniform-random 4-bit codes (not SVD-residual codes: the clock of a power-limited kernel is data dependent)",
+                "weights": ("uniform-random 4-bit codes (not SVD-residual codes: the clock of a power-limited kernel is data dependent)" if args.weight_codes == "uniform"
+                            else "4-bit codes distributed like a quantised Gaussian residual, rne(N(0, 2.9^2)) clamped to +-7 (SURVEY 8d; --weight-codes uniform is the round 1-4 default)"),
                 "parallelism": f"{world} independent replica(s), one image each; weights broadcast once over RCCL "
                                f"({bcast_bytes / 1e9:.2f} GB)" + ("; step replayed as one HIP graph" if args.graph else ""),
                 "output_finite": finite,

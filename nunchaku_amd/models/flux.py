@@ -29,7 +29,7 @@ from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rot
                          linear_pair, linear_pair_quantized, quantize_two)
 from ..utils import pad_tensor
 from .embeddings import flux_pos_embed, pack_rotemb
-from .linear import AWQW4A16Linear, SVDQW4A4Linear
+from .linear import AWQW4A16Linear, SVDQW4A4Linear, synthetic_codes_
 
 
 def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 10000.0) -> torch.Tensor:
@@ -425,8 +425,9 @@ class FluxEngineMixin:
             m.reset_lora()
 
     @torch.no_grad()
-    def init_synthetic_(self, seed: int = 0, repack: bool = True):
-        """Random-init weights of FLUX shape (no checkpoints in this environment): int4 codes uniform,
+    def init_synthetic_(self, seed: int = 0, repack: bool = True, codes: str = "uniform"):
+        """Random-init weights of FLUX shape (no checkpoints in this environment): int4 codes uniform or with the
+        distribution of a quantised Gaussian residual (``codes``: models/linear.py ``synthetic_codes_``),
         scales/low-rank factors small so activations stay O(1).  Parameters are written in the
         checkpoint layout (random nibbles are random int4 codes) and repacked like a real checkpoint."""
         dev = self.proj_out.weight.device
@@ -441,9 +442,7 @@ class FluxEngineMixin:
         for m in self.modules():
             if isinstance(m, SVDQW4A4Linear):
                 K = m.in_features
-                m.qweight.copy_(torch.randint(-128, 128, m.qweight.shape, generator=g, device=dev, dtype=torch.int16))
-                # 4-bit uniform codes have std ~4.6: scale so that |W row| ~ 1/sqrt(K)
-                m.wscales.copy_((uni(m.wscales.shape) * 0.5 + 0.75) * (1.0 / (4.6 * math.sqrt(K))))
+                synthetic_codes_(m.qweight, m.wscales, K, g, codes)  # scaled so that |W row| ~ 1/sqrt(K)
                 if m.bias is not None:
                     m.bias.copy_(rnd(m.bias.shape, 0.02))
                 m.smooth_factor.copy_(uni((K,)) + 0.5)

@@ -16,12 +16,35 @@ repacked layer (which drops tensor attributes) stays correct.
 
 from __future__ import annotations
 
+import math
+
 import torch
 from torch import nn
 
 from .. import layout
 from ..ops.gemm import svdq_gemm_w4a4_cuda
 from ..ops.quantize import svdq_quantize_w4a4_act_fuse_lora_cuda
+
+
+def synthetic_codes_(qweight: torch.Tensor, wscales: torch.Tensor, in_features: int, generator: torch.Generator, codes: str = "uniform"):
+    """Random 4-bit weight codes + group scales in the checkpoint layout (no checkpoints in this environment), in place.
+
+    ``codes="uniform"``: every nibble uniform in [-8, 7] (std 4.6).  ``codes="residual"``: the distribution of an SVDQuant residual as SURVEY.md 8(d)
+    prescribes synthetic layers -- a Gaussian weight quantised symmetrically per group of 64 with scale = amax / 7: code = rne(7 x / amax), and amax
+    of 64 standard normal samples is 2.41 on average, so the codes are rne(N(0, 2.9^2)) clamped to +-7.  Both fill the packed tensor nibble by nibble
+    (the checkpoint's permutation does not change an i.i.d. distribution).  The scales make the dequantised rows ~ 1 / sqrt(K) either way."""
+    dev = qweight.device
+    if codes == "uniform":
+        qweight.copy_(torch.randint(-128, 128, qweight.shape, generator=generator, device=dev, dtype=torch.int16))
+        std = 4.6
+    elif codes == "residual":
+        std = 7.0 / 2.41
+        lo = torch.randn(qweight.shape, generator=generator, device=dev).mul_(std).round_().clamp_(-7, 7).to(torch.int16)
+        hi = torch.randn(qweight.shape, generator=generator, device=dev).mul_(std).round_().clamp_(-7, 7).to(torch.int16)
+        qweight.copy_((((lo & 15) | ((hi & 15) << 4)) ^ 128) - 128)  # two's-complement nibbles, low nibble first, as a signed byte
+    else:
+        raise ValueError(f"codes must be 'uniform' or 'residual', got {codes!r}")
+    wscales.copy_((torch.rand(wscales.shape, generator=generator, device=dev) * 0.5 + 0.75) * (1.0 / (std * math.sqrt(in_features))))
 
 
 class SVDQW4A4Linear(nn.Module):

@@ -34,7 +34,7 @@ from ..ops.fused import (fused_gelu_mlp, fused_gelu_mlp_pair, fused_qkv_norm_rot
 from ..ops.gemv import awq_gemv_w4a16_batched, awq_gemv_w4a16_cuda
 from ..utils import pad_tensor
 from .embeddings import pack_rotemb
-from .linear import AWQW4A16Linear, SVDQW4A4Linear
+from .linear import AWQW4A16Linear, SVDQW4A4Linear, synthetic_codes_
 from .offload import CPUOffloadManager
 from .transformer_flux import NunchakuModelLoaderMixin
 
@@ -443,15 +443,15 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
         return super().to(*args, **kwargs)
 
     @torch.no_grad()
-    def init_synthetic_(self, seed: int = 0):
-        """Random-init weights of the Qwen-Image shape (no checkpoints in this environment), written in the checkpoint layout."""
+    def init_synthetic_(self, seed: int = 0, codes: str = "uniform"):
+        """Random-init weights of the Qwen-Image shape (no checkpoints in this environment), written in the checkpoint layout
+        (``codes``: models/linear.py ``synthetic_codes_``)."""
         dev = self.proj_out.weight.device
         g = torch.Generator(device=dev).manual_seed(seed)
         for m in self.modules():
             if isinstance(m, SVDQW4A4Linear):
                 K = m.in_features
-                m.qweight.copy_(torch.randint(-128, 128, m.qweight.shape, generator=g, device=dev, dtype=torch.int16))
-                m.wscales.copy_((torch.rand(m.wscales.shape, generator=g, device=dev) * 0.5 + 0.75) * (1.0 / (4.6 * math.sqrt(K))))
+                synthetic_codes_(m.qweight, m.wscales, K, g, codes)
                 if m.bias is not None:
                     m.bias.copy_(torch.randn(m.bias.shape, generator=g, device=dev) * 0.02)
                 m.smooth_factor.copy_(torch.rand((K,), generator=g, device=dev) + 0.5)
