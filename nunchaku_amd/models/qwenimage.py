@@ -476,8 +476,6 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
                 txt_seq_lens=None, guidance=None, attention_kwargs=None, controlnet_block_samples=None, return_dict: bool = True):
         """hidden_states [1, T_img, 64] (packed 2x2 latent patches); encoder_hidden_states [1, T_txt, 3584]; timestep [1] (already
         divided by 1000 by the pipeline); img_shapes [(frames, H/2, W/2)] of the latent grid.  -> [1, T_img, 64]."""
-        if controlnet_block_samples is not None:
-            raise NotImplementedError("ControlNet residuals are out of scope (SURVEY.md section 8)")
         dt = self.dtype_
         hidden = self.img_in(hidden_states)
         enc = self.txt_in(self.txt_norm(encoder_hidden_states))
@@ -530,6 +528,15 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
             else:
                 enc, hidden = block(hidden_states=hidden, encoder_hidden_states=enc, encoder_hidden_states_mask=encoder_hidden_states_mask,
                                     temb=temb, image_rotary_emb=rot, joint_attention_kwargs=attention_kwargs, kv_valid=kv_valid)
+            if controlnet_block_samples is not None:
+                # the reference's (= diffusers') choice of the residual behind block i (transformer_qwenimage.py:546-550): one 16-bit add on the image
+                # stream; the fused path needs the LayerNorm statistics of the sum -- the same pass.  Padded image rows get a zero residual.
+                smp = controlnet_block_samples[i // -(-len(self.transformer_blocks) // len(controlnet_block_samples))].to(hidden.dtype)
+                if smp.shape[1] != hidden.shape[1]:
+                    smp = F.pad(smp, (0, 0, 0, hidden.shape[1] - smp.shape[1]))
+                hidden, h_stats = residual_gate_stats(hidden, smp.contiguous(), want_stats=fused)
+                if fused:
+                    stats = (stats[0], h_stats)
             if self.offload:
                 self.offload_manager.step(compute_stream)
         hidden = hidden[:, :t_img]

@@ -271,6 +271,54 @@ def test_qwen_model_fused_passes_match_the_torch_op_blocks(dtype):
     assert torch.isfinite(outs[True]).all() and psnr > 45.0 and rel < 2.5e-2, (psnr, rel)
 
 
+def test_qwen_controlnet_residuals_on_the_fused_path():
+    """`controlnet_block_samples` (reference transformer_qwenimage.py:546-550: hidden += samples[block // ceil(blocks / samples)] behind every block):
+    the fused path (the add and the next LayerNorm's statistics in one pass) against the torch-op block sequence with a plain 16-bit add, at a token
+    count that is padded (300 image tokens -> 512 rows: the padded rows get a zero residual) and with fewer samples than blocks."""
+    from nunchaku_amd import mode
+    from nunchaku_amd.models.qwenimage import NunchakuQwenImageTransformer2DModel
+
+    model = NunchakuQwenImageTransformer2DModel(num_layers=3, num_attention_heads=2, attention_head_dim=128, in_channels=64, out_channels=16,
+                                                joint_attention_dim=128, device="cuda").init_synthetic_(seed=6).eval()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    lat = torch.randn(1, 300, 64, device="cuda", generator=g).bfloat16()
+    enc = torch.randn(1, 40, 128, device="cuda", generator=g).bfloat16()
+    ctrl = [torch.randn(1, 300, 256, device="cuda", generator=g).bfloat16() * 0.5 for _ in range(2)]  # blocks 0, 1 -> sample 0; block 2 -> sample 1
+    t = torch.tensor([0.4], device="cuda")
+    outs = {}
+    with torch.no_grad(), mode.deterministic_mode():
+        plain = model(lat, enc, None, t, [(1, 15, 20)]).sample.float()
+        for fused in (True, False):
+            NunchakuQwenImageTransformer2DModel.fused_norm = fused
+            try:
+                outs[fused] = model(lat, enc, None, t, [(1, 15, 20)], controlnet_block_samples=ctrl).sample.float()
+            finally:
+                NunchakuQwenImageTransformer2DModel.fused_norm = True
+        # the torch-op blocks with the add done here, outside the model: what the reference's loop computes
+        NunchakuQwenImageTransformer2DModel.fused_norm = False
+        try:
+            hooks, k = [], [0]
+
+            def add(_m, _inp, out):
+                i = k[0]
+                k[0] += 1
+                smp = torch.nn.functional.pad(ctrl[i // 2], (0, 0, 0, out[1].shape[1] - 300))
+                return out[0], out[1] + smp
+            for b in model.transformer_blocks:
+                hooks.append(b.register_forward_hook(add))
+            by_hand = model(lat, enc, None, t, [(1, 15, 20)]).sample.float()
+        finally:
+            for h in hooks:
+                h.remove()
+            NunchakuQwenImageTransformer2DModel.fused_norm = True
+    assert plain.shape == (1, 300, 16) and torch.isfinite(outs[True]).all()
+    assert torch.equal(outs[False], by_hand), "torch-op path: the model's ControlNet add differs from the reference loop's"
+    assert not torch.equal(outs[True], plain)
+    psnr, rel = psnr_rel(outs[True], outs[False])
+    print(f"qwen controlnet fused vs torch-op blocks: PSNR {psnr:.1f} dB rel {rel:.2e}")
+    assert psnr > 45.0 and rel < 2.5e-2, (psnr, rel)
+
+
 def test_qwen_rope_tables():
     from nunchaku_amd.models.qwenimage import pack_qwen_rotary, qwen_rope_freqs
 

@@ -164,8 +164,9 @@ typedef int v6i_ __attribute__((ext_vector_type(6)));
 #define TG_NOFMA(PN, SN) \
     "v_mfma_scale_f32_32x32x64_f8f6f4 %[" #PN "], %[w6], %[a6], 0, %[mx], %[mx] op_sel_hi:[0,0,0] cbsz:2 blgp:2\n" \
     "v_mfma_f32_32x32x16_bf16 %[" #SN "], %[x], %[y], 0\n"
-#define GEMM_KERNEL(name, BODYSTR)                                                                                            \
-    __global__ __launch_bounds__(512, 2) void name(long long *out, int iters) {                                               \
+#define GEMM_KERNEL(name, BODYSTR) GEMM_KERNEL_T(name, BODYSTR, 512)
+#define GEMM_KERNEL_T(name, BODYSTR, THREADS)                                                                                 \
+    __global__ __launch_bounds__(THREADS) void name(long long *out, int iters) {                                               \
         v16f p0 = {}, p1 = {}, s0 = {}, s1 = {};                                                                               \
         v4f x = {1.f, 2.f, 3.f, 4.f}, y = {1.f, 1.f, 1.f, 1.f};                                                                \
         v6i_ w6 = {0x11111111, 0x22222222, 0x12121212, 0x21212121, 0x11221122, 0x22112211}, a6 = w6;                           \
@@ -184,6 +185,10 @@ typedef int v6i_ __attribute__((ext_vector_type(6)));
     }
 GEMM_KERNEL(g_full, TG(p0, s0, p1, s1) TG(p1, s1, p0, s0) TG(p0, s0, p1, s1) TG(p1, s1, p0, s0))
 GEMM_KERNEL(g_mfma_only, TG_NOFMA(p1, s1) TG_NOFMA(p0, s0) TG_NOFMA(p1, s1) TG_NOFMA(p0, s0))
+// the same arithmetic at one, three and four waves per SIMD (round 4: does more thread-level parallelism fill the issue port better than two waves do?)
+GEMM_KERNEL_T(g_full_w1, TG(p0, s0, p1, s1) TG(p1, s1, p0, s0) TG(p0, s0, p1, s1) TG(p1, s1, p0, s0), 256)
+GEMM_KERNEL_T(g_full_w3, TG(p0, s0, p1, s1) TG(p1, s1, p0, s0) TG(p0, s0, p1, s1) TG(p1, s1, p0, s0), 768)
+GEMM_KERNEL_T(g_full_w4, TG(p0, s0, p1, s1) TG(p1, s1, p0, s0) TG(p0, s0, p1, s1) TG(p1, s1, p0, s0), 1024)
 
 struct Entry { const char *name; void (*fn)(long long *, int); };
 #define E1(k) {#k "_1", k_##k##_1}, {#k "_2", k_##k##_2}, {#k "_4", k_##k##_4}, {#k "_5", k_##k##_5}, {#k "_6", k_##k##_6}, {#k "_8", k_##k##_8},
@@ -227,6 +232,7 @@ int main(int argc, char **argv) {
     std::vector<Entry> es2 = {{"2 waves/SIMD: none", w2_none}, {"2 waves/SIMD: fma_2", w2_fma_2}, {"2 waves/SIMD: fma_4", w2_fma_4}, {"2 waves/SIMD: fma_6", w2_fma_6},
                               {"2 waves/SIMD: fma_8", w2_fma_8}, {"2 waves/SIMD: fma_8 + ds_read", w2_fma_8_dsr}, {"2 waves/SIMD: fma_8 + 2 ds_read + salu", w2_fma_8_2dsr_salu}};
     setvbuf(stdout, nullptr, _IONBF, 0);
+    if (argc >= 2 && !strcmp(argv[1], "gemm")) { es.clear(); es2.clear(); }  // only the GEMM-arithmetic kernels
     long long *d;
     const int G = 256, iters = 2000;
     hipMalloc(&d, G * sizeof(long long));
@@ -263,7 +269,8 @@ int main(int argc, char **argv) {
         for (auto v : h) s += v;
         printf("%-40s %7.2f cycles / MFMA of one wave = %6.2f per MFMA of the SIMD   (%s)\n", e.name, s / G / (iters * 8.0), s / G / (iters * 16.0), hipGetErrorString(hipGetLastError()));
     }
-    struct { const char *name; void (*fn)(long long *, int); } gs[] = {{"GEMM arithmetic: P + S + 16 v_fmac per tile-group", g_full}, {"GEMM arithmetic: P + S only", g_mfma_only}};
+    struct { const char *name; void (*fn)(long long *, int); int threads; } gs[] = {{"GEMM arithmetic: P + S + 16 v_fmac per tile-group", g_full, 512}, {"GEMM arithmetic: P + S only", g_mfma_only, 512},
+        {"GEMM arithmetic, 1 wave per SIMD", g_full_w1, 256}, {"GEMM arithmetic, 3 waves per SIMD", g_full_w3, 768}, {"GEMM arithmetic, 4 waves per SIMD", g_full_w4, 1024}};
     for (auto &e : gs) {
         hipEvent_t ev0, ev1;
         hipEventCreate(&ev0); hipEventCreate(&ev1);
@@ -271,7 +278,7 @@ int main(int argc, char **argv) {
         const int it = iters * 5;
         for (int rep = 0; rep < 2; rep++) {
             hipEventRecord(ev0, 0);
-            hipLaunchKernelGGL(e.fn, dim3(G), dim3(512), 0, 0, d, it);
+            hipLaunchKernelGGL(e.fn, dim3(G), dim3(e.threads), 0, 0, d, it);
             hipEventRecord(ev1, 0);
             hipDeviceSynchronize();
             hipEventElapsedTime(&ms, ev0, ev1);
@@ -279,7 +286,7 @@ int main(int argc, char **argv) {
         hipMemcpy(h.data(), d, G * sizeof(long long), hipMemcpyDeviceToHost);
         double s = 0;
         for (auto v : h) s += v;
-        const double tg = (double)G * 8 * it * 4;  // tile-groups (32 x 32 x 64) of the launch
+        const double tg = (double)G * (e.threads / 64) * it * 4;  // tile-groups (32 x 32 x 64) of the launch
         printf("%-52s %6.1f cycles per tile-group of one wave, wall %.3f ms = %.0f TOP/s (2 x 32 x 32 x 64 per tile-group), clock %.2f GHz  (%s)\n", e.name,
                s / G / (it * 4.0), ms, tg * 2 * 32 * 32 * 64 / (ms * 1e-3) / 1e12, s / G / (ms * 1e-3) / 1e9, hipGetErrorString(hipGetLastError()));
     }
