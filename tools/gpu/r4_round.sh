@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: all GPU tests, smoke(), the default bench line (with cpu_baseline), the config lines (dev / qwen, square and the reference's 1664 x 928 gate,
-# 1360 x 768), and the rocprofv3 evidence of the default command.   usage: r4_round.sh <outdir> [skip-tests]
+# 1360 x 768), and the rocprofv3 evidence of the default command.   usage: r4_round.sh <outdir> [skip-tests [no-prof]]
+# (the bench lines quote profiles/r4_bench_gemm_*.json with a staleness stamp: after a kernel change run once for the counters, copy them to profiles/, run again with no-prof)
 O=gpurun_out/$1; mkdir -p $O
 if [ -z "$2" ]; then
   T0=$(date +%s); timeout 1700 python -m pytest tests -m gpu -q > $O/pytest_all.txt 2>&1; tail -6 $O/pytest_all.txt; echo "pytest $(( $(date +%s) - T0 )) s"
@@ -19,4 +20,4 @@ try:
 except Exception as e: print(sys.argv[1], 'FAILED', e)
 PY
 done
-bash tools/gpu/r4_profile_bench.sh $1/prof > $O/prof.log 2>&1; tail -30 $O/prof.log
+if [ -z "$3" ]; then bash tools/gpu/r4_profile_bench.sh $1/prof > $O/prof.log 2>&1; tail -30 $O/prof.log; fi
