@@ -32,10 +32,19 @@ from .embeddings import flux_pos_embed, pack_rotemb
 from .linear import AWQW4A16Linear, SVDQW4A4Linear, synthetic_codes_
 
 
+_FREQS: dict = {}
+
+
 def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 10000.0) -> torch.Tensor:
-    """Sinusoidal embedding, (cos, sin) order, as diffusers' ``Timesteps(flip_sin_to_cos=True)``."""
+    """Sinusoidal embedding, (cos, sin) order, as diffusers' ``Timesteps(flip_sin_to_cos=True)``.  (The frequency table is a constant
+    of (dim, period, device): built once -- three tiny launches less per call.)"""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    key = (half, max_period, str(t.device))
+    freqs = _FREQS.get(key)
+    if freqs is None or torch.cuda.is_current_stream_capturing():
+        freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+        if not torch.cuda.is_current_stream_capturing():
+            _FREQS[key] = freqs
     args = t.float()[:, None] * freqs[None]
     return torch.cat([args.cos(), args.sin()], dim=-1)
 
