@@ -40,10 +40,11 @@ def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 1000
     of (dim, period, device): built once -- three tiny launches less per call.)"""
     half = dim // 2
     key = (half, max_period, str(t.device))
-    freqs = _FREQS.get(key)
-    if freqs is None or torch.cuda.is_current_stream_capturing():
+    capturing = t.is_cuda and torch.cuda.is_current_stream_capturing()  # (a tensor made under capture lives in the graph's pool: not kept)
+    freqs = None if capturing else _FREQS.get(key)
+    if freqs is None:
         freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
-        if not torch.cuda.is_current_stream_capturing():
+        if not capturing:
             _FREQS[key] = freqs
     args = t.float()[:, None] * freqs[None]
     return torch.cat([args.cos(), args.sin()], dim=-1)
