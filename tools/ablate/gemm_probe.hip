@@ -193,6 +193,11 @@ int main(int argc, char **argv) {
                        "\"life_us_alone\":%.2f,\"life_us_paired\":%.2f,\"life_us_min\":%.2f,\"life_us_max\":%.2f,\"span_us\":%.2f}}\n",
                        n, uniq.size(), cus1, cus2, cus3, cus2 ? ov / cus2 : 0.0, n1 ? life1 / n1 * 0.01 : 0.0, n2 ? life2 / n2 * 0.01 : 0.0,
                        life_min * 0.01, life_max * 0.01, (t_max - t_min) * 0.01);
+                if (getenv("SVDQ_PROBE_LIFETIMES")) { // every workgroup's lifetime and END time (us since the first start), by blockIdx
+                    printf("{\"lifetimes_us\":[");
+                    for (int i = 0, k = 0; i < 512; i++) if (hc[4 * i + 1] > 0) printf("%s[%d,%.1f,%.1f]", k++ ? "," : "", i, hc[4 * i + 1] * 0.01, (hc[4 * i + 2] + hc[4 * i + 1] - t_min) * 0.01);
+                    printf("]}\n");
+                }
             }
             if (set_trace && do_trace) { // per-segment phase stamps of workgroup 0
                 long long *tr; CK(hipMalloc((void **)&tr, 192 * sizeof(long long))); CK(hipMemset(tr, 0, 192 * sizeof(long long)));
