@@ -50,8 +50,8 @@ FLUX_STEP_GOP = 59.5e3 + 0.83e3
 # COMMITTED measurement of the same command and says so ("traffic_source"); null when the profile file is absent.
 # Both files carry "csrc_sha16": the hash of the kernel sources they were measured on (kernel_sources_sha16 below, stamped by
 # tools/gpu/r4_profile_bench.sh); a line printed from a tree whose kernels changed since says "stale": true next to the number.
-TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r4_bench_gemm_hbm_counters.json", "r3_bench_gemm_hbm_counters.json")]
-MFMA_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r4_bench_gemm_mfma_util.json", "r3_bench_gemm_mfma_util.json")]
+TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r5_bench_gemm_hbm_counters.json", "r4_bench_gemm_hbm_counters.json")]
+MFMA_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r5_bench_gemm_mfma_util.json", "r4_bench_gemm_mfma_util.json")]
 
 
 def kernel_sources_sha16():
@@ -209,10 +209,18 @@ def main():
                          "gate (tests/v1/qwenimage/test_qwenimage.py:21): token counts that are not a multiple of 256 run the same fused path "
                          "on padded streams")
     ap.add_argument("--txt-tokens", type=int, default=512)
-    ap.add_argument("--weight-codes", choices=["uniform", "residual"], default="uniform",
-                    help="distribution of the random 4-bit weight codes: uniform, or that of a quantised Gaussian residual (SURVEY 8d's synthetic layers); "
-                         "both kernels of the step run at the chip's power limit, where the clock depends on the data")
-    ap.add_argument("--no-prof", action="store_true", help="no per-launch events in the timed region (their cost: ~0.5 %%)")
+    ap.add_argument("--weight-codes", choices=["uniform", "residual"], default="residual",
+                    help="distribution of the random 4-bit weight codes: that of a quantised Gaussian residual (SURVEY 8d's synthetic layers; the default "
+                         "since round 5) or uniform (the round 1-4 default; profiles/r4_weight_codes_ab.txt: no measurable difference)")
+    ap.add_argument("--rank", type=int, default=32, metavar="R",
+                    help="rank of every low-rank branch (a multiple of 16): 32 = the SVDQuant default; 128 = the reference's r128 Qwen-Image / "
+                         "FLUX checkpoints (tests/v1/qwenimage/test_qwenimage.py:20-26)")
+    ap.add_argument("--lora", type=int, default=0, metavar="r",
+                    help="attach a runtime LoRA of rank r to every SVDQuant linear (set_lora: the low-rank branch becomes rank R + r with per-16-rank "
+                         "scales -- the reference's update_lora_params, transformer_flux.py:783-855)")
+    ap.add_argument("--prof-steps", type=int, default=10, metavar="P",
+                    help="steps bracketed with per-launch HIP events AFTER the timed region (the roofline object); 0 = none")
+    ap.add_argument("--no-prof", action="store_true", help="same as --prof-steps 0")
     ap.add_argument("--layers", type=int, nargs=2, default=(19, 38), help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attention-geometry", type=int, default=0, choices=[0, 1, 2],
@@ -265,13 +273,19 @@ def main():
         from nunchaku_amd.models.qwenimage import NunchakuQwenImageTransformer2DModel
 
         n_blocks = args.layers[0] if "--layers" in " ".join(sys.argv) else 60
-        model = NunchakuQwenImageTransformer2DModel(num_layers=n_blocks, device=dev)
+        model = NunchakuQwenImageTransformer2DModel(num_layers=n_blocks, rank=args.rank, device=dev)
     else:
-        model = FluxTransformerAMD(num_layers=args.layers[0], num_single_layers=args.layers[1], guidance_embeds=not schnell, device=dev)
+        model = FluxTransformerAMD(num_layers=args.layers[0], num_single_layers=args.layers[1], guidance_embeds=not schnell, rank=args.rank, device=dev)
     if rank == 0:
         model.init_synthetic_(seed=0, codes=args.weight_codes)
     bcast_bytes = replica.broadcast_module_(model, src=0)
     model.eval()
+    if args.lora:
+        # the same synthetic LoRA on every rank (seeded): W += 0.8 * up @ down on every SVDQuant linear, through the widened low-rank branch
+        gl = torch.Generator(device=dev).manual_seed(99)
+        for m in model.svdq_layers():
+            m.set_lora(torch.randn(args.lora, m.in_features, generator=gl, device=dev) * (0.5 / m.in_features ** 0.5),
+                       torch.randn(m.out_features, args.lora, generator=gl, device=dev) * (0.5 / args.lora ** 0.5), strength=0.8)
     if qwen and args.offload:
         model.set_offload(True, num_blocks_on_gpu=args.offload)
 
@@ -317,11 +331,10 @@ def main():
             return captured(lat, sigmas[i].reshape(1), (sigmas[i + 1] - sigmas[i]).reshape(1))
 
     n_gemm = sum(1 for _ in model.svdq_layers())
-    # HIP events bracket every gemm_w4a4 launch of the timed steps (the roofline kernel) and nothing else: an event pair
-    # serialises the queue for ~3 us, bracketing all 665 library launches of a step cost 5 % of the step time
-    if not args.no_prof and not args.graph:
-        _lib.check(lib.svdq_prof_select(1 << 0), "svdq_prof_select")
-        _lib.check(lib.svdq_prof_enable(max(1, 2 * n_gemm * (args.steps + 1) + 64)), "svdq_prof_enable")
+    # The timed region carries NO instrumentation (an event pair around a launch serialises the queue for ~3 us; 228 GEMM launches
+    # per step were ~1.3 % of the reported step).  The roofline object is measured right behind it: P more steps of the same loop with HIP events
+    # around every gemm_w4a4 launch (and nothing else), timed as well -> ms_per_step_instrumented.
+    prof_steps = 0 if (args.no_prof or args.graph) else max(0, args.prof_steps)
     clock = ClockSampler(local_rank)
     replica.barrier()
     torch.cuda.synchronize()
@@ -333,10 +346,21 @@ def main():
     own = time.perf_counter() - t0          # this replica's own time for its K steps (before it waits for the others)
     replica.barrier()
     elapsed = time.perf_counter() - t0
-    clock_ghz = clock.stop()
     elapsed = replica.max_over_ranks(elapsed, dev)
     own_max, own_min = replica.max_over_ranks(own, dev), -replica.max_over_ranks(-own, dev)
     finite = bool(torch.isfinite(latents.float()).all())
+    ms_instrumented = None
+    if prof_steps:
+        _lib.check(lib.svdq_prof_select(1 << 0), "svdq_prof_select")
+        _lib.check(lib.svdq_prof_enable(max(1, 2 * n_gemm * (prof_steps + 1) + 64)), "svdq_prof_enable")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lat_p = latents
+        for i in range(prof_steps):
+            lat_p = step(total - 1 - (i % max(1, args.steps)), lat_p)
+        torch.cuda.synchronize()
+        ms_instrumented = (time.perf_counter() - t1) / prof_steps * 1e3
+    clock_ghz = clock.stop()
 
     def prof(cls):
         n, ms, work = C.c_int64(), C.c_double(), C.c_double()
@@ -350,7 +374,7 @@ def main():
         step(total - 1, latents.clone())
         torch.cuda.synchronize()
     n_g, ms_g, ops_g = prof(0)
-    prof_steps = 1 if args.graph else args.steps
+    prof_steps = 1 if args.graph else max(prof_steps, 1)
     per_variant = {}
     for name, fuse in (("default", 0), ("silu", 1), ("gelu_quant", 2), ("rmsnorm_rope", 3)):
         n_v_, ms_v_, ops_v_ = prof(0 | ((fuse + 1) << 8))  # SVDQ_PROF_GEMM_VARIANT(fuse), include/svdq_amd.h
@@ -384,23 +408,26 @@ def main():
         traffic, traffic_file, traffic_fresh = committed_traffic()
         if qwen:
             workload = (f"Qwen-Image-shaped transformer step, {res_name} ({t_img} image + {t_txt} text tokens), bs=1 "
-                        f"per GPU, {len(model.transformer_blocks)} dual-stream blocks, int4 rank-32, random-init weights, " +
+                        f"per GPU, {len(model.transformer_blocks)} dual-stream blocks, int4 rank-{args.rank}" + (f" + rank-{args.lora} runtime LoRA" if args.lora else "") + ", random-init weights, " +
                         (f"layer-wise host offload with {args.offload} blocks resident ({model.offload_manager.host_bytes_per_block() / 1e6:.0f} MB "
                          f"per block over PCIe)" if args.offload else "all blocks resident"))
         else:
             workload = (f"FLUX.1-{'schnell' if schnell else 'dev'}-shaped transformer step, {res_name} "
                         f"({t_img} image + {t_txt} text tokens), bs=1 per GPU, {args.layers[0]} joint + "
-                        f"{args.layers[1]} single blocks, guidance embedding {'off' if schnell else 'on'}, int4 rank-32, random-init weights")
+                        f"{args.layers[1]} single blocks, guidance embedding {'off' if schnell else 'on'}, int4 rank-{args.rank}" +
+                        (f" + rank-{args.lora} runtime LoRA" if args.lora else "") + ", random-init weights")
         line = {
-            "metric": (f"denoise steps/sec Qwen-Image {res_name} bs=1 (4-bit SVDQuant W4A4 + rank-32)" if qwen else
-                       f"denoise steps/sec FLUX.1-schnell {res_name} bs=1 (4-bit SVDQuant W4A4 + rank-32)" if schnell else
-                       f"denoise steps/sec FLUX.1-dev {res_name} bs=1 (4-bit SVDQuant W4A4 + rank-32)").replace("1024x1024", "1024^2").replace("512x512", "512^2"),
+            "metric": (f"denoise steps/sec Qwen-Image {res_name} bs=1 (4-bit SVDQuant W4A4 + rank-{args.rank})" if qwen else
+                       f"denoise steps/sec FLUX.1-schnell {res_name} bs=1 (4-bit SVDQuant W4A4 + rank-{args.rank})" if schnell else
+                       f"denoise steps/sec FLUX.1-dev {res_name} bs=1 (4-bit SVDQuant W4A4 + rank-{args.rank})").replace("1024x1024", "1024^2").replace("512x512", "512^2"),
             "value": world * args.steps / elapsed,
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # the same loop with HIP events around every gemm_w4a4 launch (the steps the roofline object was measured on; null: --no-prof / --graph)
+            "ms_per_step_instrumented": ms_instrumented,
             "higher_is_better": True,
             "scaling": "weak",
             # aggregate steps/s (value) and the slowest / fastest replica's own rate over its K steps
@@ -411,8 +438,9 @@ def main():
             "config": {
                 "workload": workload,
                 "gemm_geometry": args.geometry, "attention_geometry": args.attention_geometry, "deterministic": args.deterministic,
-                "weights": ("uniform-random 4-bit codes (not SVD-residual codes: the clock of a power-limited kernel is data dependent)" if args.weight_codes == "uniform"
-                            else "4-bit codes distributed like a quantised Gaussian residual, rne(N(0, 2.9^2)) clamped to +-7 (SURVEY 8d; --weight-codes uniform is the round 1-4 default)"),
+                "weights": ("uniform-random 4-bit codes (--weight-codes uniform: the round 1-4 default)" if args.weight_codes == "uniform"
+                            else "4-bit codes distributed like a quantised Gaussian residual, rne(N(0, 2.9^2)) clamped to +-7 (SURVEY 8d)"),
+                "rank": args.rank, "runtime_lora_rank": args.lora,
                 "parallelism": f"{world} independent replica(s), one image each; weights broadcast once over RCCL "
                                f"({bcast_bytes / 1e9:.2f} GB)" + ("; step replayed as one HIP graph" if args.graph else ""),
                 "output_finite": finite,
@@ -436,9 +464,11 @@ def main():
                 "effective_clock_ghz": clock_ghz,
                 "per_variant": per_variant,
                 "launches": n_g,
+                "prof_steps": prof_steps,
                 "avg_launch_us": ms_g * 1e3 / max(n_g, 1),
                 "gemm_ms_per_step": ms_g / prof_steps,
-                "measured_on": "one extra eager step (graph replay in the timed region)" if args.graph else "the timed steps",
+                "measured_on": "one extra eager step (graph replay in the timed region)" if args.graph else
+                               f"{prof_steps} steps run right behind the timed region with HIP events around every gemm_w4a4 launch (the timed region itself carries none)",
                 "quantize": {"launches": n_q, "ms_per_step": ms_q, "measured_on": "one extra untimed step",
                              "GBps": bytes_q / (ms_q * 1e-3) / 1e9 if ms_q > 0 else 0.0, "bound": "hbm"},
                 "attention": {"launches": n_a, "ms_per_step": ms_a, "measured_on": "one extra untimed step",

@@ -60,26 +60,32 @@ class _Workspace:
 
 _status_pool = None  # pinned int32 words handed to the workspaces (allocated once, outside any stream capture)
 _status_used = 0
-_status_free: list = []  # words of evicted workspaces, handed out again
+_status_free: list = []  # words of evicted workspaces: handed out again only behind a device synchronisation (below)
 
 
 def _status_word():
     """One word of pinned, device-visible host memory, or None (pool exhausted, or first use inside a stream capture, where
-    pinning is not permitted: such a workspace runs without the host-visible flag; the device-side error word stays)."""
+    pinning is not permitted: such a workspace runs without the host-visible flag; the device-side error word stays).
+
+    A word that belonged to an evicted workspace may still be the target of a late give-up write of a kernel queued on that workspace's
+    stream (the buffer itself is only freed once that work has finished).  Fresh words are preferred, and an evicted word is reused only
+    when the pool of 256 is exhausted and after a device synchronisation (nothing can be in flight behind it): the rare path of a process
+    that has gone through more than 256 (device, stream, kind) workspaces."""
     global _status_pool, _status_used
     if _status_pool is None:
         if torch.cuda.is_current_stream_capturing():
             return None
         _status_pool = torch.zeros(256, dtype=torch.int32).pin_memory()
-    if _status_free:
+    if _status_used < _status_pool.numel():
+        w = _status_pool[_status_used:_status_used + 1]
+        _status_used += 1
+        return w
+    if _status_free and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()  # every kernel that could still raise an evicted word has retired
         w = _status_free.pop()
         w.zero_()
         return w
-    if _status_used >= _status_pool.numel():
-        return None
-    w = _status_pool[_status_used:_status_used + 1]
-    _status_used += 1
-    return w
+    return None
 
 
 _WORKSPACE_LIMIT = 8  # per kind: LRU bound (64 MB GEMM / 33 MB attention each); pools of temporary streams recycle entries
@@ -122,11 +128,14 @@ def _workspace(device: torch.device, kind: str = "gemm") -> _Workspace:
 
 
 def release_workspaces() -> None:
-    """Drop every cached workspace (e.g. after a pool of temporary streams has been destroyed; graphs captured with them must be gone too)."""
-    for ws in _workspaces.values():
+    """Drop every cached workspace (e.g. after a pool of temporary streams has been destroyed).  Workspaces whose pointers are baked into a
+    captured HIP graph (``captured``) are KEPT: a replay would otherwise read freed memory -- destroy the graphs first and pass nothing
+    else; their entries go when the process does.  The same rule holds for the models' rotary-table caches: tables computed while a stream
+    is capturing live in the graph's pool, never in the cache (models/flux.py, models/qwenimage.py)."""
+    for k in [k for k, ws in _workspaces.items() if not ws.captured]:
+        ws = _workspaces.pop(k)
         if ws.status is not None:
             _status_free.append(ws.status)
-    _workspaces.clear()
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -798,6 +798,21 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 const bool all_real = k0 + ATT_KB <= p.kv_len0 || (k0 >= p.kv_start1 && k0 + ATT_KB <= p.kv_end1);
+                // which of this lane's 2 x 16 score rows (keys) are real: ONE bit mask per key tile, computed once per extra tile (it does not depend on
+                // the row tile) and made opaque to the optimiser -- the selects below can only become bit test + v_cndmask on it, never control flow
+                // around the accumulator writes (the if-conversion hazard described above; tests/test_gpu_attention.py keeps the two-range case)
+                unsigned km[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; kt++) {
+                    unsigned m = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int key = k0 + 32 * kt + 8 * (r >> 2) + 4 * h + (r & 3); // C layout of S^T: row (key) = 8 (r / 4) + 4 h + r % 4
+                        m |= (unsigned)((int)all_real | real_key(key)) << r;
+                    }
+                    asm volatile("" : "+v"(m));
+                    km[kt] = m;
+                }
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
@@ -811,10 +826,7 @@ __global__ __launch_bounds__(256, 1) void attention_kernel64(const AttnParams p)
                             acc = Half<DT>::mfma32(__builtin_bit_cast(V8, kw), qfrag(rt, ds), acc);
                         }
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int key = k0 + 32 * kt + 8 * (r >> 2) + 4 * h + (r & 3); // C layout of S^T: row (key) = 8 (r / 4) + 4 h + r % 4
-                            SA[rt][16 * kt + r] = ((int)all_real | real_key(key)) ? acc[r] : -INFINITY;
-                        }
+                        for (int r = 0; r < 16; r++) SA[rt][16 * kt + r] = ((km[kt] >> r) & 1u) ? acc[r] : -INFINITY;
                     }
                     float mloc = SA[rt][0];
 #pragma unroll

@@ -344,6 +344,14 @@ class FluxSingleBlockAMD(nn.Module):
         return hidden, (st, pool)
 
 
+def _ids_versions(*ids):
+    """version counters of the position-id tensors, or None when one of them does not track a version (inference tensors raise on ._version)"""
+    try:
+        return tuple(None if t is None else t._version for t in ids) if not any(t is not None and t.is_inference() for t in ids) else None
+    except RuntimeError:
+        return None
+
+
 class FluxEngineMixin:
     """Everything of the FLUX.1 transformer that is not construction: the denoising-step forward over the module tree
     ``x_embedder / context_embedder / time_text_embed / transformer_blocks / single_transformer_blocks / norm_out / proj_out``
@@ -514,9 +522,15 @@ class FluxEngineMixin:
         attn0 = (self.blocks[0] if len(self.blocks) else self.single_blocks[0]).attn
         pad_streams = FluxAttentionAMD.padded_tokens and attn0.attention_impl == "svdq" and attn0.head_dim == 128
         # the rotary tables depend on the position ids only: a denoise loop passes the same two tensor OBJECTS every step -- built once and kept
-        # (one entry; the cache holds the id tensors themselves, so "the same object, unmodified" cannot be a recycled address)
-        key = (txt_ids._version, img_ids._version, pad_streams)
-        cached = getattr(self, "_rot_cache", None)
+        # (one entry; the cache holds the id tensors themselves, so "the same object, unmodified" cannot be a recycled address).  Not cached:
+        #  * ids whose version counter cannot be read (tensors created under torch.inference_mode() do not track one): "unmodified" is unknowable;
+        #  * while the stream is capturing: the tables are computed INSIDE the graph (its pool owns them and ids passed as static graph inputs
+        #    keep their meaning on replay); a graph must never bake in pointers to tables that only this one-entry cache keeps alive -- a later
+        #    eager call with other ids would free them under the graph (same hazard as _Workspace.captured, _C.release_workspaces).
+        vers = _ids_versions(txt_ids, img_ids)
+        use_cache = vers is not None and not (hidden.is_cuda and torch.cuda.is_current_stream_capturing())
+        key = (vers, pad_streams)
+        cached = getattr(self, "_rot_cache", None) if use_cache else None
         if cached is not None and cached[0] is txt_ids and cached[1] is img_ids and cached[2] == key:
             rot_txt, rot_img, rot_all, p_txt, p_img = cached[3]
         else:
@@ -527,7 +541,8 @@ class FluxEngineMixin:
             # joint table: every stream on a 256-row boundary when the streams are padded (below), the plain concatenation otherwise
             rot_all = pack_rotemb(torch.cat([rot_t, rot_i], dim=1)) if pad_streams and kv_valid_ranges(t_txt, t_img) is not None \
                 else pack_rotemb(pad_tensor(rot, 256, 1))
-            self._rot_cache = (txt_ids, img_ids, key, (rot_txt, rot_img, rot_all, p_txt, p_img))
+            if use_cache:
+                self._rot_cache = (txt_ids, img_ids, key, (rot_txt, rot_img, rot_all, p_txt, p_img))
         # EVERY token count runs the hot path (the reference pads any M to 256 rows, Linear.cpp:445-446, and masks the padded K rows of its
         # attention, epilogues.cuh:427-550): both streams are padded to 256 rows with zero tokens right behind the embedders -- the joint
         # sequence is [text | pad | image | pad], every stream starts on a 256-row boundary as the grouped launches need -- every launch of

@@ -97,6 +97,7 @@ class SVDQW4A4Linear(nn.Module):
         # (reference: GEMM_W4A4::lora_scales, src/Linear.h:98, Linear.cpp:131; ops/gemm.py:125-127)
         self.lora_scales: list[float] | None = None
         self._base_lowrank = None
+        self._offloaded = False  # set by CPUOffloadManager while the owning block lives in host memory (set_lora then raises)
 
         # names of the parameters that currently hold the MI355X kernel layout (empty: everything is in the reference /
         # checkpoint layout).  Tracked per tensor: a partial load_state_dict (strict=False, only the 16-bit tensors, ...)
@@ -268,10 +269,10 @@ class SVDQW4A4Linear(nn.Module):
         widening the low-rank branch to rank ``R + r`` -- the mechanism of the reference's ``update_lora_params`` /
         ``set_lora_strength`` (transformer_flux.py:783-855: concatenate along the rank axis, per-16-rank scales).
         The 4-bit weights are untouched; ``strength`` can be changed later with :meth:`set_lora_strength` for free."""
-        if getattr(self, "_offloaded", False):
+        if self._offloaded:
             raise RuntimeError("set_lora: this layer belongs to a block that lives in host memory (CPUOffloadManager): its device slots are sized "
-                               "for the checkpoint's rank.  Attach the LoRA before set_offload(True) is NOT supported either -- merge it into the "
-                               "checkpoint, or keep the block resident (num_blocks_on_gpu)")
+                               "for the checkpoint's rank.  Attaching a LoRA to an offloaded block is unsupported whether it happens before or after "
+                               "set_offload(True): merge it into the checkpoint, or keep the block resident (num_blocks_on_gpu)")
         self._ensure_layout()
         self.reset_lora()
         r, K = down.shape

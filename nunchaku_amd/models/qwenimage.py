@@ -484,14 +484,18 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
         shape = img_shapes[0] if img_shapes else (1, int(math.isqrt(hidden.shape[1])), int(math.isqrt(hidden.shape[1])))
         if isinstance(shape, (list, tuple)) and isinstance(shape[0], (list, tuple)):
             shape = shape[0]
-        # the rotary tables depend on the grid, the text length and the device only: built once per (shape, length) and kept (one entry)
+        # the rotary tables depend on the grid, the text length and the device only: built once per (shape, length) and kept (one entry) --
+        # except while the stream is capturing: then they are computed inside the graph, whose pool owns them (a graph must not point at
+        # tables that only this cache keeps alive: the next eager call with another grid would free them under it; models/flux.py)
         rkey = (tuple(shape), t_txt, str(hidden.device))
-        cached = getattr(self, "_rot_cache", None)
+        use_cache = not (hidden.is_cuda and torch.cuda.is_current_stream_capturing())
+        cached = getattr(self, "_rot_cache", None) if use_cache else None
         if cached is not None and cached[0] == rkey:
             rot = cached[1]
         else:
             rot = pack_qwen_rotary(*qwen_rope_freqs(tuple(shape), t_txt, self.axes, device=hidden.device))
-            self._rot_cache = (rkey, rot)
+            if use_cache:
+                self._rot_cache = (rkey, rot)
         compute_stream = torch.cuda.current_stream()
         if self.offload:
             self.offload_manager.initialize(compute_stream)

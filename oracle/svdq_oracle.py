@@ -25,6 +25,21 @@ reference-run output (no NVIDIA GPU, no checkpoints).  The PTX approximations
 ``__fdividef`` have no CPU twin; the oracle uses exact IEEE math in their
 place (documented per function).
 
+Approximation envelope (round 5)
+--------------------------------
+How far may the REFERENCE itself sit from this oracle?  Every PTX approximation on the
+path has a documented error bound (``PTX_APPROX`` below).  The ``*_envelope`` functions
+carry an interval through the same operation chain -- each approximate instruction's
+result is widened by its documented bound, every exactly specified operation (16-bit
+roundings, fp32 multiplies, rint, saturation) is applied to both ends (they are monotone)
+-- and return, per output, the closed range [lo, hi] that ANY implementation whose
+approximate instructions respect those bounds must land in: the reference's CUDA kernels,
+the IEEE oracle above, and the MI355X kernels (``x * v_rcp_f32(smooth)`` for
+``__fdividef``, exp2 + rcp for ``tanh.approx``).  Tests assert HIP outputs inside the
+envelope AND a bounded flip rate against the IEEE values (< 1e-3 for
+the quantiser).  The envelope is a statement about arithmetic only; it does not pin the
+restatement itself (that still needs reference-run vectors, which do not exist).
+
 Conventions
 -----------
 16-bit tensors ("half_t" in the reference: bf16 or fp16) are carried as
@@ -310,6 +325,107 @@ def quantize_rows(xh: np.ndarray, dtype: str, unsigned: bool):
     return q, ascales
 
 
+# --------------------------------------------------------------------------
+# Approximation envelope: where an implementation built on approximate instructions may land
+# --------------------------------------------------------------------------
+# Documented bounds of the PTX instructions the reference uses on this path (PTX ISA, "Floating Point
+# Instructions"; CUDA C Programming Guide, "Intrinsic Functions": __fdividef(x, y) has a maximum error of
+# 2 ulp for 2^-126 <= y <= 2^126).  Relative to the infinitely precise result.
+PTX_APPROX = {
+    "rcp.approx.ftz.f32": {"max_ulp": 1, "used": "cuda_frcp: 1 / scale in the quantiser (gemm_utils.cuh:260-264, gemm_w4a4.cuh:479-495)"},
+    "div.approx (__fdividef)": {"max_ulp": 2, "used": "h2div: x / smooth (gemm_utils.cuh:329-344, gemm_w4a4.cuh:990-993)"},
+    "ex2.approx.ftz.f32": {"max_ulp": 2, "used": "cuda_sigmoidf -> silu (gemm_utils.cuh:290-303)"},
+    "rsqrt.approx.ftz.f32": {"max_ulp": 2, "used": "RMSNorm coefficient (epilogues.cuh:343-360)"},
+    "tanh.approx.f32": {"max_rel": 2.0 ** -11, "used": "gelu_half2 (gemm_utils.cuh:305-312)"},
+}
+_ORACLE_SLACK_ULP = 1  # the IEEE value the interval is centred on is itself a rounding of the exact result
+
+
+def _widen32(x: np.ndarray, ulps: int):
+    """[x - ulps, x + ulps] in units of float32 steps (nextafter), elementwise; x float32"""
+    lo = np.asarray(x, dtype=F32).copy()
+    hi = lo.copy()
+    for _ in range(ulps + _ORACLE_SLACK_ULP):
+        lo = np.nextafter(lo, F32(-np.inf))
+        hi = np.nextafter(hi, F32(np.inf))
+    return lo, hi
+
+
+def quantize_rows_envelope(xlo: np.ndarray, xhi: np.ndarray, dtype: str, unsigned: bool):
+    """:func:`quantize_rows` on an interval input [xlo, xhi] (16-bit representable, xlo <= xhi elementwise) with the
+    reciprocal of the scale an APPROXIMATE instruction (rcp.approx: 1 ulp).  Every other step is exactly specified and
+    monotone, so it maps interval ends to interval ends:
+      amax in [max |x|_lo, max |x|_hi];  scale = fp32(amax * (1/7 | 1/15));  stored scale = round16(scale);
+      rcp in widen(1 / scale, 1 ulp);  v = fp32(x * rcp);  q = sat(rint(v)).
+    Returns dict(q_lo, q_hi int8 [M, K], s_lo, s_hi [K/64, M])."""
+    M, K = xlo.shape
+    G = K // GROUP
+    lo = xlo.reshape(M, G, GROUP).astype(F32)
+    hi = xhi.reshape(M, G, GROUP).astype(F32)
+    straddle = (lo <= 0) & (hi >= 0)
+    abs_lo = np.where(straddle, F32(0), np.minimum(np.abs(lo), np.abs(hi)))
+    abs_hi = np.maximum(np.abs(lo), np.abs(hi))
+    recip_q = F32(1.0) / F32(15.0 if unsigned else 7.0)
+    sc_lo = (abs_lo.max(axis=2).astype(F32) * recip_q).astype(F32)
+    sc_hi = (abs_hi.max(axis=2).astype(F32) * recip_q).astype(F32)
+    qmin, qmax = (0, 15) if unsigned else (-8, 7)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        r_hi = _widen32((F32(1.0) / sc_lo).astype(F32), PTX_APPROX["rcp.approx.ftz.f32"]["max_ulp"])[1]  # largest reciprocal: of the smallest scale
+        r_lo = _widen32((F32(1.0) / sc_hi).astype(F32), PTX_APPROX["rcp.approx.ftz.f32"]["max_ulp"])[0]
+        cands = [(a * r[:, :, None]).astype(F32) for a in (lo, hi) for r in (r_lo, r_hi)]
+        v_lo = np.minimum.reduce(cands)
+        v_hi = np.maximum.reduce(cands)
+        q_lo = np.clip(np.where(np.isnan(v_lo), 0.0, np.rint(v_lo)), qmin, qmax)
+        q_hi = np.clip(np.where(np.isnan(v_hi), 0.0, np.rint(v_hi)), qmin, qmax)
+    zero_hi = sc_hi == 0          # the whole group is exactly zero: scale 0 -> code 0 (quantize_rows)
+    zero_lo = (sc_lo == 0) & ~zero_hi  # the group MAY be all zero: nothing can be said about its codes beyond the saturation range
+    q_lo = np.where(zero_hi[:, :, None], 0, np.where(zero_lo[:, :, None], qmin, q_lo))
+    q_hi = np.where(zero_hi[:, :, None], 0, np.where(zero_lo[:, :, None], qmax, q_hi))
+    return {"q_lo": q_lo.astype(np.int8).reshape(M, K), "q_hi": q_hi.astype(np.int8).reshape(M, K),
+            "s_lo": round16(sc_lo, dtype).T.copy(), "s_hi": round16(sc_hi, dtype).T.copy()}
+
+
+def quantize_envelope(x: np.ndarray, smooth: np.ndarray | None, dtype: str = "bf16", pad_size: int = PAD_M):
+    """Envelope of :func:`quantize_w4a4_act_fuse_lora`'s codes and scales: the smoothing division is ``__fdividef``
+    (2 ulp of the exact quotient, then the exact rounding to 16 bits), the scale reciprocal ``rcp.approx`` (1 ulp)."""
+    M, K = x.shape
+    M_pad = ceil_div(M, pad_size) * pad_size
+    xp = np.zeros((M_pad, K), dtype=F32)
+    xp[:M] = x
+    if smooth is not None:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (xp / smooth.astype(F32)[None, :]).astype(F32)
+        lo32, hi32 = _widen32(t, PTX_APPROX["div.approx (__fdividef)"]["max_ulp"])
+        xlo, xhi = round16(lo32, dtype), round16(hi32, dtype)
+    else:
+        xlo = xhi = xp
+    return quantize_rows_envelope(xlo, xhi, dtype, unsigned=False)
+
+
+def gelu_tanh_envelope(x: np.ndarray):
+    """[lo, hi] of gelu_half2 (gemm_utils.cuh:305-312) in fp32 when tanh is ``tanh.approx.f32`` (relative error <= 2^-11) and the
+    surrounding fp32 operations may or may not be contracted into FMAs (nvcc contracts by default: +-2 float32 steps on the argument and
+    the product cover either choice).  The MI355X form x / (1 + exp2(-2 u log2 e)) lies inside: its error is ~1e-6 relative."""
+    x64 = x.astype(np.float64)
+    u = 0.79788456 * (x64 + 0.044715 * x64 ** 3)
+    ulo, uhi = _widen32(u.astype(F32), 2)
+    th_lo, th_hi = np.tanh(ulo.astype(np.float64)), np.tanh(uhi.astype(np.float64))
+    rel = PTX_APPROX["tanh.approx.f32"]["max_rel"]
+    th_lo = th_lo - rel * np.abs(th_lo)
+    th_hi = th_hi + rel * np.abs(th_hi)
+    a, b = x64 * (0.5 + 0.5 * th_lo), x64 * (0.5 + 0.5 * th_hi)
+    lo, _ = _widen32(np.minimum(a, b).astype(F32), 2)
+    _, hi = _widen32(np.maximum(a, b).astype(F32), 2)
+    return lo, hi
+
+
+def envelope_report(codes: np.ndarray, env: dict, ieee: np.ndarray) -> dict:
+    """fraction of codes outside [q_lo, q_hi], flip rate against the IEEE codes, and how wide the envelope itself is"""
+    c = codes.astype(np.int32)
+    return {"outside": float(((c < env["q_lo"]) | (c > env["q_hi"])).mean()), "flips_vs_ieee": float((c != ieee).mean()),
+            "max_abs_diff_vs_ieee": int(np.abs(c - ieee.astype(np.int32)).max()), "envelope_open": float((env["q_lo"] != env["q_hi"]).mean())}
+
+
 def lora_down_project(x16: np.ndarray, lora_down: np.ndarray) -> np.ndarray:
     """lora_act[M, R] = x @ lora_down, 16-bit operands, fp32 accumulate
     (lora.cuh:253-339 EpilogueLoraDown; fp32 atomics across CTAs :82-94).  The oracle sums in
@@ -448,6 +564,7 @@ def gemm_w4a4(
     norm_k=None,
     rot=None,
     accum: str = "fp32",  # "fp32": exact accumulation ; "ref16": the reference's 16-bit chain
+    envelope: bool = False,  # gelu_quant: also return the approximation envelope of codes and scales ("envelope": quantize_rows_envelope's dict)
 ):
     """kernels::gemm_w4a4 (gemm_w4a4_launch_impl.cuh:7-424) with the epilogue chain
     Bias -> LoraUp -> Mid(Gelu|Silu|Nop) -> [LoraDown] -> Next(Default|Quantize|RMSNormRope)
@@ -526,6 +643,20 @@ def gemm_w4a4(
             xh = round16((sh / next_smooth.astype(F32)[None, :]).astype(F32), dtype)
         q, osc = quantize_rows(xh, dtype, unsigned=True)
         res["qout"], res["oscales"] = q, osc
+        if envelope:
+            # the same chain on intervals: tanh.approx in the GELU, __fdividef in the smoothing division, rcp.approx in the quantiser
+            glo, ghi = gelu_tanh_envelope(y16)
+            glo, ghi = round16(glo, dtype), round16(ghi, dtype)
+            slo, shi = round16((glo + F32(GELU_SHIFT)).astype(F32), dtype), round16((ghi + F32(GELU_SHIFT)).astype(F32), dtype)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ns = next_smooth.astype(F32)[None, :]
+                cands = []
+                for e in (slo, shi):
+                    l32, h32 = _widen32((e / ns).astype(F32), PTX_APPROX["div.approx (__fdividef)"]["max_ulp"])
+                    cands += [l32, h32]
+            env = quantize_rows_envelope(round16(np.minimum.reduce(cands), dtype), round16(np.maximum.reduce(cands), dtype), dtype, unsigned=True)
+            res["envelope"] = env
+            res["g16_lo"], res["g16_hi"] = glo, ghi
         return res
     raise ValueError(fuse)
 

@@ -80,6 +80,66 @@ def test_captured_step_replays_like_eager(built_lib):
     assert psnr_db(got, ref) > 45.0, psnr_db(got, ref)
 
 
+def _tiny_inputs(side=16, t_txt=128, seed=4):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    lat = torch.randn(1, side * side, 64, device="cuda", generator=g).bfloat16()
+    enc = torch.randn(1, t_txt, 128, device="cuda", generator=g).bfloat16()
+    pooled = torch.randn(1, 64, device="cuda", generator=g).bfloat16()
+    img_ids = torch.zeros(side * side, 3, device="cuda")
+    img_ids[:, 1] = torch.arange(side, device="cuda").repeat_interleave(side)
+    img_ids[:, 2] = torch.arange(side, device="cuda").repeat(side)
+    return lat, enc, pooled, img_ids, torch.zeros(t_txt, 3, device="cuda")
+
+
+def test_forward_under_inference_mode(built_lib):
+    """ids created under torch.inference_mode() track no version counter: the rotary cache must step aside, not raise"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from nunchaku_amd import mode
+
+    kw = dict(num_layers=1, num_single_layers=1, dim=256, heads=2, in_channels=64, joint_attention_dim=128, pooled_projection_dim=64)
+    model = FluxTransformerAMD(**kw, device="cuda").init_synthetic_(seed=2).eval()
+    lat, enc, pooled, img_ids, txt_ids = _tiny_inputs()
+    t, gd = torch.tensor([0.5], device="cuda"), torch.tensor([3.5], device="cuda")
+    with mode.deterministic_mode():
+        with torch.no_grad():
+            ref = model(lat, enc, pooled, t, img_ids, txt_ids, gd)
+        with torch.inference_mode():
+            lat_i, enc_i, pooled_i, img_i, txt_i = _tiny_inputs()  # inference tensors: ._version raises
+            assert img_i.is_inference()
+            a = model(lat_i, enc_i, pooled_i, t.clone(), img_i, txt_i, gd.clone())
+            b = model(lat_i, enc_i, pooled_i, t.clone(), img_i, txt_i, gd.clone())
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+
+
+def test_captured_step_survives_a_later_eager_call_with_other_ids(built_lib):
+    """a captured graph must not point at rotary tables that only the one-entry cache keeps alive -- an eager call with another grid
+    replaces the cache entry; the next replay has to give the same answer as before"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from nunchaku_amd import mode
+    from nunchaku_amd.graph import CapturedStep
+
+    kw = dict(num_layers=1, num_single_layers=1, dim=256, heads=2, in_channels=64, joint_attention_dim=128, pooled_projection_dim=64)
+    model = FluxTransformerAMD(**kw, device="cuda").init_synthetic_(seed=2).eval()
+    lat, enc, pooled, img_ids, txt_ids = _tiny_inputs()
+    gd = torch.tensor([3.5], device="cuda")
+    fn = lambda x, t: model(x, enc, pooled, t, img_ids, txt_ids, gd)
+    with mode.deterministic_mode():
+        cap = CapturedStep(fn, [lat, torch.tensor([0.5], device="cuda")])
+        t = torch.tensor([0.4], device="cuda")
+        first = cap(lat, t).clone()
+        # another grid / text length through the eager path: evicts the cache entry, allocates and frees tables of its own
+        lat2, enc2, pooled2, img2, txt2 = _tiny_inputs(side=32, t_txt=256, seed=9)
+        with torch.no_grad():
+            for _ in range(2):
+                model(lat2, enc2, pooled2, t, img2, txt2, gd)
+            junk = [torch.full((1 << 16,), float("nan"), device="cuda") for _ in range(32)]  # recycle whatever the eager call freed
+        again = cap(lat, t).clone()
+        del junk
+    assert torch.isfinite(again).all() and torch.equal(first, again)
+
+
 def test_pipeline_facing_class_call_contract(built_lib, tmp_path):
     """NunchakuFluxTransformer2DModelV2: from_pretrained on a safetensors file and the keyword call a FluxPipeline makes."""
     if not torch.cuda.is_available():
