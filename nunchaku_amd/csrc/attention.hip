@@ -195,7 +195,7 @@ __device__ __forceinline__ void finish_rows(const AttnParams &p, const v16f (&o)
                     for (int e = 0; e < 4; e++) {
                         const float o16 = round16<T>(o[dt][c * 4 + e] * inv);
                         const float sm = h2f(hfrom<T>(sv[e]));
-                        const float v = round16<T>(div_rn(o16, sm, __builtin_amdgcn_rcpf(sm)));
+                        const float v = smooth_div16<T>(o16, __builtin_amdgcn_rcpf(sm));
                         xh[16 * t + c * 4 + e] = v;
                         amax = fmaxf(amax, fabsf(v));
                     }

@@ -4,7 +4,7 @@
 // Replaces the reference's quantize_w4a4_fuse_lora_kernel (gemm_w4a4.cuh:1097-1184; launch
 // gemm_w4a4_launch_impl.cuh:451-521).  Arithmetic (DESIGN.md "Quantiser"):
 //   lora_act[m, r] = sum_k x[m,k] * lora_down[k,r]        16-bit MFMA, fp32 accumulate, on raw x
-//   x_hat = round16(x / smooth)                           IEEE fp32 divide (reference: __fdividef)
+//   x_hat = round16(x * rcp(smooth))                      the reference's __fdividef form (svdq_common.h smooth_div16; oracle: quantize_envelope)
 //   amax  = max_{k in group} |x_hat|;  scale = amax * (1/7)  (fp32);  ascales = round16(scale)
 //   q     = clamp(rne(x_hat * (1/scale)), -8, 7)          IEEE reciprocal (reference: rcp.approx)
 //
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const float sm = h2f(hfrom<T>(sv[grp][tc][e]));
-                        xh[4 * tc + e] = round16<T>(div_rn(h2f(hfrom<T>(xv[grp][tc][e])), sm, __builtin_amdgcn_rcpf(sm)));
+                        xh[4 * tc + e] = smooth_div16<T>(h2f(hfrom<T>(xv[grp][tc][e])), __builtin_amdgcn_rcpf(sm));
                     }
                 } else {
 #pragma unroll
@@ -304,15 +304,6 @@ template <> struct Pair16<SVDQ_FP16> {
     static __device__ __forceinline__ unsigned pack(v2f v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2)); }
     static __device__ __forceinline__ v2f unpack(unsigned u) { return __builtin_convertvector(__builtin_bit_cast(f16x2, u), v2f); }
 };
-// div_rn on pairs (same operations, same order)
-__device__ __forceinline__ v2f div_rn2(v2f a, v2f b, v2f rb) {
-    v2f q = a * rb;
-    v2f e = __builtin_elementwise_fma(-q, b, a);
-    q = __builtin_elementwise_fma(e, rb, q);
-    e = __builtin_elementwise_fma(-q, b, a);
-    return __builtin_elementwise_fma(e, rb, q);
-}
-
 
 // One 4-channel piece (e0 e1 | e2 e3 in the dwords d0 | d1) of a lane's record through the LayerNorm front end and the
 // smoothing division.  Parameters arrive in pair order (e0 e2 | e1 e3).  Out: the 16-bit activations the low-rank MFMA
@@ -322,7 +313,7 @@ __device__ __forceinline__ v2f div_rn2(v2f a, v2f b, v2f rb) {
 //         conversion that follows into ONE v_fma_mix*_f16 (a single rounding; oracle: _round16_fma), which a packed
 //         multiply followed by a packed conversion would round twice (1 value in ~10^6 differs in the last bit).
 template <int DT, bool LN, bool SMOOTH>
-__device__ __forceinline__ void quant_piece(unsigned d0, unsigned d1, v2f mean2, v2f rstd2, bool valid, v4f ms, v4f mh, v4f sm, v4f rs,
+__device__ __forceinline__ void quant_piece(unsigned d0, unsigned d1, v2f mean2, v2f rstd2, bool valid, v4f ms, v4f mh, v4f rs,
                                             unsigned &a0, unsigned &a1, v2f &xe, v2f &xo) {
     using T = typename Half<DT>::T;
     using P16 = Pair16<DT>;
@@ -340,8 +331,8 @@ __device__ __forceinline__ void quant_piece(unsigned d0, unsigned d1, v2f mean2,
             a1 = __builtin_amdgcn_perm(ho, he, 0x07060302u); // (e2 e3)
         }
         if constexpr (SMOOTH) {
-            xe = P16::unpack(P16::pack(div_rn2(xe, v2f{sm[0], sm[1]}, v2f{rs[0], rs[1]})));
-            xo = P16::unpack(P16::pack(div_rn2(xo, v2f{sm[2], sm[3]}, v2f{rs[2], rs[3]})));
+            xe = P16::unpack(P16::pack(xe * v2f{rs[0], rs[1]})); // smooth_div16 on pairs
+            xo = P16::unpack(P16::pack(xo * v2f{rs[2], rs[3]}));
         }
     } else {
         const f16x2 h0 = __builtin_bit_cast(f16x2, d0), h1 = __builtin_bit_cast(f16x2, d1);
@@ -355,7 +346,7 @@ __device__ __forceinline__ void quant_piece(unsigned d0, unsigned d1, v2f mean2,
                 x16[i] = valid ? f2h<T>(y) : (T)0.f;
             }
             xf[i] = h2f(x16[i]);
-            if constexpr (SMOOTH) xf[i] = round16<T>(div_rn(xf[i], sm[i], rs[i]));
+            if constexpr (SMOOTH) xf[i] = smooth_div16<T>(xf[i], rs[i]);
         }
         if constexpr (LN) {
             a0 = __builtin_bit_cast(unsigned, f16x2{x16[0], x16[2]});
@@ -457,8 +448,7 @@ __global__ __launch_bounds__(256, 4) void quantize_kernel_v2(QuantParams p) {
             const int slot = (lane >> 1) * 4 + (lane & 1);
             __attribute__((address_space(3))) float *P = (__attribute__((address_space(3))) float *)W;
             if constexpr (SMOOTH) {
-                const v2f sm = P16::unpack(sm2);
-                P[slot] = sm[0]; P[slot + 2] = sm[1];
+                const v2f sm = P16::unpack(sm2);  // (only the reciprocals are kept: smooth_div16)
                 P[128 + slot] = __builtin_amdgcn_rcpf(sm[0]); P[128 + slot + 2] = __builtin_amdgcn_rcpf(sm[1]);
             }
             if constexpr (LN) {
@@ -482,11 +472,11 @@ __global__ __launch_bounds__(256, 4) void quantize_kernel_v2(QuantParams p) {
                 for (int t = 0; t < 2; t++) {
                     const int tc = 2 * q + t;
                     const int pofs = (grp * 64 + 8 * tc + 4 * h) * 4; // byte offset of this piece in a parameter array
-                    v4f ms = {}, mh = {}, sm = {}, rs = {};
+                    v4f ms = {}, mh = {}, rs = {};
                     if constexpr (LN) { ms = *(const lds_v4f *)(W + 2 * 512 + pofs); mh = *(const lds_v4f *)(W + 3 * 512 + pofs); }
-                    if constexpr (SMOOTH) { sm = *(const lds_v4f *)(W + pofs); rs = *(const lds_v4f *)(W + 512 + pofs); }
+                    if constexpr (SMOOTH) rs = *(const lds_v4f *)(W + 512 + pofs);
                     v2f xe, xo;
-                    quant_piece<DT, LN, SMOOTH>(xv[grp][tc].x, xv[grp][tc].y, mean2, rstd2, valid, ms, mh, sm, rs, ae[t], ao[t], xe, xo);
+                    quant_piece<DT, LN, SMOOTH>(xv[grp][tc].x, xv[grp][tc].y, mean2, rstd2, valid, ms, mh, rs, ae[t], ao[t], xe, xo);
                     ev[2 * tc] = xe[0]; ev[2 * tc + 1] = xe[1];
                     od[2 * tc] = xo[0]; od[2 * tc + 1] = xo[1];
                     amax = fmaxf(fmaxf(amax, fabsf(xe[0])), fabsf(xe[1]));

@@ -89,16 +89,13 @@ template <typename T> __device__ __forceinline__ f32x2_t round16_pair(float a, f
     }
 }
 
-// a / b rounded to nearest for normal-range operands: two Newton steps on the hardware reciprocal rb ~ 1/b
-// (the quotient of the v_div_scale / v_div_fmas / v_div_fixup sequence without its ~7 scaling instructions;
-// activations and smoothing factors are far from the fp32 exponent limits those instructions guard)
-__device__ __forceinline__ float div_rn(float a, float b, float rb) {
-    float q = a * rb;
-    float e = __builtin_fmaf(-q, b, a);
-    q = __builtin_fmaf(e, rb, q);
-    e = __builtin_fmaf(-q, b, a);
-    return __builtin_fmaf(e, rb, q);
-}
+// x / smooth the way the reference divides (h2div -> __fdividef, gemm_utils.cuh:329-344; gemm_w4a4.cuh:990-993): the numerator times the hardware
+// reciprocal of the denominator -- ONE multiply where the exactly rounded quotient (rounds 1-4: two Newton steps on the reciprocal, 5 operations) cost
+// 4.5 of the quantiser's 13 VALU operations per element.  v_rcp_f32 is accurate to 1 ulp, the product adds half an ulp: inside __fdividef's documented
+// 2 ulp, i.e. exactly as faithful to the reference as the IEEE quotient (oracle: quantize_envelope; the 16-bit result differs from the IEEE one on
+// ~2^-15 (bf16) / ~2^-12 (fp16) of the elements).  `rs` = __builtin_amdgcn_rcpf(smooth): every kernel of the library forms it the same way, so the
+// stand-alone quantiser, its fast path and the attention / GEMM epilogues that quantise emit identical bits for identical inputs.
+template <typename T> __device__ __forceinline__ float smooth_div16(float x, float rs) { return round16<T>(x * rs); }
 
 // ---- order-independent accumulation format of the low-rank activations ("deterministic mode") -------------------
 // fp32 atomics make lora_act depend on the arrival order of the K-slice / column-tile partial sums (the reference's own

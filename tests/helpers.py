@@ -61,3 +61,27 @@ def psnr_db(got, ref) -> float:
     got, ref = got.float(), ref.float()
     mse = ((got - ref) ** 2).mean().item()
     return float("inf") if mse == 0 else 10.0 * float(torch.log10(ref.abs().max() ** 2 / mse))
+
+
+def checked_codes(qx, asc, x: np.ndarray, smooth, dtype: str, max_flips: float = 1e-3, rows=None):
+    """The operands a GEMM launch consumed -- the GPU quantiser's codes [M_pad, K] and scales [K/64, M_pad] as numpy -- after checking them against
+    the oracle: every code and scale inside the approximation envelope (oracle.quantize_envelope: the reference divides with __fdividef and
+    inverts the scale with rcp.approx; this library with v_rcp_f32 -- neither is the IEEE quotient, both must land in the envelope), and at most
+    ``max_flips`` of the codes / scales different from the IEEE oracle's (SURVEY.md section 8c's tolerance: +-1 LSB on < 1e-3 of the elements).
+    GEMM tests then hold the GEMM to 1 ulp on the operands it really read.  ``rows``: check (and return) only these rows of a large launch; ``x`` is
+    then the full input."""
+    from nunchaku_amd import layout
+
+    K = x.shape[1]
+    codes = layout.unpack_act(qx, K).cpu().numpy()
+    scales = f32(layout.unpack_scales(asc, codes.shape[0]))
+    if rows is not None:
+        x, codes, scales = x[rows], codes[rows], scales[:, rows]
+    q_ieee, a_ieee, _ = O.quantize_w4a4_act_fuse_lora(x, smooth, None, dtype, pad_size=1 if rows is not None else O.PAD_M)
+    env = O.quantize_envelope(x, smooth, dtype, pad_size=1 if rows is not None else O.PAD_M)
+    rep = O.envelope_report(codes, env, q_ieee)
+    assert rep["outside"] == 0.0, f"quantiser codes outside the approximation envelope: {rep}"
+    assert rep["flips_vs_ieee"] <= max_flips and rep["max_abs_diff_vs_ieee"] <= 1, f"quantiser codes vs the IEEE oracle: {rep}"
+    assert np.all(scales >= env["s_lo"]) and np.all(scales <= env["s_hi"]), "quantiser scales outside the approximation envelope"
+    assert (scales != a_ieee).mean() <= max_flips, f"{(scales != a_ieee).sum()} scales differ from the IEEE oracle"
+    return codes, scales

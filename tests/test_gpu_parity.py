@@ -1,7 +1,10 @@
 """HIP path vs the CPU oracle on identical seeded inputs (run on a real MI355X: pytest -m gpu).
 
 Everything goes through the C ABI (ctypes -> libsvdq_amd.so).  Tolerances:
-  * layout kernels, quantiser codes and scales: BIT-EXACT (integer / specified-op arithmetic);
+  * layout kernels: BIT-EXACT;
+  * quantiser codes and scales: inside the oracle's approximation envelope (the reference divides by the smoothing factor with __fdividef and
+    inverts the scale with rcp.approx: bounded-error instructions, oracle.quantize_envelope) AND different from the IEEE oracle on < 1e-3 of the
+    elements, by one step; bit-identical between calls and between the library's own kernels;
   * low-rank projections (fp32 accumulation order differs): rtol 2e-5 of the row's |x|.|w|;
   * GEMM outputs: 1 ulp of the 16-bit output type against the exact (float64) oracle;
   * fused GELU -> requantise: codes within +-1 on < 0.5 % of elements (tanhf / rounding-boundary
@@ -13,7 +16,7 @@ import pytest
 import torch
 
 from oracle import svdq_oracle as O
-from tests.helpers import TORCH_DT, assert_close_16, f32, make_module, t16
+from tests.helpers import TORCH_DT, assert_close_16, checked_codes, f32, make_module, t16
 
 pytestmark = pytest.mark.gpu
 
@@ -57,9 +60,7 @@ def test_repack_kernels_match_reference_packer(golden_dir):
 # ----------------------------------------------------------------------------- quantiser
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,K,R", [(256, 256, 32), (300, 384, 32), (1, 128, 16), (513, 3072, 32), (77, 256, 48)])
-def test_quantize_bit_exact(dtype, M, K, R):
-    from nunchaku_amd import layout
-
+def test_quantize_codes_and_scales(dtype, M, K, R):
     L = O.make_svdq_layer(K, 128, R, seed=M, dtype=dtype, cheap=True)
     x = O.make_activations(M, K, seed=M, dtype=dtype)
     mod = make_module(L, dtype)
@@ -67,9 +68,8 @@ def test_quantize_bit_exact(dtype, M, K, R):
     q_ref, asc_ref, la_ref = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"], dtype)
     M_pad = q_ref.shape[0]
     assert qx.shape == (M_pad, K * 3 // 4) and asc.shape == (K // 64, M_pad) and la.shape == (M_pad, R)
-    codes = layout.unpack_act(qx, K).cpu().numpy()
-    assert np.array_equal(codes, q_ref), f"{(codes != q_ref).sum()} code mismatches"
-    assert np.array_equal(f32(layout.unpack_scales(asc, M_pad)), asc_ref)
+    codes, scales = checked_codes(qx, asc, x, L["smooth"], dtype)  # envelope + flip budget against the IEEE codes
+    assert not codes[M:].any() and not scales[:, M:].any()           # padded rows: code 0, scale 0
     xp = np.zeros((M_pad, K), np.float32)
     xp[:M] = x
     bound = 2e-5 * (np.abs(xp) @ np.abs(L["proj_down"])) + 1e-6
@@ -127,9 +127,7 @@ def test_quantize_strided_input_and_zero_rows():
     big[:, :256] = t16(x, "bf16")
     mod = make_module(L, "bf16")
     qx, asc, la = mod.quantize(big[:, :256])  # row stride 512
-    q_ref, asc_ref, _ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"])
-    assert np.array_equal(layout.unpack_act(qx, 256).cpu().numpy(), q_ref)
-    assert np.array_equal(f32(layout.unpack_scales(asc, q_ref.shape[0])), asc_ref)
+    checked_codes(qx, asc, x, L["smooth"], "bf16")
     assert not layout.unpack_act(qx, 256)[10].any()
 
 
@@ -153,8 +151,8 @@ def test_linear_forward_matches_oracle(dtype, M, K, N, R):
     # (1) the GEMM itself: oracle on the very lora_act the kernel consumed (the quantiser's low-rank
     # sums differ from float64 in the last fp32 bits -- and between calls, fp32 atomics over K slices --
     # which can flip their 16-bit rounding) -> 1 ulp
-    q, a, _ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"], dtype)
     qx, asc, la = mod.quantize(xt)
+    q, a = checked_codes(qx, asc, x, L["smooth"], dtype)
     la_gpu = la.cpu().numpy()
     got_q = f32(mod.forward_quant(qx, asc, la))[:M]
     ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=la_gpu,
@@ -162,7 +160,8 @@ def test_linear_forward_matches_oracle(dtype, M, K, N, R):
     assert_close_16(got_q, ref, dtype, "gemm on GPU lora_act", max_bad_frac=0.0, ulps=1.0)
     # (2) whole layer vs the pure oracle: additionally one 16-bit ulp of the largest lora_act value
     # times the largest |proj_up| entry (a flipped rounding of one low-rank activation)
-    ref_full = O.svdq_linear(x, L, dtype, "fp32")["out"]
+    ref_full = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=O.lora_down_project(
+        np.concatenate([x, np.zeros((q.shape[0] - M, K), np.float32)]), L["proj_down"]), lora_up=L["proj_up"])["out"][:M]
     la_ulp = (2.0 ** -8 if dtype == "bf16" else 2.0 ** -11) * np.abs(la_gpu).max() * 2
     slack = la_ulp * np.abs(L["proj_up"]).max() * 2
     rel = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
@@ -183,8 +182,8 @@ def test_linear_no_bias_and_lora_scales():
     out = torch.empty(256, 128, dtype=torch.bfloat16, device="cuda")
     svdq_gemm_w4a4_cuda(act=qx, wgt=mod.qweight, out=out, ascales=asc, wscales=mod.wscales, lora_act_in=la,
                         lora_up=mod.proj_up, lora_scales=[0.5, 2.0])
-    q, a, l_ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"])
-    ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], lora_act_in=l_, lora_up=L["proj_up"], lora_scales=[0.5, 2.0])["out"]
+    q, a = checked_codes(qx, asc, x, L["smooth"], "bf16")
+    ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], lora_act_in=la.cpu().numpy(), lora_up=L["proj_up"], lora_scales=[0.5, 2.0])["out"]
     assert_close_16(f32(out), ref, "bf16", "lora_scales")
 
 
@@ -200,7 +199,8 @@ def test_silu_epilogue(dtype):
     out = torch.empty(256, 128, dtype=TORCH_DT[dtype], device="cuda")
     svdq_gemm_w4a4_cuda(act=qx, wgt=mod.qweight, out=out, ascales=asc, wscales=mod.wscales, lora_act_in=la,
                         lora_up=mod.proj_up, bias=mod.bias, fuse_silu=True)
-    ref = O.svdq_linear(x, L, dtype, "fp32", fuse="silu")["out"]
+    q, a = checked_codes(qx, asc, x, L["smooth"], dtype)
+    ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=la.cpu().numpy(), lora_up=L["proj_up"], fuse="silu")["out"]
     assert_close_16(f32(out), ref, dtype, "silu", max_bad_frac=2e-3, ulps=1.0)
     assert_close_16(f32(out), ref, dtype, "silu(2ulp)", ulps=2.0)
 
@@ -226,8 +226,9 @@ def test_qkv_rmsnorm_rope(dtype, M, K, H):
 
     packed = torch.from_numpy(O.pack_rotemb_ref(rot)).cuda().view(1, M_pad, 128)
     y = fused_qkv_norm_rottary(t16(x, dtype).view(1, M, K), mod, W(nq), W(nk), packed)
-    q, a, _ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"], dtype)
-    l_ = mod.quantize(t16(x, dtype))[2].cpu().numpy()  # the lora_act the kernel consumed
+    qx_, asc_, la_ = mod.quantize(t16(x, dtype))
+    q, a = checked_codes(qx_, asc_, x, L["smooth"], dtype)
+    l_ = la_.cpu().numpy()  # the lora_act the kernel consumed
     ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=l_,
                       lora_up=L["proj_up"], fuse="rmsnorm_rope", norm_q=nq, norm_k=nk, rot=rot)["out"][:M]
     got = f32(y)[0]
@@ -258,7 +259,8 @@ def test_gelu_quant_next_low_rank_down_by_rank(r2):
     m2._ensure_layout()
     svdq_gemm_w4a4_cuda(act=qx, wgt=m1.qweight, qout=qh, ascales=asc, wscales=m1.wscales, oscales=sh, lora_act_in=la, lora_up=m1.proj_up,
                         lora_down=m2.proj_down, lora_act_out=lh, bias=m1.bias, smooth_factor=m2.smooth_factor)
-    q, a, l_ = O.quantize_w4a4_act_fuse_lora(x, fc1["smooth"], fc1["proj_down"], dtype)
+    q, a = checked_codes(qx, asc, x, fc1["smooth"], dtype)
+    l_ = O.quantize_w4a4_act_fuse_lora(x, None, fc1["proj_down"], dtype)[2]
     r = O.gemm_w4a4(q, a, fc1["qweight"], fc1["wscales"], dtype=dtype, bias=fc1["bias"], lora_act_in=l_, lora_up=fc1["proj_up"], fuse="gelu_quant",
                     next_smooth=fc2["smooth"], next_lora_down=fc2["proj_down"])
     codes = layout.unpack_act(qh, Hd, unsigned=True).cpu().numpy()[:M]
@@ -296,12 +298,18 @@ def test_fused_gelu_mlp(dtype):
     svdq_gemm_w4a4_cuda(act=qx, wgt=m1.qweight, qout=qh, ascales=asc, wscales=m1.wscales, oscales=sh, lora_act_in=la,
                         lora_up=m1.proj_up, lora_down=m2.proj_down, lora_act_out=lh, bias=m1.bias,
                         smooth_factor=m2.smooth_factor)
-    q, a, l_ = O.quantize_w4a4_act_fuse_lora(x, fc1["smooth"], fc1["proj_down"], dtype)
+    q, a = checked_codes(qx, asc, x, fc1["smooth"], dtype)
+    l_ = O.quantize_w4a4_act_fuse_lora(x, None, fc1["proj_down"], dtype)[2]
     r = O.gemm_w4a4(q, a, fc1["qweight"], fc1["wscales"], dtype=dtype, bias=fc1["bias"], lora_act_in=l_,
-                    lora_up=fc1["proj_up"], fuse="gelu_quant", next_smooth=fc2["smooth"], next_lora_down=fc2["proj_down"])
+                    lora_up=fc1["proj_up"], fuse="gelu_quant", next_smooth=fc2["smooth"], next_lora_down=fc2["proj_down"], envelope=True)
     codes = layout.unpack_act(qh, Hd, unsigned=True).cpu().numpy()[:M]
     diff = np.abs(codes.astype(int) - r["qout"][:M].astype(int))
     assert diff.max() <= 1 and (diff != 0).mean() < 5e-3, f"code mismatch frac {(diff != 0).mean():.2e} max {diff.max()}"
+    # ... and inside the approximation envelope (tanh.approx / __fdividef / rcp.approx at their documented bounds: where the REFERENCE may land);
+    # the few codes outside are elements whose 16-bit pre-activation the GPU's fp32 accumulation order rounded the other way
+    env = {k: v[:M] for k, v in r["envelope"].items() if k.startswith("q_")}
+    rep = O.envelope_report(codes, env, r["qout"][:M])
+    assert rep["outside"] < 1e-3, rep
     sh_nat = layout.unpack_scales(sh, M_pad)
     s_got, s_ref = f32(sh_nat)[:, :M], r["oscales"][:, :M]
     assert (s_got != s_ref).mean() < 5e-3 and np.allclose(s_got, s_ref, rtol=2 ** -6)
@@ -335,8 +343,8 @@ def test_full_size_properties():
     qx, asc, la = mod.quantize(xt)
     assert torch.equal(mod.forward_quant(qx, asc, la), mod.forward_quant(qx, asc, la))  # the GEMM is deterministic
     rows = np.array([0, 1, 255, 256, 1000, 2047, 4095])
-    q, a, l_ = O.quantize_w4a4_act_fuse_lora(x[rows], L["smooth"], L["proj_down"])
-    ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], bias=L["bias"], lora_act_in=l_, lora_up=L["proj_up"])["out"][: len(rows)]
+    q, a = checked_codes(qx, asc, x, L["smooth"], "bf16", rows=rows)
+    ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], bias=L["bias"], lora_act_in=la.cpu().numpy()[rows], lora_up=L["proj_up"])["out"]
     assert_close_16(f32(y1)[0][rows], ref, "bf16", "full-size row sample")
 
 
@@ -364,7 +372,8 @@ def test_runtime_lora_widens_the_low_rank_branch():
     pad = np.zeros((32 - r, K), np.float32)
     L2["proj_down"] = np.concatenate([L["proj_down"], np.concatenate([down, pad]).T], axis=1)
     L2["proj_up"] = np.concatenate([L["proj_up"], up, np.zeros((N, 32 - r), np.float32)], axis=1)
-    q, a, la = O.quantize_w4a4_act_fuse_lora(x, L2["smooth"], L2["proj_down"], dtype)
+    q, a = checked_codes(*mod.quantize(t16(x, dtype))[:2], x, L2["smooth"], dtype)
+    la = O.quantize_w4a4_act_fuse_lora(x, None, L2["proj_down"], dtype)[2]
     ref = O.gemm_w4a4(q, a, L2["qweight"], L2["wscales"], dtype=dtype, bias=L2["bias"], lora_act_in=la, lora_up=L2["proj_up"],
                       lora_scales=[1.0, 1.0, 0.75, 0.75])["out"][:M]
     assert_close_16(got, ref, dtype, "lora", max_bad_frac=2e-3)
@@ -395,7 +404,7 @@ def test_partial_state_dict_update_of_a_repacked_layer():
     L2 = dict(L)
     L2["bias"] = new_bias
     qx, asc, la = mod.quantize(t16(x, dtype))
-    q, a, _ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], L["proj_down"], dtype)
+    q, a = checked_codes(qx, asc, x, L["smooth"], dtype)
     ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=new_bias, lora_act_in=la.cpu().numpy(), lora_up=L["proj_up"])["out"][:M]
     assert_close_16(f32(mod.forward_quant(qx, asc, la))[:M], ref, dtype, "after the bias-only update")
     assert np.abs(y1 - y0).max() > 0.1  # the bias really changed
@@ -458,7 +467,9 @@ def test_reference_style_calls_with_reference_sized_buffers_and_checkpoint_layou
     out = torch.empty(M, Hd, dtype=td, device="cuda")
     ops.gemm_w4a4(qx, p1["qweight"], out, None, asc, p1["wscales"], None, None, la, p1["proj_up"], None, None, None, None, None,
                   p1["bias"], None, None, None, False, [1.0, 1.0], False, False, 1.0, None, None, None, None, 0)
-    q, a, _ = O.quantize_w4a4_act_fuse_lora(x, fc1["smooth"], fc1["proj_down"], dtype)
+    from nunchaku_amd._C import _fp6_image
+
+    q, a = checked_codes(_fp6_image(qx, M_pad, C, False, "test"), asc, x, fc1["smooth"], dtype)  # (the FP6 image behind the reference-sized buffer)
     ref = O.gemm_w4a4(q, a, fc1["qweight"], fc1["wscales"], dtype=dtype, bias=fc1["bias"], lora_act_in=la.cpu().numpy(),
                       lora_up=fc1["proj_up"])["out"][:M]
     assert_close_16(f32(out), ref, dtype, "reference-style linear")

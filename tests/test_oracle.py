@@ -109,3 +109,66 @@ def test_quantize_fuse_glu_is_the_plain_quantiser_on_the_gated_input():
     a = O.quantize_w4a4_act_fuse_lora(x2, L["smooth"], L["proj_down"], "bf16", fuse_glu=True)
     b = O.quantize_w4a4_act_fuse_lora(g, L["smooth"], L["proj_down"], "bf16")
     assert all(np.array_equal(p, q) for p, q in zip(a, b))
+
+
+# ----------------------------------------------------------------------------- approximation envelope (round 5)
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_quantize_envelope_holds_the_ieee_oracle_and_every_bounded_error_divider(dtype):
+    """oracle.quantize_envelope: the IEEE quotient, a reciprocal-multiply with a 1-ulp reciprocal (this library's v_rcp_f32 form) and a quotient
+    pushed to __fdividef's documented 2 ulp in either direction all produce codes and scales inside [lo, hi]; the envelope is narrow (open on
+    ~1e-3 of the codes) and a 16-bit step outside it is detected."""
+    K = 384
+    L = O.make_svdq_layer(K, 128, 32, seed=3, dtype=dtype, cheap=True)
+    x = O.make_activations(300, K, seed=3, dtype=dtype)
+    env = O.quantize_envelope(x, L["smooth"], dtype)
+    q, a, _ = O.quantize_w4a4_act_fuse_lora(x, L["smooth"], None, dtype)
+    rep = O.envelope_report(q, env, q)
+    assert rep["outside"] == 0.0 and rep["envelope_open"] < 3e-3
+    assert np.all(a >= env["s_lo"]) and np.all(a <= env["s_hi"])
+    xp = np.zeros((q.shape[0], K), np.float32)
+    xp[:300] = x
+    rng = np.random.default_rng(0)
+    exact = xp.astype(np.float64) / L["smooth"].astype(np.float64)[None, :]
+    variants = {
+        "x * rcp (1-ulp reciprocal, rounded product)": (xp * (np.float32(1) / L["smooth"]).astype(np.float32)[None, :] *
+                                                          (1 + rng.choice([-1, 0, 1], size=K) * 2.0 ** -24).astype(np.float32)[None, :]).astype(np.float32),
+        "+2 ulp": (exact * (1 + 2 * 2.0 ** -24)).astype(np.float32),
+        "-2 ulp": (exact * (1 - 2 * 2.0 ** -24)).astype(np.float32),
+    }
+    for name, quot in variants.items():
+        qv, av = O.quantize_rows(O.round16(quot, dtype), dtype, unsigned=False)
+        rep = O.envelope_report(qv, env, q)
+        assert rep["outside"] == 0.0, (name, rep)
+        assert rep["flips_vs_ieee"] < 1e-3 and rep["max_abs_diff_vs_ieee"] <= 1, (name, rep)
+        assert np.all(av >= env["s_lo"]) and np.all(av <= env["s_hi"]), name
+    # a quotient that is one 16-bit step off on every element is NOT inside
+    off = O.round16(exact.astype(np.float32), dtype)
+    off = np.nextafter(off.astype(np.float16), np.float16(np.inf)).astype(np.float32) if dtype == "fp16" else \
+        (off.view(np.uint32) + np.uint32(0x10000)).view(np.float32)
+    qo, _ = O.quantize_rows(off, dtype, unsigned=False)
+    assert O.envelope_report(qo, env, q)["outside"] > 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gelu_quant_envelope(dtype):
+    """the GELU -> requantise chain on intervals: the IEEE oracle and the MI355X epilogue's form of the GELU (x * rcp(1 + exp2(.)), emulated in
+    float32) both land inside; the envelope says how far the reference's tanh.approx may move the codes: open on < 1 % of them"""
+    K, N = 256, 384
+    L1 = O.make_svdq_layer(K, N, 32, seed=5, dtype=dtype, cheap=True)
+    L2 = O.make_svdq_layer(N, 128, 32, seed=6, dtype=dtype, cheap=True)
+    x = O.make_activations(200, K, seed=5, dtype=dtype)
+    q, a, la = O.quantize_w4a4_act_fuse_lora(x, L1["smooth"], L1["proj_down"], dtype)
+    r = O.gemm_w4a4(q, a, L1["qweight"], L1["wscales"], dtype=dtype, bias=L1["bias"], lora_act_in=la, lora_up=L1["proj_up"], fuse="gelu_quant",
+                    next_smooth=L2["smooth"], next_lora_down=L2["proj_down"], envelope=True)
+    env = r["envelope"]
+    rep = O.envelope_report(r["qout"], env, r["qout"])
+    assert rep["outside"] == 0.0 and rep["envelope_open"] < 1e-2, rep
+    # the kernel's GELU form in float32 on the same 16-bit pre-activation
+    y16 = O.gemm_w4a4(q, a, L1["qweight"], L1["wscales"], dtype=dtype, bias=L1["bias"], lora_act_in=la, lora_up=L1["proj_up"])["out"]
+    f = np.float32
+    A = f(-2.0 * 0.79788456 * 1.4426950408889634)
+    B = f(A * f(0.044715))
+    t = (y16 * (y16 * y16 * B + A).astype(f)).astype(f)
+    g = (y16 * (f(1) / (f(1) + np.exp2(t).astype(f))).astype(f)).astype(f)
+    g16 = O.round16(g, dtype)
+    assert np.all(g16 >= r["g16_lo"]) and np.all(g16 <= r["g16_hi"])

@@ -33,7 +33,8 @@ def test_known_answers_cover_every_operator():
     for dt in ("bf16", "fp16"):
         for key in ("quant.codes", "quant.ascales", "quant.lora_act", "quant_glu.codes", "gemm.none.fp32.out", "gemm.none.ref16.out",
                     "gemm.silu.fp32.out", "gemm.rmsnorm_rope.out", "gemm.gelu_quant.qout", "gemm.gelu_quant.oscales",
-                    "gemm.gelu_quant.lora_act_out", "gemm.lora_scales_nobias.out", "mlp.out", "att.out", "awq.out", "glue.y", "glue.stats", "glue.mod"):
+                    "gemm.gelu_quant.lora_act_out", "gemm.lora_scales_nobias.out", "mlp.out", "att.out", "awq.out", "glue.y", "glue.stats", "glue.mod",
+                    "quant.env.q_lo", "quant.env.q_hi", "quant.env.s_lo", "quant.env.s_hi", "gemm.gelu_quant.env.q_lo", "gemm.gelu_quant.env.q_hi"):
             assert f"{dt}.{key}" in names, f"{dt}.{key}"
     # the vectors are not degenerate: codes use the whole range, outputs are finite and non-constant
     assert stored["bf16.quant.codes"].min() == -7 and stored["bf16.quant.codes"].max() == 7

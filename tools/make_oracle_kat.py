@@ -53,6 +53,9 @@ def compute(seed: int, stored: dict | None = None) -> dict:
         # quantiser (signed, smoothing + low-rank down), and its fuse_glu form
         q, asc, la = O.quantize_w4a4_act_fuse_lora(x, lay["smooth"], lay["proj_down"], dtype)
         d[f"{t}.quant.codes"], d[f"{t}.quant.ascales"], d[f"{t}.quant.lora_act"] = q, asc, la
+        # round 5: the approximation envelope of the same call (__fdividef / rcp.approx widened by their documented bounds)
+        env = O.quantize_envelope(x, lay["smooth"], dtype)
+        d[f"{t}.quant.env.q_lo"], d[f"{t}.quant.env.q_hi"], d[f"{t}.quant.env.s_lo"], d[f"{t}.quant.env.s_hi"] = env["q_lo"], env["q_hi"], env["s_lo"], env["s_hi"]
         x2 = inp(f"{t}.x_glu", lambda: O.round16(np.random.default_rng(77 + seed).standard_normal((40, 2 * K)).astype(F32), dtype))
         qg, ascg, _ = O.quantize_w4a4_act_fuse_lora(x2, lay["smooth"], None, dtype, fuse_glu=True)
         d[f"{t}.quant_glu.codes"], d[f"{t}.quant_glu.ascales"] = qg, ascg
@@ -78,8 +81,9 @@ def compute(seed: int, stored: dict | None = None) -> dict:
         lay2 = {k: inp(f"{t}.l2.{k}", lambda k=k: _layer_inputs(O.make_svdq_layer(N, 128, R, seed=seed + 10, dtype=dtype))[k])
                 for k in ("qweight", "wscales", "smooth", "proj_down", "proj_up", "bias")}
         r = O.gemm_w4a4(q, asc, lay["qweight"], lay["wscales"], dtype=dtype, bias=lay["bias"], lora_act_in=la, lora_up=lay["proj_up"],
-                        fuse="gelu_quant", next_smooth=lay2["smooth"], next_lora_down=lay2["proj_down"])
+                        fuse="gelu_quant", next_smooth=lay2["smooth"], next_lora_down=lay2["proj_down"], envelope=True)
         d[f"{t}.gemm.gelu_quant.qout"], d[f"{t}.gemm.gelu_quant.oscales"], d[f"{t}.gemm.gelu_quant.lora_act_out"] = r["qout"], r["oscales"], r["lora_act_out"]
+        d[f"{t}.gemm.gelu_quant.env.q_lo"], d[f"{t}.gemm.gelu_quant.env.q_hi"] = r["envelope"]["q_lo"], r["envelope"]["q_hi"]
         d[f"{t}.mlp.out"] = O.fused_gelu_mlp(x, lay, lay2, dtype)
         # attention restatement (one head, 128 queries x 192 keys)
         rng = np.random.default_rng(500 + seed)
@@ -111,7 +115,7 @@ def compute(seed: int, stored: dict | None = None) -> dict:
             v = d[k]
             if v.ndim == 2 and v.shape[0] == 256:
                 d[k] = v[:KEEP].copy()
-            elif v.ndim == 2 and v.shape[1] == 256 and k.endswith(("ascales", "oscales")):
+            elif v.ndim == 2 and v.shape[1] == 256 and k.endswith(("ascales", "oscales", "s_lo", "s_hi")):
                 d[k] = v[:, :KEEP].copy()
     return d
 
