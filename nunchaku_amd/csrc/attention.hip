@@ -147,19 +147,21 @@ __device__ __forceinline__ void finish_rows(const AttnParams &p, const v16f (&o)
         const bool s2 = p.qsplit_rows > 0 && q0 >= p.qsplit_rows; // wave-uniform
         const T *smooth = (const T *)(s2 ? p.qsmooth2 : p.qsmooth) + head * ATT_D;
         const int K = p.H * ATT_D, KP = p.H;
-        if (p.qR > 0) { // lora_act[q][rank] += sum_d o16[q][d] * down[d][rank] over this head's 128 channels
+        // lora_act[q][rank] += sum_d o16[q][d] * down[d][rank] over this head's 128 channels, 32 ranks per pass (rank 128 checkpoints and runtime LoRAs
+        // take 2 .. 8 passes; the body of a pass is the rank <= 32 code of rounds 2-4, unchanged: it sits at the register limit of the 4 x 64 kernels)
+        auto lowrank_pass = [&](int rank0) {
             const T *ld = (const T *)(s2 ? p.qlora_down2 : p.qlora_down) + head * ATT_D; // rank-major [R][K]
             v16f dl;
 #pragma unroll
             for (int i = 0; i < 16; i++) dl[i] = 0.f;
-            const bool live = lr < p.qR;
+            const bool live = rank0 + lr < p.qR;
 #pragma unroll
             for (int dt = 0; dt < 4; dt++)
 #pragma unroll
                 for (int qq = 0; qq < 2; qq++) {
                     V8 wv, gv;
                     if (live) {
-                        const T *src = ld + (size_t)lr * K + dt * 32 + qq * 16 + h * 4;
+                        const T *src = ld + (size_t)(rank0 + lr) * K + dt * 32 + qq * 16 + h * 4;
                         const u16x4 w0 = *reinterpret_cast<const u16x4 *>(src);
                         const u16x4 w1 = *reinterpret_cast<const u16x4 *>(src + 8);
 #pragma unroll
@@ -173,12 +175,14 @@ __device__ __forceinline__ void finish_rows(const AttnParams &p, const v16f (&o)
                     dl = Half<DT>::mfma32(gv, wv, dl);
                 }
             if (live) { // C layout: column (rank) = lane & 31, rows (i & 3) + 8 (i >> 2) + 4 h
-                const size_t at = (size_t)(q0 + h * 4) * p.qR + lr;
+                const size_t at = (size_t)(q0 + h * 4) * p.qR + rank0 + lr;
                 const int mode = 1 | (p.qlora_q32 ? 2 : 0); // the H heads add to the same element
 #pragma unroll
                 for (int i = 0; i < 16; i++) lora_act_add(p.qlora_act, at + (size_t)((i & 3) + 8 * (i >> 2)) * p.qR, dl[i], mode);
             }
-        }
+        };
+        if (p.qR > 0) lowrank_pass(0);                                     // (straight-line, as in rounds 2-4: the rank-32 step runs exactly this)
+        for (int rank0 = 32; rank0 < p.qR; rank0 += 32) lowrank_pass(rank0); // the slabs beyond rank 32
         uint32_t rec[12];
         T sc16[2];
 #pragma unroll
@@ -1072,8 +1076,8 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     if (!a) { set_error("svdq_attention: args is NULL"); return SVDQ_E_INVALID; }
     if (!a->q || !a->k || !a->vt || (!a->out && !a->qact)) { set_error("svdq_attention: q, k, vt and out (or qact) are required"); return SVDQ_E_INVALID; }
     if (a->qact) {
-        if (!a->qscales || !a->qsmooth || a->L % 256 || a->qR < 0 || a->qR > 32 || a->qR % 16 || (a->qR > 0 && (!a->qlora_down || !a->qlora_act))) {
-            set_error("svdq_attention: fused quantiser needs qscales, qsmooth, L %% 256 == 0 and R=%d in {0, 16, 32} with qlora_down / qlora_act", a->qR);
+        if (!a->qscales || !a->qsmooth || a->L % 256 || a->qR < 0 || a->qR > 256 || a->qR % 16 || (a->qR > 0 && (!a->qlora_down || !a->qlora_act))) {
+            set_error("svdq_attention: fused quantiser needs qscales, qsmooth, L %% 256 == 0 and R=%d a multiple of 16 in [0, 256] with qlora_down / qlora_act", a->qR);
             return SVDQ_E_INVALID;
         }
         if (a->qsmooth2 && (a->qsplit_rows <= 0 || a->qsplit_rows % 256 || a->qsplit_rows >= a->L || (a->qR > 0 && !a->qlora_down2))) {

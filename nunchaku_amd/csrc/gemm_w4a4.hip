@@ -88,9 +88,13 @@ template <int NW> struct Geo {
     // read by the epilogue from LDS instead of from memory: lora_act_in [BM][32] fp32 (16-byte chunk c of row r at position c ^ (r & 7)),
     // lora_up [128][32] 16-bit (linear), bias [128] 16-bit
     static constexpr int STG_OFF = NSTAGE * STAGE_BYTES + EPI_BYTES + MAIL_BYTES;
-    static constexpr int STG_LU = 32768, STG_BIAS = 40960;
+    // rank > 32 (round 5): the region holds the tile's lora_up for EVERY rank instead -- [128 rows][R / 8 + 1 chunks of 16 bytes] (one pad chunk per row:
+    // an odd pitch in 16-byte units, so the epilogue's 16-byte reads of one chunk over 32 rows spread over the banks), up to rank 160 = 43008 bytes,
+    // staged by the C++ prologue of the loop call (stage_lu_all below); lora_act_in then comes through registers in batches of 64 ranks
+    static constexpr int STG_LU = 32768, STG_BIAS = 43008;
+    static constexpr int STG_LU_ALL_MAX_R = 160;
     static constexpr int STG_BYTES = NW == 8 ? STG_BIAS + 256 : 0;
-    static constexpr int LDS_BYTES = STG_OFF + STG_BYTES; // 160016 | 80912 (two of them: 158 of 160 KiB)
+    static constexpr int LDS_BYTES = STG_OFF + STG_BYTES; // 162064 (of 163840) | 80912 (two of them: 158 of 160 KiB)
     static constexpr int WG_PER_CU = NW == 8 ? 1 : 2;
 };
 // workspace header: 2048 int32 words.  Words [0, 1023): per-remainder-tile arrival counters of the stream-K split (at most
@@ -134,6 +138,8 @@ struct GemmParams {
     int *status;             // optional host-visible status word (svdq_gemm_args.status)
     float q_scale;           // RMSNORM_ROPE: factor of the Q third, applied before its rounding to 16-bit (svdq_gemm_args.q_scale; 1 = off)
     int stage_lora;          // NW = 8: rank 32, fp32 lora_act_in, 16-byte aligned operands: the loop stages lora_act_in / lora_up of a tile in LDS
+    int stage_lu_all;        // NW = 8, no carry: 32 < rank <= 160, fp32 lora_act_in, 16-byte aligned: the tile's lora_up (all ranks) is staged in LDS, lora_act_in comes
+                             // through registers in batches of 64 ranks (every load of a batch in flight at once); value = ceil(65536 / (R / 8 + 1)), the divider of the gather
     int rowrun;              // NW = 8, GELU_QUANT: run length of the row-run schedule (GemmSchedule::init_runs; 0 = the plain schedule): the next layer's
                              // low-rank down projection accumulates in LDS over a workgroup's run of column tiles, one flush of atomics per run
     int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
@@ -155,9 +161,13 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x));
 typedef __attribute__((address_space(3))) void lds_void;
 
 template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q31.32 (deterministic mode) */,
-          bool CARRY = false /* GELU_QUANT, NW = 8, fp32 lora_act_out of rank <= 32: the next layer's low-rank down projection accumulates in LDS */>
+          bool CARRY = false /* GELU_QUANT, NW = 8, fp32 lora_act_out of rank <= 32: the next layer's low-rank down projection accumulates in LDS */,
+          bool RALL = false /* NW = 8, fp32 lora_act_in of rank 48 .. 160 (the r128 checkpoints, a runtime LoRA on top of rank 32): the tile's lora_up for EVERY rank is
+                               staged in LDS, lora_act_in comes through registers in batches of 64 ranks (GemmParams::stage_lu_all).  A kernel of its own, so that the
+                               rank-32 kernels of the step keep their instruction stream and register allocation to the bit */>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams p) {
     static_assert(!CARRY || (NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ), "the low-rank-down carry lives in the 256 x 128 geometry's staging region");
+    static_assert(!RALL || (NW == 8 && !LAQ && !CARRY), "the all-rank lora_up image lives in the 256 x 128 geometry's staging region");
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     using G_ = Geo<NW>;
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             unsigned stg_flags = 0;
             const char *stg_la = (const char *)p.wgt, *stg_lu = stg_la, *stg_b = stg_la;
             if (NW == 8 && kp1 == KP) {
-                if (!LAQ && p.stage_lora) {
+                if (!LAQ && !RALL && p.stage_lora) {
                     stg_flags |= CARRY ? 5u : 1u;
                     stg_la = (const char *)p.lora_act_in + ((size_t)m0 + 32 * wv) * 128;
                     stg_lu = (const char *)(bm >= split_bm ? p.lora_up2 : p.lora_up) + ((size_t)n0 + 16 * wv) * 64;
@@ -428,6 +438,32 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             const int stg_issues = min((int)kp_s, (int)(kp_s + ncnt) - NSTAGE);
             stg_counted = stg_issues >= 3;
             const unsigned stg_lds = lds_base + G_::STG_OFF;
+            if constexpr (RALL) {
+                if (kp1 == KP) {
+                    // rank > 32: the tile's lora_up rows n0 .. n0 + 127, ALL ranks (256 R contiguous bytes), go to the staging region by LDS-DMA from
+                    // here -- older than every DMA of the loop, landing under it like the generated prologue's pieces.  LDS image: row r, 16-byte
+                    // chunk c at ((r (C + 1) + c) * 16), C = R / 8: the odd pitch spreads the epilogue's reads (one chunk over 32 rows) over the banks.
+                    // An LDS-DMA writes 64 consecutive 16-byte slots: lane i of piece q fills slot 64 q + i, i.e. fetches chunk (slot % (C + 1)) of row
+                    // slot / (C + 1) (the pad slot fetches chunk 0 again).  Waves take pieces w, w + 8, ...; the barrier keeps the previous tile's readers
+                    // of the region out of the way.
+                    __syncthreads();
+                    const unsigned C1 = (unsigned)p.R / 8u + 1u, pieces = 2u * C1, magic = (unsigned)p.stage_lu_all;
+                    unsigned lane_s = lane; // (through an empty asm statement: the per-lane gather offsets are loop-invariant, and hoisted out of the tile loop they
+                    asm volatile("" : "+v"(lane_s)); //  would live -- spilled -- across the main loop's asm block, which leaves ~30 registers free)
+                    const char *lu_tile = (const char *)(bm >= split_bm ? p.lora_up2 : p.lora_up) + (size_t)n0 * (unsigned)p.R * 2u;
+                    const unsigned long long lu_tile_u = (unsigned long long)lu_tile;
+#pragma unroll
+                    for (unsigned i = 0; i < (2u * (G_::STG_LU_ALL_MAX_R / 8 + 1) + 7u) / 8u; i++) {
+                        const unsigned q = (unsigned)wv + 8u * i;
+                        if (q < pieces) { // wave-uniform
+                            const unsigned slot = 64u * q + lane_s, row = (slot * magic) >> 16, c = slot - row * C1;
+                            const unsigned voff = row * (unsigned)p.R * 2u + (c == C1 - 1u ? 0u : c * 16u);
+                            const unsigned dst = __builtin_amdgcn_readfirstlane(stg_lds + 1024u * q);
+                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(lu_tile_u) : "memory", "m0");
+                        }
+                    }
+                }
+            }
             const unsigned long long stg_la_u = (unsigned long long)stg_la, stg_lu_u = (unsigned long long)stg_lu, stg_b_u = (unsigned long long)stg_b;
 #define SVDQ_LOOP2_OPERANDS                                                                                             \
                 : "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[1][0]), "={v[48:63]}"(acc[1][1]),         \
@@ -565,7 +601,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         lds_cbytes *stg = (lds_cbytes *)((lds_void *)lds) + G_::STG_OFF;
         bool staged_l = false; // block-uniform
         if constexpr (NW == 8) {
-            staged_l = !LAQ && p.stage_lora;
+            staged_l = !LAQ && !RALL && p.stage_lora;
             if (stg_counted) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads(); // every wave's pieces are in LDS
@@ -614,7 +650,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             for (int ni = 0; ni < 2; ni++)
                 u[ni] = *reinterpret_cast<__attribute__((address_space(3))) const V8 *>(stg + G_::STG_LU + ((unsigned)(wn * 64 + ni * 32) + lr_e) * 64u + (unsigned)rc * 2u + h_e * 16u);
         };
-        auto lora_mfma = [&](int rc, const LaRegs &t, const V8 (&u)[2]) {
+        auto lora_mfma = [&](int rc, const LaRegs &t, const V8 (&u)[2], auto &&after_convert) {
             const float sc = p.lora_scales[rc >> 4];
             V8 la[2];
             auto convert = [&](auto unit) { // unit: the scale of these 16 ranks is 1 (the default; block-uniform): v * 1 = v, no multiply
@@ -631,14 +667,34 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             };
             if (sc == 1.0f) convert(std::true_type{});
             else convert(std::false_type{});
+            after_convert(); // (the all-rank kernel re-uses t's registers for the unit 64 ranks further on)
 #pragma unroll
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(u[ni], la[mi], acc[ni][mi]);
         };
+        auto no_hook = []() {};
+        // rank > 32 with the tile's lora_up staged for every rank (stage_lu_all): lora_act_in comes through registers in batches of 64 ranks -- the 8 (LAQ: -)
+        // loads of a batch are all in flight at once, two batches deep where the registers allow it (one round trip for rank <= 128 instead of one per
+        // 16 ranks) -- and the up-projection fragments are 16-byte LDS reads.  Same arithmetic, same order: one MFMA per 16 ranks, ascending.
+        struct LaBatch { LaRegs x[4]; };
+        // (every load of a batch is issued unconditionally -- a unit beyond the rank re-reads the last one -- so that the batch registers are plainly
+        //  defined values: conditionally loaded ones look loop-carried to the register allocator, which then keeps them alive, i.e. spilled, across
+        //  the main loop's asm block)
+        auto issue_batch = [&](int rc0, LaBatch &b) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) load_la(min(rc0 + 16 * i, Rr - 16), b.x[i]);
+        };
+        auto staged_lu_all = [&](int rc, V8 (&u)[2]) {
+            const unsigned C1 = (unsigned)Rr / 8u + 1u;
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+                u[ni] = *reinterpret_cast<__attribute__((address_space(3))) const V8 *>(stg + ((((unsigned)(wn * 64 + ni * 32) + lr_e) * C1 + (unsigned)rc / 8u + h_e) * 16u));
+        };
         LaRegs x0 = {}, x1 = {};
         V8 u0[2] = {}, u1[2] = {};
-        if (staged_l) {
+        if constexpr (RALL) {
+        } else if (staged_l) {
             if constexpr (CARRY) { load_la(0, x0); load_la(16, x1); }  // (the region's lora_act_in slot holds the carry)
             else { staged_la(0, x0); staged_la(16, x1); }
             staged_lu(0, u0); staged_lu(16, u1);
@@ -650,6 +706,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         // GELU_QUANT: the next layer's smoothing factors and the first 32 ranks of its low-rank down projection ride on the
         // same round trip (they are consumed ~2000 instructions later, behind the GELU and the requantisation)
         u16x4 nsv[2][4] = {}, ldw[2][2][2] = {};
+        auto load_next_params = [&]() {
         if constexpr (FUSE == SVDQ_FUSE_GELU_QUANT) {
             const char *ns_base = (const char *)(bm >= split_bm ? p.next_smooth2 : p.next_smooth);
 #pragma unroll
@@ -668,27 +725,64 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                     }
             }
         }
-        if (use_bias) {
+        };
+        if constexpr (!RALL) load_next_params(); // (the all-rank kernel's ring of low-rank activations needs the registers first: it asks behind the up projection)
+        auto apply_bias = [&]() {
+            if (use_bias) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++) {
-                V8 bw, one;
+                for (int ni = 0; ni < 2; ni++) {
+                    V8 bw, one;
 #pragma unroll
-                for (int j = 0; j < 8; j++) { bw[j] = (T)0.f; one[j] = (T)0.f; }
-                bw[0] = hfrom<T>((uint16_t)(h_e == (unsigned)ni ? bias_bits : 0u));
-                one[0] = h_e == (unsigned)ni ? (T)1.0f : (T)0.f;
+                    for (int j = 0; j < 8; j++) { bw[j] = (T)0.f; one[j] = (T)0.f; }
+                    bw[0] = hfrom<T>((uint16_t)(h_e == (unsigned)ni ? bias_bits : 0u));
+                    one[0] = h_e == (unsigned)ni ? (T)1.0f : (T)0.f;
 #pragma unroll
-                for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(bw, one, acc[ni][mi]);
+                    for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(bw, one, acc[ni][mi]);
+                }
+            }
+        };
+        if constexpr (RALL) {
+            // a ring of four 16-rank units (64 VGPRs): the first 64 ranks are requested up front (above the wait for the staged operands); each unit's
+            // registers are re-used for the unit 64 ranks further on as soon as its values are converted -- the next loads fly under this unit's MFMAs
+            LaBatch ring;
+            issue_batch(0, ring);
+            apply_bias();
+            for (int rc0 = 0; rc0 < Rr; rc0 += 64) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int rc = rc0 + 16 * i;
+                    if (rc < Rr) { // block-uniform
+                        V8 u[2];
+                        staged_lu_all(rc, u);
+                        lora_mfma(rc, ring.x[i], u, [&]() { if (rc + 64 < Rr) load_la(rc + 64, ring.x[i]); });
+                    }
+                }
+            }
+            load_next_params();
+        } else {
+        apply_bias();
+        if (Rr > 0) lora_mfma(0, x0, u0, no_hook);
+        if (Rr > 16) {
+            if constexpr (LAQ) { load_la(16, x0); lora_mfma(16, x0, u1, no_hook); }
+            else lora_mfma(16, x1, u1, no_hook);
+        }
+        // beyond rank 32 without the all-rank kernel (the 128 x 128 geometry, the fixed-point accumulator format, the carry kernel, unaligned operands,
+        // rank > 160).  128 x 128 geometry: 32 ranks per round trip, every load of the pair in flight before the first MFMA; elsewhere 16
+        if constexpr (NW == 4 && !LAQ) {
+            for (int rc = 32; rc < Rr; rc += 32) {
+                load_la(rc, x0);
+                load_lu(rc, u0);
+                if (rc + 16 < Rr) { load_la(rc + 16, x1); load_lu(rc + 16, u1); }
+                lora_mfma(rc, x0, u0, no_hook);
+                if (rc + 16 < Rr) lora_mfma(rc + 16, x1, u1, no_hook);
+            }
+        } else {
+            for (int rc = 32; rc < Rr; rc += 16) {
+                load_la(rc, x0);
+                load_lu(rc, u0);
+                lora_mfma(rc, x0, u0, no_hook);
             }
         }
-        if (Rr > 0) lora_mfma(0, x0, u0);
-        if (Rr > 16) {
-            if constexpr (LAQ) { load_la(16, x0); lora_mfma(16, x0, u1); }
-            else lora_mfma(16, x1, u1);
-        }
-        for (int rc = 32; rc < Rr; rc += 16) { // runtime LoRA beyond rank 32: one round trip per 16 ranks
-            load_la(rc, x0);
-            load_lu(rc, u0);
-            lora_mfma(rc, x0, u0);
         }
         // NW = 8: nothing of this epilogue has gone to memory yet -- whatever is outstanding is the next tile's prefetch (and a fused
         // epilogue's own parameter loads): waiting here proves the prefetch landed (`landed` above) so that the next loop call need not
@@ -891,32 +985,45 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) d[mi] = zero16;
                     const bool live = t2 + lr < p.R2;
+                    // this pass's 32 ranks of the down-projection weights are in `ldw` (ranks 0..31: requested at the top of the epilogue; later
+                    // passes: by the pass before -- one memory round trip per 32 ranks, hidden under the previous pass's MFMAs and atomics)
+                    V8 wv[2][2];
 #pragma unroll
                     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                         for (int q = 0; q < 2; q++) {
-                            V8 wv;
                             if (live) {
-                                u16x4 w0 = ldw[ni][q][0], w1 = ldw[ni][q][1]; // ranks 0..31: requested at the top of the epilogue
-                                if (!CARRY && t2 > 0) {
-                                    const T *src = ld + (size_t)(t2 + lr) * p.N + nw0 + ni * 32 + q * 16 + h * 4;
-                                    w0 = *reinterpret_cast<const u16x4 *>(src);
-                                    w1 = *reinterpret_cast<const u16x4 *>(src + 8);
-                                }
+                                const u16x4 w0 = ldw[ni][q][0], w1 = ldw[ni][q][1];
 #pragma unroll
-                                for (int j = 0; j < 4; j++) { wv[j] = hfrom<T>(w0[j]); wv[4 + j] = hfrom<T>(w1[j]); }
+                                for (int j = 0; j < 4; j++) { wv[ni][q][j] = hfrom<T>(w0[j]); wv[ni][q][4 + j] = hfrom<T>(w1[j]); }
                             } else {
 #pragma unroll
-                                for (int j = 0; j < 8; j++) wv[j] = (T)0.f;
+                                for (int j = 0; j < 8; j++) wv[ni][q][j] = (T)0.f;
                             }
+                        }
+                    if constexpr (!CARRY) {
+                        if (t2 + 32 < p.R2 && t2 + 32 + lr < p.R2) {
+#pragma unroll
+                            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                                for (int q = 0; q < 2; q++) {
+                                    const T *src = ld + (size_t)(t2 + 32 + lr) * p.N + nw0 + ni * 32 + q * 16 + h * 4;
+                                    ldw[ni][q][0] = *reinterpret_cast<const u16x4 *>(src);
+                                    ldw[ni][q][1] = *reinterpret_cast<const u16x4 *>(src + 8);
+                                }
+                        }
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                        for (int q = 0; q < 2; q++)
 #pragma unroll
                             for (int mi = 0; mi < 2; mi++) {
                                 V8 gv;
 #pragma unroll
                                 for (int j = 0; j < 8; j++) gv[j] = f2h<T>(acc[ni][mi][q * 8 + j]);
-                                d[mi] = Half<DT>::mfma32(gv, wv, d[mi]);
+                                d[mi] = Half<DT>::mfma32(gv, wv[ni][q], d[mi]);
                             }
-                        }
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) {
                         const size_t at = (size_t)(mw0 + mi * 32 + h * 4) * p.R2 + t2 + lr;
@@ -1178,6 +1285,12 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
         }
     }
     dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
+    if constexpr (NW == 8 && !LAQ) {
+        if (p.stage_lu_all) { // 32 < rank <= 160: the kernel with the all-rank lora_up image
+            hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true>), grid, block, 0, st, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ>), grid, block, 0, st, p);
 }
 template <int DT, int FUSE, int NW>
@@ -1394,6 +1507,11 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     // the 256 x 128 geometry stages a tile's low-rank operands in LDS when they are whole 1 KiB pieces: rank 32, fp32, 16-byte aligned
     p.stage_lora = a->R == 32 && a->lora_act_format == SVDQ_LORA_ACT_F32 && a->lora_act_in && a->lora_up &&
                    (((uintptr_t)a->lora_act_in | (uintptr_t)a->lora_up | (uintptr_t)a->lora_up2) & 15) == 0;
+    // ... or, beyond rank 32, the tile's lora_up for every rank (Geo::STG_LU_ALL_MAX_R): value = the gather's divider ceil(65536 / (R / 8 + 1))
+    p.stage_lu_all = 0;
+    if (a->R > 32 && a->R <= Geo<8>::STG_LU_ALL_MAX_R && a->lora_act_format == SVDQ_LORA_ACT_F32 && a->lora_act_in && a->lora_up &&
+        (((uintptr_t)a->lora_act_in | (uintptr_t)a->lora_up | (uintptr_t)a->lora_up2) & 15) == 0)
+        p.stage_lu_all = 65536 / (a->R / 8 + 1) + 1;
     p.status = a->status;
     p.q_scale = a->q_scale == 0.f ? 1.0f : a->q_scale;
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, OCC) void quantize_kernel(const typename Half<
 
 
 // --------------------------------------------------------------------------------------------------------------------
-// Fast path (R <= 32, i.e. every SVDQuant checkpoint's own low-rank branch): same arithmetic, same outputs, built for
+// Fast path (any rank since round 5; template MULTI for rank > 32): same arithmetic, same outputs, built for
 // latency instead of registers.  Counters of the general kernel above at the FLUX.1 shape (profiles/r2_quantize_pmc.txt): a
 // wave lives ~21 us for ONE chunk, its VALU is busy 14 % of that; 43 % is s_waitcnt on 80 narrow loads (64 of them re-read
 // per-channel parameters every row tile needs alike), 38 % issue stalls; 236 VGPRs hold two workgroups per CU.  Here:
@@ -356,8 +356,13 @@ __device__ __forceinline__ void quant_piece(unsigned d0, unsigned d1, v2f mean2,
     }
 }
 
-template <int DT, bool LORA, bool LN, bool SMOOTH>
-__global__ __launch_bounds__(256, 4) void quantize_kernel_v2(QuantParams p) {
+// MULTI (round 5): rank > 32 -- the r128 checkpoints, a runtime LoRA on top of the rank-32 branch.  The chunk's 16-bit activations (the MFMA A operands:
+// 32 registers) are kept, and behind the quantisation proper the remaining 32-rank slabs of lora_down take the same path one after the other: slice ->
+// LDS by LDS-DMA, 8 MFMAs, the four waves' partial tiles combined in the fixed order, one set of atomics.  A kernel of its own: the rank <= 32 kernels keep
+// their registers (4 workgroups per CU) and their instruction stream.
+template <int DT, bool LORA, bool LN, bool SMOOTH, bool MULTI = false>
+__global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantParams p) {
+    static_assert(!MULTI || LORA, "MULTI: more than one 32-rank slab of lora_down");
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     using P16 = Pair16<DT>;
@@ -394,6 +399,8 @@ __global__ __launch_bounds__(256, 4) void quantize_kernel_v2(QuantParams p) {
     v16f accL;
 #pragma unroll
     for (int j = 0; j < 16; j++) accL[j] = 0.f;
+    v4i aop[MULTI ? 2 : 1][MULTI ? 4 : 1] = {}; // MULTI: the chunk's MFMA A operands, kept for the slabs beyond rank 32
+    unsigned ldo_keep[4] = {0, 0, 0, 0};
 
     if (active) {
         // ---- 1. every global access of the chunk goes out back to back: 16 activation loads (this lane's record: row r,
@@ -414,6 +421,10 @@ __global__ __launch_bounds__(256, 4) void quantize_kernel_v2(QuantParams p) {
         // all address arithmetic happens BEFORE the first load is issued (the backend otherwise interleaves it with the loads
         // and, reusing a load's destination as the undefined half of a 64-bit multiply-add operand, waits for that load)
         asm volatile("" : "+v"(xoff), "+v"(ldo[0]), "+v"(ldo[1]), "+v"(ldo[2]), "+v"(ldo[3]));
+        if constexpr (MULTI) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) ldo_keep[j] = ldo[j];
+        }
         uint2 xv[2][8];
 #pragma unroll
         for (int grp = 0; grp < 2; grp++)
@@ -485,6 +496,7 @@ __global__ __launch_bounds__(256, 4) void quantize_kernel_v2(QuantParams p) {
                 if constexpr (LORA) {
                     // D[m][rank] += x[m][k] * lora_down[k][rank]: pieces 2q, 2q+1 of every lane are k-slots 8h .. 8h+7
                     const V8 a = __builtin_bit_cast(V8, v4i{(int)ae[0], (int)ao[0], (int)ae[1], (int)ao[1]});
+                    if constexpr (MULTI) aop[grp][q] = v4i{(int)ae[0], (int)ao[0], (int)ae[1], (int)ao[1]};
                     const int piece = grp * 8 + 2 * q; // 16-byte pieces of rank r's row: this lane's half (8 h) of pieces `piece`, `piece + 1`
                     if (grp == 0 && q == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the LDS-DMA of the slice has landed
                     const u32x2 b0 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + ((piece ^ (r & 15)) << 4) + 8 * h);
@@ -517,18 +529,48 @@ __global__ __launch_bounds__(256, 4) void quantize_kernel_v2(QuantParams p) {
 
     if constexpr (LORA) {
         // combine the four waves' partial sums in a fixed order (each wave parks its tile in its own region)
-        *(lds_v16f *)(W + QV2_PARAM_BYTES + lane * 64) = accL;
-        __syncthreads();
-        if (wave == 0) {
-            const lds_u8 *B = (const lds_u8 *)lds + QV2_PARAM_BYTES + lane * 64;
-            const v16f s = ((*(const lds_v16f *)(B) + *(const lds_v16f *)(B + QV2_WAVE_BYTES)) + *(const lds_v16f *)(B + 2 * QV2_WAVE_BYTES)) +
-                           *(const lds_v16f *)(B + 3 * QV2_WAVE_BYTES);
-            if (r < p.R) { // C layout: col (rank) = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+        auto combine = [&](int rank0) {
+            *(lds_v16f *)(W + QV2_PARAM_BYTES + lane * 64) = accL;
+            __syncthreads();
+            if (wave == 0) {
+                const lds_u8 *B = (const lds_u8 *)lds + QV2_PARAM_BYTES + lane * 64;
+                const v16f s = ((*(const lds_v16f *)(B) + *(const lds_v16f *)(B + QV2_WAVE_BYTES)) + *(const lds_v16f *)(B + 2 * QV2_WAVE_BYTES)) +
+                               *(const lds_v16f *)(B + 3 * QV2_WAVE_BYTES);
+                if (rank0 + r < p.R) { // C layout: col (rank) = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int m = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    lora_act_add(p.lora_act, (size_t)m * p.R + r, s[i], p.use_atomics);
+                    for (int i = 0; i < 16; i++) {
+                        const int m = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        lora_act_add(p.lora_act, (size_t)m * p.R + rank0 + r, s[i], p.use_atomics);
+                    }
                 }
+            }
+        };
+        combine(0);
+        if constexpr (MULTI) {
+            // the slabs beyond rank 32: same slice layout, same MFMA operand order, same combination -- one slab at a time through the wave's region
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)lora_down, 0, (int)((size_t)p.R * K * 2), 0x00020000);
+            typedef __attribute__((address_space(3))) void lds_void;
+            for (int rank0 = 32; rank0 < p.R; rank0 += 32) {
+                __syncthreads(); // wave 0 has read every wave's parked tile: the regions are free for the next slice
+#pragma unroll
+                for (int j = 0; j < 16; j++) accL[j] = 0.f;
+                if (active) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) // (ranks >= R lie beyond the descriptor's range and read as zero)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void *)(W + QV2_PARAM_BYTES + i * 1024), 16, ldo_keep[i & 3], ((i >> 2) * 16 + rank0) * K * 2, 0, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int grp = 0; grp < 2; grp++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int piece = grp * 8 + 2 * q;
+                            const u32x2 b0 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + ((piece ^ (r & 15)) << 4) + 8 * h);
+                            const u32x2 b1 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + (((piece + 1) ^ (r & 15)) << 4) + 8 * h);
+                            const V8 b = __builtin_bit_cast(V8, v4i{(int)b0[0], (int)b0[1], (int)b1[0], (int)b1[1]});
+                            accL = Half<DT>::mfma32(__builtin_bit_cast(V8, aop[grp][q]), b, accL);
+                        }
+                }
+                combine(rank0);
             }
         }
     }
@@ -553,15 +595,16 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     dim3 grid(tiles * slices), block(256);
     const int rt32 = (a->R + 31) / 32;
     QuantSecond s2{a->x2, a->smooth2, a->lora_down2, a->mod_scale2, a->mod_shift2, a->ln_stats2, a->M2, a->ldx2, a->split_rows};
-    if (!a->fuse_glu && rt32 <= 1 && cpw == 4 && (long long)a->M_pad * (a->ldx > a->ldx2 ? a->ldx : a->ldx2) * 2 < 0x7fffffffLL) {
+    if (!a->fuse_glu && cpw == 4 && (long long)a->M_pad * (a->ldx > a->ldx2 ? a->ldx : a->ldx2) * 2 < 0x7fffffffLL && (long long)a->R * a->K * 2 < 0x7fffffffLL) {
         // fast path: one chunk per wave, 4 waves = 4 neighbouring chunks of one row tile (same grid as the general kernel at cpw = 4)
         QuantParams qp{a->x, a->smooth, a->lora_down, a->mod_scale, a->mod_shift, a->ln_stats, (uint8_t *)a->act, a->ascales, a->lora_act,
                        a->M, a->K, a->R, a->ldx, atomics, s2};
-        const int sel = (a->R > 0 ? 4 : 0) | (a->ln_stats ? 2 : 0) | (a->smooth ? 1 : 0);
+        const int sel = (a->R > 32 ? 8 : 0) | (a->R > 0 ? 4 : 0) | (a->ln_stats ? 2 : 0) | (a->smooth ? 1 : 0);
         switch (sel) {
-#define SVDQ_QV2(n, LORA, LN, SM) case n: hipLaunchKernelGGL((quantize_kernel_v2<DT, LORA, LN, SM>), grid, block, 0, st, qp); break;
-            SVDQ_QV2(0, false, false, false) SVDQ_QV2(1, false, false, true) SVDQ_QV2(2, false, true, false) SVDQ_QV2(3, false, true, true)
-            SVDQ_QV2(4, true, false, false) SVDQ_QV2(5, true, false, true) SVDQ_QV2(6, true, true, false) SVDQ_QV2(7, true, true, true)
+#define SVDQ_QV2(n, LORA, LN, SM, MULTI) case n: hipLaunchKernelGGL((quantize_kernel_v2<DT, LORA, LN, SM, MULTI>), grid, block, 0, st, qp); break;
+            SVDQ_QV2(0, false, false, false, false) SVDQ_QV2(1, false, false, true, false) SVDQ_QV2(2, false, true, false, false) SVDQ_QV2(3, false, true, true, false)
+            SVDQ_QV2(4, true, false, false, false) SVDQ_QV2(5, true, false, true, false) SVDQ_QV2(6, true, true, false, false) SVDQ_QV2(7, true, true, true, false)
+            SVDQ_QV2(12, true, false, false, true) SVDQ_QV2(13, true, false, true, true) SVDQ_QV2(14, true, true, false, true) SVDQ_QV2(15, true, true, true, true)
 #undef SVDQ_QV2
         }
         return hip_check(hipGetLastError(), "svdq_quantize_w4a4_act_fuse_lora launch");

@@ -137,8 +137,8 @@ class NunchakuQwenAttention(nn.Module):
         if qres is not None:
             txt, img = linear_pair_quantized(*qres, self.to_add_out, self.to_out[0], t_txt)
             return img, txt
-        # (rank > 32 -- e.g. the r128 checkpoints -- or a runtime LoRA on the output projections: the attention epilogue cannot emit their quantised
-        #  input; Q left the QKV GEMM prescaled all the same)
+        # (shapes the attention epilogue's quantiser does not take -- the two projections' ranks differ, e.g. a runtime LoRA on one of them: the 16-bit
+        #  round trip; Q left the QKV GEMM prescaled all the same)
         o = attention_packed(qkv, vt, self.heads, q_prescaled=True, kv_valid=kv_valid).unsqueeze(0)
         txt, img = linear_pair(o[:, :t_txt], self.to_add_out, o[:, t_txt:], self.to_out[0])
         return img, txt

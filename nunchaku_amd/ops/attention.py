@@ -75,7 +75,7 @@ def attention_packed_quantized(qkv: torch.Tensor, vt: torch.Tensor, heads: int, 
     L, three_hd = qkv.shape
     D = three_hd // (3 * heads)
     K, R = heads * D, lin.rank
-    if D != 128 or L % 256 or K != lin.in_features or R > 32 or R % 16 or (lin_first is not None and (
+    if D != 128 or L % 256 or K != lin.in_features or R > 256 or R % 16 or (lin_first is not None and (
             lin_first.rank != R or lin_first.in_features != K or split_rows % 256 or not 0 < split_rows < L)):
         return None
     lin._ensure_layout()

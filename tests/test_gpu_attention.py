@@ -383,13 +383,14 @@ def test_attention_full_size_properties():
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("joint", [False, True])
-def test_attention_fused_output_quantiser(dtype, joint):
+@pytest.mark.parametrize("R", [32, 48, 128], ids=["r32", "r48", "r128"])
+def test_attention_fused_output_quantiser(dtype, joint, R):
     """The attention epilogue emits the output projection's quantised input: identical codes and scales to quantising the
     16-bit attention output with the stand-alone kernel; lora_act up to fp32 summation order."""
     from nunchaku_amd import layout
     from nunchaku_amd.ops.attention import attention_packed, attention_packed_quantized
 
-    H, L, R = 2, 512, 32
+    H, L = 2, 512   # (R: every rank runs in the attention epilogue since round 5 -- 32-rank passes; r128 = the reference's Qwen-Image / FLUX r128 checkpoints)
     K = H * 128
     td = TORCH_DT[dtype]
     g = torch.Generator(device="cuda").manual_seed(3)

@@ -59,7 +59,8 @@ def test_repack_kernels_match_reference_packer(golden_dir):
 
 # ----------------------------------------------------------------------------- quantiser
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("M,K,R", [(256, 256, 32), (300, 384, 32), (1, 128, 16), (513, 3072, 32), (77, 256, 48)])
+@pytest.mark.parametrize("M,K,R", [(256, 256, 32), (300, 384, 32), (1, 128, 16), (513, 3072, 32), (77, 256, 48), (300, 384, 64), (513, 1024, 128),
+                                   (256, 256, 160), (64, 128, 176)])
 def test_quantize_codes_and_scales(dtype, M, K, R):
     L = O.make_svdq_layer(K, 128, R, seed=M, dtype=dtype, cheap=True)
     x = O.make_activations(M, K, seed=M, dtype=dtype)
@@ -140,7 +141,7 @@ def _gemm_inputs(M, K, N, R, dtype, seed, unsigned=False, bias=True):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,K,N,R", [(256, 128, 128, 32), (200, 384, 256, 32), (512, 3072, 384, 32), (33, 256, 128, 16),
-                                     (256, 256, 128, 80)])
+                                     (256, 256, 128, 80), (300, 256, 384, 48), (512, 384, 256, 128), (256, 256, 128, 160), (256, 128, 128, 176)])
 def test_linear_forward_matches_oracle(dtype, M, K, N, R):
     L, x = _gemm_inputs(M, K, N, R, dtype, seed=K + N)
     mod = make_module(L, dtype)
@@ -238,8 +239,9 @@ def test_qkv_rmsnorm_rope(dtype, M, K, H):
     assert_close_16(got[:, : 2 * N // 3], ref[:, : 2 * N // 3], dtype, "QK", max_bad_frac=2e-3, ulps=2.0)
 
 
-@pytest.mark.parametrize("r2", [16, 32, 48], ids=["next-rank-16", "next-rank-32", "next-rank-48"])
-def test_gelu_quant_next_low_rank_down_by_rank(r2):
+@pytest.mark.parametrize("r1", [32, 128], ids=["rank-32", "rank-128"])
+@pytest.mark.parametrize("r2", [16, 32, 48, 128], ids=["next-rank-16", "next-rank-32", "next-rank-48", "next-rank-128"])
+def test_gelu_quant_next_low_rank_down_by_rank(r2, r1):
     """The GELU_QUANT epilogue's low-rank down projection for the NEXT layer at ranks on both sides of the carry kernel's limit (round 4: rank <= 32
     accumulates in the workgroup's LDS carry -- rank 16 with half the lanes idle --, rank 48 keeps the per-tile atomics over two passes of 32 ranks):
     codes, scales and lora_act_out against the oracle, several column tiles per row block so that the carry really sums."""
@@ -247,7 +249,7 @@ def test_gelu_quant_next_low_rank_down_by_rank(r2):
     from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
 
     dtype, M, C, Hd = "bf16", 300, 256, 1024
-    fc1 = O.make_svdq_layer(C, Hd, 32, seed=31, dtype=dtype, cheap=True)
+    fc1 = O.make_svdq_layer(C, Hd, r1, seed=31, dtype=dtype, cheap=True)
     fc2 = O.make_svdq_layer(Hd, C, r2, seed=32, dtype=dtype, cheap=True)
     x = O.make_activations(M, C, seed=33, dtype=dtype)
     m1, m2 = make_module(fc1, dtype), make_module(fc2, dtype, act_unsigned=True)

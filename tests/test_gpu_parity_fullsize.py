@@ -46,15 +46,37 @@ def _geometry(request):
     _Ops.gemm_geometry = 0
 
 
-@functools.lru_cache(maxsize=None)
-def _layer(K, N, seed, dtype):
-    return O.make_random_svdq_layer(K, N, R, seed=seed, dtype=dtype)
+LORA_STRENGTH = 0.75
 
 
 @functools.lru_cache(maxsize=None)
-def _module(K, N, seed, dtype, unsigned=False):
-    m = make_module(_layer(K, N, seed, dtype), dtype, act_unsigned=unsigned)
+def _layer(K, N, seed, dtype, rank=R, lora=0):
+    """oracle layer; ``lora`` > 0: the layer a runtime LoRA of that rank turns it into (set_lora: the low-rank branch widened by ceil16(lora) ranks,
+    the new ranks scaled by LORA_STRENGTH -- the reference's update_lora_params / set_lora_strength, transformer_flux.py:783-855)"""
+    L = O.make_random_svdq_layer(K, N, rank, seed=seed, dtype=dtype)
+    if lora:
+        rng = np.random.default_rng(1000 + seed)
+        rp = (lora + 15) // 16 * 16
+        down = np.zeros((rp, K), np.float32)
+        up = np.zeros((N, rp), np.float32)
+        down[:lora] = O.round16(rng.standard_normal((lora, K)).astype(np.float32) / np.sqrt(K), dtype)
+        up[:, :lora] = O.round16(rng.standard_normal((N, lora)).astype(np.float32) * 0.5, dtype)
+        L = dict(L)
+        L["lora_down_user"], L["lora_up_user"] = down[:lora], up[:, :lora]
+        L["proj_down"] = np.concatenate([L["proj_down"], down.T], axis=1)
+        L["proj_up"] = np.concatenate([L["proj_up"], up], axis=1)
+        L["lora_scales"] = [1.0] * (rank // 16) + [LORA_STRENGTH] * (rp // 16)
+    return L
+
+
+@functools.lru_cache(maxsize=None)
+def _module(K, N, seed, dtype, unsigned=False, rank=R, lora=0):
+    m = make_module(_layer(K, N, seed, dtype, rank), dtype, act_unsigned=unsigned)
     m._ensure_layout()
+    if lora:
+        L = _layer(K, N, seed, dtype, rank, lora)
+        m.set_lora(t16(L["lora_down_user"], dtype), t16(L["lora_up_user"], dtype), strength=LORA_STRENGTH)
+        assert m.rank == L["proj_up"].shape[1] and m.lora_scales == L["lora_scales"]
     return m
 
 
@@ -116,6 +138,21 @@ def _same_up_to_add_order(a, b, dtype, what):
 @pytest.mark.parametrize("Ma,Mb", [(512, 0), (1024, 0), (1536, 0), (4096, 0), (4608, 0), (512, 1024), (512, 4096)],
                          ids=["M512", "M1024", "M1536", "M4096", "M4608", "grouped512+1024", "grouped512+4096"])
 def test_block_projections_at_flux_shapes(dtype, Ma, Mb):
+    _block_projections(dtype, Ma, Mb)
+
+
+@pytest.mark.parametrize("dtype,Ma,Mb,rank,lora", [("bf16", 4608, 0, 128, 0), ("fp16", 4608, 0, 128, 0), ("bf16", 256, 6144, 128, 0), ("bf16", 4608, 0, 32, 16),
+                                                  ("bf16", 1536, 0, 64, 0)],
+                         ids=["r128-M4608-bf16", "r128-M4608-fp16", "r128-qwen1664x928-grouped256+6144", "r32+lora16-M4608", "r64-M1536"])
+def test_block_projections_at_other_ranks(dtype, Ma, Mb, rank, lora):
+    """the reference's own Qwen-Image gate runs rank 32 AND rank 128 (tests/v1/qwenimage/test_qwenimage.py:20-26, 1664 x 928 = 6032 image
+    tokens -> 6144 padded rows + a padded text stream), and every runtime LoRA makes the rank 32 + r (transformer_flux.py:783-855).  Same chain, same
+    bounds as the rank-32 grid above; the launches run the all-rank kernels (lora_up of a tile staged for every rank, lora_act_in in a ring of 64-rank
+    batches), the quantiser's multi-slab fast path and the multi-pass low-rank down projection of the GELU_QUANT epilogue."""
+    _block_projections(dtype, Ma, Mb, rank=rank, lora=lora)
+
+
+def _block_projections(dtype, Ma, Mb, rank=R, lora=0):
     from nunchaku_amd import layout
     from nunchaku_amd.ops import fused
     from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
@@ -132,8 +169,8 @@ def test_block_projections_at_flux_shapes(dtype, Ma, Mb):
 
     def quantize(K, N, seed0, src, unsigned=False):
         """-> (act, asc, lact, modules, layers): one or two streams quantised into one set of row-side buffers"""
-        mods = [_module(K, N, seed0 + s, dtype, unsigned) for s in sets]
-        lays = [_layer(K, N, seed0 + s, dtype) for s in sets]
+        mods = [_module(K, N, seed0 + s, dtype, unsigned, rank, lora) for s in sets]
+        lays = [_layer(K, N, seed0 + s, dtype, rank, lora) for s in sets]
         if grouped:
             act, asc, lact, _ = fused._quantize_pair(src[:Ma].unsqueeze(0), mods[0], src[Ma:].unsqueeze(0), mods[1])
         else:
@@ -172,7 +209,7 @@ def test_block_projections_at_flux_shapes(dtype, Ma, Mb):
         out = torch.zeros(M, QKV, dtype=td, device="cuda")
         vt = torch.zeros(QKV // 3, M_pad, dtype=td, device="cuda")
         svdq_gemm_w4a4_cuda(act=act, wgt=mods[0].qweight, out=out, ascales=asc, wscales=mods[0].wscales, lora_act_in=lact,
-                            lora_up=mods[0].proj_up, bias=mods[0].bias, norm_q=nq_t[0][0], norm_k=nq_t[0][1], rotary_emb=packed,
+                            lora_up=mods[0].proj_up, lora_scales=mods[0].lora_scales, bias=mods[0].bias, norm_q=nq_t[0][0], norm_k=nq_t[0][1], rotary_emb=packed,
                             out_vt=vt, **(second(mods, norm_q=nq_t[1][0], norm_k=nq_t[1][1]) if grouped else {}))
         return out, vt
 
@@ -180,7 +217,7 @@ def test_block_projections_at_flux_shapes(dtype, Ma, Mb):
         r = rows[idx]
         q, a = checked_codes(act, asc, x, L["smooth"], dtype, rows=r)  # the operands the launch read: envelope + flip budget vs the IEEE oracle
         return {"out": O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=la_gpu[r],
-                                   lora_up=L["proj_up"], fuse="rmsnorm_rope", norm_q=nqk[s][0], norm_k=nqk[s][1], rot=rot[r])["out"]}
+                                   lora_up=L["proj_up"], lora_scales=L.get("lora_scales"), fuse="rmsnorm_rope", norm_q=nqk[s][0], norm_k=nqk[s][1], rot=rot[r])["out"]}
 
     ref = oracle_rows(lays, qkv_ref)["out"]
     got = {}
@@ -201,14 +238,14 @@ def test_block_projections_at_flux_shapes(dtype, Ma, Mb):
     def out_launch():
         out = torch.zeros(M, HID, dtype=td, device="cuda")
         svdq_gemm_w4a4_cuda(act=act, wgt=mods[0].qweight, out=out, ascales=asc, wscales=mods[0].wscales, lora_act_in=lact,
-                            lora_up=mods[0].proj_up, bias=mods[0].bias, **second(mods))
+                            lora_up=mods[0].proj_up, lora_scales=mods[0].lora_scales, bias=mods[0].bias, **second(mods))
         return out
 
     def out_ref(L, idx, s):
         r = rows[idx]
         q, a = checked_codes(act, asc, x, L["smooth"], dtype, rows=r)  # the operands the launch read: envelope + flip budget vs the IEEE oracle
         return {"out": O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=la_gpu[r],
-                                   lora_up=L["proj_up"])["out"]}
+                                   lora_up=L["proj_up"], lora_scales=L.get("lora_scales"))["out"]}
 
     ref = oracle_rows(lays, out_ref)["out"]
     got = {}
@@ -220,15 +257,16 @@ def test_block_projections_at_flux_shapes(dtype, Ma, Mb):
     # ---------------------------------------------------------------- fc1: GELU -> u4 requantisation + fc2 low-rank down
     act, asc, lact, mods, lays = quantize(HID, MLP, 30, xt)
     la_gpu = lact.cpu().numpy()
-    m2 = [_module(MLP, HID, 40 + s, dtype, True) for s in sets]
-    l2 = [_layer(MLP, HID, 40 + s, dtype) for s in sets]
+    m2 = [_module(MLP, HID, 40 + s, dtype, True, rank, lora) for s in sets]
+    l2 = [_layer(MLP, HID, 40 + s, dtype, rank, lora) for s in sets]
+    R2 = l2[0]["proj_up"].shape[1]
 
     def fc1_launch():
         qh = torch.empty(layout.act_image_shape(M_pad, MLP), dtype=torch.uint8, device="cuda")
         sh = torch.empty(MLP // 64, M_pad, dtype=td, device="cuda")
-        lh = torch.full((M_pad, R), 7.0, dtype=torch.float32, device="cuda")  # must be zeroed by the op
+        lh = torch.full((M_pad, R2), 7.0, dtype=torch.float32, device="cuda")  # must be zeroed by the op
         svdq_gemm_w4a4_cuda(act=act, wgt=mods[0].qweight, qout=qh, ascales=asc, wscales=mods[0].wscales, oscales=sh, lora_act_in=lact,
-                            lora_up=mods[0].proj_up, lora_down=m2[0].proj_down, lora_act_out=lh, bias=mods[0].bias,
+                            lora_up=mods[0].proj_up, lora_scales=mods[0].lora_scales, lora_down=m2[0].proj_down, lora_act_out=lh, bias=mods[0].bias,
                             smooth_factor=m2[0].smooth_factor,
                             **(second(mods, smooth_factor=m2[1].smooth_factor, lora_down=m2[1].proj_down) if grouped else {}))
         return qh, sh, lh
@@ -237,7 +275,7 @@ def test_block_projections_at_flux_shapes(dtype, Ma, Mb):
         r = rows[idx]
         q, a = checked_codes(act, asc, x, L["smooth"], dtype, rows=r)  # the operands the launch read: envelope + flip budget vs the IEEE oracle
         res = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=la_gpu[r],
-                          lora_up=L["proj_up"], fuse="gelu_quant", next_smooth=l2[s]["smooth"], next_lora_down=l2[s]["proj_down"], envelope=True)
+                          lora_up=L["proj_up"], lora_scales=L.get("lora_scales"), fuse="gelu_quant", next_smooth=l2[s]["smooth"], next_lora_down=l2[s]["proj_down"], envelope=True)
         return {"qout": res["qout"], "oscales": res["oscales"].T.copy(), "lora": res["lora_act_out"], "q_lo": res["envelope"]["q_lo"], "q_hi": res["envelope"]["q_hi"]}
 
     ref = oracle_rows(lays, fc1_ref)
@@ -272,13 +310,13 @@ def test_block_projections_at_flux_shapes(dtype, Ma, Mb):
 
     def fc2_launch():
         out = torch.zeros(M, HID, dtype=td, device="cuda")
-        svdq_gemm_w4a4_cuda(act=qh, wgt=m2[0].qweight, out=out, ascales=sh, wscales=m2[0].wscales, lora_act_in=lh, lora_up=m2[0].proj_up,
+        svdq_gemm_w4a4_cuda(act=qh, wgt=m2[0].qweight, out=out, ascales=sh, wscales=m2[0].wscales, lora_act_in=lh, lora_up=m2[0].proj_up, lora_scales=m2[0].lora_scales,
                             bias=m2[0].bias, act_unsigned=True, **second(m2))
         return out
 
     def fc2_ref(L, idx, s):
         return {"out": O.gemm_w4a4(codes_rows[idx], sc_rows[:, idx], L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"],
-                                   lora_act_in=lh_rows[idx], lora_up=L["proj_up"])["out"]}
+                                   lora_act_in=lh_rows[idx], lora_up=L["proj_up"], lora_scales=L.get("lora_scales"))["out"]}
 
     ref = oracle_rows(l2, fc2_ref)["out"]
     got = {}

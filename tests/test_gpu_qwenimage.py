@@ -331,22 +331,31 @@ def test_qwen_rope_tables():
     assert p["img"].shape == (1, 256, 128) and p["txt"].shape == (1, 256, 128) and p["all"].shape == (1, 512, 128)
 
 
-def _attention_launches(fn):
+def _launch_counts(fn):
+    """-> (fn(), {"gemm": n, "quantize": n, "attention": n}): the library's launches while fn runs (svdq_prof_* event counters)"""
     import ctypes as C
 
     from nunchaku_amd import _lib
     lib = _lib.load()
-    _lib.check(lib.svdq_prof_select(1 << 2), "svdq_prof_select")
-    _lib.check(lib.svdq_prof_enable(256), "svdq_prof_enable")
+    _lib.check(lib.svdq_prof_select((1 << 0) | (1 << 1) | (1 << 2)), "svdq_prof_select")
+    _lib.check(lib.svdq_prof_enable(4096), "svdq_prof_enable")
+    counts = {}
     try:
         out = fn()
         torch.cuda.synchronize()
-        n, ms, work = C.c_int64(0), C.c_double(0), C.c_double(0)
-        _lib.check(lib.svdq_prof_read(2, C.byref(n), C.byref(ms), C.byref(work)), "svdq_prof_read")
+        for name, cls in (("gemm", 0), ("quantize", 1), ("attention", 2)):
+            n, ms, work = C.c_int64(0), C.c_double(0), C.c_double(0)
+            _lib.check(lib.svdq_prof_read(cls, C.byref(n), C.byref(ms), C.byref(work)), "svdq_prof_read")
+            counts[name] = n.value
     finally:
         lib.svdq_prof_enable(0)
         lib.svdq_prof_select(0xFFFFFFFF)
-    return out, n.value
+    return out, counts
+
+
+def _attention_launches(fn):
+    out, counts = _launch_counts(fn)
+    return out, counts["attention"]
 
 
 # VERDICT r3 #2: the reference's own Qwen-Image quality gate runs 1664 x 928 (tests/v1/qwenimage/test_qwenimage.py:21,118): a 58 x 104 grid of
@@ -377,12 +386,13 @@ def test_qwen_block_on_padded_streams_matches_the_reference_op_sequence(grid, t_
     assert torch.isfinite(e).all() and torch.isfinite(h).all()  # the padded rows stay finite (they are V^T columns of the next block)
 
 
-@pytest.mark.parametrize("rank", [32, 64], ids=["r32", "r64"])
+@pytest.mark.parametrize("rank", [32, 64, 128], ids=["r32", "r64", "r128"])
 def test_qwen_model_odd_token_counts_run_the_fused_path(rank):
     """The model pads both streams itself and keeps the fused path -- with the pipeline's real call signature (an all-ones
     ``encoder_hidden_states_mask``, ignored as the reference's processor ignores it) -- against the reference's torch-op block sequence with no
-    padding anywhere.  rank 64: the attention epilogue cannot emit the output projections' quantised input (rank > 32), the fallback attention
-    call reads the PRESCALED Q (it used to apply the softmax scale twice)."""
+    padding anywhere.  Every rank takes the same launches since round 5 (rank > 32 used to leave the attention epilogue's quantiser, the
+    staged epilogue operands and the quantiser's fast path): the launch counters of rank 64 / 128 (the reference's r128 checkpoints,
+    tests/v1/qwenimage/test_qwenimage.py:20-26) equal rank 32's -- no stand-alone quantiser behind the attention, no extra GEMM."""
     from nunchaku_amd import mode
     from nunchaku_amd.models.qwenimage import NunchakuQwenAttention, NunchakuQwenImageTransformer2DModel
 
@@ -396,8 +406,15 @@ def test_qwen_model_odd_token_counts_run_the_fused_path(rank):
     t = torch.tensor([0.3], device="cuda")
     call = lambda: model(lat, enc, mask, t, [(1, grid[0], grid[1])], txt_seq_lens=[t_txt]).sample.float()
     with torch.no_grad(), mode.deterministic_mode():
-        hot, launches = _attention_launches(call)
-        assert launches == layers, f"{launches} svdq_attention launches for {layers} blocks"
+        hot, counts = _launch_counts(call)
+        assert counts["attention"] == layers, f"{counts['attention']} svdq_attention launches for {layers} blocks"
+        if rank != 32:  # the same launches as the rank-32 model: nothing fell back to an unfused sequence
+            m32 = NunchakuQwenImageTransformer2DModel(num_layers=layers, num_attention_heads=2, attention_head_dim=128, in_channels=64, out_channels=16,
+                                                      joint_attention_dim=128, rank=32, device="cuda").init_synthetic_(seed=7).eval()
+            _, c32 = _launch_counts(lambda: m32(lat, enc, mask, t, [(1, grid[0], grid[1])], txt_seq_lens=[t_txt]).sample)
+            print(f"launches per step, rank 32: {c32}; rank {rank}: {counts}")
+            assert counts == c32, (counts, c32)
+            del m32
         assert torch.equal(hot, call())
         NunchakuQwenImageTransformer2DModel.padded_tokens, NunchakuQwenAttention.fused_qkv = False, False
         try:

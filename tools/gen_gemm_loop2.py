@@ -73,7 +73,7 @@ S_PHASE = 52  # in ("dph" builds): 1 for waves 4..7
 # staging of the epilogue operands (nw = 8): in: s51 flags (bit 0: low-rank operands, bit 1: bias, bit 2: of the low-rank operands only lora_up; bits 8..10: wave), s54 LDS address of the
 # staging region, s[88:89] this wave's 4 KiB of lora_act_in, s[90:91] its 1 KiB of lora_up, s[92:93] the tile's 256 bytes of bias
 S_STGF, S_STGB, S_SLA, S_SLU, S_SB = 51, 54, 88, 90, 92
-STG_LU, STG_BIAS = 32768, 40960   # offsets inside the staging region (lora_act_in at 0)
+STG_LU, STG_BIAS = 32768, 43008   # offsets inside the staging region (lora_act_in at 0; rank > 32: the tile's lora_up for every rank at 0, gemm_w4a4.hip Geo)
 
 
 def vr(a, n=1):
