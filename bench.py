@@ -226,7 +226,7 @@ def main():
     ap.add_argument("--attention-geometry", type=int, default=0, choices=[0, 1, 2],
                     help="workgroup geometry of the attention kernel (svdq_attention_args.geometry): 0 = the library's choice (4 waves x 64 "
                          "rows on the prescaled Q the QKV GEMM emits), 1 = 8 waves x 32 rows, 2 = 4 x 64 with its persistent schedule (same-box A/B)")
-    ap.add_argument("--geometry", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+    ap.add_argument("--geometry", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
                     help="workgroup geometry of the W4A4 GEMM (svdq_gemm_args.geometry): 0 = the library's choice, 1 = 256x128 "
                          "tiles / one workgroup per CU, 2 = 128x128 tiles / two per CU out of phase, 3 = 2 without the phase offset")
     ap.add_argument("--deterministic", action="store_true",

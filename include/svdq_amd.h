@@ -187,8 +187,10 @@ typedef struct svdq_gemm_args {
      * stalls under the other's main loop) that DRAW their tiles from per-XCD queues in the workspace (falls back to 3 without
      * a workspace, for launches of at most one tile per workgroup, and where a stream-K split pays); 3 = 128 x 128 tiles,
      * fixed tile lists + stream-K tail; 4 / 5 = 2 / 3 with the second workgroup of a CU started half a tile late (A/B
-     * measurements).  Results are bit-identical across geometries for launches without a stream-K split (the split points,
-     * hence the fp32 summation order of a split tile, differ). */
+     * measurements); 6 = GELU_QUANT launches with a next-layer low-rank branch of rank <= 128 (fp32 accumulators) run 128 x 128 tiles with ONE
+     * workgroup per CU, whose LDS then holds the low-rank-down carry of a whole run of column tiles (what geometry 0 picks for next-layer ranks
+     * 48 .. 128 at two or more tiles per CU; 6 asks for it at any size -- tests), every other launch as with 0.  Results are bit-identical across
+     * geometries for launches without a stream-K split (the split points, hence the fp32 summation order of a split tile, differ). */
     int32_t geometry;
     /* Grouped launch (optional): rows [split_rows, M_pad) use a SECOND weight set of the same shape, rank and
      * epilogue -- one launch for the text and the image stream of a joint FLUX block (same layer type, different

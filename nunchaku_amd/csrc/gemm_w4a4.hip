@@ -142,6 +142,7 @@ struct GemmParams {
                              // through registers in batches of 64 ranks (every load of a batch in flight at once); value = ceil(65536 / (R / 8 + 1)), the divider of the gather
     int rowrun;              // NW = 8, GELU_QUANT: run length of the row-run schedule (GemmSchedule::init_runs; 0 = the plain schedule): the next layer's
                              // low-rank down projection accumulates in LDS over a workgroup's run of column tiles, one flush of atomics per run
+    int solo_carry;          // host dispatch: GELU_QUANT with a next-layer low-rank branch of rank 48 .. 128 (fp32): 128 x 128 tiles, one workgroup per CU, the carry behind its ring
     int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
     float lora_scales[MAX_LORA_TILES];
     SVDQ_PROBE_PARAMS
@@ -166,13 +167,20 @@ template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q
                                staged in LDS, lora_act_in comes through registers in batches of 64 ranks (GemmParams::stage_lu_all).  A kernel of its own, so that the
                                rank-32 kernels of the step keep their instruction stream and register allocation to the bit */>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams p) {
-    static_assert(!CARRY || (NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ), "the low-rank-down carry lives in the 256 x 128 geometry's staging region");
+    static_assert(!CARRY || (FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ), "the low-rank-down carry: GELU_QUANT with fp32 low-rank accumulators");
     static_assert(!RALL || (NW == 8 && !LAQ && !CARRY), "the all-rank lora_up image lives in the 256 x 128 geometry's staging region");
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     using G_ = Geo<NW>;
     constexpr int BM = G_::BM, NSTAGE = G_::NSTAGE, A_BYTES = G_::A_BYTES, STAGE_BYTES = G_::STAGE_BYTES;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[G_::LDS_BYTES];
+    // CARRY on 128 x 128 tiles (round 5): next-layer ranks 48 .. 128.  ONE 4-wave workgroup per CU (one wave per SIMD: 90 % of the loop throughput of two
+    // co-resident workgroups, profiles/r4_gemm_one_wave_per_simd.txt) has the CU's whole LDS: the ring of this geometry (78 KiB) + a carry of
+    // [128 rows][128 ranks] fp32 = 64 KiB behind it -- four 32-rank slabs in the layout of the 256 x 128 kernel's one.  The 256-row tile's carry for rank 128
+    // (128 KiB) fits nowhere, and per-tile fp32 atomics of 128 ranks cost as much as the whole rank-32 launch (profiles/r5_rank_ab.txt: 615 vs 318 us).
+    constexpr int CARRY_SLABS = !CARRY ? 0 : NW == 8 ? 1 : 4;
+    constexpr int CARRY_OFF = NW == 8 ? G_::STG_OFF : G_::LDS_BYTES;
+    constexpr int LDS_TOTAL = G_::LDS_BYTES + (CARRY && NW == 4 ? CARRY_SLABS * BM * 32 * 4 : 0);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TOTAL];
 
     const int tid = threadIdx.x;
     SVDQ_PROBE_BEGIN();
@@ -332,13 +340,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
     // stages lora_up and bias only (stg_flags bit 2) and the epilogue loads its lora_act_in rows from memory.  The column waves of a tile add
     // their partial sums here; the carry goes to lora_act_out when the workgroup leaves the row block: with the row-run schedule once per run.
     typedef __attribute__((address_space(3))) float lds_float;
-    lds_float *carry = (lds_float *)((lds_void *)lds) + G_::STG_OFF / 4;
+    lds_float *carry = (lds_float *)((lds_void *)lds) + CARRY_OFF / 4; // [slab][row / 4][32 ranks][row % 4]
     bool carry_dirty = false; // block-uniform
     if constexpr (CARRY) {
         typedef __attribute__((address_space(3))) v4f lds_v4f;
         const v4f z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < BM * 32 / 4 / (64 * NW); i++) ((lds_v4f *)carry)[i * 64 * NW + tid] = z4;
+        for (int i = 0; i < CARRY_SLABS * BM * 32 / 4 / (64 * NW); i++) ((lds_v4f *)carry)[i * 64 * NW + tid] = z4;
         __syncthreads();
     }
 
@@ -980,7 +988,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             // atomic instruction hits two 128-byte lines instead of 64 different ones.
             if (p.R2 > 0 && !SVDQ_PROBE_OFF(4)) {
                 const T *ld = (const T *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
-                for (int t2 = 0; t2 < (CARRY ? 32 : p.R2); t2 += 32) { // (CARRY: rank <= 32, one pass)
+                for (int t2 = 0; t2 < (CARRY && NW == 8 ? 32 : p.R2); t2 += 32) { // (CARRY on 256 x 128 tiles: rank <= 32, one pass)
                     v16f d[2];
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) d[mi] = zero16;
@@ -1001,7 +1009,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                                 for (int j = 0; j < 8; j++) wv[ni][q][j] = (T)0.f;
                             }
                         }
-                    if constexpr (!CARRY) {
+                    if constexpr (!CARRY || NW == 4) {
                         if (t2 + 32 < p.R2 && t2 + 32 + lr < p.R2) {
 #pragma unroll
                             for (int ni = 0; ni < 2; ni++)
@@ -1050,7 +1058,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                             // measured 21 k cycles per tile for these 32 instructions per wave, profiles/r4_gemm_rowrun.txt).  The two column waves
                             // of a row block add to the same words: wave column 0 first, a barrier, then wave column 1.
                             typedef __attribute__((address_space(3))) v4f lds_v4f;
-                            lds_v4f *c4 = (lds_v4f *)carry + ((unsigned)(wm * 16) + h_e) * 32u + lr_e; // + (mi * 8 + 2 g) * 32
+                            lds_v4f *c4 = (lds_v4f *)carry + (unsigned)(t2 >> 5) * (BM * 8u) + ((unsigned)(wm * 16) + h_e) * 32u + lr_e; // + (mi * 8 + 2 g) * 32
                             carry_dirty = true;
 #pragma unroll
                             for (int turn = 0; turn < 2; turn++) {
@@ -1164,17 +1172,19 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             // float4 t + 512 j of the carry = rank t & 31 of the four rows 4 ((t >> 5) + 16 j) + 0..3
             typedef __attribute__((address_space(3))) v4f lds_v4f;
             const unsigned rank = tid_e & 31u, rg0 = tid_e >> 5;
-            float *dst = (float *)p.lora_act_out + ((size_t)m0 + 4 * rg0) * p.R2 + rank;
-            lds_v4f *src = (lds_v4f *)carry + tid_e;
-            const bool live = (int)rank < p.R2;
             const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < CARRY_SLABS && 32 * sl < p.R2; sl++) { // (256 x 128 tiles: one slab)
+                float *dst = (float *)p.lora_act_out + ((size_t)m0 + 4 * rg0) * p.R2 + 32 * sl + rank;
+                lds_v4f *src = (lds_v4f *)carry + sl * (BM * 8) + tid_e;
+                const bool live = 32 * sl + (int)rank < p.R2;
 #pragma unroll
-            for (int j = 0; j < BM * 32 / 4 / (64 * NW); j++) {
-                const v4f v = src[j * (64 * NW)];
-                src[j * (64 * NW)] = z4;
-                if (live) {
+                for (int j = 0; j < BM * 32 / 4 / (64 * NW); j++) {
+                    const v4f v = src[j * (64 * NW)];
+                    src[j * (64 * NW)] = z4;
+                    if (live) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) unsafeAtomicAdd(dst + (size_t)(j * (64 * NW / 32) * 4 + e) * p.R2, v[e]);
+                        for (int e = 0; e < 4; e++) unsafeAtomicAdd(dst + (size_t)(j * (64 * NW / 32) * 4 + e) * p.R2, v[e]);
+                    }
                 }
             }
         }
@@ -1244,6 +1254,9 @@ static int persistent_grid(int tiles, int sk_gs, int slots) {
 static int pick_geometry(const svdq_gemm_args *a, bool with_ws) {
     if (a->geometry != 0) return a->geometry;
     if (!with_ws) return 1;
+    // (beyond rank 32 the two geometries cost the same again: measured on one box, profiles/r5_rank_ab.txt -- QKV 4608 x 9216 x 3072 at rank 128: 213.8 us with
+    //  the all-rank kernel on 256 x 128 tiles, 196.8 us on the 128 x 128 queue with a memory round trip per 32 ranks; rank 48: 181.0 vs 162.1 -- the same
+    //  ~17 us the queue's balance is worth at rank 32: the low-rank activations' row-per-lane loads cost either geometry the same line requests)
     const int cus = device_cus();
     const int tiles1 = (a->M_pad / 256) * (a->N / BN), tiles2 = 2 * tiles1;
     if (tiles1 <= cus || streamk_groups_for(tiles1, a->K / 128, cus) > 0) return 1;
@@ -1271,6 +1284,18 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
     p.rowrun = 0;
     // the low-rank-down carry (and, from two tiles per workgroup, the row-run schedule that makes it pay): GELU_QUANT on 256 x 128 tiles with an fp32
     // next-layer low-rank branch of rank <= 32
+    // ... next-layer ranks 48 .. 128: the carry lives behind the ring of ONE 128 x 128 workgroup per CU (svdq_gemm_w4a4 picks that geometry: solo_carry)
+    if constexpr (NW == 4 && FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ) {
+        if (p.solo_carry) {
+            const int TM = p.M_pad / G_::BM, TN = p.N / BN, cus = device_cus();
+            p.sk_gs = 0; p.dynamic = 0; p.stagger = 0;
+            p.rowrun = GemmSchedule::run_length(TM, TN, cus);
+            const int g4 = (TM * ((TN + p.rowrun - 1) / p.rowrun) + 7) / 8 * 8;
+            dim3 grid(SVDQ_PROBE_GRID(g4, tiles, cus)), block(G_::THREADS);
+            hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true>), grid, block, 0, st, p);
+            return;
+        }
+    }
     constexpr bool CAN_CARRY = NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ;
     if constexpr (CAN_CARRY) {
         if (p.R2 > 0 && p.R2 <= 32) {
@@ -1416,7 +1441,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         set_error("svdq_gemm_w4a4: variant and reserved must be 0 (timing experiments live in tools/ablate, not in this library)");
         return SVDQ_E_INVALID;
     }
-    if (a->geometry < 0 || a->geometry > 5) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto) .. 5"); return SVDQ_E_INVALID; }
+    if (a->geometry < 0 || a->geometry > 6) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto) .. 6"); return SVDQ_E_INVALID; }
     if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_gemm_w4a4: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
@@ -1518,7 +1543,15 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     SVDQ_PROBE_FILL(p);
 
     const bool with_ws = p.workspace && p.workspace_bytes >= workspace_bytes_needed();
-    const int geo = pick_geometry(a, with_ws);
+    int geo = pick_geometry(a, with_ws);
+    // GELU_QUANT with a next-layer low-rank branch beyond rank 32 (fp32 accumulators) and at least two 128 x 128 tiles per CU: the solo-carry kernel
+    // (geometry 6 asks for it at any size and any next-layer rank <= 128: tests; launches it cannot serve run as with geometry 0)
+    const bool solo_ok = a->fuse == SVDQ_FUSE_GELU_QUANT && a->R2 > 0 && a->R2 <= 128 && a->lora_act_format == SVDQ_LORA_ACT_F32;
+    // (measured, profiles/r5_rank_ab.txt: next rank 128: 559 us against 615 us with per-tile atomics on 256 x 128 tiles; next rank 48: 310 against 285 -- one wave
+    //  per SIMD runs the VALU-bound GELU epilogue at half the issue rate, which only pays once the atomics of >= 96 ranks are what it replaces)
+    p.solo_carry = solo_ok && (a->geometry == 6 || (a->geometry == 0 && a->R2 >= 96 && (long long)(a->M_pad / 128) * (a->N / BN) >= 2LL * device_cus()));
+    if (p.solo_carry) geo = 3;
+    else if (geo == 6) { svdq_gemm_args b = *a; b.geometry = 0; geo = pick_geometry(&b, with_ws); }
     p.dynamic = geo == 2 || geo == 4;
     p.stagger = geo == 4 || geo == 5;
     hipStream_t st = (hipStream_t)stream;

@@ -289,7 +289,9 @@ struct QuantParams {
 };
 
 constexpr int QV2_PARAM_BYTES = 4 * 128 * 4;     // per wave: smooth, 1/smooth, mod_scale, mod_shift as fp32
-constexpr int QV2_WAVE_BYTES = QV2_PARAM_BYTES + 32 * 256; // + lora_down slice [32 ranks][128 channels] 16-bit
+constexpr int QV2_SLAB_BYTES = 32 * 256;         // lora_down slice [32 ranks][128 channels] 16-bit
+constexpr int QV2_WAVE_BYTES = QV2_PARAM_BYTES + QV2_SLAB_BYTES;
+constexpr int QV2_WAVE_BYTES_MULTI = QV2_PARAM_BYTES + 2 * QV2_SLAB_BYTES; // MULTI: two slice buffers (the next 32-rank slab lands under the current one's MFMAs)
 
 template <int DT> struct Pair16;
 template <> struct Pair16<SVDQ_BF16> {
@@ -366,7 +368,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     using P16 = Pair16<DT>;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * QV2_WAVE_BYTES];
+    constexpr int WAVE_BYTES = MULTI ? QV2_WAVE_BYTES_MULTI : QV2_WAVE_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * WAVE_BYTES];
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     typedef __attribute__((address_space(3))) v4f lds_v4f;
     typedef __attribute__((address_space(3))) v2f lds_v2f;
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
     const int slices = (KP + 3) / 4;
     const int rt = blockIdx.x / slices, kp = (blockIdx.x % slices) * 4 + wave;
     const bool active = kp < KP; // wave-uniform
-    lds_u8 *const W = (lds_u8 *)lds + wave * QV2_WAVE_BYTES; // this wave's private region: no workgroup barrier before the final sum
+    lds_u8 *const W = (lds_u8 *)lds + wave * WAVE_BYTES; // this wave's private region: no workgroup barrier before the final sum
 
     // grouped launch: this row tile's stream (block-uniform); outputs stay addressed by the joint row tile index rt
     const bool second = p.s2.x != nullptr && rt * 32 >= p.s2.split_rows;
@@ -498,7 +501,17 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
                     const V8 a = __builtin_bit_cast(V8, v4i{(int)ae[0], (int)ao[0], (int)ae[1], (int)ao[1]});
                     if constexpr (MULTI) aop[grp][q] = v4i{(int)ae[0], (int)ao[0], (int)ae[1], (int)ao[1]};
                     const int piece = grp * 8 + 2 * q; // 16-byte pieces of rank r's row: this lane's half (8 h) of pieces `piece`, `piece + 1`
-                    if (grp == 0 && q == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the LDS-DMA of the slice has landed
+                    if (grp == 0 && q == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the LDS-DMA of the slice has landed
+                        if constexpr (MULTI) { // ranks 32 .. 63 -> the second slice buffer, under the whole quantisation pass
+                            const __amdgpu_buffer_rsrc_t rl1 = __builtin_amdgcn_make_buffer_rsrc((void *)lora_down, 0, (int)((size_t)p.R * K * 2), 0x00020000);
+                            typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+                            for (int i = 0; i < 8; i++)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rl1, (lds_void *)(W + QV2_PARAM_BYTES + QV2_SLAB_BYTES + i * 1024), 16, ldo_keep[i & 3],
+                                                                         ((i >> 2) * 16 + 32) * K * 2, 0, 0);
+                        }
+                    }
                     const u32x2 b0 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + ((piece ^ (r & 15)) << 4) + 8 * h);
                     const u32x2 b1 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + (((piece + 1) ^ (r & 15)) << 4) + 8 * h);
                     const V8 b = __builtin_bit_cast(V8, v4i{(int)b0[0], (int)b0[1], (int)b1[0], (int)b1[1]});
@@ -529,13 +542,13 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
 
     if constexpr (LORA) {
         // combine the four waves' partial sums in a fixed order (each wave parks its tile in its own region)
-        auto combine = [&](int rank0) {
-            *(lds_v16f *)(W + QV2_PARAM_BYTES + lane * 64) = accL;
+        auto combine = [&](int rank0, int buf) { // (the tile is parked in the slice buffer whose slab it came from: this wave has finished reading it)
+            *(lds_v16f *)(W + QV2_PARAM_BYTES + buf * QV2_SLAB_BYTES + lane * 64) = accL;
             __syncthreads();
             if (wave == 0) {
-                const lds_u8 *B = (const lds_u8 *)lds + QV2_PARAM_BYTES + lane * 64;
-                const v16f s = ((*(const lds_v16f *)(B) + *(const lds_v16f *)(B + QV2_WAVE_BYTES)) + *(const lds_v16f *)(B + 2 * QV2_WAVE_BYTES)) +
-                               *(const lds_v16f *)(B + 3 * QV2_WAVE_BYTES);
+                const lds_u8 *B = (const lds_u8 *)lds + QV2_PARAM_BYTES + buf * QV2_SLAB_BYTES + lane * 64;
+                const v16f s = ((*(const lds_v16f *)(B) + *(const lds_v16f *)(B + WAVE_BYTES)) + *(const lds_v16f *)(B + 2 * WAVE_BYTES)) +
+                               *(const lds_v16f *)(B + 3 * WAVE_BYTES);
                 if (rank0 + r < p.R) { // C layout: col (rank) = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
@@ -545,32 +558,40 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
                 }
             }
         };
-        combine(0);
+        combine(0, 0);
         if constexpr (MULTI) {
-            // the slabs beyond rank 32: same slice layout, same MFMA operand order, same combination -- one slab at a time through the wave's region
+            // the slabs beyond rank 32: same slice layout, same MFMA operand order, same combination.  Slab s sits in buffer s & 1 (slab 1 was requested under the
+            // quantisation pass); at the top of its turn the slab after it is requested into the other buffer -- free once wave 0 has read the tiles parked there
             const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)lora_down, 0, (int)((size_t)p.R * K * 2), 0x00020000);
             typedef __attribute__((address_space(3))) void lds_void;
             for (int rank0 = 32; rank0 < p.R; rank0 += 32) {
-                __syncthreads(); // wave 0 has read every wave's parked tile: the regions are free for the next slice
+                const int buf = (rank0 >> 5) & 1;
+                __syncthreads(); // wave 0 has read every wave's parked tile of the slab before
 #pragma unroll
                 for (int j = 0; j < 16; j++) accL[j] = 0.f;
                 if (active) {
+                    if (rank0 + 32 < p.R) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) // (ranks >= R lie beyond the descriptor's range and read as zero)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void *)(W + QV2_PARAM_BYTES + i * 1024), 16, ldo_keep[i & 3], ((i >> 2) * 16 + rank0) * K * 2, 0, 0);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        for (int i = 0; i < 8; i++) // (ranks >= R lie beyond the descriptor's range and read as zero)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void *)(W + QV2_PARAM_BYTES + (buf ^ 1) * QV2_SLAB_BYTES + i * 1024), 16, ldo_keep[i & 3],
+                                                                     ((i >> 2) * 16 + rank0 + 32) * K * 2, 0, 0);
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // this slab has landed (in-order retirement); the next one may still fly
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
 #pragma unroll
                     for (int grp = 0; grp < 2; grp++)
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             const int piece = grp * 8 + 2 * q;
-                            const u32x2 b0 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + ((piece ^ (r & 15)) << 4) + 8 * h);
-                            const u32x2 b1 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + (((piece + 1) ^ (r & 15)) << 4) + 8 * h);
+                            const lds_u8 *S = W + QV2_PARAM_BYTES + buf * QV2_SLAB_BYTES;
+                            const u32x2 b0 = *(const lds_u2 *)(S + r * 256 + ((piece ^ (r & 15)) << 4) + 8 * h);
+                            const u32x2 b1 = *(const lds_u2 *)(S + r * 256 + (((piece + 1) ^ (r & 15)) << 4) + 8 * h);
                             const V8 b = __builtin_bit_cast(V8, v4i{(int)b0[0], (int)b0[1], (int)b1[0], (int)b1[1]});
                             accL = Half<DT>::mfma32(__builtin_bit_cast(V8, aop[grp][q]), b, accL);
                         }
                 }
-                combine(rank0);
+                combine(rank0, buf);
             }
         }
     }

@@ -239,12 +239,25 @@ def test_qkv_rmsnorm_rope(dtype, M, K, H):
     assert_close_16(got[:, : 2 * N // 3], ref[:, : 2 * N // 3], dtype, "QK", max_bad_frac=2e-3, ulps=2.0)
 
 
+@pytest.mark.parametrize("geometry", [0, 6], ids=["auto", "solo-carry"])
 @pytest.mark.parametrize("r1", [32, 128], ids=["rank-32", "rank-128"])
 @pytest.mark.parametrize("r2", [16, 32, 48, 128], ids=["next-rank-16", "next-rank-32", "next-rank-48", "next-rank-128"])
-def test_gelu_quant_next_low_rank_down_by_rank(r2, r1):
+def test_gelu_quant_next_low_rank_down_by_rank(r2, r1, geometry):
     """The GELU_QUANT epilogue's low-rank down projection for the NEXT layer at ranks on both sides of the carry kernel's limit (round 4: rank <= 32
     accumulates in the workgroup's LDS carry -- rank 16 with half the lanes idle --, rank 48 keeps the per-tile atomics over two passes of 32 ranks):
     codes, scales and lora_act_out against the oracle, several column tiles per row block so that the carry really sums."""
+    from nunchaku_amd import layout
+    from nunchaku_amd._C import _Ops
+    from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
+
+    _Ops.gemm_geometry = geometry  # 6: the 128 x 128 one-workgroup-per-CU kernel with the carry behind its ring (what rank 48 .. 128 takes at full size)
+    try:
+        _gelu_quant_next_low_rank_down(r2, r1)
+    finally:
+        _Ops.gemm_geometry = 0
+
+
+def _gelu_quant_next_low_rank_down(r2, r1):
     from nunchaku_amd import layout
     from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
 

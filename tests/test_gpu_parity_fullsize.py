@@ -36,9 +36,10 @@ def _need_gpu(built_lib):
     _lib.load()
 
 
-@pytest.fixture(params=[1, 2], ids=["tile256x128", "tile128x128-queued"], autouse=True)
+@pytest.fixture(params=[1, 2, 0], ids=["tile256x128", "tile128x128-queued", "auto"], autouse=True)
 def _geometry(request):
-    """Every test of this module runs under both workgroup geometries of the GEMM (svdq_gemm_args.geometry)."""
+    """Every test of this module runs under both workgroup geometries of the GEMM (svdq_gemm_args.geometry) and under the library's own choice
+    (0: what the step runs -- beyond next-layer rank 32 the GELU_QUANT launch then takes the solo-carry kernel)."""
     from nunchaku_amd._C import _Ops
 
     _Ops.gemm_geometry = request.param
