@@ -986,6 +986,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             // k-slots 8h + j: no data movement; the weight operand is gathered in the matching order.  With
             // the activations as the A operand the result tile has the RANK along the lanes, so every fp32
             // atomic instruction hits two 128-byte lines instead of 64 different ones.
+            // (round 5, tried and removed: summing the two column waves of a row block BEFORE the atomics -- one wave hands its GELU fragments to the other through
+            //  the dead staging region, which contracts all 128 columns and issues half the atomics.  Same-box: rank-128 fc1 434.8 vs 455.3 us, rank 32 + 16
+            //  312.5 vs 285.4 us, deterministic mode 319 vs 289 us.  What these atomics cost is not their number per CU but their number per WAVE: the next
+            //  loop's first vmcnt wait retires in order behind them (profiles/r4_gemm_rowrun.txt), and the reducing wave still issued 32 per pass.)
             if (p.R2 > 0 && !SVDQ_PROBE_OFF(4)) {
                 const T *ld = (const T *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
                 for (int t2 = 0; t2 < (CARRY && NW == 8 ? 32 : p.R2); t2 += 32) { // (CARRY on 256 x 128 tiles: rank <= 32, one pass)
