@@ -989,7 +989,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             // (round 5, tried and removed: summing the two column waves of a row block BEFORE the atomics -- one wave hands its GELU fragments to the other through
             //  the dead staging region, which contracts all 128 columns and issues half the atomics.  Same-box: rank-128 fc1 434.8 vs 455.3 us, rank 32 + 16
             //  312.5 vs 285.4 us, deterministic mode 319 vs 289 us.  What these atomics cost is not their number per CU but their number per WAVE: the next
-            //  loop's first vmcnt wait retires in order behind them (profiles/r4_gemm_rowrun.txt), and the reducing wave still issued 32 per pass.)
+            //  loop's first vmcnt wait retires in order behind them (profiles/r4_gemm_rowrun.txt), and the reducing wave still issued 32 per pass.
+            //  Also tried: the atomics AHEAD of the requantisation, to retire under its ~8 k cycles of arithmetic: rank-128 fc1 486 vs 455 us, rank 32 + 16 348 vs
+            //  ~297 us on that box (d, the weights and the requantiser's reciprocals live together: ~120 spill instructions per tile).)
             if (p.R2 > 0 && !SVDQ_PROBE_OFF(4)) {
                 const T *ld = (const T *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
                 for (int t2 = 0; t2 < (CARRY && NW == 8 ? 32 : p.R2); t2 += 32) { // (CARRY on 256 x 128 tiles: rank <= 32, one pass)
