@@ -165,10 +165,14 @@ template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q
           bool CARRY = false /* GELU_QUANT, NW = 8, fp32 lora_act_out of rank <= 32: the next layer's low-rank down projection accumulates in LDS */,
           bool RALL = false /* NW = 8, fp32 lora_act_in of rank 48 .. 160 (the r128 checkpoints, a runtime LoRA on top of rank 32): the tile's lora_up for EVERY rank is
                                staged in LDS, lora_act_in comes through registers in batches of 64 ranks (GemmParams::stage_lu_all).  A kernel of its own, so that the
-                               rank-32 kernels of the step keep their instruction stream and register allocation to the bit */>
+                               rank-32 kernels of the step keep their instruction stream and register allocation to the bit */,
+          bool HYB = false /* CARRY on 256 x 128 tiles with a next-layer rank beyond 32 (a runtime LoRA on fc2; rank 48 .. 80 checkpoints): the first 32 ranks go through
+                              the carry, the passes behind them keep their per-tile atomics -- half (rank 48 / 64) or a quarter less of what the next loop's first
+                              wait retires behind.  (The carry of more ranks does not fit: 256 rows x 48 ranks x 4 bytes > the 42 KiB staging region.) */>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams p) {
     static_assert(!CARRY || (FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ), "the low-rank-down carry: GELU_QUANT with fp32 low-rank accumulators");
     static_assert(!RALL || (NW == 8 && !LAQ && !CARRY), "the all-rank lora_up image lives in the 256 x 128 geometry's staging region");
+    static_assert(!HYB || (CARRY && NW == 8), "HYB: a carry kernel on 256 x 128 tiles");
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
     using G_ = Geo<NW>;
@@ -994,7 +998,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             //  ~297 us on that box (d, the weights and the requantiser's reciprocals live together: ~120 spill instructions per tile).)
             if (p.R2 > 0 && !SVDQ_PROBE_OFF(4)) {
                 const T *ld = (const T *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
-                for (int t2 = 0; t2 < (CARRY && NW == 8 ? 32 : p.R2); t2 += 32) { // (CARRY on 256 x 128 tiles: rank <= 32, one pass)
+                for (int t2 = 0; t2 < (CARRY && NW == 8 && !HYB ? 32 : p.R2); t2 += 32) { // (CARRY on 256 x 128 tiles: rank <= 32, one pass; HYB: the carry takes pass 0)
+                    const bool to_carry = CARRY && (!HYB || t2 == 0); // block-uniform
                     v16f d[2];
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++) d[mi] = zero16;
@@ -1015,7 +1020,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                                 for (int j = 0; j < 8; j++) wv[ni][q][j] = (T)0.f;
                             }
                         }
-                    if constexpr (!CARRY || NW == 4) {
+                    if constexpr (!CARRY || NW == 4 || HYB) {
                         if (t2 + 32 < p.R2 && t2 + 32 + lr < p.R2) {
 #pragma unroll
                             for (int ni = 0; ni < 2; ni++)
@@ -1043,7 +1048,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                         const size_t at = (size_t)(mw0 + mi * 32 + h * 4) * p.R2 + t2 + lr;
                         if (SVDQ_PROBE_OFF(1)) {
                             asm volatile("" :: "v"(d[mi]));
-                        } else if constexpr (CARRY) {
+                        } else if (to_carry) {
                             // into the workgroup's carry: below, both row tiles at once (the two column waves of a row block take turns)
                         } else if (live && LAQ) {
                             // deterministic mode: Q31.32 fixed point, 64-bit INTEGER atomics -- the sum does not depend on the order
@@ -1058,7 +1063,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                         }
                     }
                     if constexpr (CARRY) {
-                        if (!SVDQ_PROBE_OFF(1)) {
+                        if (to_carry && !SVDQ_PROBE_OFF(1)) {
                             // carry layout [row / 4][rank][row % 4] fp32: a lane's registers 4 g .. 4 g + 3 (rows 8 g + 4 h + 0..3 of its row tile, rank lr)
                             // are 16 contiguous bytes -- plain 16-byte reads and writes, no LDS atomics (ds_add_f32 runs at ~1 lane per clock:
                             // measured 21 k cycles per tile for these 32 instructions per wave, profiles/r4_gemm_rowrun.txt).  The two column waves
@@ -1179,7 +1184,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             typedef __attribute__((address_space(3))) v4f lds_v4f;
             const unsigned rank = tid_e & 31u, rg0 = tid_e >> 5;
             const v4f z4 = {0.f, 0.f, 0.f, 0.f};
-            for (int sl = 0; sl < CARRY_SLABS && 32 * sl < p.R2; sl++) { // (256 x 128 tiles: one slab)
+            for (int sl = 0; sl < CARRY_SLABS && 32 * sl < p.R2; sl++) { // (256 x 128 tiles: one slab -- with HYB the first 32 of the next layer's ranks)
                 float *dst = (float *)p.lora_act_out + ((size_t)m0 + 4 * rg0) * p.R2 + 32 * sl + rank;
                 lds_v4f *src = (lds_v4f *)carry + sl * (BM * 8) + tid_e;
                 const bool live = 32 * sl + (int)rank < p.R2;
@@ -1274,7 +1279,7 @@ static int pick_geometry(const svdq_gemm_args *a, bool with_ws) {
 // Row runs (GELU_QUANT on 256 x 128 tiles with a next-layer low-rank branch of rank <= 32 and no K split): worth it from two tiles per
 // workgroup (profiles/r4_gemm_rowrun.txt: the per-tile atomics of the low-rank down projection cost 12 % of the fc1 launch)
 static bool rowrun_applies(int M_pad, int N, int R2, int sk_gs, int slots) {
-    return R2 > 0 && R2 <= 32 && sk_gs == 0 && (M_pad / 256) * (N / BN) >= 2 * slots;
+    return R2 > 0 && sk_gs == 0 && (M_pad / 256) * (N / BN) >= 2 * slots; // (callers: R2 <= 32, or the hybrid carry kernel beyond)
 }
 
 template <int DT, int FUSE, int NW, bool LAQ>
@@ -1304,6 +1309,14 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
     }
     constexpr bool CAN_CARRY = NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ;
     if constexpr (CAN_CARRY) {
+        if (p.R2 > 32 && rowrun_applies(p.M_pad, p.N, p.R2, p.sk_gs, slots)) { // beyond rank 32 (and not the solo-carry kernel's case): the hybrid carry
+            const int TM = p.M_pad / G_::BM, TN = p.N / BN;
+            p.rowrun = GemmSchedule::run_length(TM, TN, slots);
+            g = (TM * ((TN + p.rowrun - 1) / p.rowrun) + 7) / 8 * 8;
+            dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
+            hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true, false, true>), grid, block, 0, st, p);
+            return;
+        }
         if (p.R2 > 0 && p.R2 <= 32) {
             if (rowrun_applies(p.M_pad, p.N, p.R2, p.sk_gs, slots)) {
                 const int TM = p.M_pad / G_::BM, TN = p.N / BN;

@@ -1,4 +1,4 @@
-O=gpurun_out/t5; mkdir -p $O
+O=gpurun_out/t6; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_fullsize.py tests/test_gpu_geometry_determinism.py -m gpu -q -x -k "gelu or other_ranks or determin or mlp" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
 run() { name=$1; shift; timeout 400 python bench.py --no-cpu-baseline "$@" > $O/bench_$name.json 2> $O/bench_$name.err; python3 - $O/bench_$name.json <<'PY'
 import json,sys
@@ -9,7 +9,7 @@ except Exception as e: print(sys.argv[1], 'FAILED', e)
 PY
 }
 run dev1024_r32 --steps 20 --warmup 3
-run dev1024_r32_det --steps 20 --warmup 3 --deterministic
 run dev1024_r32_lora16 --steps 20 --warmup 3 --lora 16
 run dev1024_r128_auto --steps 20 --warmup 3 --rank 128
 run dev1024_r128_geo1 --steps 20 --warmup 3 --rank 128 --geometry 1
+run dev1024_r64 --steps 20 --warmup 3 --rank 64

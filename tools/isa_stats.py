@@ -61,12 +61,14 @@ def classify(op):
 def gemm_stats(funcs):
     out = {}
     for name, ins in funcs.items():
-        m = re.search(r"gemm_w4a4_kernelILi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+        m = re.search(r"gemm_w4a4_kernelILi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
         if not m:
             continue
-        dt, fuse, nw, laq, carry, rall = (int(x) for x in m.groups())
+        dt, fuse, nw, laq, carry, rall, hyb = (int(x) for x in m.groups())
         if rall:  # the rank 48 .. 160 kernels (all-rank lora_up image): keyed with carry = 2
             carry = 2
+        if hyb:   # the hybrid carry kernels (next-layer rank > 32: carry for the first 32 ranks, atomics behind): carry = 3
+            carry = 3
         ops = [ln.split()[0] for ln in ins]
         loop = [i for i, o in enumerate(ops) if o.startswith("v_mfma_scale")]
         post = ops[loop[-1] + 1:]
@@ -88,7 +90,7 @@ def main():
     st = gemm_stats(disassemble(lib))
     for (dt, fuse, nw, laq, carry), r in sorted(st.items()):
         p = r["post_loop"]
-        print(f"{'bf16' if dt == 0 else 'fp16'} {FUSE_NAMES[fuse]:13s} NW={nw} LAQ={laq} CARRY={carry}{' (RALL)' if carry == 2 else ''}: behind the loop VALU {p.get('valu', 0):5d} MFMA {p.get('mfma', 0):3d} "
+        print(f"{'bf16' if dt == 0 else 'fp16'} {FUSE_NAMES[fuse]:13s} NW={nw} LAQ={laq} CARRY={carry}{' (RALL)' if carry == 2 else ' (HYB)' if carry == 3 else ''}: behind the loop VALU {p.get('valu', 0):5d} MFMA {p.get('mfma', 0):3d} "
               f"SALU {p.get('salu', 0):5d} LDS {p.get('lds', 0):4d} VMEM {p.get('vmem', 0):4d} | scratch {r['scratch']} ds_add_f32 {r['lds_atomics']} "
               f"ds_cmpst {r['lds_cas']} global_atomic {r['global_atomics']}")
     if "-v" in sys.argv:
