@@ -558,18 +558,24 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
                 }
             }
         };
-        combine(0, 0);
-        if constexpr (MULTI) {
-            // the slabs beyond rank 32: same slice layout, same MFMA operand order, same combination.  Slab s sits in buffer s & 1 (slab 1 was requested under the
-            // quantisation pass); at the top of its turn the slab after it is requested into the other buffer -- free once wave 0 has read the tiles parked there
+        if constexpr (!MULTI) {
+            combine(0, 0);
+        } else {
+            // the slabs beyond rank 32 (up to rank 160: four more): same slice layout, same MFMA operand order.  Slab s sits in the wave's slice buffer s & 1
+            // (slab 1 was requested under the quantisation pass); at the top of its turn the slab after it is requested into the other buffer (this wave
+            // has finished reading it: the buffers are private to the wave, no workgroup barrier in this loop).  Every slab keeps its own accumulator
+            // tile; the four waves' tiles are combined once at the end, one slab per wave.
             const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)lora_down, 0, (int)((size_t)p.R * K * 2), 0x00020000);
             typedef __attribute__((address_space(3))) void lds_void;
-            for (int rank0 = 32; rank0 < p.R; rank0 += 32) {
-                const int buf = (rank0 >> 5) & 1;
-                __syncthreads(); // wave 0 has read every wave's parked tile of the slab before
+            v16f accS[4];
 #pragma unroll
-                for (int j = 0; j < 16; j++) accL[j] = 0.f;
-                if (active) {
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) accS[s][j] = 0.f;
+#pragma unroll
+            for (int s = 1; s <= 4; s++) {
+                const int rank0 = 32 * s, buf = s & 1;
+                if (rank0 < p.R && active) { // wave-uniform
                     if (rank0 + 32 < p.R) {
 #pragma unroll
                         for (int i = 0; i < 8; i++) // (ranks >= R lie beyond the descriptor's range and read as zero)
@@ -588,10 +594,35 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
                             const u32x2 b0 = *(const lds_u2 *)(S + r * 256 + ((piece ^ (r & 15)) << 4) + 8 * h);
                             const u32x2 b1 = *(const lds_u2 *)(S + r * 256 + (((piece + 1) ^ (r & 15)) << 4) + 8 * h);
                             const V8 b = __builtin_bit_cast(V8, v4i{(int)b0[0], (int)b0[1], (int)b1[0], (int)b1[1]});
-                            accL = Half<DT>::mfma32(__builtin_bit_cast(V8, aop[grp][q]), b, accL);
+                            accS[s - 1] = Half<DT>::mfma32(__builtin_bit_cast(V8, aop[grp][q]), b, accS[s - 1]);
                         }
                 }
-                combine(rank0, buf);
+            }
+            // combine: every wave parks its tiles of slabs 0 .. 3 in its own region (4 x 4 KiB: the parameter block and both slice buffers are dead), then wave w
+            // sums slab w over the four regions in the fixed order and adds it to lora_act -- the atomics of the slabs go out in parallel; slab 4 (rank > 128)
+            // takes a second, one-tile round
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            *(lds_v16f *)(W + 0 * 4096 + lane * 64) = accL;
+#pragma unroll
+            for (int s = 1; s < 4; s++) *(lds_v16f *)(W + s * 4096 + lane * 64) = accS[s - 1];
+            __syncthreads();
+            auto sum_slab = [&](int slot, int rank0) {
+                const lds_u8 *B = (const lds_u8 *)lds + slot * 4096 + lane * 64;
+                const v16f sm = ((*(const lds_v16f *)(B) + *(const lds_v16f *)(B + WAVE_BYTES)) + *(const lds_v16f *)(B + 2 * WAVE_BYTES)) + *(const lds_v16f *)(B + 3 * WAVE_BYTES);
+                if (rank0 + r < p.R) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int m = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        lora_act_add(p.lora_act, (size_t)m * p.R + rank0 + r, sm[i], p.use_atomics);
+                    }
+                }
+            };
+            if (32 * wave < p.R) sum_slab(wave, 32 * wave);
+            if (p.R > 128) { // block-uniform
+                __syncthreads();
+                *(lds_v16f *)(W + lane * 64) = accS[3];
+                __syncthreads();
+                if (wave == 0) sum_slab(0, 128);
             }
         }
     }
@@ -616,11 +647,11 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     dim3 grid(tiles * slices), block(256);
     const int rt32 = (a->R + 31) / 32;
     QuantSecond s2{a->x2, a->smooth2, a->lora_down2, a->mod_scale2, a->mod_shift2, a->ln_stats2, a->M2, a->ldx2, a->split_rows};
-    if (!a->fuse_glu && cpw == 4 && (long long)a->M_pad * (a->ldx > a->ldx2 ? a->ldx : a->ldx2) * 2 < 0x7fffffffLL && (long long)a->R * a->K * 2 < 0x7fffffffLL) {
+    if (!a->fuse_glu && a->R <= 160 && cpw == 4 && (long long)a->M_pad * (a->ldx > a->ldx2 ? a->ldx : a->ldx2) * 2 < 0x7fffffffLL && (long long)a->R * a->K * 2 < 0x7fffffffLL) {
         // fast path: one chunk per wave, 4 waves = 4 neighbouring chunks of one row tile (same grid as the general kernel at cpw = 4)
         QuantParams qp{a->x, a->smooth, a->lora_down, a->mod_scale, a->mod_shift, a->ln_stats, (uint8_t *)a->act, a->ascales, a->lora_act,
                        a->M, a->K, a->R, a->ldx, atomics, s2};
-        const int sel = (a->R > 32 ? 8 : 0) | (a->R > 0 ? 4 : 0) | (a->ln_stats ? 2 : 0) | (a->smooth ? 1 : 0);
+        const int sel = (a->R > 32 ? 8 : 0) | (a->R > 0 ? 4 : 0) | (a->ln_stats ? 2 : 0) | (a->smooth ? 1 : 0); // (rank > 160: the general kernel, above)
         switch (sel) {
 #define SVDQ_QV2(n, LORA, LN, SM, MULTI) case n: hipLaunchKernelGGL((quantize_kernel_v2<DT, LORA, LN, SM, MULTI>), grid, block, 0, st, qp); break;
             SVDQ_QV2(0, false, false, false, false) SVDQ_QV2(1, false, false, true, false) SVDQ_QV2(2, false, true, false, false) SVDQ_QV2(3, false, true, true, false)

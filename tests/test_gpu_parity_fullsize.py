@@ -127,12 +127,14 @@ class _Both:
         ops.gemm_workspace_status()  # no owner timed out
 
 
-def _same_up_to_add_order(a, b, dtype, what):
-    """two schedules of one GEMM differ by the fp32 summation order of the K slices only: <= 1 ulp, on a tiny fraction"""
+def _same_up_to_add_order(a, b, dtype, what, ulps=1.0):
+    """two schedules of one GEMM differ by the fp32 summation order of the K slices only: <= 1 ulp, on a tiny fraction (the RMSNorm + RoPE epilogue sits
+    behind a 16-bit rounding point: a flipped rounding there shows as up to 2 ulp in Q / K, the bound those outputs have against the oracle as well --
+    and under the library's own geometry choice the two runs may take different workgroup geometries)"""
     a, b = f32(a), f32(b)
     diff = a != b
     assert diff.mean() < 2e-3, f"{what}: {diff.mean():.2e} of the elements differ between the two schedules"
-    assert_close_16(a, b, dtype, what + " (ws vs nows)", ulps=1.0)
+    assert_close_16(a, b, dtype, what + " (ws vs nows)", ulps=ulps)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
@@ -230,7 +232,7 @@ def _block_projections(dtype, Ma, Mb, rank=R, lora=0):
         # V goes to out_vt (transposed), 1 ulp; the V columns of `out` stay untouched
         assert_close_16(f32(vt)[:, rows].T, ref[:, 2 * QKV // 3:], dtype, f"V^T {tag}")
         assert not out[:, 2 * QKV // 3:].any()
-    _same_up_to_add_order(got["ws"], got["nows"], dtype, "QKV")
+    _same_up_to_add_order(got["ws"], got["nows"], dtype, "QKV", ulps=2.0)
 
     # ---------------------------------------------------------------- attention output projection: default epilogue
     act, asc, lact, mods, lays = quantize(HID, HID, 20, xt)

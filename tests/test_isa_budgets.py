@@ -27,12 +27,20 @@ def stats(built_lib):
     return mod.gemm_stats(mod.disassemble(_lib.lib_path()))
 
 
-# (fuse, carry) of the kernels the FLUX / Qwen-Image step launches on 256 x 128 tiles, bf16 and fp16, fp32 low-rank accumulators
-BUDGET_VALU = {  # static VALU instructions behind the main loop (64 outputs per lane)
-    (0, 0): 900,    # default: bias + low-rank up on the matrix pipe, 16-bit conversion, 8 x 16-byte stores (+ stream-K publish / collect)
-    (2, 1): 2320,   # GELU -> requantise -> next low-rank down into the workgroup's carry
-    (3, 0): 2320,   # RMSNorm + RoPE (+ the V^T store path of the V third)
+# (fuse, carry) of the kernels the FLUX / Qwen-Image step launches on 256 x 128 tiles, bf16 and fp16, fp32 low-rank accumulators.  carry: 0 = none, 1 = the
+# low-rank-down carry (rank <= 32), 2 = the all-rank kernels (rank 48 .. 160: a tile's lora_up staged for every rank), 3 = the hybrid carry (next rank > 32)
+BUDGET_VALU = {  # static VALU instructions behind the main loop (64 outputs per lane); round 5: lowered to ~3 % above the committed build
+    (0, 0): 860,    # default: bias + low-rank up on the matrix pipe, 16-bit conversion, 8 x 16-byte stores (+ stream-K publish / collect)        [836]
+    (2, 1): 2180,   # GELU -> requantise -> next low-rank down into the workgroup's carry                                                          [2113]
+    (3, 0): 2230,   # RMSNorm + RoPE (+ the V^T store path of the V third)                                                                          [2165]
+    (0, 2): 830,    # default, rank 48 .. 160: the ring of low-rank activation batches + LDS reads of the staged lora_up                             [805]
+    (2, 2): 2340,   # GELU_QUANT, rank 48 .. 160, per-tile atomics of the next layer's ranks in 32-rank passes                                        [2267]
+    (3, 2): 2210,   # RMSNorm + RoPE, rank 48 .. 160                                                                                                 [2139]
+    (2, 3): 2540,   # GELU_QUANT hybrid carry (next rank > 32: pass 0 into the carry, atomics behind)                                                 [2465]
 }
+# vector-memory instructions behind the loop (every path of the kernel, static): what VERDICT r4 #3a counted.  The per-tile dynamic mix is a subset (the
+# stream-K publish / collect loops, both V^T store variants and the unstaged fallback loads are all in the count)
+BUDGET_VMEM = {(0, 0): 76, (2, 1): 116, (3, 0): 215, (0, 2): 92, (3, 2): 230}
 
 
 @pytest.mark.parametrize("dt", [0, 1], ids=["bf16", "fp16"])
@@ -42,6 +50,19 @@ def test_epilogue_valu_budgets(stats, dt):
         valu = r["post_loop"].get("valu", 0)
         slack = 1.12 if dt == 1 else 1.0  # fp16 adds the +-65504 clamps and scalar conversions
         assert valu <= budget * slack, f"dtype {dt} fuse {fuse} carry {carry}: {valu} VALU instructions behind the loop (budget {budget * slack:.0f})"
+    for (fuse, carry), budget in BUDGET_VMEM.items():
+        vmem = stats[(dt, fuse, 8, 0, carry)]["post_loop"].get("vmem", 0)
+        assert vmem <= budget, f"dtype {dt} fuse {fuse} carry {carry}: {vmem} vector-memory instructions behind the loop (budget {budget})"
+
+
+def test_rank_kernels_do_not_spill(stats):
+    """round 5: the all-rank kernels keep 64 accumulators + a 64-register ring of low-rank activations + the epilogue's own operands inside the
+    256-register file of two waves per SIMD; the solo-carry kernel (128 x 128 tiles, one workgroup per CU) likewise"""
+    for dt in (0, 1):
+        for fuse in (0, 1, 2, 3):
+            assert stats[(dt, fuse, 8, 0, 2)]["scratch"] == 0, (dt, fuse, stats[(dt, fuse, 8, 0, 2)]["scratch"])
+        assert stats[(dt, 2, 4, 0, 1)]["scratch"] == 0
+        assert stats[(dt, 2, 8, 0, 3)]["scratch"] <= 24
 
 
 def test_gelu_quant_carry_kernel_memory_instructions(stats):
