@@ -69,6 +69,7 @@ constexpr int W_BYTES = (BN / 32) * F6_CHUNK;  // 12288
 constexpr int AS_BYTES = 1024;                 // (BM / 32) x 128 B used; the DMA writes whole 1 KiB planes
 constexpr int WS_BYTES = 1024;                 // 512 used
 constexpr int MAX_LORA_TILES = 16;             // R <= 256
+struct float16_scales { float v[MAX_LORA_TILES]; };
 
 // Workgroup geometry (tools/gen_gemm_loop2.py: class Geometry -- keep in step).
 //   NW = 8: 512 threads, tile 256 x 128, ONE workgroup per CU (156 KiB of LDS), 3-stage ring + the tile's staged epilogue operands.
@@ -138,6 +139,8 @@ struct GemmParams {
     int *status;             // optional host-visible status word (svdq_gemm_args.status)
     float q_scale;           // RMSNORM_ROPE: factor of the Q third, applied before its rounding to 16-bit (svdq_gemm_args.q_scale; 1 = off)
     int stage_lora;          // NW = 8: rank 32, fp32 lora_act_in, 16-byte aligned operands: the loop stages lora_act_in / lora_up of a tile in LDS
+    const void *lu_packed;   // solo-carry kernel (128 x 128 tiles, no LDS to stage lora_up in): lora_up as MFMA operand fragments as well (pack_lora_up_kernel)
+    const void *la_packed;   // all-rank kernels: lora_act_in as 16-bit MFMA operand fragments (pack_lora_act_kernel, in the workspace tail), scales applied
     int stage_lu_all;        // NW = 8, no carry: 32 < rank <= 160, fp32 lora_act_in, 16-byte aligned: the tile's lora_up (all ranks) is staged in LDS, lora_act_in comes
                              // through registers in batches of 64 ranks (every load of a batch in flight at once); value = ceil(65536 / (R / 8 + 1)), the divider of the gather
     int rowrun;              // NW = 8, GELU_QUANT: run length of the row-run schedule (GemmSchedule::init_runs; 0 = the plain schedule): the next layer's
@@ -160,6 +163,47 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 typedef __attribute__((address_space(3))) void lds_void;
+
+// lora_act_in for the all-rank kernels (rank 48 .. 160), packed once per launch: fp32 [M_pad][R] -> the 16-bit MFMA operand fragments the up projection
+// consumes, [M_pad / 32 row tiles][R / 16 units][64 lanes][8 values] -- lane (row & 31, h) holds ranks 16 u + 8 h .. + 7 of its row, scaled per 16 ranks and
+// rounded exactly as the epilogue's own conversion does (lora.cuh:145-158).  A row-per-lane read of the fp32 rows costs the epilogue the cache lines it
+// touches, not its bytes: 32 rows x 128-byte lines per instruction for 16 bytes each, the same 256 KB per tile fetched by both column waves of a row block
+// -- 17 k cycles per 256 x 128 tile at rank 128 against 2.5 k for the staged rank-32 operands (profiles/r5_gemm_phase_trace.txt).  Packed, a fragment is ONE
+// coalesced 16-byte load per lane (1 KiB per wave instruction, every byte used) and the conversion leaves the epilogue.  The image lives in the tail of the
+// caller's workspace (valid for launches ordered on one stream, like the stream-K slabs in front of it).
+constexpr long long LA_PACK_BYTES = 16LL << 20; // M_pad * R * 2 bytes: 65536 rows at rank 128
+template <int DT>
+__global__ __launch_bounds__(256) void pack_lora_act_kernel(const float *__restrict__ la, typename Half<DT>::V8 *__restrict__ out, int R, int units, float16_scales sc) {
+    using T = typename Half<DT>::T;
+    using V8 = typename Half<DT>::V8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.y * 4 + wave, rt = blockIdx.x;
+    if (unit >= units) return;
+    const int lr = lane & 31, h = lane >> 5;
+    const float *src = la + (size_t)(rt * 32 + lr) * R + unit * 16 + h * 8;
+    const v4f a = *reinterpret_cast<const v4f *>(src), b = *reinterpret_cast<const v4f *>(src + 4);
+    const float s1 = sc.v[unit];
+    V8 o;
+    if (s1 == 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[j] = f2h<T>(a[j]); o[4 + j] = f2h<T>(b[j]); }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[j] = f2h<T>(a[j] * s1); o[4 + j] = f2h<T>(b[j] * s1); }
+    }
+    out[((size_t)rt * units + unit) * 64 + lane] = o;
+}
+
+// the same for lora_up [N][R] 16-bit (a pure permutation): [N / 32 column tiles][R / 16 units][64 lanes][8 values], lane (n & 31, h) <- ranks 16 u + 8 h .. + 7
+constexpr long long LU_PACK_BYTES = 8LL << 20;
+template <int DT>
+__global__ __launch_bounds__(256) void pack_lora_up_kernel(const typename Half<DT>::T *__restrict__ lu, typename Half<DT>::V8 *__restrict__ out, int R, int units) {
+    using V8 = typename Half<DT>::V8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.y * 4 + wave, ct = blockIdx.x;
+    if (unit >= units) return;
+    out[((size_t)ct * units + unit) * 64 + lane] = *reinterpret_cast<const V8 *>(lu + (size_t)(ct * 32 + (lane & 31)) * R + unit * 16 + (lane >> 5) * 8);
+}
 
 template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q31.32 (deterministic mode) */,
           bool CARRY = false /* GELU_QUANT, NW = 8, fp32 lora_act_out of rank <= 32: the next layer's low-rank down projection accumulates in LDS */,
@@ -705,7 +749,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         };
         LaRegs x0 = {}, x1 = {};
         V8 u0[2] = {}, u1[2] = {};
+        // the solo-carry kernel (128 x 128 tiles) with both low-rank operands packed as MFMA fragments (block-uniform): no natural-order loads at all
+        constexpr bool SOLO = NW == 4 && CARRY;
+        bool solo_pk = false;
+        if constexpr (SOLO) solo_pk = p.lu_packed != nullptr && p.la_packed != nullptr;
         if constexpr (RALL) {
+        } else if (SOLO && solo_pk) {
         } else if (staged_l) {
             if constexpr (CARRY) { load_la(0, x0); load_la(16, x1); }  // (the region's lora_act_in slot holds the carry)
             else { staged_la(0, x0); staged_la(16, x1); }
@@ -754,23 +803,70 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             }
         };
         if constexpr (RALL) {
-            // a ring of four 16-rank units (64 VGPRs): the first 64 ranks are requested up front (above the wait for the staged operands); each unit's
-            // registers are re-used for the unit 64 ranks further on as soon as its values are converted -- the next loads fly under this unit's MFMAs
-            LaBatch ring;
-            issue_batch(0, ring);
+            // the low-rank activations arrive as packed 16-bit MFMA fragments (pack_lora_act_kernel): one coalesced 16-byte load per lane, row tile and
+            // 16-rank unit.  A ring of eight units (64 VGPRs): rank <= 128 is requested whole, up front (above the wait for the staged operands); beyond,
+            // a unit's registers are re-used for the unit 128 ranks further on as soon as its MFMAs are issued.
+            const V8 *lap = (const V8 *)p.la_packed;
+            const unsigned units = (unsigned)Rr / 16u;
+            const unsigned lap0 = (((unsigned)(mw0 >> 5)) * units) * 64u + lane_e; // + (mi * units + unit) * 64
+            V8 ring[8][2];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const unsigned un = min((unsigned)i, units - 1u); // (unconditional loads: a unit beyond the rank re-reads the last one)
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++) ring[i][mi] = lap[lap0 + ((unsigned)mi * units + un) * 64u];
+            }
+            apply_bias();
+            for (int rc0 = 0; rc0 < Rr; rc0 += 128) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int rc = rc0 + 16 * i;
+                    if (rc < Rr) { // block-uniform
+                        V8 u[2];
+                        staged_lu_all(rc, u);
+#pragma unroll
+                        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                            for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(u[ni], ring[i][mi], acc[ni][mi]);
+                        if (rc + 128 < Rr) {
+#pragma unroll
+                            for (int mi = 0; mi < 2; mi++) ring[i][mi] = lap[lap0 + ((unsigned)mi * units + (unsigned)(rc + 128) / 16u) * 64u];
+                        }
+                    }
+                }
+            }
+            load_next_params();
+        } else if (SOLO && solo_pk) {
+            // four units in flight (64 VGPRs: two row-tile fragments of lora_act_in + two column-tile fragments of lora_up each), every load one coalesced
+            // 16 bytes per lane; a unit's registers are re-used for the unit 64 ranks further on once its MFMAs are issued
+            const V8 *lap = (const V8 *)p.la_packed, *lup = (const V8 *)p.lu_packed;
+            const unsigned units = (unsigned)Rr / 16u;
+            const unsigned lap0 = (((unsigned)(mw0 >> 5)) * units) * 64u + lane_e, lup0 = (((unsigned)(nw0 >> 5)) * units) * 64u + lane_e;
+            V8 ra[4][2], ru[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned un = min((unsigned)i, units - 1u);
+#pragma unroll
+                for (int t = 0; t < 2; t++) { ra[i][t] = lap[lap0 + ((unsigned)t * units + un) * 64u]; ru[i][t] = lup[lup0 + ((unsigned)t * units + un) * 64u]; }
+            }
             apply_bias();
             for (int rc0 = 0; rc0 < Rr; rc0 += 64) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int rc = rc0 + 16 * i;
                     if (rc < Rr) { // block-uniform
-                        V8 u[2];
-                        staged_lu_all(rc, u);
-                        lora_mfma(rc, ring.x[i], u, [&]() { if (rc + 64 < Rr) load_la(rc + 64, ring.x[i]); });
+#pragma unroll
+                        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                            for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(ru[i][ni], ra[i][mi], acc[ni][mi]);
+                        if (rc + 64 < Rr) {
+                            const unsigned un = (unsigned)(rc + 64) / 16u;
+#pragma unroll
+                            for (int t = 0; t < 2; t++) { ra[i][t] = lap[lap0 + ((unsigned)t * units + un) * 64u]; ru[i][t] = lup[lup0 + ((unsigned)t * units + un) * 64u]; }
+                        }
                     }
                 }
             }
-            load_next_params();
         } else {
         apply_bias();
         if (Rr > 0) lora_mfma(0, x0, u0, no_hook);
@@ -1225,7 +1321,9 @@ static int device_cus() {
     return cus;
 }
 // one size for both geometries: 2 slabs per workgroup slot, 256 x 128 tiles on `cus` slots == 128 x 128 tiles on 2 * cus
-static long long workspace_bytes_needed() { return SK_HEADER_BYTES + 2LL * device_cus() * 256 * BN * 4; }
+static long long workspace_slab_bytes() { return SK_HEADER_BYTES + 2LL * device_cus() * 256 * BN * 4; }
+// ... + the packed lora_act_in image of the all-rank kernels (LA_PACK_BYTES) behind the slabs
+static long long workspace_bytes_needed() { return workspace_slab_bytes() + LA_PACK_BYTES + LU_PACK_BYTES; }
 
 // Stream-K heuristic.  The remainder R = tiles % slots of the last round leaves CUs idle for a whole tile time;
 // splitting those tiles along K costs every split ~2 x 128 KiB of fp32 partial traffic plus a prologue
@@ -1265,9 +1363,10 @@ static int persistent_grid(int tiles, int sk_gs, int slots) {
 static int pick_geometry(const svdq_gemm_args *a, bool with_ws) {
     if (a->geometry != 0) return a->geometry;
     if (!with_ws) return 1;
-    // (beyond rank 32 the two geometries cost the same again: measured on one box, profiles/r5_rank_ab.txt -- QKV 4608 x 9216 x 3072 at rank 128: 213.8 us with
-    //  the all-rank kernel on 256 x 128 tiles, 196.8 us on the 128 x 128 queue with a memory round trip per 32 ranks; rank 48: 181.0 vs 162.1 -- the same
-    //  ~17 us the queue's balance is worth at rank 32: the low-rank activations' row-per-lane loads cost either geometry the same line requests)
+    // from rank 96 (fp32 accumulators, up to rank 160): the all-rank kernels of the 256 x 128 geometry -- lora_up of a tile staged in LDS, lora_act_in as packed
+    // fragments; the 128 x 128 geometry has neither (profiles/r5_gemm_phase_trace.txt: 16-18 k cycles of low-rank operand traffic per 128 x 128 tile)
+    // (from rank 96: measured on one box, rank 128: QKV 182 us against 194 us on the 128 x 128 queue; rank 48: 179 against 166 -- there the queue's balance is worth more)
+    if (a->R >= 96 && a->R <= Geo<8>::STG_LU_ALL_MAX_R && a->lora_act_format == SVDQ_LORA_ACT_F32 && (long long)a->M_pad * a->R * 2 <= LA_PACK_BYTES) return 1;
     const int cus = device_cus();
     const int tiles1 = (a->M_pad / 256) * (a->N / BN), tiles2 = 2 * tiles1;
     if (tiles1 <= cus || streamk_groups_for(tiles1, a->K / 128, cus) > 0) return 1;
@@ -1303,6 +1402,15 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
             p.rowrun = GemmSchedule::run_length(TM, TN, cus);
             const int g4 = (TM * ((TN + p.rowrun - 1) / p.rowrun) + 7) / 8 * 8;
             dim3 grid(SVDQ_PROBE_GRID(g4, tiles, cus)), block(G_::THREADS);
+            if (p.lu_packed && p.la_packed) { // both low-rank operands as MFMA fragments (the grouped launch's second lora_up is not packed: see svdq_gemm_w4a4)
+                float16_scales sc;
+                for (int i = 0; i < MAX_LORA_TILES; i++) sc.v[i] = p.lora_scales[i];
+                const int units = p.R / 16;
+                hipLaunchKernelGGL((pack_lora_act_kernel<DT>), dim3(p.M_pad / 32, (units + 3) / 4), dim3(256), 0, st, (const float *)p.lora_act_in,
+                                   (typename Half<DT>::V8 *)p.la_packed, p.R, units, sc);
+                hipLaunchKernelGGL((pack_lora_up_kernel<DT>), dim3(p.N / 32, (units + 3) / 4), dim3(256), 0, st, (const typename Half<DT>::T *)p.lora_up,
+                                   (typename Half<DT>::V8 *)p.lu_packed, p.R, units);
+            }
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true>), grid, block, 0, st, p);
             return;
         }
@@ -1330,7 +1438,12 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
     }
     dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
     if constexpr (NW == 8 && !LAQ) {
-        if (p.stage_lu_all) { // 32 < rank <= 160: the kernel with the all-rank lora_up image
+        if (p.stage_lu_all && p.la_packed) { // 32 < rank <= 160: the kernel with the all-rank lora_up image, behind the pack of its low-rank activations
+            float16_scales sc;
+            for (int i = 0; i < MAX_LORA_TILES; i++) sc.v[i] = p.lora_scales[i];
+            const int units = p.R / 16;
+            hipLaunchKernelGGL((pack_lora_act_kernel<DT>), dim3(p.M_pad / 32, (units + 3) / 4), dim3(256), 0, st, (const float *)p.lora_act_in,
+                               (typename Half<DT>::V8 *)p.la_packed, p.R, units, sc);
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true>), grid, block, 0, st, p);
             return;
         }
@@ -1556,12 +1669,16 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     if (a->R > 32 && a->R <= Geo<8>::STG_LU_ALL_MAX_R && a->lora_act_format == SVDQ_LORA_ACT_F32 && a->lora_act_in && a->lora_up &&
         (((uintptr_t)a->lora_act_in | (uintptr_t)a->lora_up | (uintptr_t)a->lora_up2) & 15) == 0)
         p.stage_lu_all = 65536 / (a->R / 8 + 1) + 1;
+    p.la_packed = nullptr; // (set below once the workspace is known to hold the image)
     p.status = a->status;
     p.q_scale = a->q_scale == 0.f ? 1.0f : a->q_scale;
     for (int i = 0; i < MAX_LORA_TILES; i++) p.lora_scales[i] = (a->lora_scales && i < a->R / 16) ? a->lora_scales[i] : 1.0f;
     SVDQ_PROBE_FILL(p);
 
     const bool with_ws = p.workspace && p.workspace_bytes >= workspace_bytes_needed();
+    if (p.stage_lu_all && with_ws && (long long)a->M_pad * a->R * 2 <= LA_PACK_BYTES) p.la_packed = p.workspace + workspace_slab_bytes();
+    else p.stage_lu_all = 0; // (no workspace, or an image beyond its tail: the rank > 32 fallback loads of the plain kernels)
+    p.lu_packed = nullptr;
     int geo = pick_geometry(a, with_ws);
     // GELU_QUANT with a next-layer low-rank branch beyond rank 32 (fp32 accumulators) and at least two 128 x 128 tiles per CU: the solo-carry kernel
     // (geometry 6 asks for it at any size and any next-layer rank <= 128: tests; launches it cannot serve run as with geometry 0)
@@ -1569,7 +1686,12 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     // (measured, profiles/r5_rank_ab.txt: next rank 128: 559 us against 615 us with per-tile atomics on 256 x 128 tiles; next rank 48: 310 against 285 -- one wave
     //  per SIMD runs the VALU-bound GELU epilogue at half the issue rate, which only pays once the atomics of >= 96 ranks are what it replaces)
     p.solo_carry = solo_ok && (a->geometry == 6 || (a->geometry == 0 && a->R2 >= 96 && (long long)(a->M_pad / 128) * (a->N / BN) >= 2LL * device_cus()));
-    if (p.solo_carry) geo = 3;
+    if (p.solo_carry) {
+        geo = 3;
+        // its low-rank up projection reads packed fragments of both operands when they fit the workspace tail (rank 48 .. 160, fp32, one weight set)
+        if (p.la_packed && !a->wgt2 && (long long)a->N * a->R * 2 <= LU_PACK_BYTES) p.lu_packed = p.workspace + workspace_slab_bytes() + LA_PACK_BYTES;
+        else p.la_packed = nullptr;
+    }
     else if (geo == 6) { svdq_gemm_args b = *a; b.geometry = 0; geo = pick_geometry(&b, with_ws); }
     p.dynamic = geo == 2 || geo == 4;
     p.stagger = geo == 4 || geo == 5;

@@ -67,6 +67,7 @@ typedef const char *(*err_fn)(void);
 
 int main(int argc, char **argv) {
     std::string lib = "nunchaku_amd/csrc/libsvdq_amd.so";
+    int R2opt = 32;
     int M = 4096, K = 12288, N = 3072, R = 32, fuse = 0, iters = 20, warm = 1500, dtype = SVDQ_BF16, reserved = 0, use_ws = 1, split = 0;
     bool zero = false, do_trace = false, q32 = false;
     double sustain = 0;
@@ -76,6 +77,7 @@ int main(int argc, char **argv) {
         if (a == "--lib") lib = argv[++i];
         else if (a == "--shape") { M = atoi(argv[++i]); K = atoi(argv[++i]); N = atoi(argv[++i]); }
         else if (a == "--R") R = atoi(argv[++i]);
+        else if (a == "--R2") R2opt = atoi(argv[++i]);
         else if (a == "--fuse") fuse = atoi(argv[++i]);
         else if (a == "--iters") iters = atoi(argv[++i]);
         else if (a == "--warm") warm = atoi(argv[++i]);
@@ -117,7 +119,7 @@ int main(int argc, char **argv) {
         CK(hipMalloc(&a.qout, (size_t)M_pad * N * 3 / 4));
         CK(hipMalloc(&a.oscales, (size_t)(N / 64) * M_pad * 2));
         a.next_smooth = dev_half(N, dtype, 0.5f, 2.0f, false);
-        a.R2 = 32;
+        a.R2 = R2opt;
         a.next_lora_down = dev_half((size_t)N * a.R2, dtype, -0.05f, 0.05f, zero);
         CK(hipMalloc((void **)&a.lora_act_out, (size_t)M_pad * a.R2 * 8)); CK(hipMemset(a.lora_act_out, 0, (size_t)M_pad * a.R2 * 8));
     } else if (fuse == SVDQ_FUSE_RMSNORM_ROPE) {
