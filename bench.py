@@ -52,6 +52,8 @@ FLUX_STEP_GOP = 59.5e3 + 0.83e3
 # tools/gpu/r4_profile_bench.sh); a line printed from a tree whose kernels changed since says "stale": true next to the number.
 TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r5_bench_gemm_hbm_counters.json", "r4_bench_gemm_hbm_counters.json")]
 MFMA_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r5_bench_gemm_mfma_util.json", "r4_bench_gemm_mfma_util.json")]
+# per-variant share of a tile spent behind the main loop (shader-cycle stamps of the probe build, tools/gpu/r5_gemm_trace.sh + tools/epilogue_share.py): committed, stamped
+EPILOGUE_SHARE_PROFILE = os.path.join(ROOT, "profiles", "r5_gemm_epilogue_share.json")
 
 
 def kernel_sources_sha16():
@@ -90,6 +92,16 @@ def committed_mfma_util():
         except Exception:
             continue
     return None
+
+
+def committed_epilogue_share():
+    try:
+        d = json.load(open(EPILOGUE_SHARE_PROFILE))
+        d["file"] = os.path.relpath(EPILOGUE_SHARE_PROFILE, ROOT)
+        d["stale"] = d.get("csrc_sha16") != kernel_sources_sha16()
+        return d
+    except Exception:
+        return None
 
 
 class ClockSampler:
@@ -459,6 +471,9 @@ def main():
                                   "2*FETCH_SIZE + WRITE_SIZE per gemm_w4a4 dispatch); not measured in this run",
                 "traffic_stale": not traffic_fresh,   # true: the kernel sources changed since that file was measured
                 "mfma_util": committed_mfma_util(),
+                # share of a tile's cycles behind the main loop per epilogue variant (committed probe measurement): what the launch-level
+                # fraction loses against the loop's own
+                "epilogue_share": committed_epilogue_share(),
                 # shader clock during the timed region (pp_dpm_sclk sampled every 50 ms on rank 0): the chip runs these kernels at its power
                 # limit; profiles/r4_clock_instrument.txt ties this reading to GRBM_GUI_ACTIVE / dispatch duration
                 "effective_clock_ghz": clock_ghz,

@@ -54,6 +54,7 @@ def test_bench_n_ranks_on_one_gpu(config, ranks):
     assert 0 < pr["min_steps_per_s"] <= pr["max_steps_per_s"] and d["value"] <= ranks * pr["max_steps_per_s"] * 1.0001
     rf = d["roofline"]
     assert isinstance(rf["traffic_stale"], bool) and (rf["mfma_util"] is None or isinstance(rf["mfma_util"]["stale"], bool))
+    assert rf["epilogue_share"] is None or (isinstance(rf["epilogue_share"]["stale"], bool) and "gelu_quant" in rf["epilogue_share"]["per_variant"])
     assert rf["effective_clock_ghz"] is None or 0.05 < rf["effective_clock_ghz"] < 3.0
     pv = rf["per_variant"]
     assert {"default", "gelu_quant", "rmsnorm_rope"} <= set(pv), pv.keys()
