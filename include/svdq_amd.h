@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 18
+#define SVDQ_ABI_VERSION 19
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -160,8 +160,9 @@ typedef struct svdq_gemm_args {
     int32_t M_pad;            /* multiple of 256                                                */
     int32_t N;                /* multiple of 128                                                */
     int32_t K;                /* multiple of 128                                                */
-    int32_t R;                /* rank of lora_up (multiple of 16; 0 = none)                     */
-    int32_t R2;               /* rank of next_lora_down (multiple of 16; 0 = none)              */
+    int32_t R;                /* rank of lora_up (multiple of 16 in [0, 256]; 0 = none).  Every rank runs the fused path; 32 (the SVDQuant default),
+                               * 48 .. 160 (the r128 checkpoints, a runtime LoRA on top of rank 32) have kernels of their own */
+    int32_t R2;               /* rank of next_lora_down (multiple of 16 in [0, 256]; 0 = none)  */
     int32_t ldo;              /* row stride of out in elements (>= N)                           */
     int32_t dtype;            /* SVDQ_BF16 | SVDQ_FP16                                          */
     int32_t act_unsigned;     /* informational: the FP6 image already encodes signedness        */
@@ -219,7 +220,10 @@ typedef struct svdq_gemm_args {
 } svdq_gemm_args;
 
 int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
-/* size of the stream-K workspace for the current device (1023 arrival counters + 1 error word + 2 fp32 tiles of 256 x 128 per CU) */
+/* size of the GEMM workspace for the current device: 1023 arrival counters + 1 error word + 2 fp32 tiles of 256 x 128 per CU (the stream-K tail), and
+ * -- ABI 19 -- a 24 MB tail in which a launch of rank 48 .. 160 keeps its low-rank operands as packed 16-bit MFMA fragments (written by a small pack
+ * kernel the call enqueues in front of the GEMM; valid, like the rest, for launches ordered on ONE stream).  Without a workspace (or with one of the
+ * ABI 18 size) such launches take the plain kernels' rank > 32 path: same results, a memory round trip per 16 ranks in every tile's epilogue. */
 int64_t svdq_gemm_workspace_bytes(void);
 /* Synchronises `stream`, then returns SVDQ_E_HIP (and clears the flag) if a launch that used `workspace` timed out
  * waiting for partial tiles -- see svdq_gemm_args.workspace; SVDQ_OK otherwise.  Test / debugging aid. */
