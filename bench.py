@@ -214,6 +214,8 @@ def main():
                          "1024^2 = 4096 image + 512 text tokens); with --offload N the blocks live in pinned host memory and N stay resident")
     ap.add_argument("--offload", type=int, default=0, metavar="N",
                     help="qwen1024 only: layer-wise host offload with N blocks resident on the GPU (0 = everything resident)")
+    ap.add_argument("--offload-slots", type=int, default=4, metavar="S",
+                    help="qwen1024 --offload: device slots of the offload ring (CPUOffloadManager num_slots: one computes while S - 1 fill)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
                     help="torch.distributed backend for --gpus > 1 (default: nccl = RCCL; gloo lets several ranks share one GPU: smoke tests)")
     ap.add_argument("--resolution", type=int, nargs="+", default=None, metavar="PIXELS",
@@ -299,7 +301,7 @@ def main():
             m.set_lora(torch.randn(args.lora, m.in_features, generator=gl, device=dev) * (0.5 / m.in_features ** 0.5),
                        torch.randn(m.out_features, args.lora, generator=gl, device=dev) * (0.5 / args.lora ** 0.5), strength=0.8)
     if qwen and args.offload:
-        model.set_offload(True, num_blocks_on_gpu=args.offload)
+        model.set_offload(True, num_blocks_on_gpu=args.offload, num_slots=args.offload_slots)
 
     # ---- one independent image per rank ------------------------------------------------------
     gh, gw = height // 16, width // 16   # the grid of 2 x 2 latent patches
@@ -422,7 +424,7 @@ def main():
             workload = (f"Qwen-Image-shaped transformer step, {res_name} ({t_img} image + {t_txt} text tokens), bs=1 "
                         f"per GPU, {len(model.transformer_blocks)} dual-stream blocks, int4 rank-{args.rank}" + (f" + rank-{args.lora} runtime LoRA" if args.lora else "") + ", random-init weights, " +
                         (f"layer-wise host offload with {args.offload} blocks resident ({model.offload_manager.host_bytes_per_block() / 1e6:.0f} MB "
-                         f"per block over PCIe)" if args.offload else "all blocks resident"))
+                         f"per block over PCIe, ring of {args.offload_slots} device slots)" if args.offload else "all blocks resident"))
         else:
             workload = (f"FLUX.1-{'schnell' if schnell else 'dev'}-shaped transformer step, {res_name} "
                         f"({t_img} image + {t_txt} text tokens), bs=1 per GPU, {args.layers[0]} joint + "

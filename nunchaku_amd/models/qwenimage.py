@@ -426,7 +426,10 @@ class NunchakuQwenImageTransformer2DModel(_DiffusersQwen if HAVE_DIFFUSERS_QWEN 
             self.offload_manager = CPUOffloadManager(
                 list(self.transformer_blocks), device=kwargs.get("device", self.device), use_pin_memory=kwargs.get("use_pin_memory", True),
                 on_gpu_modules=[self.img_in, self.txt_in, self.txt_norm, self.time_text_embed, self.norm_out, self.proj_out],
-                num_blocks_on_gpu=kwargs.get("num_blocks_on_gpu", 1), num_slots=kwargs.get("num_slots", 2))
+                num_blocks_on_gpu=kwargs.get("num_blocks_on_gpu", 1),
+                # four device slots (the reference ping-pongs between two buffers, models/utils.py:188-221): measured 239.9 / 228.0 / 220.5 ms per 1024^2
+                # step with 2 / 3 / 4 slots, 237 with 6 or 8 (profiles/r5_qwen_offload_ring_depth.txt): three loads in flight keep the link busier
+                num_slots=kwargs.get("num_slots", 4))
         else:
             # the blocks are complete modules on pinned host memory: bring them back (the reference leaves them on the CPU and
             # relies on a later .to(device); a model that has just been told "no offload" should simply run)
