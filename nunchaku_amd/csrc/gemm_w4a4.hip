@@ -215,7 +215,8 @@ template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q
                               wait retires behind.  (The carry of more ranks does not fit: 256 rows x 48 ranks x 4 bytes > the 42 KiB staging region.) */>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams p) {
     static_assert(!CARRY || (FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ), "the low-rank-down carry: GELU_QUANT with fp32 low-rank accumulators");
-    static_assert(!RALL || (NW == 8 && !LAQ && !CARRY), "the all-rank lora_up image lives in the 256 x 128 geometry's staging region");
+    static_assert(!RALL || (!LAQ && !CARRY), "the all-rank kernels: fp32 low-rank accumulators, no carry");
+    // (RALL on 128 x 128 tiles: no LDS to stage lora_up in -- both low-rank operands come as packed MFMA fragments from the workspace tail, like the solo-carry kernel's)
     static_assert(!HYB || (CARRY && NW == 8), "HYB: a carry kernel on 256 x 128 tiles");
     using T = typename Half<DT>::T;
     using V8 = typename Half<DT>::V8;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             const int stg_issues = min((int)kp_s, (int)(kp_s + ncnt) - NSTAGE);
             stg_counted = stg_issues >= 3;
             const unsigned stg_lds = lds_base + G_::STG_OFF;
-            if constexpr (RALL) {
+            if constexpr (RALL && NW == 8) {
                 if (kp1 == KP) {
                     // rank > 32: the tile's lora_up rows n0 .. n0 + 127, ALL ranks (256 R contiguous bytes), go to the staging region by LDS-DMA from
                     // here -- older than every DMA of the loop, landing under it like the generated prologue's pieces.  LDS image: row r, 16-byte
@@ -750,10 +751,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         LaRegs x0 = {}, x1 = {};
         V8 u0[2] = {}, u1[2] = {};
         // the solo-carry kernel (128 x 128 tiles) with both low-rank operands packed as MFMA fragments (block-uniform): no natural-order loads at all
-        constexpr bool SOLO = NW == 4 && CARRY;
+        constexpr bool SOLO = NW == 4 && (CARRY || RALL); // (RALL on 128 x 128 tiles: always packed)
         bool solo_pk = false;
-        if constexpr (SOLO) solo_pk = p.lu_packed != nullptr && p.la_packed != nullptr;
-        if constexpr (RALL) {
+        if constexpr (SOLO) solo_pk = RALL || (p.lu_packed != nullptr && p.la_packed != nullptr);
+        if constexpr (RALL && NW == 8) {
         } else if (SOLO && solo_pk) {
         } else if (staged_l) {
             if constexpr (CARRY) { load_la(0, x0); load_la(16, x1); }  // (the region's lora_act_in slot holds the carry)
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             }
         }
         };
-        if constexpr (!RALL) load_next_params(); // (the all-rank kernel's ring of low-rank activations needs the registers first: it asks behind the up projection)
+        if constexpr (!(RALL && NW == 8)) load_next_params(); // (the all-rank kernel's ring of low-rank activations needs the registers first: it asks behind the up projection)
         auto apply_bias = [&]() {
             if (use_bias) {
 #pragma unroll
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                 }
             }
         };
-        if constexpr (RALL) {
+        if constexpr (RALL && NW == 8) {
             // the low-rank activations arrive as packed 16-bit MFMA fragments (pack_lora_act_kernel): one coalesced 16-byte load per lane, row tile and
             // 16-rank unit.  A ring of eight units (64 VGPRs): rank <= 128 is requested whole, up front (above the wait for the staged operands); beyond,
             // a unit's registers are re-used for the unit 128 ranks further on as soon as its MFMAs are issued.
@@ -837,30 +838,32 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             }
             load_next_params();
         } else if (SOLO && solo_pk) {
-            // four units in flight (64 VGPRs: two row-tile fragments of lora_act_in + two column-tile fragments of lora_up each), every load one coalesced
-            // 16 bytes per lane; a unit's registers are re-used for the unit 64 ranks further on once its MFMAs are issued
+            // eight units in flight (128 VGPRs: two row-tile fragments of lora_act_in + two column-tile fragments of lora_up each -- one wave per SIMD has the
+            // registers): rank <= 128 is requested whole, above the bias MFMAs; every load is one coalesced 16 bytes per lane.  (Four in flight: 9.6 k cycles
+            // for this phase at rank 128 -- one wave per SIMD has nobody to hide a unit's load latency behind, profiles/r5_gemm_phase_trace_final.txt.)
             const V8 *lap = (const V8 *)p.la_packed, *lup = (const V8 *)p.lu_packed;
             const unsigned units = (unsigned)Rr / 16u;
             const unsigned lap0 = (((unsigned)(mw0 >> 5)) * units) * 64u + lane_e, lup0 = (((unsigned)(nw0 >> 5)) * units) * 64u + lane_e;
-            V8 ra[4][2], ru[4][2];
+            constexpr int RING = CARRY ? 8 : 4; // (two workgroups per CU -- the all-rank kernel of this geometry -- share the SIMD's registers: four units, 64 VGPRs)
+            V8 ra[RING][2], ru[RING][2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < RING; i++) {
                 const unsigned un = min((unsigned)i, units - 1u);
 #pragma unroll
                 for (int t = 0; t < 2; t++) { ra[i][t] = lap[lap0 + ((unsigned)t * units + un) * 64u]; ru[i][t] = lup[lup0 + ((unsigned)t * units + un) * 64u]; }
             }
             apply_bias();
-            for (int rc0 = 0; rc0 < Rr; rc0 += 64) {
+            for (int rc0 = 0; rc0 < Rr; rc0 += 16 * RING) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < RING; i++) {
                     const int rc = rc0 + 16 * i;
                     if (rc < Rr) { // block-uniform
 #pragma unroll
                         for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                             for (int mi = 0; mi < 2; mi++) acc[ni][mi] = Half<DT>::mfma32(ru[i][ni], ra[i][mi], acc[ni][mi]);
-                        if (rc + 64 < Rr) {
-                            const unsigned un = (unsigned)(rc + 64) / 16u;
+                        if (rc + 16 * RING < Rr) {
+                            const unsigned un = (unsigned)(rc + 16 * RING) / 16u;
 #pragma unroll
                             for (int t = 0; t < 2; t++) { ra[i][t] = lap[lap0 + ((unsigned)t * units + un) * 64u]; ru[i][t] = lup[lup0 + ((unsigned)t * units + un) * 64u]; }
                         }
@@ -1363,10 +1366,10 @@ static int persistent_grid(int tiles, int sk_gs, int slots) {
 static int pick_geometry(const svdq_gemm_args *a, bool with_ws) {
     if (a->geometry != 0) return a->geometry;
     if (!with_ws) return 1;
-    // from rank 96 (fp32 accumulators, up to rank 160): the all-rank kernels of the 256 x 128 geometry -- lora_up of a tile staged in LDS, lora_act_in as packed
-    // fragments; the 128 x 128 geometry has neither (profiles/r5_gemm_phase_trace.txt: 16-18 k cycles of low-rank operand traffic per 128 x 128 tile)
-    // (from rank 96: measured on one box, rank 128: QKV 182 us against 194 us on the 128 x 128 queue; rank 48: 179 against 166 -- there the queue's balance is worth more)
-    if (a->R >= 96 && a->R <= Geo<8>::STG_LU_ALL_MAX_R && a->lora_act_format == SVDQ_LORA_ACT_F32 && (long long)a->M_pad * a->R * 2 <= LA_PACK_BYTES) return 1;
+    // rank 48 .. 160: both geometries have all-rank kernels (256 x 128: lora_up of a tile staged in LDS + packed lora_act_in; 128 x 128: both operands packed), so
+    // the choice below is the rank-32 one -- except for a grouped launch from rank 96, whose second lora_up only the 256 x 128 kernel serves without the plain
+    // kernels' row-per-lane loads (16-18 k cycles per 128 x 128 tile at rank 128, profiles/r5_gemm_phase_trace.txt)
+    if (a->wgt2 && a->R >= 96 && a->R <= Geo<8>::STG_LU_ALL_MAX_R && a->lora_act_format == SVDQ_LORA_ACT_F32 && (long long)a->M_pad * a->R * 2 <= LA_PACK_BYTES) return 1;
     const int cus = device_cus();
     const int tiles1 = (a->M_pad / 256) * (a->N / BN), tiles2 = 2 * tiles1;
     if (tiles1 <= cus || streamk_groups_for(tiles1, a->K / 128, cus) > 0) return 1;
@@ -1412,6 +1415,20 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
                                    (typename Half<DT>::V8 *)p.lu_packed, p.R, units);
             }
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true>), grid, block, 0, st, p);
+            return;
+        }
+    }
+    if constexpr (NW == 4 && !LAQ) {
+        if (p.lu_packed && p.la_packed) { // rank 48 .. 160 on 128 x 128 tiles: both low-rank operands packed, then the all-rank kernel of this geometry
+            float16_scales sc;
+            for (int i = 0; i < MAX_LORA_TILES; i++) sc.v[i] = p.lora_scales[i];
+            const int units = p.R / 16;
+            hipLaunchKernelGGL((pack_lora_act_kernel<DT>), dim3(p.M_pad / 32, (units + 3) / 4), dim3(256), 0, st, (const float *)p.lora_act_in,
+                               (typename Half<DT>::V8 *)p.la_packed, p.R, units, sc);
+            hipLaunchKernelGGL((pack_lora_up_kernel<DT>), dim3(p.N / 32, (units + 3) / 4), dim3(256), 0, st, (const typename Half<DT>::T *)p.lora_up,
+                               (typename Half<DT>::V8 *)p.lu_packed, p.R, units);
+            dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
+            hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true>), grid, block, 0, st, p);
             return;
         }
     }
@@ -1693,6 +1710,8 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         else p.la_packed = nullptr;
     }
     else if (geo == 6) { svdq_gemm_args b = *a; b.geometry = 0; geo = pick_geometry(&b, with_ws); }
+    // rank 48 .. 160 on 128 x 128 tiles (no LDS to stage in): both low-rank operands as packed fragments when they fit the workspace tail (one weight set)
+    if (!p.solo_carry && geo != 1 && p.la_packed && !a->wgt2 && (long long)a->N * a->R * 2 <= LU_PACK_BYTES) p.lu_packed = p.workspace + workspace_slab_bytes() + LA_PACK_BYTES;
     p.dynamic = geo == 2 || geo == 4;
     p.stagger = geo == 4 || geo == 5;
     hipStream_t st = (hipStream_t)stream;

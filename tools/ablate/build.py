@@ -42,6 +42,12 @@ def build(opts: str = ""):
     lib = os.path.join(HERE, f"libsvdq_amd_probe{suffix}.so")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     subprocess.run([hipcc, *flags, "-o", lib, *SOURCES], cwd=CSRC, check=True)
+    # the hash of the kernel sources this probe library was built from (bench.kernel_sources_sha16): tools/epilogue_share.py stamps its output with THIS value,
+    # so a trace taken with a probe library older than the product sources shows up as stale in the bench line instead of borrowing the current hash
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(lib + ".sha16", "w") as f:
+        f.write(bench.kernel_sources_sha16())
     probe = os.path.join(HERE, "gemm_probe")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}", "-o", probe,
                     os.path.join(HERE, "gemm_probe.hip"), "-ldl"], check=True)

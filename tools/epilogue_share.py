@@ -18,7 +18,9 @@ NAMES = {0: "default", 2: "gelu_quant", 3: "rmsnorm_rope"}
 def main(src, dst):
     import bench
 
-    out = {"csrc_sha16": bench.kernel_sources_sha16(),
+    sha_file = os.path.join(ROOT, "tools", "ablate", "libsvdq_amd_probe.so.sha16")
+    probe_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else "unknown (probe library built before the stamp existed)"
+    out = {"csrc_sha16": probe_sha,  # the sources the PROBE library was built from (tools/ablate/build.py), not whatever the tree holds now
            "source": "tools/gpu/r5_gemm_trace.sh: shader-cycle stamps of workgroup 0 (probe build of the library), rank 32, geometry 0, M = 4608; "
                      "share = (segment - loop) / segment, median over its whole-tile segments", "per_variant": {}}
     case, shares = None, {}
