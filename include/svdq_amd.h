@@ -225,6 +225,17 @@ int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
  * kernel the call enqueues in front of the GEMM; valid, like the rest, for launches ordered on ONE stream).  Without a workspace (or with one of the
  * ABI 18 size) such launches take the plain kernels' rank > 32 path: same results, a memory round trip per 16 ranks in every tile's epilogue. */
 int64_t svdq_gemm_workspace_bytes(void);
+/* What the calling thread's last svdq_gemm_w4a4 launched (ABI 19; a test / diagnostics aid, no effect on results): out8 = {tile rows (256 | 128), kernel variant,
+ * grid, stream-K groups (0 = whole tiles), row-run length (0 = plain schedule), lora_act_in packed (0 | 1), lora_up packed (0 | 1), dynamic tile queue (0 | 1)}.
+ * Variants: 0 plain (rank <= 32 staged / any rank through the fallback loads; GELU_QUANT: per-tile atomics), 1 low-rank-down carry (GELU_QUANT, next rank <= 32),
+ * 2 all-rank (rank 48 .. 160: packed lora_act_in; 256-row tiles: lora_up staged in LDS, 128-row tiles: lora_up packed too), 3 hybrid carry (GELU_QUANT, next rank
+ * 48 .. 80 -- or any next rank > 32 the solo kernel does not take), 4 solo carry (GELU_QUANT, next rank >= 96: 128 x 128 tiles, one workgroup per CU). */
+#define SVDQ_PLAN_PLAIN 0
+#define SVDQ_PLAN_CARRY 1
+#define SVDQ_PLAN_ALL_RANK 2
+#define SVDQ_PLAN_HYBRID_CARRY 3
+#define SVDQ_PLAN_SOLO_CARRY 4
+int svdq_gemm_last_plan(int32_t *out8);
 /* Synchronises `stream`, then returns SVDQ_E_HIP (and clears the flag) if a launch that used `workspace` timed out
  * waiting for partial tiles -- see svdq_gemm_args.workspace; SVDQ_OK otherwise.  Test / debugging aid. */
 int svdq_gemm_workspace_status(void *workspace, void *stream);

@@ -284,6 +284,17 @@ class _Ops:
             if ws.status is not None:
                 ws.status.zero_()
 
+    PLAN_VARIANTS = ("plain", "carry", "all_rank", "hybrid_carry", "solo_carry")
+
+    @staticmethod
+    def gemm_last_plan() -> dict:
+        """What this thread's last ``gemm_w4a4`` launched (``svdq_gemm_last_plan``): tile rows, kernel variant, grid, stream-K groups, row-run length,
+        packed low-rank operands, dynamic queue.  Tests assert with it that no rank / shape / format fell back to a slower kernel than documented."""
+        out = (C.c_int32 * 8)()
+        _lib.check(_lib.load().svdq_gemm_last_plan(out), "gemm_last_plan")
+        return {"tile_rows": out[0], "variant": _Ops.PLAN_VARIANTS[out[1]], "grid": out[2], "streamk_groups": out[3], "rowrun": out[4],
+                "lora_act_packed": bool(out[5]), "lora_up_packed": bool(out[6]), "dynamic_queue": bool(out[7])}
+
     # False: plain grid (one workgroup per task) instead of the persistent schedule; tests compare the two
     attention_use_workspace = True
     # Workgroup geometry of the attention kernel (svdq_attention_args.geometry): 0 = the library's choice, 1 = 8 waves x 32 query

@@ -92,6 +92,7 @@ EXPORTS = {
     "svdq_residual_gate_stats": (C.c_int, [C.POINTER(ResidualArgs), C.c_void_p]),
     "svdq_gemm_workspace_bytes": (C.c_int64, []),
     "svdq_gemm_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "svdq_gemm_last_plan": (C.c_int, [C.POINTER(C.c_int32)]),
     "svdq_attention_workspace_bytes": (C.c_int64, []),
     "svdq_attention_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "svdq_attention_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),

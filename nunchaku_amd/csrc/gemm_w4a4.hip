@@ -1310,6 +1310,18 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
 }
 
 
+// What the last svdq_gemm_w4a4 call of this thread launched (svdq_gemm_last_plan): tile rows (256 | 128), kernel variant, grid, stream-K groups, row-run length,
+// whether the low-rank operands were packed.  Filled by the dispatch code itself -- tests read it to assert that no rank, shape or format fell back to a slower
+// kernel than the one documented for it (include/svdq_amd.h).
+enum { PLAN_PLAIN = 0, PLAN_CARRY = 1, PLAN_ALL_RANK = 2, PLAN_HYBRID_CARRY = 3, PLAN_SOLO_CARRY = 4 };
+static thread_local int32_t g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static void record_plan(int tile_rows, int variant, int grid, const GemmParams &p) {
+    g_last_plan[0] = tile_rows; g_last_plan[1] = variant; g_last_plan[2] = grid; g_last_plan[3] = p.sk_gs; g_last_plan[4] = p.rowrun;
+    g_last_plan[5] = (p.la_packed != nullptr && (variant == PLAN_ALL_RANK || variant == PLAN_SOLO_CARRY)) ? 1 : 0;
+    g_last_plan[6] = (p.lu_packed != nullptr && (variant == PLAN_SOLO_CARRY || (variant == PLAN_ALL_RANK && tile_rows == 128))) ? 1 : 0;
+    g_last_plan[7] = p.dynamic;
+}
+
 // compute units the persistent grids are sized for (a multiple of 8: the XCD-aware numbering deals workgroups to the 8
 // XCDs; at most 256: the stream-K header holds 1023 arrival counters for up to 2 x 256 workgroups)
 static int device_cus() {
@@ -1414,6 +1426,7 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
                 hipLaunchKernelGGL((pack_lora_up_kernel<DT>), dim3(p.N / 32, (units + 3) / 4), dim3(256), 0, st, (const typename Half<DT>::T *)p.lora_up,
                                    (typename Half<DT>::V8 *)p.lu_packed, p.R, units);
             }
+            record_plan(G_::BM, PLAN_SOLO_CARRY, (int)grid.x, p);
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true>), grid, block, 0, st, p);
             return;
         }
@@ -1428,6 +1441,7 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
             hipLaunchKernelGGL((pack_lora_up_kernel<DT>), dim3(p.N / 32, (units + 3) / 4), dim3(256), 0, st, (const typename Half<DT>::T *)p.lora_up,
                                (typename Half<DT>::V8 *)p.lu_packed, p.R, units);
             dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
+            record_plan(G_::BM, PLAN_ALL_RANK, (int)grid.x, p);
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true>), grid, block, 0, st, p);
             return;
         }
@@ -1439,6 +1453,7 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
             p.rowrun = GemmSchedule::run_length(TM, TN, slots);
             g = (TM * ((TN + p.rowrun - 1) / p.rowrun) + 7) / 8 * 8;
             dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
+            record_plan(G_::BM, PLAN_HYBRID_CARRY, (int)grid.x, p);
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true, false, true>), grid, block, 0, st, p);
             return;
         }
@@ -1449,6 +1464,7 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
                 g = (TM * ((TN + p.rowrun - 1) / p.rowrun) + 7) / 8 * 8; // a multiple of 8: the XCD-aware numbering keeps consecutive runs on one XCD
             }
             dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
+            record_plan(G_::BM, PLAN_CARRY, (int)grid.x, p);
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true>), grid, block, 0, st, p);
             return;
         }
@@ -1461,10 +1477,12 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
             const int units = p.R / 16;
             hipLaunchKernelGGL((pack_lora_act_kernel<DT>), dim3(p.M_pad / 32, (units + 3) / 4), dim3(256), 0, st, (const float *)p.lora_act_in,
                                (typename Half<DT>::V8 *)p.la_packed, p.R, units, sc);
+            record_plan(G_::BM, PLAN_ALL_RANK, (int)grid.x, p);
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true>), grid, block, 0, st, p);
             return;
         }
     }
+    record_plan(G_::BM, PLAN_PLAIN, (int)grid.x, p);
     hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ>), grid, block, 0, st, p);
 }
 template <int DT, int FUSE, int NW>
@@ -1487,6 +1505,12 @@ static void launch_fuse(GemmParams &p, int fuse, bool with_ws, hipStream_t st) {
 using namespace svdq;
 
 extern "C" int64_t svdq_gemm_workspace_bytes(void) { return workspace_bytes_needed(); }
+
+extern "C" int svdq_gemm_last_plan(int32_t *out8) {
+    if (!out8) { set_error("svdq_gemm_last_plan: out is NULL"); return SVDQ_E_INVALID; }
+    for (int i = 0; i < 8; i++) out8[i] = g_last_plan[i];
+    return SVDQ_OK;
+}
 
 // Reads the sticky error word of a stream-K workspace after the work queued on `stream` has drained (this call
 // SYNCHRONISES the stream: a test / debugging aid, not part of the hot path -- the hot path's cheap check is the
