@@ -420,6 +420,64 @@ def gelu_tanh_envelope(x: np.ndarray):
     return lo, hi
 
 
+def silu_envelope(x: np.ndarray):
+    """[lo, hi] of cuda_sigmoidf-based silu (gemm_utils.cuh:290-303,323-327) in fp32: t = -log2(e) x (exact fp32 multiply), e = ex2.approx(t) (2 ulp),
+    d = e + 1 (exact fp32 add), r = rcp.approx(d) (1 ulp), x * r.  The intervals are propagated through the monotone steps."""
+    x = x.astype(F32)
+    t = (F32(-1.442695041) * x).astype(F32)
+    with np.errstate(over="ignore"):
+        e = np.exp2(t.astype(np.float64)).astype(F32)
+    e_lo, e_hi = _widen32(e, PTX_APPROX["ex2.approx.ftz.f32"]["max_ulp"])
+    d_lo, d_hi = (e_lo + F32(1)).astype(F32), (e_hi + F32(1)).astype(F32)
+    with np.errstate(divide="ignore"):
+        r_hi = _widen32((F32(1) / d_lo).astype(F32), PTX_APPROX["rcp.approx.ftz.f32"]["max_ulp"])[1]
+        r_lo = _widen32((F32(1) / d_hi).astype(F32), PTX_APPROX["rcp.approx.ftz.f32"]["max_ulp"])[0]
+    a, b = (x * r_lo).astype(F32), (x * r_hi).astype(F32)
+    return np.minimum(a, b), np.maximum(a, b)
+
+
+def rmsnorm_coef_envelope(sq: np.ndarray):
+    """[lo, hi] of the RMSNorm coefficient rsqrt.approx(mean(y^2) + 1e-6) (epilogues.cuh:343-360): 2 ulp on the reciprocal square root; the mean's own fp32
+    summation order adds a few steps (the reference sums 128 squares across a warp in an unspecified tree: +-4 float32 steps here)."""
+    m = (sq.astype(F32) / F32(128.0) + F32(RMS_EPS)).astype(F32)
+    m_lo, m_hi = _widen32(m, 4)
+    c_hi = _widen32((F32(1.0) / np.sqrt(m_lo.astype(np.float64))).astype(F32), PTX_APPROX["rsqrt.approx.ftz.f32"]["max_ulp"])[1]
+    c_lo = _widen32((F32(1.0) / np.sqrt(m_hi.astype(np.float64))).astype(F32), PTX_APPROX["rsqrt.approx.ftz.f32"]["max_ulp"])[0]
+    return c_lo, c_hi
+
+
+def rmsnorm_rope_envelope(y16: np.ndarray, norm_q, norm_k, rot: np.ndarray, dtype: str):
+    """[lo, hi] (16-bit) of :func:`rmsnorm_rope`'s Q / K outputs when the coefficient comes from rsqrt.approx (:func:`rmsnorm_coef_envelope`) and the
+    rotation's fp32 products may or may not be contracted into FMAs (+- 2^-22 of the products' magnitude on each rotated value: it may be a cancelling difference).  V columns: lo == hi == the input."""
+    M, N = y16.shape
+    H3 = N // 128
+    y = y16.astype(F32).reshape(M, H3, 128)
+    lo, hi = y.copy(), y.copy()
+    sin = rot[:, :, 0].astype(F32)[:, None, :]
+    cos = rot[:, :, 1].astype(F32)[:, None, :]
+    for part, w in ((0, norm_q), (1, norm_k)):
+        sl = slice(part * H3 // 3, (part + 1) * H3 // 3)
+        blk = y[:, sl, :]
+        sq = (blk.astype(np.float64) ** 2).sum(axis=2).astype(F32)
+        c_lo, c_hi = rmsnorm_coef_envelope(sq)
+        outs, mags = [], []
+        for c in (c_lo, c_hi):
+            b = (blk * (c[:, :, None] * w.astype(F32)[None, None, :]).astype(F32)).astype(F32)
+            xe, xo = b[:, :, 0::2], b[:, :, 1::2]
+            o, g = np.empty_like(b), np.empty_like(b)
+            o[:, :, 0::2] = (xe * cos - xo * sin).astype(F32)
+            o[:, :, 1::2] = (xe * sin + xo * cos).astype(F32)
+            g[:, :, 0::2] = np.abs(xe * cos) + np.abs(xo * sin)   # magnitude of the two products: what the rounding errors of a (possibly
+            g[:, :, 1::2] = np.abs(xe * sin) + np.abs(xo * cos)   # cancelling) difference scale with, whether or not it is contracted into an FMA
+            outs.append(o)
+            mags.append(g)
+        # the rotated values are linear in the coefficient: between its two ends every output moves monotonically; +- 2^-22 of the product magnitude
+        # covers the fp32 roundings of either evaluation order
+        slack = (np.maximum(mags[0], mags[1]) * F32(2.0 ** -22)).astype(F32)
+        lo[:, sl, :], hi[:, sl, :] = np.minimum(outs[0], outs[1]) - slack, np.maximum(outs[0], outs[1]) + slack
+    return round16(lo.reshape(M, N), dtype), round16(hi.reshape(M, N), dtype)
+
+
 def envelope_report(codes: np.ndarray, env: dict, ieee: np.ndarray) -> dict:
     """fraction of codes outside [q_lo, q_hi], flip rate against the IEEE codes, and how wide the envelope itself is"""
     c = codes.astype(np.int32)

@@ -172,3 +172,30 @@ def test_gelu_quant_envelope(dtype):
     g = (y16 * (f(1) / (f(1) + np.exp2(t).astype(f))).astype(f)).astype(f)
     g16 = O.round16(g, dtype)
     assert np.all(g16 >= r["g16_lo"]) and np.all(g16 <= r["g16_hi"])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_silu_and_rmsnorm_rope_envelopes(dtype):
+    """the remaining PTX approximations on the path (ex2.approx + rcp.approx in SiLU, rsqrt.approx in the RMSNorm coefficient): the IEEE oracle lies inside
+    their envelopes, and the envelopes say how little of the 16-bit output these approximations can move: open on < 2 % of the elements, never by more
+    than one 16-bit step"""
+    rng = np.random.default_rng(7)
+    x = O.round16(rng.standard_normal((64, 256)).astype(np.float32) * 3, dtype)
+    lo, hi = O.silu_envelope(x)
+    s16, lo16, hi16 = O.round16(O.silu(x), dtype), O.round16(lo, dtype), O.round16(hi, dtype)
+    assert np.all(s16 >= lo16) and np.all(s16 <= hi16)
+    assert (lo16 != hi16).mean() < 0.02
+    # RMSNorm + RoPE
+    M, H = 96, 2
+    y16 = O.round16(rng.standard_normal((M, 3 * H * 128)).astype(np.float32) * 2, dtype)
+    nq = O.round16((1 + 0.1 * rng.standard_normal(128)).astype(np.float32), dtype)
+    nk = O.round16((1 + 0.1 * rng.standard_normal(128)).astype(np.float32), dtype)
+    ang = rng.uniform(0, 6.28, (M, 64)).astype(np.float32)
+    rot = np.stack([np.sin(ang), np.cos(ang)], axis=-1).astype(np.float32)
+    ref = O.rmsnorm_rope(y16, nq, nk, rot, dtype)
+    lo, hi = O.rmsnorm_rope_envelope(y16, nq, nk, rot, dtype)
+    assert np.all(ref >= lo) and np.all(ref <= hi)
+    qk = slice(0, 2 * H * 128)
+    step = np.abs(ref[:, qk]) * (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10) + 1e-30
+    assert (lo[:, qk] != hi[:, qk]).mean() < 0.02 and np.all(hi[:, qk] - lo[:, qk] <= 1.01 * step + 1e-6)
+    assert np.array_equal(lo[:, 2 * H * 128:], hi[:, 2 * H * 128:])  # V: untouched
