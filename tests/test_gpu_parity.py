@@ -204,6 +204,13 @@ def test_silu_epilogue(dtype):
     ref = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=la.cpu().numpy(), lora_up=L["proj_up"], fuse="silu")["out"]
     assert_close_16(f32(out), ref, dtype, "silu", max_bad_frac=2e-3, ulps=1.0)
     assert_close_16(f32(out), ref, dtype, "silu(2ulp)", ulps=2.0)
+    # inside the approximation envelope of the reference's own SiLU (ex2.approx + rcp.approx at their documented bounds) but for the elements whose 16-bit
+    # pre-activation the GPU's fp32 accumulation order rounded the other way
+    y16 = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=la.cpu().numpy(), lora_up=L["proj_up"])["out"]
+    lo, hi = O.silu_envelope(y16)
+    got = f32(out)
+    outside = ((got < O.round16(lo, dtype)[: got.shape[0]]) | (got > O.round16(hi, dtype)[: got.shape[0]])).mean()
+    assert outside < 2e-3, f"silu: {outside:.2e} of the outputs outside the approximation envelope"
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
@@ -237,6 +244,13 @@ def test_qkv_rmsnorm_rope(dtype, M, K, H):
     # with rare 1-ulp flips of the pre-norm value
     assert_close_16(got[:, 2 * N // 3:], ref[:, 2 * N // 3:], dtype, "V")
     assert_close_16(got[:, : 2 * N // 3], ref[:, : 2 * N // 3], dtype, "QK", max_bad_frac=2e-3, ulps=2.0)
+    # Q / K inside the approximation envelope of the reference's epilogue (rsqrt.approx, FMA-contraction freedom) but for rows whose pre-norm 16-bit values
+    # the GPU's fp32 accumulation order rounded the other way (one flipped element moves its whole row's coefficient)
+    y16 = O.gemm_w4a4(q, a, L["qweight"], L["wscales"], dtype=dtype, bias=L["bias"], lora_act_in=l_, lora_up=L["proj_up"])["out"]
+    lo, hi = O.rmsnorm_rope_envelope(y16, nq, nk, rot, dtype)
+    qk = slice(0, 2 * N // 3)
+    outside = ((got[:, qk] < lo[:M, qk]) | (got[:, qk] > hi[:M, qk])).mean()
+    assert outside < 2e-2, f"RMSNorm + RoPE: {outside:.2e} of the Q / K outputs outside the approximation envelope"
 
 
 @pytest.mark.parametrize("geometry", [0, 6], ids=["auto", "solo-carry"])
