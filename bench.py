@@ -240,9 +240,11 @@ def main():
     ap.add_argument("--attention-geometry", type=int, default=0, choices=[0, 1, 2],
                     help="workgroup geometry of the attention kernel (svdq_attention_args.geometry): 0 = the library's choice (4 waves x 64 "
                          "rows on the prescaled Q the QKV GEMM emits), 1 = 8 waves x 32 rows, 2 = 4 x 64 with its persistent schedule (same-box A/B)")
-    ap.add_argument("--geometry", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
+    ap.add_argument("--geometry", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7],
                     help="workgroup geometry of the W4A4 GEMM (svdq_gemm_args.geometry): 0 = the library's choice, 1 = 256x128 "
-                         "tiles / one workgroup per CU, 2 = 128x128 tiles / two per CU out of phase, 3 = 2 without the phase offset")
+                         "tiles / one workgroup per CU, 2 = 128x128 tiles / two per CU out of phase, 3 = 2 without the phase offset; "
+                         "6 / 7 = GELU_QUANT launches with a next-layer rank beyond 32 on the solo-carry kernel / with the split low-rank "
+                         "down projection (A/B of what 0 picks from rank 96), everything else as 0")
     ap.add_argument("--deterministic", action="store_true",
                     help="fixed-point low-rank accumulation (nunchaku_amd.mode): bit-reproducible steps")
     ap.add_argument("--graph", action="store_true",

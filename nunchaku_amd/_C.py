@@ -92,7 +92,7 @@ _WORKSPACE_LIMIT = 8  # per kind: LRU bound (64 MB GEMM / 33 MB attention each);
 _workspaces: "collections.OrderedDict[tuple[int, int, str], _Workspace]" = collections.OrderedDict()
 
 
-def _workspace(device: torch.device, kind: str = "gemm") -> _Workspace:
+def _workspace(device: torch.device, kind: str = "gemm", min_bytes: int = 0) -> _Workspace:
     """Scratch of the GEMM's stream-K tail (arrival counters + fp32 partial tiles) or, ``kind="attention"``, of the
     attention kernel's persistent schedule (counters + fp32 partial (O, m, l)); one per (device, STREAM, kind).
 
@@ -103,15 +103,25 @@ def _workspace(device: torch.device, kind: str = "gemm") -> _Workspace:
     from the torch caching allocator, zero-filled once; the kernels leave the counters at zero.  The cache is bounded
     (least recently used entry dropped beyond ``_WORKSPACE_LIMIT`` per kind); a launch that gave up (status word) has its
     counters cleared by ``_Workspace.check`` before the error is raised, so a later tenant of the stream handle never
-    inherits a stale count."""
+    inherits a stale count.
+
+    ``min_bytes`` (GEMM, ABI 20: ``svdq_gemm_workspace_bytes_for``): a launch that wants more than the base size -- the 16-bit output image of a
+    GELU_QUANT launch with a split low-rank down projection -- gets a larger buffer in the stream's slot; the smaller one it replaces is freed by the
+    caching allocator once the work queued on it has finished, its status word moves over.  A workspace a captured graph points at is never replaced,
+    nor is one grown during a capture (the launch then takes the path the existing size allows)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream, kind)
     ws = _workspaces.get(key)
+    if ws is not None and ws.buf.numel() < min_bytes and not ws.captured and not torch.cuda.is_current_stream_capturing():
+        with torch.cuda.device(idx):
+            buf = torch.zeros(int(min_bytes), dtype=torch.uint8, device=device)
+        ws = _Workspace(buf, ws.status)
+        _workspaces[key] = ws
     if ws is None:
         lib = _lib.load()
         size = lib.svdq_attention_workspace_bytes() if kind == "attention" else lib.svdq_gemm_workspace_bytes()
         with torch.cuda.device(idx):
-            buf = torch.zeros(int(size), dtype=torch.uint8, device=device)
+            buf = torch.zeros(max(int(size), int(min_bytes)), dtype=torch.uint8, device=device)
         ws = _Workspace(buf, _status_word())
         _workspaces[key] = ws
         # least recently used entries beyond the limit go -- except workspaces a captured graph points at
@@ -284,7 +294,7 @@ class _Ops:
             if ws.status is not None:
                 ws.status.zero_()
 
-    PLAN_VARIANTS = ("plain", "carry", "all_rank", "hybrid_carry", "solo_carry")
+    PLAN_VARIANTS = ("plain", "carry", "all_rank", "hybrid_carry", "solo_carry", "split_down")
 
     @staticmethod
     def gemm_last_plan() -> dict:
@@ -514,6 +524,12 @@ class _Ops:
             raise ValueError("gemm_w4a4: out_vt needs the RMSNorm+RoPE epilogue (rotary_emb, norm_q, norm_k)")
         if out_vt is not None and out_vt.shape[1] < a.M:
             raise ValueError("gemm_w4a4: out_vt has fewer columns than out has rows")
+        if _Ops.gemm_use_workspace and a.fuse == _lib.FUSE_GELU_QUANT and a.R2 > 32:
+            # ABI 20: a next-layer rank beyond 32 can run its low-rank down projection split, given room for the launch's 16-bit output image
+            need = int(lib.svdq_gemm_workspace_bytes_for(C.byref(a)))
+            if need > a.workspace_bytes:
+                ws = _workspace(act.device, min_bytes=need)
+                a.workspace, a.workspace_bytes = ws.buf.data_ptr(), ws.buf.numel()
         _lib.check(lib.svdq_gemm_w4a4(C.byref(a), _stream()), "gemm_w4a4")
         del keep, keep2
         if packed_qkv is not None:

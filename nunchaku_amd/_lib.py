@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 19
+ABI_VERSION = 20
 LORA_ACT_F32, LORA_ACT_Q32 = 0, 1
 
 
@@ -91,6 +91,7 @@ EXPORTS = {
     "svdq_gemv_awq_batched": (C.c_int, [C.POINTER(GemvAwqArgs), C.c_int32, C.c_void_p]),
     "svdq_residual_gate_stats": (C.c_int, [C.POINTER(ResidualArgs), C.c_void_p]),
     "svdq_gemm_workspace_bytes": (C.c_int64, []),
+    "svdq_gemm_workspace_bytes_for": (C.c_int64, [C.POINTER(GemmArgs)]),
     "svdq_gemm_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "svdq_gemm_last_plan": (C.c_int, [C.POINTER(C.c_int32)]),
     "svdq_attention_workspace_bytes": (C.c_int64, []),

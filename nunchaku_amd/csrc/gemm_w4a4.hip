@@ -146,6 +146,9 @@ struct GemmParams {
     int rowrun;              // NW = 8, GELU_QUANT: run length of the row-run schedule (GemmSchedule::init_runs; 0 = the plain schedule): the next layer's
                              // low-rank down projection accumulates in LDS over a workgroup's run of column tiles, one flush of atomics per run
     int solo_carry;          // host dispatch: GELU_QUANT with a next-layer low-rank branch of rank 48 .. 128 (fp32): 128 x 128 tiles, one workgroup per CU, the carry behind its ring
+    void *act16_packed;      // split low-rank down (template SPLIT): the GELU_QUANT epilogue writes its 16-bit output as MFMA operand fragments here (workspace, behind the
+                             // packed low-rank images) and lowrank_down_split_kernel contracts them with the next layer's down projection; the kernel itself sees R2 = 0
+    int split_R2;            // ... the next layer's rank the host kept for that kernel
     int lora_fixed;          // host dispatch (template LAQ): lora_act_in and lora_act_out hold Q31.32 fixed point (svdq_amd.h "lora_act formats")
     float lora_scales[MAX_LORA_TILES];
     SVDQ_PROBE_PARAMS
@@ -205,6 +208,140 @@ __global__ __launch_bounds__(256) void pack_lora_up_kernel(const typename Half<D
     out[((size_t)ct * units + unit) * 64 + lane] = *reinterpret_cast<const V8 *>(lu + (size_t)(ct * 32 + (lane & 31)) * R + unit * 16 + (lane >> 5) * 8);
 }
 
+// ---- split low-rank down (next-layer rank 96 .. 160 of a GELU_QUANT launch; DESIGN.md 5 "Round 5") --------------------------------------------------------------
+// The next layer's low-rank down projection D'[m][r] = sum_n g[m][n] * ld[n][r] (lora.cuh:243-353, launch_impl.cuh:226-262) is a GEMM over the WHOLE output row of
+// the launch; inside a 128-column tile every workgroup holds a 1/96 partial of it, which beyond 32 ranks neither fits an LDS carry on 256 x 128 tiles nor is cheap as
+// per-tile fp32 atomics (rank 128: as much as the rank-32 launch itself; the solo-carry kernel buys the LDS with one wave per SIMD).  Split: the epilogue stores the
+// 16-bit GELU output it already holds as MFMA A-operand fragments (one coalesced 16-byte store per lane and 16 columns -- the bytes of a default epilogue's store),
+// and this kernel streams that image once: 64 rows x all ranks per wave, K split over the four waves of a workgroup (summed through LDS in a fixed order) and over
+// `ks` workgroups (fp32 atomics, ks x M_pad x R2 of them where the tiles issued N / 128 x as many).
+//   act16:  [M_pad / 32 row tiles][N / 16 units][64 lanes][8]   lane (row & 31, h), slot j <- column 16 u + 8 (j >> 2) + 4 h + (j & 3)   (the C layout's own order)
+//   ldp:    [N / 16 units][NB rank blocks][64 lanes][8]         lane (rank & 31, h), slot j <- the same column of rank 32 b + (lane & 31); ranks >= R2: zeros
+template <int DT>
+__global__ __launch_bounds__(256) void pack_lora_down_kernel(const typename Half<DT>::T *__restrict__ ld /* rank-major [R2][N] */, typename Half<DT>::V8 *__restrict__ out,
+                                                             int N, int R2, int nb) {
+    using T = typename Half<DT>::T;
+    using V8 = typename Half<DT>::V8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 4 + wave; // (unit, block)
+    if (idx >= (N / 16) * nb) return;
+    const int unit = idx / nb, b = idx % nb, rank = b * 32 + (lane & 31), h = lane >> 5;
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = (T)0.f;
+    if (rank < R2) {
+        const T *src = ld + (size_t)rank * N + unit * 16 + h * 4;
+        const u16x4 w0 = *reinterpret_cast<const u16x4 *>(src), w1 = *reinterpret_cast<const u16x4 *>(src + 8);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[j] = hfrom<T>(w0[j]); o[4 + j] = hfrom<T>(w1[j]); }
+    }
+    out[(size_t)idx * 64 + lane] = o;
+}
+
+template <int DT, int NB>
+__global__ __launch_bounds__(256, 2) void lowrank_down_split_kernel(const typename Half<DT>::V8 *__restrict__ a16, const typename Half<DT>::V8 *__restrict__ ldp,
+                                                                     const typename Half<DT>::V8 *__restrict__ ldp2, float *__restrict__ out, int split_row,
+                                                                     int units_n, int R2, int ks) {
+    using V8 = typename Half<DT>::V8;
+    // UN units per step and wave.  The activation fragments (HBM: the long round trip) are double-buffered -- the next step's are requested before this step's
+    // MFMAs; the weight fragments (3-4 MB, L2-resident) are requested at the top of their step.  Two workgroups per CU: 2 NB x 16 accumulators + 2 x 2 UN x 4
+    // + UN x NB x 4 fragment registers per lane (232 at NB = 5); eight waves' loads in flight carry the bandwidth, the matrix pipe is ~ 20 % busy.
+    constexpr int UN = 2;
+    __shared__ v4f red[2 * NB * 4 * 64]; // one wave's accumulators: [(mi, block)][4 register quads][64 lanes]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg = blockIdx.x / ks, sl = blockIdx.x % ks; // 64-row group, K slice
+    const int per = units_n / ks;                         // (host: a multiple of 4 * UN)
+    // uniform byte pointers + ONE 32-bit lane offset: every load takes the saddr form
+    const char *pb = (const char *)(rg * 64 >= split_row ? ldp2 : ldp);
+    const char *pa0 = (const char *)a16 + (size_t)(rg * 2) * units_n * 1024, *pa1 = pa0 + (size_t)units_n * 1024;
+    const unsigned lo = (unsigned)lane * 16u;
+    v16f d[2][NB];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) d[mi][b][i] = 0.f;
+    struct AFrags { V8 a[UN][2]; };
+    auto load_a = [&](AFrags &f, int u) {
+        const char *qa0 = pa0 + (size_t)u * 1024, *qa1 = pa1 + (size_t)u * 1024;
+#pragma unroll
+        for (int k = 0; k < UN; k++) {
+            f.a[k][0] = *reinterpret_cast<const V8 *>(qa0 + k * 1024 + lo);
+            f.a[k][1] = *reinterpret_cast<const V8 *>(qa1 + k * 1024 + lo);
+        }
+    };
+    // one step: every load of the step is issued -- this step's weight fragments, then the NEXT step's activation fragments -- before the first MFMA (the
+    // scheduling barriers keep the compiler from sinking loads between the MFMAs to save registers: it would leave two loads in flight per wave)
+    auto step = [&](const AFrags &f, AFrags &next, int u, int un) {
+        const char *qb = pb + (size_t)u * (NB * 1024);
+        V8 w[UN][NB];
+#pragma unroll
+        for (int k = 0; k < UN; k++)
+#pragma unroll
+            for (int b = 0; b < NB; b++) w[k][b] = *reinterpret_cast<const V8 *>(qb + (k * NB + b) * 1024 + lo);
+        load_a(next, un);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < UN; k++)
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++) d[mi][b] = Half<DT>::mfma32(f.a[k][mi], w[k][b], d[mi][b]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int steps = per / (4 * UN); // per wave, uniform, even (host: a slice is a multiple of 16 units)
+    int u = sl * per + wave * UN;
+    AFrags x, y;
+    load_a(x, u);
+    for (int i = 0; i < steps; i += 2) {
+        const int u1 = u + 4 * UN, u2 = i + 2 < steps ? u1 + 4 * UN : u1; // (the last step requests its own fragments again: no branch around the loads)
+        step(x, y, u, u1);
+        step(y, x, u1, u2);
+        u = u2;
+    }
+    // the four waves' partial sums, added in a fixed order through LDS (wave 3 writes, 2, 1, 0 add), then a quarter of the atomics per wave
+    v4f *mine = red + lane;
+    if (wave == 3) {
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) mine[((mi * NB + b) * 4 + g) * 64] = v4f{d[mi][b][4 * g], d[mi][b][4 * g + 1], d[mi][b][4 * g + 2], d[mi][b][4 * g + 3]};
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int turn = 2; turn >= 0; turn--) {
+        if (wave == turn) {
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        v4f *slot = mine + ((mi * NB + b) * 4 + g) * 64;
+                        const v4f o = *slot;
+                        *slot = v4f{d[mi][b][4 * g] + o[0], d[mi][b][4 * g + 1] + o[1], d[mi][b][4 * g + 2] + o[2], d[mi][b][4 * g + 3] + o[3]};
+                    }
+        }
+        __syncthreads();
+    }
+    const int lr = lane & 31, h = lane >> 5;
+    for (int pr = wave; pr < 2 * NB; pr += 4) { // pair (mi, block)
+        const int mi = pr / NB, b = pr % NB;
+        if (b * 32 + lr < R2) {
+            float *dst = out + (size_t)(rg * 64 + mi * 32 + h * 4) * R2 + b * 32 + lr;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const v4f v = mine[(pr * 4 + g) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; e++) unsafeAtomicAdd(dst + (size_t)(e + 8 * g) * R2, v[e]); // register 4 g + e = row 8 g + 4 h + e of the row tile
+            }
+        }
+    }
+}
+
 template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q31.32 (deterministic mode) */,
           bool CARRY = false /* GELU_QUANT, NW = 8, fp32 lora_act_out of rank <= 32: the next layer's low-rank down projection accumulates in LDS */,
           bool RALL = false /* NW = 8, fp32 lora_act_in of rank 48 .. 160 (the r128 checkpoints, a runtime LoRA on top of rank 32): the tile's lora_up for EVERY rank is
@@ -212,8 +349,11 @@ template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q
                                rank-32 kernels of the step keep their instruction stream and register allocation to the bit */,
           bool HYB = false /* CARRY on 256 x 128 tiles with a next-layer rank beyond 32 (a runtime LoRA on fc2; rank 48 .. 80 checkpoints): the first 32 ranks go through
                               the carry, the passes behind them keep their per-tile atomics -- half (rank 48 / 64) or a quarter less of what the next loop's first
-                              wait retires behind.  (The carry of more ranks does not fit: 256 rows x 48 ranks x 4 bytes > the 42 KiB staging region.) */>
+                              wait retires behind.  (The carry of more ranks does not fit: 256 rows x 48 ranks x 4 bytes > the 42 KiB staging region.) */,
+          bool SPLIT = false /* all-rank GELU_QUANT kernel on 256 x 128 tiles whose next-layer low-rank down projection (rank 96 .. 160) runs as a kernel of its own
+                                behind it (lowrank_down_split_kernel): the epilogue stores its 16-bit GELU output as MFMA fragments instead of contracting it per tile */>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams p) {
+    static_assert(!SPLIT || (RALL && NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT), "SPLIT: the all-rank GELU_QUANT kernel on 256 x 128 tiles");
     static_assert(!CARRY || (FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ), "the low-rank-down carry: GELU_QUANT with fp32 low-rank accumulators");
     static_assert(!RALL || (!LAQ && !CARRY), "the all-rank kernels: fp32 low-rank accumulators, no carry");
     // (RALL on 128 x 128 tiles: no LDS to stage lora_up in -- both low-rank operands come as packed MFMA fragments from the workspace tail, like the solo-carry kernel's)
@@ -775,7 +915,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) nsv[ni][c] = *reinterpret_cast<const u16x4 *>(ns_base + b_off + (ni * 32 + c * 8) * 2);
-            if (p.R2 > 0 && (int)lr_e < p.R2) {
+            if (!SPLIT && p.R2 > 0 && (int)lr_e < p.R2) {
                 const char *ld_base = (const char *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
                 const unsigned ld_off = (lr_e * (unsigned)p.N + nw0 + h_e * 4) * 2u;
 #pragma unroll
@@ -1011,6 +1151,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                         acc[ni][mi][r + 1] = t[1];
                     }
 
+            if constexpr (SPLIT) {
+                // the 16-bit GELU output as the A-operand fragments of the next layer's low-rank down projection (lowrank_down_split_kernel): the lane's 8 columns
+                // {16 q + 8 (j >> 2) + 4 h + (j & 3)} of a 16-column unit are MFMA k-slots 8 h + j as they stand -- 8 coalesced 16-byte stores per wave-tile, ahead of
+                // the requantisation so that they retire under its arithmetic (vmcnt retires in order: the next loop's first wait would otherwise sit behind them)
+                V8 *a16 = (V8 *)p.act16_packed + ((size_t)(mw0 >> 5) * ((unsigned)p.N >> 4) + ((unsigned)nw0 >> 4)) * 64u + lane_e;
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            V8 gv;
+#pragma unroll
+                            for (int j = 0; j < 8; j++) gv[j] = f2h<T>(acc[ni][mi][q * 8 + j]);
+                            a16[((size_t)mi * ((unsigned)p.N >> 4) + (unsigned)(ni * 2 + q)) * 64u] = gv;
+                        }
+            }
+
             // EpilogueQuantize<false, unsigned> (gemm_w4a4.cuh:930-1043): 16-bit add of the shift,
             // fp32 divide by the next layer's smooth factor -> 16-bit, per (row, 64 columns) absmax,
             // scale = amax/15, unsigned 4-bit codes.  The wave's 64 columns are exactly one group of the
@@ -1095,7 +1253,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
             //  loop's first vmcnt wait retires in order behind them (profiles/r4_gemm_rowrun.txt), and the reducing wave still issued 32 per pass.
             //  Also tried: the atomics AHEAD of the requantisation, to retire under its ~8 k cycles of arithmetic: rank-128 fc1 486 vs 455 us, rank 32 + 16 348 vs
             //  ~297 us on that box (d, the weights and the requantiser's reciprocals live together: ~120 spill instructions per tile).)
-            if (p.R2 > 0 && !SVDQ_PROBE_OFF(4)) {
+            if (!SPLIT && p.R2 > 0 && !SVDQ_PROBE_OFF(4)) {
                 const T *ld = (const T *)(bm >= split_bm ? p.next_lora_down2 : p.next_lora_down); // rank-major [R2][N]
                 for (int t2 = 0; t2 < (CARRY && NW == 8 && !HYB ? 32 : p.R2); t2 += 32) { // (CARRY on 256 x 128 tiles: rank <= 32, one pass; HYB: the carry takes pass 0)
                     const bool to_carry = CARRY && (!HYB || t2 == 0); // block-uniform
@@ -1313,11 +1471,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
 // What the last svdq_gemm_w4a4 call of this thread launched (svdq_gemm_last_plan): tile rows (256 | 128), kernel variant, grid, stream-K groups, row-run length,
 // whether the low-rank operands were packed.  Filled by the dispatch code itself -- tests read it to assert that no rank, shape or format fell back to a slower
 // kernel than the one documented for it (include/svdq_amd.h).
-enum { PLAN_PLAIN = 0, PLAN_CARRY = 1, PLAN_ALL_RANK = 2, PLAN_HYBRID_CARRY = 3, PLAN_SOLO_CARRY = 4 };
+enum { PLAN_PLAIN = 0, PLAN_CARRY = 1, PLAN_ALL_RANK = 2, PLAN_HYBRID_CARRY = 3, PLAN_SOLO_CARRY = 4, PLAN_SPLIT_DOWN = 5 };
 static thread_local int32_t g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static void record_plan(int tile_rows, int variant, int grid, const GemmParams &p) {
     g_last_plan[0] = tile_rows; g_last_plan[1] = variant; g_last_plan[2] = grid; g_last_plan[3] = p.sk_gs; g_last_plan[4] = p.rowrun;
-    g_last_plan[5] = (p.la_packed != nullptr && (variant == PLAN_ALL_RANK || variant == PLAN_SOLO_CARRY)) ? 1 : 0;
+    g_last_plan[5] = (p.la_packed != nullptr && (variant == PLAN_ALL_RANK || variant == PLAN_SOLO_CARRY || variant == PLAN_SPLIT_DOWN)) ? 1 : 0;
     g_last_plan[6] = (p.lu_packed != nullptr && (variant == PLAN_SOLO_CARRY || (variant == PLAN_ALL_RANK && tile_rows == 128))) ? 1 : 0;
     g_last_plan[7] = p.dynamic;
 }
@@ -1339,6 +1497,18 @@ static int device_cus() {
 static long long workspace_slab_bytes() { return SK_HEADER_BYTES + 2LL * device_cus() * 256 * BN * 4; }
 // ... + the packed lora_act_in image of the all-rank kernels (LA_PACK_BYTES) behind the slabs
 static long long workspace_bytes_needed() { return workspace_slab_bytes() + LA_PACK_BYTES + LU_PACK_BYTES; }
+// ... + (ABI 20) the 16-bit image of a GELU_QUANT launch's output for the split low-rank down projection, behind everything else: M_pad * N * 2 bytes.
+// What the arguments alone decide (the workspace size is checked by the caller): GELU_QUANT, fp32 accumulators, own rank on the all-rank path (48 .. 160,
+// 16-byte aligned operands, image within its tail), next rank 48 .. 160 whose packed down projection(s) fit the lora_up tail.
+static bool split_down_shape_ok(const svdq_gemm_args *a) {
+    const int nb = (a->R2 + 31) / 32;
+    return a->fuse == SVDQ_FUSE_GELU_QUANT && a->lora_act_format == SVDQ_LORA_ACT_F32 && a->R2 > 32 && nb <= 5 && a->R > 32 && a->R <= Geo<8>::STG_LU_ALL_MAX_R &&
+           a->N % 256 == 0 /* (a K slice of the contraction is a multiple of the 16 units its four waves take in two steps) */ &&
+           a->lora_act_in && a->lora_up && (((uintptr_t)a->lora_act_in | (uintptr_t)a->lora_up | (uintptr_t)a->lora_up2) & 15) == 0 &&
+           (long long)a->M_pad * a->R * 2 <= LA_PACK_BYTES && (long long)(a->wgt2 ? 2 : 1) * a->N * nb * 32 * 2 <= LU_PACK_BYTES;
+}
+// the library's own choice (geometry 0): from next-layer rank 96 and a full round of 256 x 128 tiles (the solo-carry kernel's condition: it is what this replaces)
+static bool split_down_auto(const svdq_gemm_args *a) { return a->R2 >= 96 && (long long)(a->M_pad / 128) * (a->N / BN) >= 2LL * device_cus(); }
 
 // Stream-K heuristic.  The remainder R = tiles % slots of the last round leaves CUs idle for a whole tile time;
 // splitting those tiles along K costs every split ~2 x 128 KiB of fp32 partial traffic plus a prologue
@@ -1477,6 +1647,34 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
             const int units = p.R / 16;
             hipLaunchKernelGGL((pack_lora_act_kernel<DT>), dim3(p.M_pad / 32, (units + 3) / 4), dim3(256), 0, st, (const float *)p.lora_act_in,
                                (typename Half<DT>::V8 *)p.la_packed, p.R, units, sc);
+            if constexpr (FUSE == SVDQ_FUSE_GELU_QUANT) {
+                if (p.act16_packed) { // split low-rank down: pack the next layer's down projection(s), the GEMM with the fragment-storing epilogue, the contraction
+                    using V8 = typename Half<DT>::V8;
+                    using T = typename Half<DT>::T;
+                    const int R2 = p.split_R2, nb = (R2 + 31) / 32, units_n = p.N / 16, rgs = p.M_pad / 64;
+                    V8 *ldp = (V8 *)(p.workspace + workspace_slab_bytes() + LA_PACK_BYTES), *ldp2 = ldp + (size_t)units_n * nb * 64;
+                    const dim3 pg((units_n * nb + 3) / 4), pb(256);
+                    hipLaunchKernelGGL((pack_lora_down_kernel<DT>), pg, pb, 0, st, (const T *)p.next_lora_down, ldp, p.N, R2, nb);
+                    if (p.next_lora_down2 && p.split_row < p.M_pad) hipLaunchKernelGGL((pack_lora_down_kernel<DT>), pg, pb, 0, st, (const T *)p.next_lora_down2, ldp2, p.N, R2, nb);
+                    record_plan(G_::BM, PLAN_SPLIT_DOWN, (int)grid.x, p);
+                    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true, false, true>), grid, block, 0, st, p);
+                    // K split over workgroups: the largest divisor of N / 256 (a slice is then a multiple of the 16 units the four waves take in two steps) that
+                    // keeps the grid within two workgroups per CU -- one round, every slice streaming at once
+                    int ks = 1;
+                    for (int c = 1; c <= p.N / 256; c++)
+                        if ((p.N / 256) % c == 0 && (long long)rgs * c <= 2LL * device_cus()) ks = c;
+                    const dim3 sg(rgs * ks), sb(256);
+                    float *dst = (float *)p.lora_act_out;
+                    const V8 *a16 = (const V8 *)p.act16_packed;
+                    switch (nb) {
+                    case 2: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 2>), sg, sb, 0, st, a16, ldp, ldp2, dst, p.split_row, units_n, R2, ks); break;
+                    case 3: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 3>), sg, sb, 0, st, a16, ldp, ldp2, dst, p.split_row, units_n, R2, ks); break;
+                    case 4: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 4>), sg, sb, 0, st, a16, ldp, ldp2, dst, p.split_row, units_n, R2, ks); break;
+                    default: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 5>), sg, sb, 0, st, a16, ldp, ldp2, dst, p.split_row, units_n, R2, ks); break;
+                    }
+                    return;
+                }
+            }
             record_plan(G_::BM, PLAN_ALL_RANK, (int)grid.x, p);
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true>), grid, block, 0, st, p);
             return;
@@ -1505,6 +1703,14 @@ static void launch_fuse(GemmParams &p, int fuse, bool with_ws, hipStream_t st) {
 using namespace svdq;
 
 extern "C" int64_t svdq_gemm_workspace_bytes(void) { return workspace_bytes_needed(); }
+// ABI 20: the size with which THIS launch takes every fast path it has -- svdq_gemm_workspace_bytes(), plus the 16-bit output image of a GELU_QUANT launch whose
+// next-layer low-rank down projection can run split (M_pad * N * 2 bytes).  A smaller workspace is never an error: the launch takes the path that fits.
+extern "C" int64_t svdq_gemm_workspace_bytes_for(const svdq_gemm_args *a) {
+    if (!a) return workspace_bytes_needed();
+    if (a->M_pad <= 0 || a->N <= 0 || a->M_pad % 256 || a->N % 128 || a->R < 0 || a->R2 < 0) return workspace_bytes_needed();
+    const bool want = split_down_shape_ok(a) && (a->geometry == 7 || (a->geometry == 0 && split_down_auto(a)));
+    return workspace_bytes_needed() + (want ? (long long)a->M_pad * a->N * 2 : 0);
+}
 
 extern "C" int svdq_gemm_last_plan(int32_t *out8) {
     if (!out8) { set_error("svdq_gemm_last_plan: out is NULL"); return SVDQ_E_INVALID; }
@@ -1614,7 +1820,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         set_error("svdq_gemm_w4a4: variant and reserved must be 0 (timing experiments live in tools/ablate, not in this library)");
         return SVDQ_E_INVALID;
     }
-    if (a->geometry < 0 || a->geometry > 6) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto) .. 6"); return SVDQ_E_INVALID; }
+    if (a->geometry < 0 || a->geometry > 7) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto) .. 7"); return SVDQ_E_INVALID; }
     if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_gemm_w4a4: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
@@ -1727,6 +1933,19 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     // (measured, profiles/r5_rank_ab.txt: next rank 128: 559 us against 615 us with per-tile atomics on 256 x 128 tiles; next rank 48: 310 against 285 -- one wave
     //  per SIMD runs the VALU-bound GELU epilogue at half the issue rate, which only pays once the atomics of >= 96 ranks are what it replaces)
     p.solo_carry = solo_ok && (a->geometry == 6 || (a->geometry == 0 && a->R2 >= 96 && (long long)(a->M_pad / 128) * (a->N / BN) >= 2LL * device_cus()));
+    // ... or, with a workspace that holds the launch's 16-bit output image behind the packed operands (svdq_gemm_workspace_bytes_for), the split low-rank down
+    // projection: the all-rank kernel on 256 x 128 tiles stores fragments, lowrank_down_split_kernel contracts them (geometry 7 asks for it at any size and from
+    // next-layer rank 48: tests, A/B).  It takes the solo-carry kernel's launches: rank-128 fc1 of FLUX 380 -> ~250 us (profiles/r5_split_down_ab.txt).
+    p.act16_packed = nullptr;
+    p.split_R2 = 0;
+    if (p.la_packed && split_down_shape_ok(a) && p.workspace_bytes >= workspace_bytes_needed() + (long long)a->M_pad * a->N * 2 &&
+        (a->geometry == 7 || (a->geometry == 0 && split_down_auto(a)))) {
+        p.act16_packed = p.workspace + workspace_bytes_needed();
+        p.split_R2 = a->R2;
+        p.R2 = 0; // (the GEMM kernel neither loads nor contracts the down projection)
+        p.solo_carry = 0;
+        geo = 1;
+    } else if (geo == 7) { svdq_gemm_args b = *a; b.geometry = 0; geo = pick_geometry(&b, with_ws); }
     if (p.solo_carry) {
         geo = 3;
         // its low-rank up projection reads packed fragments of both operands when they fit the workspace tail (rank 48 .. 160, fp32, one weight set)

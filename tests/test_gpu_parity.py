@@ -253,9 +253,9 @@ def test_qkv_rmsnorm_rope(dtype, M, K, H):
     assert outside < 2e-2, f"RMSNorm + RoPE: {outside:.2e} of the Q / K outputs outside the approximation envelope"
 
 
-@pytest.mark.parametrize("geometry", [0, 6], ids=["auto", "solo-carry"])
+@pytest.mark.parametrize("geometry", [0, 6, 7], ids=["auto", "solo-carry", "split-down"])
 @pytest.mark.parametrize("r1", [32, 128], ids=["rank-32", "rank-128"])
-@pytest.mark.parametrize("r2", [16, 32, 48, 128], ids=["next-rank-16", "next-rank-32", "next-rank-48", "next-rank-128"])
+@pytest.mark.parametrize("r2", [16, 32, 48, 128, 144], ids=["next-rank-16", "next-rank-32", "next-rank-48", "next-rank-128", "next-rank-144"])
 def test_gelu_quant_next_low_rank_down_by_rank(r2, r1, geometry):
     """The GELU_QUANT epilogue's low-rank down projection for the NEXT layer at ranks on both sides of the carry kernel's limit (round 4: rank <= 32
     accumulates in the workgroup's LDS carry -- rank 16 with half the lanes idle --, rank 48 keeps the per-tile atomics over two passes of 32 ranks):
@@ -264,9 +264,14 @@ def test_gelu_quant_next_low_rank_down_by_rank(r2, r1, geometry):
     from nunchaku_amd._C import _Ops
     from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
 
-    _Ops.gemm_geometry = geometry  # 6: the 128 x 128 one-workgroup-per-CU kernel with the carry behind its ring (what rank 48 .. 128 takes at full size)
-    try:
+    _Ops.gemm_geometry = geometry  # 6: the 128 x 128 one-workgroup-per-CU kernel with the carry behind its ring; 7: the split low-rank down projection (the
+    try:                           #    all-rank kernel stores 16-bit fragments, a second kernel contracts them: what rank 96 .. 160 takes at full size)
         _gelu_quant_next_low_rank_down(r2, r1)
+        if geometry == 7:
+            from nunchaku_amd._C import ops
+
+            plan = ops.gemm_last_plan()  # own rank on the all-rank path (48 .. 160) and a next rank beyond 32: the split runs; everything else as geometry 0
+            assert (plan["variant"] == "split_down") == (r1 == 128 and r2 > 32), plan
     finally:
         _Ops.gemm_geometry = 0
 

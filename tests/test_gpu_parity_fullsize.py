@@ -137,6 +137,8 @@ def _check_plan(which, tag, R, R2, grouped, M_pad, N):
         cus = torch.cuda.get_device_properties(0).multi_processor_count
         if R2 <= 32:
             want = "carry" if (geo in (0, 1) or not ws) and plan["tile_rows"] == 256 else None
+        elif geo == 0 and ws and 96 <= R2 <= 160 and 32 < R <= 160 and N % 256 == 0 and (M_pad // 128) * (N // 128) >= 2 * cus:
+            want = "split_down"   # (ABI 20: the workspace ops.gemm_w4a4 asks for holds the launch's 16-bit output image)
         elif geo == 0 and ws and R2 >= 96 and R2 <= 128 and (M_pad // 128) * (N // 128) >= 2 * cus:
             want = "solo_carry"
         elif plan["tile_rows"] == 256 and (M_pad // 256) * (N // 128) >= 2 * cus and plan["streamk_groups"] == 0:
@@ -147,6 +149,8 @@ def _check_plan(which, tag, R, R2, grouped, M_pad, N):
             assert plan["variant"] == want, (which, tag, geo, R, R2, plan)
         if plan["variant"] == "solo_carry" and 32 < R <= 160 and not grouped and ws:  # (the packed fragments live in the workspace tail)
             assert plan["lora_act_packed"] and plan["lora_up_packed"], (tag, plan)
+        if plan["variant"] == "split_down":
+            assert plan["tile_rows"] == 256 and plan["lora_act_packed"] and not plan["lora_up_packed"], (tag, plan)
     elif 32 < R <= 160 and ws:   # the all-rank kernels (a workspace holds the packed fragments)
         if plan["tile_rows"] == 256 or not grouped:
             assert plan["variant"] == "all_rank" and plan["lora_act_packed"], (which, tag, geo, R, plan)

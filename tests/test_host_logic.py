@@ -33,3 +33,39 @@ def test_status_words_are_not_recycled_while_fresh_ones_remain(monkeypatch):
     again = _C._status_word()            # pool exhausted: the evicted word, behind a device synchronisation, zeroed
     assert again.data_ptr() == w0.data_ptr() and synced and int(again[0]) == 0
     assert _C._status_word() is None
+
+
+def test_gemm_workspace_bytes_for_the_split_low_rank_down(built_lib):
+    """ABI 20: svdq_gemm_workspace_bytes_for() adds the launch's 16-bit output image (M_pad * N * 2 bytes) exactly for the GELU_QUANT launches whose next-layer
+    low-rank down projection can run split: fp32 accumulators, own rank 48 .. 160, next rank 96 .. 160 at a full round of tiles (geometry 0) or 48 .. 160 at any
+    size (geometry 7), N a multiple of 256; every other launch gets the base size (no GPU needed: shapes and pointer alignment only)."""
+    import ctypes as C
+
+    from nunchaku_amd import _lib
+
+    lib = _lib.load()
+    base = lib.svdq_gemm_workspace_bytes()
+
+    def need(**kw):
+        a = _lib.GemmArgs()
+        a.fuse, a.M_pad, a.N, a.K, a.R, a.R2 = _lib.FUSE_GELU_QUANT, 4608, 12288, 3072, 128, 128
+        a.lora_act_in, a.lora_up = 0x1000, 0x2000  # (alignment only: never dereferenced)
+        a.lora_act_format = _lib.LORA_ACT_F32
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return lib.svdq_gemm_workspace_bytes_for(C.byref(a))
+
+    img = 4608 * 12288 * 2
+    assert need() == base + img
+    assert need(R2=160, R=144) == base + img
+    assert need(M_pad=6400, wgt2=0x3000, lora_up2=0x4000) == base + 6400 * 12288 * 2      # the grouped Qwen-Image fc1 of the reference's 1664 x 928 gate
+    assert need(R2=64) == base and need(R2=64, geometry=7) == base + img                 # below rank 96 only when asked for
+    assert need(R2=32) == base and need(R2=176) == base                                  # the carry's ranks; more than five rank blocks
+    assert need(R=32) == base and need(R=176) == base                                    # own rank off the all-rank path
+    assert need(M_pad=256, N=1024) == base and need(M_pad=256, N=1024, geometry=7) == base + 256 * 1024 * 2
+    assert need(N=12288 + 128) == base                                                   # N % 256
+    assert need(geometry=1) == base and need(geometry=6) == base                         # explicit geometries keep their kernels
+    assert need(lora_act_format=_lib.LORA_ACT_Q32) == base                               # the deterministic mode keeps its integer atomics
+    assert need(fuse=_lib.FUSE_NONE) == base
+    assert need(lora_up=0x2004) == base                                                  # unaligned operand: no all-rank kernel
+    assert lib.svdq_gemm_workspace_bytes_for(None) == base

@@ -62,6 +62,7 @@ static float *dev_f32(size_t n, float lo, float hi, bool zero) {
 
 typedef int (*gemm_fn)(const svdq_gemm_args *, void *);
 typedef int64_t (*wsb_fn)(void);
+typedef int64_t (*wsbf_fn)(const svdq_gemm_args *);
 typedef void (*clk_fn)(long long *);
 typedef const char *(*err_fn)(void);
 
@@ -133,7 +134,13 @@ int main(int argc, char **argv) {
         a.next_smooth2 = a.next_smooth; a.next_lora_down2 = a.next_lora_down; a.norm_q2 = a.norm_q; a.norm_k2 = a.norm_k;
         a.split_rows = split;
     }
-    if (use_ws) { a.workspace_bytes = wsb(); CK(hipMalloc(&a.workspace, a.workspace_bytes)); CK(hipMemset(a.workspace, 0, a.workspace_bytes)); }
+    if (use_ws) {
+        // ABI 20: room for the launch's 16-bit output image when its next-layer low-rank down projection can run split (geometry 0 from rank 96, geometry 7)
+        wsbf_fn wsbf = (wsbf_fn)dlsym(h, "svdq_gemm_workspace_bytes_for");
+        a.workspace_bytes = wsb();
+        if (wsbf) { a.geometry = 7; a.workspace_bytes = std::max<int64_t>(a.workspace_bytes, wsbf(&a)); a.geometry = 0; }
+        CK(hipMalloc(&a.workspace, a.workspace_bytes)); CK(hipMemset(a.workspace, 0, a.workspace_bytes));
+    }
     long long *clk = nullptr;
     if (set_clk) { CK(hipMalloc((void **)&clk, 4 * 512 * sizeof(long long))); }
 

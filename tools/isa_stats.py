@@ -44,6 +44,35 @@ def disassemble(lib):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def kernel_resources(lib, pattern):
+    """{mangled kernel name: {vgpr_count, agpr_count, sgpr_count, vgpr_spill_count, private_segment_fixed_size, group_segment_fixed_size}} of the
+    kernels whose name contains `pattern` (the code objects' metadata notes, llvm-readelf)"""
+    readelf = os.path.join(os.path.dirname(OBJDUMP), "llvm-readelf")
+    tmp = tempfile.mkdtemp(prefix="svdq_isa_")
+    out = {}
+    try:
+        shutil.copy(lib, os.path.join(tmp, "lib.so"))
+        subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" not in f:
+                continue
+            txt = subprocess.run([readelf, "--notes", f], cwd=tmp, check=True, capture_output=True, text=True).stdout
+            for block in txt.split("  - .agpr_count:")[1:]:
+                rec = {"agpr_count": int(block.split("\n")[0])}
+                for ln in block.split("\n")[1:]:
+                    m = re.match(r"\s+\.(\w+):\s+(\S+)", ln)
+                    if m:
+                        rec[m.group(1)] = m.group(2)
+                name = rec.get("name", "")
+                if pattern in name:
+                    out[name] = {k: int(rec[k]) for k in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "private_segment_fixed_size",
+                                                          "group_segment_fixed_size") if k in rec}
+                    out[name]["agpr_count"] = rec["agpr_count"]
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def classify(op):
     if op.startswith("v_mfma") or op.startswith("v_smfmac"):
         return "mfma"
@@ -61,14 +90,16 @@ def classify(op):
 def gemm_stats(funcs):
     out = {}
     for name, ins in funcs.items():
-        m = re.search(r"gemm_w4a4_kernelILi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+        m = re.search(r"gemm_w4a4_kernelILi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
         if not m:
             continue
-        dt, fuse, nw, laq, carry, rall, hyb = (int(x) for x in m.groups())
+        dt, fuse, nw, laq, carry, rall, hyb, split = (int(x) for x in m.groups())
         if rall:  # the rank 48 .. 160 kernels (all-rank lora_up image): keyed with carry = 2
             carry = 2
         if hyb:   # the hybrid carry kernels (next-layer rank > 32: carry for the first 32 ranks, atomics behind): carry = 3
             carry = 3
+        if split:  # the all-rank GELU_QUANT kernel that stores 16-bit fragments for the split low-rank down projection: carry = 4
+            carry = 4
         ops = [ln.split()[0] for ln in ins]
         loop = [i for i, o in enumerate(ops) if o.startswith("v_mfma_scale")]
         post = ops[loop[-1] + 1:]
@@ -90,7 +121,7 @@ def main():
     st = gemm_stats(disassemble(lib))
     for (dt, fuse, nw, laq, carry), r in sorted(st.items()):
         p = r["post_loop"]
-        print(f"{'bf16' if dt == 0 else 'fp16'} {FUSE_NAMES[fuse]:13s} NW={nw} LAQ={laq} CARRY={carry}{' (RALL)' if carry == 2 else ' (HYB)' if carry == 3 else ''}: behind the loop VALU {p.get('valu', 0):5d} MFMA {p.get('mfma', 0):3d} "
+        print(f"{'bf16' if dt == 0 else 'fp16'} {FUSE_NAMES[fuse]:13s} NW={nw} LAQ={laq} CARRY={carry}{' (RALL)' if carry == 2 else ' (HYB)' if carry == 3 else ' (SPLIT)' if carry == 4 else ''}: behind the loop VALU {p.get('valu', 0):5d} MFMA {p.get('mfma', 0):3d} "
               f"SALU {p.get('salu', 0):5d} LDS {p.get('lds', 0):4d} VMEM {p.get('vmem', 0):4d} | scratch {r['scratch']} ds_add_f32 {r['lds_atomics']} "
               f"ds_cmpst {r['lds_cas']} global_atomic {r['global_atomics']}")
     if "-v" in sys.argv:
