@@ -245,6 +245,9 @@ def main():
                          "tiles / one workgroup per CU, 2 = 128x128 tiles / two per CU out of phase, 3 = 2 without the phase offset; "
                          "6 / 7 = GELU_QUANT launches with a next-layer rank beyond 32 on the solo-carry kernel / with the split low-rank "
                          "down projection (A/B of what 0 picks from rank 96), everything else as 0")
+    ap.add_argument("--no-attention-split", action="store_true",
+                    help="A/B: keep the low-rank down projection of the attention epilogue's quantiser inside the epilogue at every rank (rank 48 .. 160 "
+                         "runs it as a contraction kernel behind the attention kernel by default)")
     ap.add_argument("--deterministic", action="store_true",
                     help="fixed-point low-rank accumulation (nunchaku_amd.mode): bit-reproducible steps")
     ap.add_argument("--graph", action="store_true",
@@ -274,6 +277,7 @@ def main():
 
     _Ops.gemm_geometry = args.geometry
     _Ops.attention_geometry = args.attention_geometry
+    _Ops.attention_split_lowrank = not args.no_attention_split
     mode.set_deterministic(args.deterministic)
     rank, local_rank, world = replica.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

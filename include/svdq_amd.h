@@ -293,7 +293,8 @@ typedef struct svdq_attention_args {
      * register layout it already holds -- so the kernel can emit that projection's quantised activation directly
      * (same arithmetic as the quantiser on the 16-bit rounded output: bit-identical codes and scales; lora_act summed
      * over the H heads with fp32 atomics).  qact != NULL enables it; out may then be NULL.  Requires L % 256 == 0,
-     * K = H*128, R a multiple of 16 <= 32, and qlora_act zeroed by the caller on this stream.
+     * K = H*128, R a multiple of 16 <= 256 (32 ranks per pass; rank 48 .. 160 with a workspace of svdq_attention_workspace_bytes_for()
+     * bytes: a contraction kernel behind the attention kernel, ABI 20), and qlora_act zeroed by the caller on this stream.
      * Rows >= qsplit_rows (a multiple of 256; 0 = off) use qsmooth2 / qlora_down2 (joint attention: text rows first). */
     void *qact;               /* FP6 image, L * (H*128) * 3/4 bytes                                 */
     void *qscales;            /* scale image, (H*128/64) * L 16-bit                                 */
@@ -334,6 +335,13 @@ int svdq_attention(const svdq_attention_args *args, void *stream);
 /* size of the persistent-schedule workspace for the current device (1023 arrival counters + 1 error word + two fp32 slabs per CU: the part a
  * contributor publishes and, for geometry 2, the part the owner of a split task parks while it runs its whole tasks) */
 int64_t svdq_attention_workspace_bytes(void);
+/* ABI 20: the workspace size with which THIS launch takes every fast path it has: svdq_attention_workspace_bytes(), plus -- fused quantiser (qact) with fp32
+ * accumulators, rank 48 .. 160 and H * 128 a multiple of 256 -- the room its low-rank down projection needs to run SPLIT: the kernel's epilogue stores the
+ * normalised 16-bit rows as MFMA operand fragments (L * H * 128 * 2 bytes) instead of contracting them in 2 .. 5 passes of atomics that all H heads aim at the same
+ * elements, and a streaming kernel behind it contracts that image with qlora_down (the kernel svdq_gemm_w4a4 uses for a GELU_QUANT launch's next layer; packed
+ * copies of qlora_down / qlora_down2 sit in front of the image).  Only shapes, ranks, formats and which pointers are given are read.  A workspace of
+ * svdq_attention_workspace_bytes() bytes is never an error: the kernel then runs its in-epilogue passes.  qlora_act differs by fp32 summation order. */
+int64_t svdq_attention_workspace_bytes_for(const svdq_attention_args *args);
 /* Synchronises `stream`, then returns SVDQ_E_HIP (and clears the flag) if a launch that used `workspace` timed out waiting
  * for partial results; SVDQ_OK otherwise.  Test / debugging aid. */
 int svdq_attention_workspace_status(void *workspace, void *stream);
@@ -347,6 +355,9 @@ int svdq_attention_schedule(int32_t L, int32_t H, int32_t cus, int32_t *out, int
  * out[2], out[3] = the main segment [j0, j1) of fully real tiles its assembly loop walks -- the remaining tiles that hold a real key run as C++ "extra"
  * tiles that continue the softmax state, tiles without a real key are skipped. */
 int svdq_attention_plan(const svdq_attention_args *args, int32_t out[4]);
+/* What the calling thread's last svdq_attention launched (ABI 20; a test / diagnostics aid): out4 = {workgroup geometry (1 | 2), workgroups of the persistent
+ * schedule (0 = plain grid), key mask on geometry 2 (0 | 1), the fused quantiser's low-rank down projection ran split (0 | 1)}. */
+int svdq_attention_last_plan(int32_t *out4);
 
 /* ------------------------------------------------------------------------------------------
  * Gated residual + LayerNorm statistics (extension; the element-wise glue between the operators of a block,

@@ -310,6 +310,15 @@ class _Ops:
     # Workgroup geometry of the attention kernel (svdq_attention_args.geometry): 0 = the library's choice, 1 = 8 waves x 32 query
     # rows, 2 = 4 waves x 64 query rows (L % 256 == 0 only; other lengths always run geometry 1)
     attention_geometry = 0
+    @staticmethod
+    def attention_last_plan() -> dict:
+        """What this thread's last ``attention`` launched (``svdq_attention_last_plan``)."""
+        out = (C.c_int32 * 4)()
+        _lib.check(_lib.load().svdq_attention_last_plan(out), "attention_last_plan")
+        return {"geometry": out[0], "persistent_groups": out[1], "masked_geometry2": bool(out[2]), "split_lowrank": bool(out[3])}
+
+    # False: the fused quantiser's low-rank down projection stays inside the attention epilogue at every rank (tests / A/B of the split path, rank 48 .. 160)
+    attention_split_lowrank = True
 
     @staticmethod
     def attention_workspace_status() -> None:
@@ -733,9 +742,13 @@ class _Ops:
             a.zero_ptr, a.zero_bytes = zero.data_ptr(), zero.numel() * zero.element_size()
         a.geometry = _Ops.attention_geometry if L % 256 == 0 else 0
         if _Ops.attention_use_workspace and L % 256 == 0:
-            ws = _workspace(q.device, "attention")
+            # (ABI 20: a fused quantiser of rank 48 .. 160 runs its low-rank down projection split when the workspace also holds its 16-bit output image)
+            need = int(lib.svdq_attention_workspace_bytes_for(C.byref(a))) if (quant is not None and _Ops.attention_split_lowrank) else 0
+            ws = _workspace(q.device, "attention", min_bytes=need)
             ws.check("attention")
             a.workspace, a.workspace_bytes = ws.buf.data_ptr(), ws.buf.numel()
+            if not _Ops.attention_split_lowrank:  # (A/B and tests: the in-epilogue passes even if an earlier launch grew the buffer)
+                a.workspace_bytes = min(a.workspace_bytes, int(lib.svdq_attention_workspace_bytes()))
             a.status = None if ws.status is None else ws.status.data_ptr()
         _lib.check(lib.svdq_attention(C.byref(a), _stream()), "attention")
 

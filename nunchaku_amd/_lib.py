@@ -95,9 +95,11 @@ EXPORTS = {
     "svdq_gemm_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "svdq_gemm_last_plan": (C.c_int, [C.POINTER(C.c_int32)]),
     "svdq_attention_workspace_bytes": (C.c_int64, []),
+    "svdq_attention_workspace_bytes_for": (C.c_int64, [C.POINTER(AttentionArgs)]),
     "svdq_attention_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "svdq_attention_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_attention_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "svdq_attention_last_plan": (C.c_int, [C.POINTER(C.c_int32)]),
     "svdq_gemm_schedule": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_gemm_schedule_ex": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "svdq_repack_qweight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

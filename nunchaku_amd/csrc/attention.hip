@@ -28,6 +28,7 @@
 // workgroup order: deterministic) and runs the epilogue.  Logical workgroup g = (blockIdx % 8) * G/8 + blockIdx / 8: the
 // workgroups of one XCD take neighbouring tasks, i.e. the same few heads, and walk their keys together.
 #include "svdq_common.h"
+#include "lowrank_split.h"
 #include <type_traits>
 
 // tools/ablate/build_attn.py builds timing variants of geometry 2's tile loop (the generator under other options) by redefining these
@@ -71,6 +72,8 @@ struct AttnParams {
     int mask_j0, mask_j1;            // geometry 2 with a key mask: the main segment [mask_j0, mask_j1) of fully real tiles (even count) the assembly loop runs
     const uint16_t *qsmooth, *qlora_down, *qsmooth2, *qlora_down2;
     int qR, qsplit_rows;
+    void *qa16;        // split low-rank down (rank 48 .. 160, fp32): the normalised 16-bit output as MFMA operand fragments [L / 32][H * 8 units][64 lanes][8]
+                       // (lowrank_split.h); the kernel then runs no low-rank pass -- lowrank_down_split_kernel contracts the image behind it
     // persistent schedule (svdq_attention_args.workspace): arrival counters + error word, then one slab per workgroup
     int *ws_flags;
     float *ws_slabs;
@@ -181,8 +184,24 @@ __device__ __forceinline__ void finish_rows(const AttnParams &p, const v16f (&o)
                 for (int i = 0; i < 16; i++) lora_act_add(p.qlora_act, at + (size_t)((i & 3) + 8 * (i >> 2)) * p.qR, dl[i], mode);
             }
         };
+        if (p.qa16) {
+            // rank 48 .. 160: the 16-bit rows as the A-operand fragments of a contraction that runs behind this kernel -- the lane's 8 channels
+            // {16 qq + 8 (j >> 2) + 4 h + (j & 3)} of unit (head, dt, qq) are k-slots 8 h + j as they stand: 8 coalesced 16-byte stores per row tile
+            // instead of 2 .. 5 passes of 8 MFMAs + 16 atomic instructions that the H heads aim at the same elements
+            V8 *a16 = (V8 *)p.qa16 + ((size_t)(q0 >> 5) * (size_t)(p.H * 8) + (size_t)head * 8) * 64 + lane;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int qq = 0; qq < 2; qq++) {
+                    V8 gv;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) gv[j] = f2h<T>(o[dt][qq * 8 + j] * inv);
+                    a16[(dt * 2 + qq) * 64] = gv;
+                }
+        } else {
         if (p.qR > 0) lowrank_pass(0);                                     // (straight-line, as in rounds 2-4: the rank-32 step runs exactly this)
         for (int rank0 = 32; rank0 < p.qR; rank0 += 32) lowrank_pass(rank0); // the slabs beyond rank 32
+        }
         uint32_t rec[12];
         T sc16[2];
 #pragma unroll
@@ -1009,6 +1028,18 @@ using namespace svdq;
 
 // header + two slabs per workgroup of the persistent schedule: the one a contributor publishes, and (geometry 2) the stash an owner parks its own part in
 extern "C" int64_t svdq_attention_workspace_bytes(void) { return ATT_WS_HEADER + 2 * (int64_t)attention_cus() * ATT_SLAB_FLOATS * 4; }
+// the fused quantiser's low-rank down projection can run split (lowrank_split.h): fp32 accumulators, rank 48 .. 160, K = H * 128 a multiple of 256
+static bool attention_split_shape_ok(const svdq_attention_args *a) {
+    return a->qact && a->qlora_act && a->qlora_down && a->qlora_act_format == SVDQ_LORA_ACT_F32 && a->L > 0 && a->L % 256 == 0 && a->H > 0 &&
+           lowrank_split_shape_ok(a->H * ATT_D, a->qR);
+}
+// ABI 20: the workspace size with which THIS launch takes every fast path: svdq_attention_workspace_bytes(), plus -- fused quantiser of rank 48 .. 160 -- the
+// packed down projection(s) and the 16-bit output image (L * H * 128 * 2 bytes) of the split low-rank down projection.  A smaller workspace is never an error.
+extern "C" int64_t svdq_attention_workspace_bytes_for(const svdq_attention_args *a) {
+    const int64_t base = svdq_attention_workspace_bytes();
+    if (!a || !attention_split_shape_ok(a)) return base;
+    return base + lowrank_split_pack_bytes(a->H * ATT_D, a->qR, a->qsmooth2 != nullptr) + (int64_t)a->L * a->H * ATT_D * 2;
+}
 
 extern "C" int svdq_attention_workspace_status(void *workspace, void *stream) {
     if (!workspace) { set_error("svdq_attention_workspace_status: workspace is NULL"); return SVDQ_E_INVALID; }
@@ -1072,6 +1103,15 @@ extern "C" int svdq_attention_plan(const svdq_attention_args *a, int32_t *out) {
     return SVDQ_OK;
 }
 
+// What the calling thread's last svdq_attention launched (svdq_attention_last_plan): {workgroup geometry, workgroups of the persistent schedule (0 = plain grid),
+// key mask on geometry 2, the fused quantiser's low-rank down projection ran split}
+static thread_local int32_t g_attn_last_plan[4] = {0, 0, 0, 0};
+extern "C" int svdq_attention_last_plan(int32_t *out4) {
+    if (!out4) { set_error("svdq_attention_last_plan: out is NULL"); return SVDQ_E_INVALID; }
+    for (int i = 0; i < 4; i++) out4[i] = g_attn_last_plan[i];
+    return SVDQ_OK;
+}
+
 extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     if (!a) { set_error("svdq_attention: args is NULL"); return SVDQ_E_INVALID; }
     if (!a->q || !a->k || !a->vt || (!a->out && !a->qact)) { set_error("svdq_attention: q, k, vt and out (or qact) are required"); return SVDQ_E_INVALID; }
@@ -1124,12 +1164,19 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.zero_vec = a->zero_ptr ? a->zero_bytes / 16 : 0;
     p.ws_flags = nullptr;
     p.ws_slabs = nullptr;
+    p.qa16 = nullptr;
+    void *split_pack = nullptr;
     SVDQ_ATTN_PROBE_FILL(p);
     if (a->workspace) {
         if (((uintptr_t)a->workspace & 15) || a->workspace_bytes < 0) { set_error("svdq_attention: workspace must be 16-byte aligned"); return SVDQ_E_INVALID; }
         if (a->workspace_bytes >= svdq_attention_workspace_bytes()) { // a smaller one is ignored (plain grid), as in svdq_gemm_w4a4
             p.ws_flags = (int *)a->workspace;
             p.ws_slabs = (float *)((uint8_t *)a->workspace + ATT_WS_HEADER);
+        }
+        // ... and behind the persistent schedule's part (ABI 20, svdq_attention_workspace_bytes_for): the split low-rank down projection of the fused quantiser
+        if (attention_split_shape_ok(a) && a->workspace_bytes >= svdq_attention_workspace_bytes_for(a)) {
+            split_pack = (uint8_t *)a->workspace + svdq_attention_workspace_bytes();
+            p.qa16 = (uint8_t *)split_pack + lowrank_split_pack_bytes(a->H * ATT_D, a->qR, a->qsmooth2 != nullptr);
         }
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1148,12 +1195,20 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     const bool mask2 = attention_masked_geometry2(a, p.mask_j0, p.mask_j1);
     const int geometry = a->kv_len0 > 0 ? (mask2 ? 2 : 1) : a->geometry ? a->geometry : (a->L % 256 == 0 && a->q_prescaled ? 2 : 1);
     const int groups = geometry == 2 && (a->geometry == 0 || mask2) ? 0 : attention_groups(p);
+    g_attn_last_plan[0] = geometry; g_attn_last_plan[1] = groups; g_attn_last_plan[2] = mask2 ? 1 : 0; g_attn_last_plan[3] = p.qa16 ? 1 : 0;
     const int prof = prof_begin(2, 4.0 * a->L * (double)a->L * a->H * ATT_D, st);
+    auto launch = [&]() {
     if (geometry == 2 && a->L % 256 == 0) { if (a->dtype == SVDQ_FP16) launch_attention64<SVDQ_FP16>(p, groups, st); else launch_attention64<SVDQ_BF16>(p, groups, st); }
     else if (groups > 0) { if (a->dtype == SVDQ_FP16) launch_attention_persistent<SVDQ_FP16>(p, groups, st); else launch_attention_persistent<SVDQ_BF16>(p, groups, st); }
     else if (a->dtype == SVDQ_FP16) { if (nw == 8) launch_attention<SVDQ_FP16, 8>(p, st); else launch_attention<SVDQ_FP16, 4>(p, st); }
     else if (nw == 8) launch_attention<SVDQ_BF16, 8>(p, st);
     else launch_attention<SVDQ_BF16, 4>(p, st);
+    };
+    if (p.qa16) { // pack the down projection(s), the attention kernel (its epilogue stores the 16-bit fragments), the contraction into qlora_act
+        const int split_row = a->qsmooth2 ? a->qsplit_rows : 0x7fffffff;
+        if (a->dtype == SVDQ_FP16) launch_lowrank_down_split<SVDQ_FP16>(p.qa16, a->qlora_down, a->qlora_down2, split_row, a->L, a->H * ATT_D, a->qR, (float *)a->qlora_act, split_pack, attention_cus(), st, launch);
+        else launch_lowrank_down_split<SVDQ_BF16>(p.qa16, a->qlora_down, a->qlora_down2, split_row, a->L, a->H * ATT_D, a->qR, (float *)a->qlora_act, split_pack, attention_cus(), st, launch);
+    } else launch();
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_attention launch");
 }

@@ -29,6 +29,7 @@
 //     and the low-rank up projection (a 16-bit MFMA issued straight onto the fp32 accumulators) are
 //     added before the single rounding to 16-bit that precedes the activation epilogues.
 #include "svdq_common.h"
+#include "lowrank_split.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -206,140 +207,6 @@ __global__ __launch_bounds__(256) void pack_lora_up_kernel(const typename Half<D
     const int unit = blockIdx.y * 4 + wave, ct = blockIdx.x;
     if (unit >= units) return;
     out[((size_t)ct * units + unit) * 64 + lane] = *reinterpret_cast<const V8 *>(lu + (size_t)(ct * 32 + (lane & 31)) * R + unit * 16 + (lane >> 5) * 8);
-}
-
-// ---- split low-rank down (next-layer rank 96 .. 160 of a GELU_QUANT launch; DESIGN.md 5 "Round 5") --------------------------------------------------------------
-// The next layer's low-rank down projection D'[m][r] = sum_n g[m][n] * ld[n][r] (lora.cuh:243-353, launch_impl.cuh:226-262) is a GEMM over the WHOLE output row of
-// the launch; inside a 128-column tile every workgroup holds a 1/96 partial of it, which beyond 32 ranks neither fits an LDS carry on 256 x 128 tiles nor is cheap as
-// per-tile fp32 atomics (rank 128: as much as the rank-32 launch itself; the solo-carry kernel buys the LDS with one wave per SIMD).  Split: the epilogue stores the
-// 16-bit GELU output it already holds as MFMA A-operand fragments (one coalesced 16-byte store per lane and 16 columns -- the bytes of a default epilogue's store),
-// and this kernel streams that image once: 64 rows x all ranks per wave, K split over the four waves of a workgroup (summed through LDS in a fixed order) and over
-// `ks` workgroups (fp32 atomics, ks x M_pad x R2 of them where the tiles issued N / 128 x as many).
-//   act16:  [M_pad / 32 row tiles][N / 16 units][64 lanes][8]   lane (row & 31, h), slot j <- column 16 u + 8 (j >> 2) + 4 h + (j & 3)   (the C layout's own order)
-//   ldp:    [N / 16 units][NB rank blocks][64 lanes][8]         lane (rank & 31, h), slot j <- the same column of rank 32 b + (lane & 31); ranks >= R2: zeros
-template <int DT>
-__global__ __launch_bounds__(256) void pack_lora_down_kernel(const typename Half<DT>::T *__restrict__ ld /* rank-major [R2][N] */, typename Half<DT>::V8 *__restrict__ out,
-                                                             int N, int R2, int nb) {
-    using T = typename Half<DT>::T;
-    using V8 = typename Half<DT>::V8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 4 + wave; // (unit, block)
-    if (idx >= (N / 16) * nb) return;
-    const int unit = idx / nb, b = idx % nb, rank = b * 32 + (lane & 31), h = lane >> 5;
-    V8 o;
-#pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = (T)0.f;
-    if (rank < R2) {
-        const T *src = ld + (size_t)rank * N + unit * 16 + h * 4;
-        const u16x4 w0 = *reinterpret_cast<const u16x4 *>(src), w1 = *reinterpret_cast<const u16x4 *>(src + 8);
-#pragma unroll
-        for (int j = 0; j < 4; j++) { o[j] = hfrom<T>(w0[j]); o[4 + j] = hfrom<T>(w1[j]); }
-    }
-    out[(size_t)idx * 64 + lane] = o;
-}
-
-template <int DT, int NB>
-__global__ __launch_bounds__(256, 2) void lowrank_down_split_kernel(const typename Half<DT>::V8 *__restrict__ a16, const typename Half<DT>::V8 *__restrict__ ldp,
-                                                                     const typename Half<DT>::V8 *__restrict__ ldp2, float *__restrict__ out, int split_row,
-                                                                     int units_n, int R2, int ks) {
-    using V8 = typename Half<DT>::V8;
-    // UN units per step and wave.  The activation fragments (HBM: the long round trip) are double-buffered -- the next step's are requested before this step's
-    // MFMAs; the weight fragments (3-4 MB, L2-resident) are requested at the top of their step.  Two workgroups per CU: 2 NB x 16 accumulators + 2 x 2 UN x 4
-    // + UN x NB x 4 fragment registers per lane (232 at NB = 5); eight waves' loads in flight carry the bandwidth, the matrix pipe is ~ 20 % busy.
-    constexpr int UN = 2;
-    __shared__ v4f red[2 * NB * 4 * 64]; // one wave's accumulators: [(mi, block)][4 register quads][64 lanes]
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rg = blockIdx.x / ks, sl = blockIdx.x % ks; // 64-row group, K slice
-    const int per = units_n / ks;                         // (host: a multiple of 4 * UN)
-    // uniform byte pointers + ONE 32-bit lane offset: every load takes the saddr form
-    const char *pb = (const char *)(rg * 64 >= split_row ? ldp2 : ldp);
-    const char *pa0 = (const char *)a16 + (size_t)(rg * 2) * units_n * 1024, *pa1 = pa0 + (size_t)units_n * 1024;
-    const unsigned lo = (unsigned)lane * 16u;
-    v16f d[2][NB];
-#pragma unroll
-    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) d[mi][b][i] = 0.f;
-    struct AFrags { V8 a[UN][2]; };
-    auto load_a = [&](AFrags &f, int u) {
-        const char *qa0 = pa0 + (size_t)u * 1024, *qa1 = pa1 + (size_t)u * 1024;
-#pragma unroll
-        for (int k = 0; k < UN; k++) {
-            f.a[k][0] = *reinterpret_cast<const V8 *>(qa0 + k * 1024 + lo);
-            f.a[k][1] = *reinterpret_cast<const V8 *>(qa1 + k * 1024 + lo);
-        }
-    };
-    // one step: every load of the step is issued -- this step's weight fragments, then the NEXT step's activation fragments -- before the first MFMA (the
-    // scheduling barriers keep the compiler from sinking loads between the MFMAs to save registers: it would leave two loads in flight per wave)
-    auto step = [&](const AFrags &f, AFrags &next, int u, int un) {
-        const char *qb = pb + (size_t)u * (NB * 1024);
-        V8 w[UN][NB];
-#pragma unroll
-        for (int k = 0; k < UN; k++)
-#pragma unroll
-            for (int b = 0; b < NB; b++) w[k][b] = *reinterpret_cast<const V8 *>(qb + (k * NB + b) * 1024 + lo);
-        load_a(next, un);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < UN; k++)
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++) d[mi][b] = Half<DT>::mfma32(f.a[k][mi], w[k][b], d[mi][b]);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    const int steps = per / (4 * UN); // per wave, uniform, even (host: a slice is a multiple of 16 units)
-    int u = sl * per + wave * UN;
-    AFrags x, y;
-    load_a(x, u);
-    for (int i = 0; i < steps; i += 2) {
-        const int u1 = u + 4 * UN, u2 = i + 2 < steps ? u1 + 4 * UN : u1; // (the last step requests its own fragments again: no branch around the loads)
-        step(x, y, u, u1);
-        step(y, x, u1, u2);
-        u = u2;
-    }
-    // the four waves' partial sums, added in a fixed order through LDS (wave 3 writes, 2, 1, 0 add), then a quarter of the atomics per wave
-    v4f *mine = red + lane;
-    if (wave == 3) {
-#pragma unroll
-        for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) mine[((mi * NB + b) * 4 + g) * 64] = v4f{d[mi][b][4 * g], d[mi][b][4 * g + 1], d[mi][b][4 * g + 2], d[mi][b][4 * g + 3]};
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int turn = 2; turn >= 0; turn--) {
-        if (wave == turn) {
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                for (int b = 0; b < NB; b++)
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        v4f *slot = mine + ((mi * NB + b) * 4 + g) * 64;
-                        const v4f o = *slot;
-                        *slot = v4f{d[mi][b][4 * g] + o[0], d[mi][b][4 * g + 1] + o[1], d[mi][b][4 * g + 2] + o[2], d[mi][b][4 * g + 3] + o[3]};
-                    }
-        }
-        __syncthreads();
-    }
-    const int lr = lane & 31, h = lane >> 5;
-    for (int pr = wave; pr < 2 * NB; pr += 4) { // pair (mi, block)
-        const int mi = pr / NB, b = pr % NB;
-        if (b * 32 + lr < R2) {
-            float *dst = out + (size_t)(rg * 64 + mi * 32 + h * 4) * R2 + b * 32 + lr;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const v4f v = mine[(pr * 4 + g) * 64];
-#pragma unroll
-                for (int e = 0; e < 4; e++) unsafeAtomicAdd(dst + (size_t)(e + 8 * g) * R2, v[e]); // register 4 g + e = row 8 g + 4 h + e of the row tile
-            }
-        }
-    }
 }
 
 template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q31.32 (deterministic mode) */,
@@ -1501,14 +1368,13 @@ static long long workspace_bytes_needed() { return workspace_slab_bytes() + LA_P
 // What the arguments alone decide (the workspace size is checked by the caller): GELU_QUANT, fp32 accumulators, own rank on the all-rank path (48 .. 160,
 // 16-byte aligned operands, image within its tail), next rank 48 .. 160 whose packed down projection(s) fit the lora_up tail.
 static bool split_down_shape_ok(const svdq_gemm_args *a) {
-    const int nb = (a->R2 + 31) / 32;
-    return a->fuse == SVDQ_FUSE_GELU_QUANT && a->lora_act_format == SVDQ_LORA_ACT_F32 && a->R2 > 32 && nb <= 5 && a->R > 32 && a->R <= Geo<8>::STG_LU_ALL_MAX_R &&
-           a->N % 256 == 0 /* (a K slice of the contraction is a multiple of the 16 units its four waves take in two steps) */ &&
-           a->lora_act_in && a->lora_up && (((uintptr_t)a->lora_act_in | (uintptr_t)a->lora_up | (uintptr_t)a->lora_up2) & 15) == 0 &&
-           (long long)a->M_pad * a->R * 2 <= LA_PACK_BYTES && (long long)(a->wgt2 ? 2 : 1) * a->N * nb * 32 * 2 <= LU_PACK_BYTES;
+    return a->fuse == SVDQ_FUSE_GELU_QUANT && a->lora_act_format == SVDQ_LORA_ACT_F32 && lowrank_split_shape_ok(a->N, a->R2) && a->R > 32 &&
+           a->R <= Geo<8>::STG_LU_ALL_MAX_R && a->lora_act_in && a->lora_up && (((uintptr_t)a->lora_act_in | (uintptr_t)a->lora_up | (uintptr_t)a->lora_up2) & 15) == 0 &&
+           (long long)a->M_pad * a->R * 2 <= LA_PACK_BYTES && lowrank_split_pack_bytes(a->N, a->R2, a->wgt2 != nullptr) <= LU_PACK_BYTES;
 }
-// the library's own choice (geometry 0): from next-layer rank 96 and a full round of 256 x 128 tiles (the solo-carry kernel's condition: it is what this replaces)
-static bool split_down_auto(const svdq_gemm_args *a) { return a->R2 >= 96 && (long long)(a->M_pad / 128) * (a->N / BN) >= 2LL * device_cus(); }
+// the library's own choice (geometry 0): every next-layer rank beyond the carry's 32, from a full round of 256 x 128 tiles (same box, profiles/r5_split_down_ab.txt:
+// next rank 48: 271 -> 258 us, 64: 296 -> 256 us against the hybrid carry; 128: 354 -> 277 us against the solo carry, 443 with per-tile atomics)
+static bool split_down_auto(const svdq_gemm_args *a) { return a->R2 > 32 && (long long)(a->M_pad / 128) * (a->N / BN) >= 2LL * device_cus(); }
 
 // Stream-K heuristic.  The remainder R = tiles % slots of the last round leaves CUs idle for a whole tile time;
 // splitting those tiles along K costs every split ~2 x 128 KiB of fp32 partial traffic plus a prologue
@@ -1649,29 +1515,10 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
                                (typename Half<DT>::V8 *)p.la_packed, p.R, units, sc);
             if constexpr (FUSE == SVDQ_FUSE_GELU_QUANT) {
                 if (p.act16_packed) { // split low-rank down: pack the next layer's down projection(s), the GEMM with the fragment-storing epilogue, the contraction
-                    using V8 = typename Half<DT>::V8;
-                    using T = typename Half<DT>::T;
-                    const int R2 = p.split_R2, nb = (R2 + 31) / 32, units_n = p.N / 16, rgs = p.M_pad / 64;
-                    V8 *ldp = (V8 *)(p.workspace + workspace_slab_bytes() + LA_PACK_BYTES), *ldp2 = ldp + (size_t)units_n * nb * 64;
-                    const dim3 pg((units_n * nb + 3) / 4), pb(256);
-                    hipLaunchKernelGGL((pack_lora_down_kernel<DT>), pg, pb, 0, st, (const T *)p.next_lora_down, ldp, p.N, R2, nb);
-                    if (p.next_lora_down2 && p.split_row < p.M_pad) hipLaunchKernelGGL((pack_lora_down_kernel<DT>), pg, pb, 0, st, (const T *)p.next_lora_down2, ldp2, p.N, R2, nb);
                     record_plan(G_::BM, PLAN_SPLIT_DOWN, (int)grid.x, p);
-                    hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true, false, true>), grid, block, 0, st, p);
-                    // K split over workgroups: the largest divisor of N / 256 (a slice is then a multiple of the 16 units the four waves take in two steps) that
-                    // keeps the grid within two workgroups per CU -- one round, every slice streaming at once
-                    int ks = 1;
-                    for (int c = 1; c <= p.N / 256; c++)
-                        if ((p.N / 256) % c == 0 && (long long)rgs * c <= 2LL * device_cus()) ks = c;
-                    const dim3 sg(rgs * ks), sb(256);
-                    float *dst = (float *)p.lora_act_out;
-                    const V8 *a16 = (const V8 *)p.act16_packed;
-                    switch (nb) {
-                    case 2: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 2>), sg, sb, 0, st, a16, ldp, ldp2, dst, p.split_row, units_n, R2, ks); break;
-                    case 3: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 3>), sg, sb, 0, st, a16, ldp, ldp2, dst, p.split_row, units_n, R2, ks); break;
-                    case 4: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 4>), sg, sb, 0, st, a16, ldp, ldp2, dst, p.split_row, units_n, R2, ks); break;
-                    default: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 5>), sg, sb, 0, st, a16, ldp, ldp2, dst, p.split_row, units_n, R2, ks); break;
-                    }
+                    launch_lowrank_down_split<DT>(p.act16_packed, p.next_lora_down, p.next_lora_down2, p.split_row, p.M_pad, p.N, p.split_R2, (float *)p.lora_act_out,
+                                                  p.workspace + workspace_slab_bytes() + LA_PACK_BYTES, device_cus(), st,
+                                                  [&]() { hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true, false, true>), grid, block, 0, st, p); });
                     return;
                 }
             }

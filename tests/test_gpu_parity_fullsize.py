@@ -137,7 +137,7 @@ def _check_plan(which, tag, R, R2, grouped, M_pad, N):
         cus = torch.cuda.get_device_properties(0).multi_processor_count
         if R2 <= 32:
             want = "carry" if (geo in (0, 1) or not ws) and plan["tile_rows"] == 256 else None
-        elif geo == 0 and ws and 96 <= R2 <= 160 and 32 < R <= 160 and N % 256 == 0 and (M_pad // 128) * (N // 128) >= 2 * cus:
+        elif geo == 0 and ws and 32 < R2 <= 160 and 32 < R <= 160 and N % 256 == 0 and (M_pad // 128) * (N // 128) >= 2 * cus:
             want = "split_down"   # (ABI 20: the workspace ops.gemm_w4a4 asks for holds the launch's 16-bit output image)
         elif geo == 0 and ws and R2 >= 96 and R2 <= 128 and (M_pad // 128) * (N // 128) >= 2 * cus:
             want = "solo_carry"

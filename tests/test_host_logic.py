@@ -37,8 +37,8 @@ def test_status_words_are_not_recycled_while_fresh_ones_remain(monkeypatch):
 
 def test_gemm_workspace_bytes_for_the_split_low_rank_down(built_lib):
     """ABI 20: svdq_gemm_workspace_bytes_for() adds the launch's 16-bit output image (M_pad * N * 2 bytes) exactly for the GELU_QUANT launches whose next-layer
-    low-rank down projection can run split: fp32 accumulators, own rank 48 .. 160, next rank 96 .. 160 at a full round of tiles (geometry 0) or 48 .. 160 at any
-    size (geometry 7), N a multiple of 256; every other launch gets the base size (no GPU needed: shapes and pointer alignment only)."""
+    low-rank down projection can run split: fp32 accumulators, own rank 48 .. 160, next rank 48 .. 160 at a full round of tiles (geometry 0) or at any size
+    (geometry 7), N a multiple of 256; every other launch gets the base size (no GPU needed: shapes and pointer alignment only)."""
     import ctypes as C
 
     from nunchaku_amd import _lib
@@ -59,7 +59,7 @@ def test_gemm_workspace_bytes_for_the_split_low_rank_down(built_lib):
     assert need() == base + img
     assert need(R2=160, R=144) == base + img
     assert need(M_pad=6400, wgt2=0x3000, lora_up2=0x4000) == base + 6400 * 12288 * 2      # the grouped Qwen-Image fc1 of the reference's 1664 x 928 gate
-    assert need(R2=64) == base and need(R2=64, geometry=7) == base + img                 # below rank 96 only when asked for
+    assert need(R2=64) == base + img and need(R2=48, R=48) == base + img                 # every next rank beyond the carry's 32 (rank 32 + a rank-16 LoRA)
     assert need(R2=32) == base and need(R2=176) == base                                  # the carry's ranks; more than five rank blocks
     assert need(R=32) == base and need(R=176) == base                                    # own rank off the all-rank path
     assert need(M_pad=256, N=1024) == base and need(M_pad=256, N=1024, geometry=7) == base + 256 * 1024 * 2
@@ -69,3 +69,34 @@ def test_gemm_workspace_bytes_for_the_split_low_rank_down(built_lib):
     assert need(fuse=_lib.FUSE_NONE) == base
     assert need(lora_up=0x2004) == base                                                  # unaligned operand: no all-rank kernel
     assert lib.svdq_gemm_workspace_bytes_for(None) == base
+
+
+def test_attention_workspace_bytes_for_the_split_low_rank_down(built_lib):
+    """ABI 20: svdq_attention_workspace_bytes_for() adds the packed down projection(s) + the 16-bit output image exactly for a fused quantiser with fp32
+    accumulators, rank 48 .. 160 and H * 128 a multiple of 256"""
+    import ctypes as C
+
+    from nunchaku_amd import _lib
+
+    lib = _lib.load()
+    base = lib.svdq_attention_workspace_bytes()
+
+    def need(**kw):
+        a = _lib.AttentionArgs()
+        a.L, a.H, a.head_dim, a.qR = 4608, 24, 128, 128
+        a.qact, a.qlora_act, a.qlora_down = 0x1000, 0x2000, 0x3000  # (which pointers are given: never dereferenced)
+        a.qlora_act_format = _lib.LORA_ACT_F32
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return lib.svdq_attention_workspace_bytes_for(C.byref(a))
+
+    K = 24 * 128
+    img, pack = 4608 * K * 2, (K // 16) * 4 * 1024
+    assert need() == base + pack + img
+    assert need(qsmooth2=0x4000) == base + 2 * pack + img                      # joint attention: two down projections
+    assert need(qR=48) == base + (K // 16) * 2 * 1024 + img and need(qR=160) == base + (K // 16) * 5 * 1024 + img
+    assert need(qR=32) == base and need(qR=176) == base and need(qR=0) == base
+    assert need(H=3) == base                                                   # K = 384: not a multiple of 256
+    assert need(qact=None) == base and need(qlora_act_format=_lib.LORA_ACT_Q32) == base
+    assert need(L=4608 + 128) == base
+    assert lib.svdq_attention_workspace_bytes_for(None) == base

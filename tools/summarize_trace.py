@@ -6,13 +6,13 @@
 import json
 import sys
 
-HEADER = """Round 5: phase stamps of workgroup 0 (probe build of the library, tools/ablate, tools/gpu/r5_gemm_trace.sh) for the four production launches of a FLUX block
-at rank 32 and at rank 128 (next-layer rank = rank), geometry 0 (the library's choice) / 1 (256 x 128 tiles) / 2 (128 x 128 queues); k cycles per segment.
-Taken BEFORE the low-rank activations were packed: at rank 128 the phase "bias + low-rank up" is 17 k cycles per 256 x 128 tile (2.5 k at rank 32 with the
-staged operands) and 16-18 k per 128 x 128 tile -- the row-per-lane fp32 loads of lora_act_in (256 KB per tile, 16 bytes used of every cache line touched,
-both column waves of a row block fetching the same rows).  With the fragments packed once per launch the bench lines of the same shapes give, on one box
-(profiles/r5_rank_ab.txt): default 129.4 -> 122.0 us, QKV 199.6 -> 182.3 us.  geo=0 at rank 128, fuse=2 is the solo-carry kernel (128 x 128 tiles, one
-workgroup per CU): its low-rank-down phase is 6.9 k cycles where the per-tile atomics of the other geometries take 32-68 k.
+HEADER = """Round 5 (final build): phase stamps of workgroup 0 (probe build of the library, tools/ablate, tools/gpu/r5_gemm_trace.sh) for the four production launches of a
+FLUX block at rank 32 and at rank 128 (next-layer rank = rank), geometry 0 (the library's choice) / 1 (256 x 128 tiles) / 2 (128 x 128 queues); k cycles per segment.
+Rank 128: lora_act_in arrives as packed 16-bit fragments (one pack launch per GEMM), lora_up staged in LDS for every rank (256 x 128) or packed too (128 x 128).
+fuse=2 (GELU_QUANT) at rank 128: geo=0 is the SPLIT low-rank down projection -- the all-rank kernel stores the 16-bit GELU output as fragments ("lowrank-down" 0.1 k
+cycles: there is none in the tile) and lowrank_down_split_kernel contracts them behind it; the launch time printed includes the pack kernels and that contraction.
+geo=1 / 2 keep the per-tile passes (hybrid carry / atomics): 30-60 k cycles per tile.  (profiles/r5_gemm_phase_trace.txt is the same trace BEFORE the fragments
+were packed: "bias + low-rank up" 17 k cycles per tile at rank 128.)
 
 """
 
