@@ -417,7 +417,7 @@ def test_workspace_status_reports_a_broken_contract():
         ops.gemm_workspace_status()
     ops.gemm_workspace_status()  # cleared by the failing call
     assert int(ws.buf.view(torch.int32)[1023]) == 0
-    assert _lib.load().svdq_gemm_workspace_bytes() == ws.buf.numel()
+    assert _lib.load().svdq_gemm_workspace_bytes() <= ws.buf.numel()  # (ABI 20: a rank > 32 GELU_QUANT launch of this process may have grown it, svdq_gemm_workspace_bytes_for)
     # the hot path's check: the kernels raise the pinned, host-visible status word; the NEXT launch on the stream raises
     # without any synchronisation and the word (and the counters) are cleared
     ws.status[0] = 1

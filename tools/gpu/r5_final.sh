@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, final build: ONE call on one box -- (1) the rocprofv3 evidence of the default bench command (kernel-trace stats; FETCH_SIZE / WRITE_SIZE / matrix-pipe
 # counters in separate --pmc passes) and the probe's phase trace, copied into profiles/ ON THE BOX so that (2) the bench lines behind them quote counters of their own
-# kernel sources (bench.py: traffic_stale / stale false), (3) smoke(), (4) every GPU test.  usage: r5_final.sh <outdir>   (the caller copies the same files into profiles/)
+# kernel sources (bench.py: traffic_stale / stale false), (3) smoke(), (4) every GPU test.  usage: r5_final.sh <outdir> [pytest -k expression instead of the whole suite]   (the caller copies the same files into profiles/)
 O=gpurun_out/$1; mkdir -p $O
 T0=$(date +%s)
 bash tools/gpu/r5_profile_bench.sh $1/prof > $O/prof.log 2>&1; tail -3 $O/prof.log | cut -c1-300
@@ -28,6 +28,9 @@ run qwen1664x928 --steps 8 --warmup 2 --prof-steps 4 --config qwen1024 --resolut
 run qwen1664x928_r128 --steps 8 --warmup 2 --prof-steps 4 --config qwen1024 --resolution 1664 928 --txt-tokens 37 --rank 128
 run dev1024_det --steps 12 --warmup 2 --prof-steps 5 --deterministic
 run schnell512 --config schnell512
+run dev1360x768 --steps 12 --warmup 2 --prof-steps 5 --resolution 1360 768
+run qwen1024 --steps 8 --warmup 2 --prof-steps 4 --config qwen1024
 echo "lines $(( $(date +%s) - T0 )) s"
-timeout 1700 python -m pytest tests -m gpu -q > $O/pytest_all.txt 2>&1; tail -4 $O/pytest_all.txt
+if [ -z "$2" ]; then timeout 1700 python -m pytest tests -m gpu -q > $O/pytest_all.txt 2>&1; tail -4 $O/pytest_all.txt
+else timeout 600 python -m pytest tests -m gpu -q -k "$2" > $O/pytest_some.txt 2>&1; tail -3 $O/pytest_some.txt; fi
 echo "all $(( $(date +%s) - T0 )) s"
