@@ -88,7 +88,8 @@ def _status_word():
     return None
 
 
-_WORKSPACE_LIMIT = 8  # per kind: LRU bound (64 MB GEMM / 33 MB attention each); pools of temporary streams recycle entries
+_WORKSPACE_LIMIT = 8  # per kind: LRU bound (88 MB GEMM / 66 MB attention each; + the 16-bit image of a split low-rank down projection once a rank > 32 launch
+#                       has asked for it: 113-157 MB GEMM / 28-39 MB attention at the FLUX / Qwen-Image shapes); pools of temporary streams recycle entries
 _workspaces: "collections.OrderedDict[tuple[int, int, str], _Workspace]" = collections.OrderedDict()
 
 

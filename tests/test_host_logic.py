@@ -100,3 +100,47 @@ def test_attention_workspace_bytes_for_the_split_low_rank_down(built_lib):
     assert need(qact=None) == base and need(qlora_act_format=_lib.LORA_ACT_Q32) == base
     assert need(L=4608 + 128) == base
     assert lib.svdq_attention_workspace_bytes_for(None) == base
+
+
+def test_workspace_grows_on_request_but_never_under_a_captured_graph(built_lib, monkeypatch):
+    """ABI 20: a stream's workspace is replaced by a larger one the first time a launch asks for more (the 16-bit image of a split low-rank down projection);
+    its status word moves over; a workspace a captured graph points at is never replaced, nor is one grown during a capture (the launch then takes the path the
+    existing size allows)."""
+    import collections
+    import contextlib
+
+    from nunchaku_amd import _C
+
+    class _Stream:
+        cuda_stream = 7
+
+    capturing = [False]
+    monkeypatch.setattr(_C, "_workspaces", collections.OrderedDict())
+    monkeypatch.setattr(_C, "_status_pool", torch.zeros(8, dtype=torch.int32))
+    monkeypatch.setattr(_C, "_status_used", 0)
+    monkeypatch.setattr(_C, "_status_free", [])
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
+    monkeypatch.setattr(torch.cuda, "device", lambda *a, **k: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing[0])
+
+    class _Fake:  # stands in for a device buffer: only its size is looked at here
+        def __init__(self, n):
+            self.n = n
+
+        def numel(self):
+            return self.n
+
+    monkeypatch.setattr(torch, "zeros", lambda n, dtype=None, device=None: _Fake(int(n)))
+    dev = torch.device("cpu")
+    base = _C._lib.load().svdq_gemm_workspace_bytes()
+    ws0 = _C._workspace(dev)
+    assert ws0.buf.numel() == base and _C._workspace(dev) is ws0 and _C._workspace(dev, min_bytes=base - 1) is ws0
+    ws1 = _C._workspace(dev, min_bytes=base + 1000)
+    assert ws1 is not ws0 and ws1.buf.numel() == base + 1000 and ws1.status is ws0.status     # replaced; the status word moved over
+    assert _C._workspace(dev) is ws1 and _C._workspace(dev, min_bytes=base + 10) is ws1       # the larger one serves every later launch of the stream
+    capturing[0] = True
+    assert _C._workspace(dev, min_bytes=base + 5000) is ws1 and ws1.captured                    # no growth during a capture ...
+    capturing[0] = False
+    assert _C._workspace(dev, min_bytes=base + 5000) is ws1                                     # ... nor afterwards: a captured graph points at it
+    assert len(_C._workspaces) == 1
