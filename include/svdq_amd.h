@@ -193,7 +193,7 @@ typedef struct svdq_gemm_args {
      * 48 .. 128 at two or more tiles per CU; 6 asks for it at any size -- tests), every other launch as with 0; 7 (ABI 20) = GELU_QUANT launches with a
      * next-layer low-rank branch of rank 48 .. 160 run it SPLIT (256 x 128 tiles whose epilogue stores the 16-bit GELU output as MFMA fragments into the
      * workspace, a second kernel contracts them with next_lora_down; needs a workspace of svdq_gemm_workspace_bytes_for() bytes and R in 48 .. 160; what
-     * geometry 0 picks from next-layer rank 96 at a full round of tiles; 7 asks for it at any size), every other launch as with 0.  Results are bit-identical
+     * geometry 0 picks for those ranks from a full round of tiles; 7 asks for it at any size), every other launch as with 0.  Results are bit-identical
      * across geometries for launches without a stream-K split (the split points, hence the fp32 summation order of a split tile, differ); lora_act_out
      * differs by fp32 summation order between all of them (atomics). */
     int32_t geometry;
@@ -230,7 +230,7 @@ int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
  * ABI 18 size) such launches take the plain kernels' rank > 32 path: same results, a memory round trip per 16 ranks in every tile's epilogue. */
 int64_t svdq_gemm_workspace_bytes(void);
 /* ABI 20: the workspace size with which THIS launch takes every fast path it has: svdq_gemm_workspace_bytes(), plus M_pad * N * 2 bytes for a GELU_QUANT
- * launch whose next-layer low-rank down projection can run split (geometry 7 above; geometry 0 from next-layer rank 96).  Only shapes, ranks, fuse, geometry,
+ * launch whose next-layer low-rank down projection can run split (geometry 7 above; geometry 0 for next-layer ranks 48 .. 160 from a full round of tiles).  Only shapes, ranks, fuse, geometry,
  * lora_act_format and the operand pointers' alignment are read.  A workspace of svdq_gemm_workspace_bytes() bytes is never an error: such a launch then runs
  * the solo-carry / hybrid-carry kernels. */
 int64_t svdq_gemm_workspace_bytes_for(const svdq_gemm_args *args);
@@ -238,8 +238,8 @@ int64_t svdq_gemm_workspace_bytes_for(const svdq_gemm_args *args);
  * grid, stream-K groups (0 = whole tiles), row-run length (0 = plain schedule), lora_act_in packed (0 | 1), lora_up packed (0 | 1), dynamic tile queue (0 | 1)}.
  * Variants: 0 plain (rank <= 32 staged / any rank through the fallback loads; GELU_QUANT: per-tile atomics), 1 low-rank-down carry (GELU_QUANT, next rank <= 32),
  * 2 all-rank (rank 48 .. 160: packed lora_act_in; 256-row tiles: lora_up staged in LDS, 128-row tiles: lora_up packed too), 3 hybrid carry (GELU_QUANT, next rank
- * 48 .. 80 -- or any next rank > 32 the solo kernel does not take), 4 solo carry (GELU_QUANT, next rank >= 96: 128 x 128 tiles, one workgroup per CU),
- * 5 split low-rank down (ABI 20: GELU_QUANT, next rank 96 .. 160 with a workspace of svdq_gemm_workspace_bytes_for() bytes: all-rank kernel on 256-row tiles
+ * 48 .. 80 -- or any next rank > 32 the solo kernel does not take; behind variant 5), 4 solo carry (GELU_QUANT, next rank >= 96: 128 x 128 tiles, one workgroup per CU; behind variant 5),
+ * 5 split low-rank down (ABI 20: GELU_QUANT, next rank 48 .. 160 with a workspace of svdq_gemm_workspace_bytes_for() bytes: all-rank kernel on 256-row tiles
  * + lowrank_down_split_kernel). */
 #define SVDQ_PLAN_PLAIN 0
 #define SVDQ_PLAN_CARRY 1
