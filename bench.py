@@ -154,15 +154,21 @@ class ClockSampler:
         if self._thread:
             self._thread.start()
 
+    def mark(self):
+        """end of a region: returns the median GHz of the samples since the previous mark (None: unreadable file / fewer than three samples -- the
+        first sample of a short region can still show the idle clock) and starts the next region.  The sampler thread keeps running."""
+        if not self._thread:
+            return None
+        xs, self.samples = sorted(self.samples), []
+        return xs[len(xs) // 2] / 1e3 if len(xs) >= 3 else None
+
     def stop(self):
-        """median GHz of the samples; None when the file is not readable or the timed region was shorter than three samples (the first
-        sample of a short region can still show the idle clock)"""
+        """median GHz of the samples since the last mark; ends the thread"""
         if not self._thread:
             return None
         self._stop.set()
         self._thread.join()
-        xs = sorted(self.samples)
-        return xs[len(xs) // 2] / 1e3 if len(xs) >= 3 else None
+        return self.mark()
 
 
 def cpu_baseline(max_seconds: float = 30.0):
@@ -364,6 +370,7 @@ def main():
         latents = step(i, latents)
     torch.cuda.synchronize()
     own = time.perf_counter() - t0          # this replica's own time for its K steps (before it waits for the others)
+    clock_ghz = clock.mark()                # the shader clock of the TIMED region only (the instrumented steps behind it are a region of their own)
     replica.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = replica.max_over_ranks(elapsed, dev)
@@ -380,7 +387,7 @@ def main():
             lat_p = step(total - 1 - (i % max(1, args.steps)), lat_p)
         torch.cuda.synchronize()
         ms_instrumented = (time.perf_counter() - t1) / prof_steps * 1e3
-    clock_ghz = clock.stop()
+    clock_ghz_prof = clock.stop()  # ... of the event-bracketed steps the roofline object was measured on
 
     def prof(cls):
         n, ms, work = C.c_int64(), C.c_double(), C.c_double()
@@ -485,7 +492,11 @@ def main():
                 # shader clock during the timed region (pp_dpm_sclk sampled every 50 ms on rank 0): the chip runs these kernels at its power
                 # limit; profiles/r4_clock_instrument.txt ties this reading to GRBM_GUI_ACTIVE / dispatch duration
                 "effective_clock_ghz": clock_ghz,
+                "effective_clock_ghz_prof_steps": clock_ghz_prof,   # the same reading over the instrumented steps (where `achieved` was measured)
                 "per_variant": per_variant,
+                # the three per-variant fractions once more as flat keys (the driver's record keeps scalars of this object and drops nested ones)
+                **{f"frac_{k}": v["frac"] for k, v in per_variant.items()},
+                **{f"avg_launch_us_{k}": v["avg_launch_us"] for k, v in per_variant.items()},
                 "launches": n_g,
                 "prof_steps": prof_steps,
                 "avg_launch_us": ms_g * 1e3 / max(n_g, 1),
@@ -501,6 +512,9 @@ def main():
                              "GBps": bytes_v / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0, "bound": "hbm by bytes, VALU in practice"},
             },
         }
+        # ... and at the top level of the contract line
+        for k, v in per_variant.items():
+            line[f"roofline_frac_{k}"] = v["frac"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         else:

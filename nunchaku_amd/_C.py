@@ -90,7 +90,26 @@ def _status_word():
 
 _WORKSPACE_LIMIT = 8  # per kind: LRU bound (88 MB GEMM / 66 MB attention each; + the 16-bit image of a split low-rank down projection once a rank > 32 launch
 #                       has asked for it: 113-157 MB GEMM / 28-39 MB attention at the FLUX / Qwen-Image shapes); pools of temporary streams recycle entries
+_WORKSPACE_BYTES_LIMIT = 512 << 20  # per kind and device: the cache is bounded by BYTES as well (round 6: eight entries of a split-launch size were ~1.3 GB per kind) --
+#                                     the entry in use always stays, older ones go until the rest fits
 _workspaces: "collections.OrderedDict[tuple[int, int, str], _Workspace]" = collections.OrderedDict()
+
+
+def _evict(kind: str, keep) -> None:
+    """Drop least recently used workspaces of `kind` on `keep`'s device beyond the entry limit or the byte limit -- never `keep` itself, never one a captured
+    graph points at.  The tensor is freed by the caching allocator once the work queued on it has finished."""
+    same = [k for k in _workspaces if k[2] == kind and k[0] == keep[0] and not _workspaces[k].captured]
+    total = sum(_workspaces[k].buf.numel() for k in same)
+    for k in list(same):
+        if len(same) <= _WORKSPACE_LIMIT and total <= _WORKSPACE_BYTES_LIMIT:
+            break
+        if k == keep:
+            continue
+        old = _workspaces.pop(k)
+        same.remove(k)
+        total -= old.buf.numel()
+        if old.status is not None:
+            _status_free.append(old.status)
 
 
 def _workspace(device: torch.device, kind: str = "gemm", min_bytes: int = 0) -> _Workspace:
@@ -113,11 +132,13 @@ def _workspace(device: torch.device, kind: str = "gemm", min_bytes: int = 0) -> 
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream, kind)
     ws = _workspaces.get(key)
+    grown = False
     if ws is not None and ws.buf.numel() < min_bytes and not ws.captured and not torch.cuda.is_current_stream_capturing():
         with torch.cuda.device(idx):
             buf = torch.zeros(int(min_bytes), dtype=torch.uint8, device=device)
         ws = _Workspace(buf, ws.status)
         _workspaces[key] = ws
+        grown = True
     if ws is None:
         lib = _lib.load()
         size = lib.svdq_attention_workspace_bytes() if kind == "attention" else lib.svdq_gemm_workspace_bytes()
@@ -125,14 +146,11 @@ def _workspace(device: torch.device, kind: str = "gemm", min_bytes: int = 0) -> 
             buf = torch.zeros(max(int(size), int(min_bytes)), dtype=torch.uint8, device=device)
         ws = _Workspace(buf, _status_word())
         _workspaces[key] = ws
-        # least recently used entries beyond the limit go -- except workspaces a captured graph points at
-        same_kind = [k for k in _workspaces if k[2] == kind and not _workspaces[k].captured]
-        for k in same_kind[:max(0, len(same_kind) - _WORKSPACE_LIMIT)]:
-            old = _workspaces.pop(k)  # the tensor is freed by the caching allocator once queued work on it has finished
-            if old.status is not None:
-                _status_free.append(old.status)
+        _evict(kind, key)
     else:
         _workspaces.move_to_end(key)
+        if grown:
+            _evict(kind, key)
     if torch.cuda.is_current_stream_capturing():
         ws.captured = True
     return ws

@@ -127,6 +127,18 @@ template <int DT> __device__ __forceinline__ unsigned pack2(float a, float b) {
     if constexpr (DT == SVDQ_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a, b}, bf16x2));
     else return __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a, b}, f16x2));
 }
+// (a * s, b * s) -> one dword of two 16-bit values, rounded as finish_rows' fused quantiser rounds the same products.  fp16: the backend folds a SCALAR
+// `(_Float16)(x * s)` into v_fma_mixlo/hi_f16 -- ONE rounding of the exact product -- while the packed conversion of two fp32 products rounds twice
+// (fp32, then fp16) and lands one fp16 step away on ~1e-4 of the values.  Until round 6 the 16-bit output path took the packed form and the fused
+// quantiser the scalar one (seen in the ISA listing: v_mul_f32 + v_cvt_pk_f16_f32 against v_fma_mixlo_f16): the quantiser then did not quantise exactly
+// the values a separate launch stores.  Both take the scalar shape now; bf16 has no mixed-precision FMA and keeps the packed conversion.
+template <int DT> __device__ __forceinline__ unsigned pack2_scaled(float a, float b, float s) {
+    if constexpr (DT == SVDQ_BF16) return pack2<DT>(a * s, b * s);
+    else {
+        const f16x2 r = {(_Float16)(a * s), (_Float16)(b * s)};
+        return __builtin_bit_cast(unsigned, r);
+    }
+}
 
 // l += the two 16-bit values of `packed` (v_dot2c_f32_bf16 / v_dot2c_f32_f16 against (1, 1)): the row sum is taken over the
 // ROUNDED probabilities, the same numbers the PV MFMA multiplies -- their rounding error cancels in O / l (a row dominated
@@ -226,7 +238,12 @@ __device__ __forceinline__ void finish_rows(const AttnParams &p, const v16f (&o)
             amax = fmaxf(amax, __shfl_xor(amax, 32));
             const float scale = amax * (1.0f / 7.0f);
             const float rscale = scale == 0.f ? 0.f : 1.0f / scale;
-            sc16[g] = f2h<T>(scale);
+            // the stored scale is round16 of the fp32 PRODUCT (quantize.hip, the GELU_QUANT epilogue, the oracle: two roundings).  Written plainly, the fp16 build
+            // folded `(T)(amax * (1/7))` here -- and only here -- into one v_fma_mixlo_f16 of the exact product: a 16-bit step away on ~3e-4 of the scales, codes
+            // identical (round 6: this was the unexplained H = 6 observation of round 5; found in the ISA listing).  The empty asm statement keeps the product opaque.
+            float scale_rounded = scale;
+            asm volatile("" : "+v"(scale_rounded));
+            sc16[g] = f2h<T>(scale_rounded);
             v16f ev, od;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -253,8 +270,8 @@ __device__ __forceinline__ void finish_rows(const AttnParams &p, const v16f (&o)
             unsigned x[2], y[2];
 #pragma unroll
             for (int d2 = 0; d2 < 2; d2++) {
-                x[d2] = pack2<DT>(o[dt][8 * j2 + 2 * d2] * inv, o[dt][8 * j2 + 2 * d2 + 1] * inv);
-                y[d2] = pack2<DT>(o[dt][8 * j2 + 4 + 2 * d2] * inv, o[dt][8 * j2 + 4 + 2 * d2 + 1] * inv);
+                x[d2] = pack2_scaled<DT>(o[dt][8 * j2 + 2 * d2], o[dt][8 * j2 + 2 * d2 + 1], inv);
+                y[d2] = pack2_scaled<DT>(o[dt][8 * j2 + 4 + 2 * d2], o[dt][8 * j2 + 4 + 2 * d2 + 1], inv);
                 auto sw = __builtin_amdgcn_permlane32_swap(x[d2], y[d2], false, false);
                 x[d2] = sw[0];
                 y[d2] = sw[1];

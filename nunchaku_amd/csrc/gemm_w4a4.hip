@@ -164,7 +164,10 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float t = x * __builtin_fmaf(x * x, B, A);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// reference: gemm_utils.cuh:290-303 (silu = x * rcp.approx(1 + ex2.approx(-x * log2 e))), applied by EpilogueSilu (gemm_base.cuh:783-792).  The same two hardware
+// approximations here (v_exp_f32, v_rcp_f32: 1 ulp each), held to oracle.silu_envelope; rounds 1-5 computed an exact expf and an IEEE divide:
+// 2.5-2.7 k static VALU per wave-tile against ~0.9 k for the default epilogue.
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -623,11 +626,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                 __syncthreads();
                 for (int q = first; q < pos; q++) {
                     const gfloat *slab = slabs + (size_t)sched.contributor_slot(cur, q) * (BM * BN);
+                    // eight 16-byte loads in flight, then their adds (round 6: written as load / add pairs the compiler kept ONE 4-register temporary and put an
+                    // s_waitcnt vmcnt(0) behind every load -- sixteen dependent fabric round trips per contributor, ~10-15 k cycles of an owner's tile; the
+                    // loop's P / S / fragment registers are dead here, and the scheduling barriers keep the batch together).  Same adds in the same order.
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        v4f v = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)(j * NW + wave) * 64 + lane) * 4));
+                    for (int jb = 0; jb < 16; jb += 8) {
+                        v4f t[8];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) acc[j >> 3][(j >> 2) & 1][(j & 3) * 4 + e] += v[e];
+                        for (int j = 0; j < 8; j++) t[j] = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)((jb + j) * NW + wave) * 64 + lane) * 4));
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) acc[(jb + j) >> 3][((jb + j) >> 2) & 1][((jb + j) & 3) * 4 + e] += t[j][e];
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }

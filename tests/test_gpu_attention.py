@@ -418,6 +418,7 @@ def _fused_output_quantiser(dtype, joint, R, H, L, K):
     Lb = O.make_svdq_layer(K, 128, R, seed=2, dtype=dtype, cheap=True)
     la, lb = make_module(La, dtype), make_module(Lb, dtype)
     o = attention_packed(qkv, vt, H)
+    assert torch.equal(o, attention_packed(qkv, vt, H)), "two svdq_attention launches on identical inputs differ"  # (persistent schedule: partials merged in a fixed order)
     if joint:
         got = attention_packed_quantized(qkv, vt, H, lb, lin_first=la, split_rows=256)
         parts = [la.quantize(o[:256]), lb.quantize(o[256:])]
@@ -430,16 +431,14 @@ def _fused_output_quantiser(dtype, joint, R, H, L, K):
         ref_codes, ref_scales, ref_la = layout.unpack_act(p[0], K), layout.unpack_scales(p[1], L), p[2]
     assert got is not None
     assert torch.equal(layout.unpack_act(got[0], K), ref_codes)
+    # bit equality at every H, rank and dtype.  (Round 5 held H = 6 to "<= 1e-3 of the scales, one step": 2 of 6144 fp16 scales differed.  Round 6 found the cause
+    # in the ISA listing: the fp16 build folded the attention epilogue's `(T)(amax * (1/7))` into ONE v_fma_mixlo_f16 -- a single rounding of the exact product --
+    # while the stand-alone quantiser (and the oracle, and the reference: gemm_w4a4.cuh:429-523) round the fp32 product and then convert; the two disagree by a
+    # 16-bit step on ~3e-4 of the scales and never on a code.  No schedule, merge order or race was involved: two launches on identical inputs are bit-equal
+    # (asserted above).  attention.hip now keeps the product opaque before the conversion.)
     gs = layout.unpack_scales(got[1], L)
     bad = (gs != ref_scales).nonzero()
-    if H == 2:
-        assert bad.numel() == 0, f"{bad.shape[0]} scales differ; first (group, row): {bad[:8].tolist()}"
-    else:
-        # H = 6 (fp16, joint, the 4 x 64 geometry on its persistent schedule; with the in-epilogue passes and with the split alike): 2 of 6144 scales come out one
-        # 16-bit step from the stand-alone quantiser's on the separately launched attention output, codes identical -- the reference path here is a second
-        # attention launch, and one step of one value of a group moves that group's absmax; held to: <= 1e-3 of the scales, one step each
-        step = (gs.view(torch.int16).int() - ref_scales.view(torch.int16).int()).abs()
-        assert bad.shape[0] <= 1e-3 * gs.numel() and int(step.max()) <= 1, f"{bad.shape[0]} scales differ by up to {int(step.max())} steps: {bad[:8].tolist()}"
+    assert bad.numel() == 0, f"{bad.shape[0]} scales differ; first (group, row): {bad[:8].tolist()}"
     assert (got[2] - ref_la).abs().max() <= 2e-3 * ref_la.abs().max() + 1e-5
 
 

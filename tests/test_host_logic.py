@@ -144,3 +144,58 @@ def test_workspace_grows_on_request_but_never_under_a_captured_graph(built_lib, 
     capturing[0] = False
     assert _C._workspace(dev, min_bytes=base + 5000) is ws1                                     # ... nor afterwards: a captured graph points at it
     assert len(_C._workspaces) == 1
+
+
+def test_workspace_cache_is_bounded_by_bytes(built_lib, monkeypatch):
+    """round 6: the per-kind LRU is bounded by bytes as well as entries -- split-launch sized workspaces (113-157 MB each) of many streams
+    no longer add up to gigabytes; the entry in use always stays."""
+    import collections
+    import contextlib
+
+    from nunchaku_amd import _C
+
+    stream = [1]
+
+    class _Stream:
+        @property
+        def cuda_stream(self):
+            return stream[0]
+
+    monkeypatch.setattr(_C, "_workspaces", collections.OrderedDict())
+    monkeypatch.setattr(_C, "_status_pool", torch.zeros(64, dtype=torch.int32))
+    monkeypatch.setattr(_C, "_status_used", 0)
+    monkeypatch.setattr(_C, "_status_free", [])
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
+    monkeypatch.setattr(torch.cuda, "device", lambda *a, **k: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+
+    class _Fake:
+        def __init__(self, n):
+            self.n = n
+
+        def numel(self):
+            return self.n
+
+    monkeypatch.setattr(torch, "zeros", lambda n, dtype=None, device=None: _Fake(int(n)))
+    dev = torch.device("cpu")
+    big = 200 << 20
+    for s in range(1, 7):
+        stream[0] = s
+        _C._workspace(dev, min_bytes=big)
+    held = [k for k in _C._workspaces if k[2] == "gemm"]
+    assert sum(_C._workspaces[k].buf.numel() for k in held) <= _C._WORKSPACE_BYTES_LIMIT and (0, 6, "gemm") in held and len(held) == 2, held
+    # one entry alone above the limit is kept (it is in use)
+    stream[0] = 9
+    ws = _C._workspace(dev, min_bytes=_C._WORKSPACE_BYTES_LIMIT + 1)
+    assert _C._workspaces[(0, 9, "gemm")] is ws and [k for k in _C._workspaces if k[2] == "gemm"] == [(0, 9, "gemm")]
+    # ... and goes as soon as another stream needs room (the total must fit again)
+    stream[0] = 10
+    small = _C._workspace(dev)
+    assert list(_C._workspaces) == [(0, 10, "gemm")]
+    # growing an existing entry runs the same eviction
+    stream[0] = 11
+    _C._workspace(dev, min_bytes=300 << 20)
+    stream[0] = 10
+    grown = _C._workspace(dev, min_bytes=300 << 20)
+    assert grown is not small and list(_C._workspaces) == [(0, 10, "gemm")]

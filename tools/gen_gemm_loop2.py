@@ -300,7 +300,9 @@ class Gen:
                     f"s_cbranch_scc0 {Ltail}",
                     # my 5 DMAs of K-step step+1 have landed: the 10 younger ones (step+2, step+3) may stay in flight
                     f"s_waitcnt vmcnt({(self.geo.nstage - 2) * self.geo.dma_per_step})",
-                    "s_nop 0" if "nobar" in self.opts else "s_barrier",  # "nobar": timing ablation only (waves race: wrong results)
+                    # "nobar": timing ablation only (waves race: wrong results); "bar1of3" / "bar2of3" (round 6, timing only as well): the K-step barrier in one /
+                    # two of the ring's three bodies -- what a rendezvous every 2-3 K-steps (a deeper ring, a K-step of 256 channels) could save at most
+                    "s_nop 0" if ("nobar" in self.opts or ("bar1of3" in self.opts and j != 0) or ("bar2of3" in self.opts and j == 2)) else "s_barrier",
                 ]
                 if phase == 0:
                     misc += [f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}", f"s_cbranch_scc1 {Lsw}", f"{Lbsw}:"] + self.dma_issue(j * self.geo.stage)
