@@ -313,7 +313,7 @@ class _Ops:
             if ws.status is not None:
                 ws.status.zero_()
 
-    PLAN_VARIANTS = ("plain", "carry", "all_rank", "hybrid_carry", "solo_carry", "split_down")
+    PLAN_VARIANTS = ("plain", "carry", "all_rank", "hybrid_carry", "solo_carry", "split_down", "wave_tile_128")
 
     @staticmethod
     def gemm_last_plan() -> dict:

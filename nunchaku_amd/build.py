@@ -6,7 +6,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libsvdq_amd.so")
 SOURCES = ["repack.hip", "quantize.hip", "gemm_w4a4.hip", "attention.hip", "gemv_awq.hip", "residual.hip"]
-HEADERS = ["svdq_common.h", "lowrank_split.h", "attention_loop64_bf16.inc", "attention_loop64_fp16.inc", "gemm_loop2_bf16.inc", "gemm_loop2_fp16.inc", "gemm_loop2_w4_bf16.inc", "gemm_loop2_w4_fp16.inc", os.path.join("..", "..", "include", "svdq_amd.h")]
+HEADERS = ["svdq_common.h", "lowrank_split.h", "attention_loop64_bf16.inc", "attention_loop64_fp16.inc", "gemm_loop2_bf16.inc", "gemm_loop2_fp16.inc", "gemm_loop2_w4_bf16.inc", "gemm_loop2_w4_fp16.inc", "gemm_loop3_bf16.inc", "gemm_loop3_fp16.inc", "gemm_epi3_bf16.inc", "gemm_epi3_fp16.inc", os.path.join("..", "..", "include", "svdq_amd.h")]
 # -ffp-contract=off: the quantiser's arithmetic is specified operation by operation;
 # the hot loop uses explicit fma.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]

@@ -135,8 +135,11 @@ template <int DT> __device__ __forceinline__ unsigned pack2(float a, float b) {
 template <int DT> __device__ __forceinline__ unsigned pack2_scaled(float a, float b, float s) {
     if constexpr (DT == SVDQ_BF16) return pack2<DT>(a * s, b * s);
     else {
-        const f16x2 r = {(_Float16)(a * s), (_Float16)(b * s)};
-        return __builtin_bit_cast(unsigned, r);
+        // (written as two scalar conversions the optimiser re-vectorises them into v_mul_f32 x 2 + v_cvt_pk_f16_f32 -- the double rounding again: the two
+        //  mixed-precision FMAs are spelled out)
+        unsigned r;
+        asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(r) : "v"(a), "v"(b), "v"(s));
+        return r;
     }
 }
 

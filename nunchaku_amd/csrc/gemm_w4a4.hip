@@ -47,6 +47,10 @@
 #define SVDQ_PROBE_FILL(p)
 #define SVDQ_PROBE_GRID(g, tiles, slots) (g)
 #define SVDQ_PROBE_OFF(bit) false
+#define SVDQ_PROBE_WT_MID_ASM
+#define SVDQ_PROBE_WT_MID_OUT
+#define SVDQ_PROBE_WT_MID_DECL
+#define SVDQ_PROBE_WT_MID_STAMP()
 #endif
 
 // generated main loops (tools/gen_gemm_loop2.py); the probe build substitutes option variants
@@ -61,6 +65,12 @@
 #endif
 #ifndef SVDQ_LOOP_INC_4_FP16
 #define SVDQ_LOOP_INC_4_FP16 "gemm_loop2_w4_fp16.inc"
+#endif
+#ifndef SVDQ_LOOP3_INC_BF16   // the 128 x 64 wave tile kernel: main loop and plain epilogue (tools/gen_gemm_loop3.py)
+#define SVDQ_LOOP3_INC_BF16 "gemm_loop3_bf16.inc"
+#define SVDQ_LOOP3_INC_FP16 "gemm_loop3_fp16.inc"
+#define SVDQ_EPI3_INC_BF16 "gemm_epi3_bf16.inc"
+#define SVDQ_EPI3_INC_FP16 "gemm_epi3_fp16.inc"
 #endif
 
 namespace svdq {
@@ -1347,10 +1357,295 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
 }
 
 
+// ---- the 128 x 64 wave tile, ONE wave per SIMD (round 6; geometry 8; the plain epilogue: bias + low-rank up + store) ---------------------------------------------------
+// Same workgroup tile (256 x 128), operand images, stage image, persistent schedule, stream-K split and arithmetic as the 8-wave kernel above -- bit-identical
+// outputs -- but FOUR waves (2 along M x 2 along N) of 4 x 2 MFMA tiles each: 128 accumulators + the P / S buffers in the 256 architectural VGPRs, fragments and
+// scale tuples in 120 AGPRs (MFMA operands and LDS-read destinations only), 332 registers per wave.  What it buys (tools/ablate/gemm128_probe, profiles/
+// r6_gemm_wave_tile_probe.txt, same box, bit-exact against this file's 8-wave kernel): 3/4 of the fragment bytes read from LDS per MAC, half the waves at the
+// K-step rendezvous, and a chip that is no longer at its power limit at the same cycles per tile-group -- 114 cycles per 32 x 32 x 64 tile-group and SIMD at
+// 2.2-2.3 GHz against ~126 at 2.0-2.2: the K = 3072 default launch 49.3 us against 56.6, K = 12288 168.5 against 185.7 (stream-K) on one box.  The generated loop
+// (tools/gen_gemm_loop3.py, option set "b2"): a ring of FOUR stages, ONE K-step of LDS-DMA per body spread one or two instructions per tile-group slot (a single
+// in-order wave pays every piece's acceptance time: issued as a burst the same loop runs 135 cycles per tile-group), the workgroup barrier in every other body.
+// One wave per SIMD runs a VALU-bound epilogue at half the issue rate of two, so only the launches whose epilogue is small take this kernel: FUSE_NONE, rank <= 32,
+// fp32 low-rank accumulators (the out-projection and fc2 of a block: 114 of the 228 GEMM launches of a FLUX step).
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int WT_NSTAGE = 4, WT_LDS_BYTES = WT_NSTAGE * Geo<8>::STAGE_BYTES; // 155648 (of 163840)
+#define SVDQ_WT_CLOB_V                                                                                                                                                  \
+    "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146",  \
+    "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165",  \
+    "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184",  \
+    "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v196", "v197", "v198", "v199", "v204", "v205"
+#define SVDQ_WT_CLOB_A                                                                                                                                                  \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23",     \
+    "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46",  \
+    "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69",  \
+    "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92",  \
+    "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113",  \
+    "a114", "a115", "a116", "a117", "a118", "a119"
+#define SVDQ_WT_CLOB_T                                                                                                                                                  \
+    "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146",  \
+    "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165",  \
+    "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184",  \
+    "v185", "v186", "v187", "v188", "v189", "v190", "v191"
+#define SVDQ_WT_CLOB_ACC                                                                                                                                                \
+    "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23",     \
+    "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",  \
+    "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69",  \
+    "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92",  \
+    "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",  \
+    "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define SVDQ_WT_CLOB_EP                                                                                                                                                 \
+    "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139",   \
+    "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159",   \
+    "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179",   \
+    "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199",   \
+    "a200"
+template <int DT>
+__global__ __launch_bounds__(256, 1) void gemm_w4a4_wt128_kernel(const GemmParams p) {
+    using T = typename Half<DT>::T;
+    using V8 = typename Half<DT>::V8;
+    constexpr int BM = 256, NW = 4, NSTAGE = WT_NSTAGE, A_BYTES = Geo<8>::A_BYTES, STAGE_BYTES = Geo<8>::STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WT_LDS_BYTES];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int KP = p.K / 128, TM = p.M_pad / BM, TN = p.N / BN, NT = TM * TN;
+    const int G = gridDim.x;
+    const int pos = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    auto tile_coords = [&](int t, int &bm, int &bn) {
+        const int strip = t / (8 * TM);
+        const int w = min(8, TN - 8 * strip);
+        const int r = t - strip * 8 * TM;
+        bm = r / w;
+        bn = 8 * strip + r % w;
+    };
+    // DMA roles (tools/gen_gemm_loop3.py): every wave the three planes of A chunks w and w + 4 and of W chunk w; wave 0 the activation scale image (8 x 128 B),
+    // wave 1 the weight scale image (4 x 128 B, twice), waves 2, 3 their first W plane once more: 10 LDS-DMA instructions per wave and K-step
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_base = (unsigned)(size_t)(lds_void *)lds;
+    const unsigned dA = lds_base + wv * F6_CHUNK, dX1 = lds_base + A_BYTES + wv * F6_CHUNK;
+    unsigned dX2 = dX1, iX2v = F6_CHUNK, offX2 = lane * 16;
+    const unsigned offA = lane * 16, offA2 = lane * 16 + 4u * KP * F6_CHUNK, offX1 = lane * 16;
+    if (wv == 0) { offX2 = ((lane >> 3) & 7) * KP * 128 + (lane & 7) * 16; dX2 = lds_base + A_BYTES + W_BYTES; iX2v = 128; }
+    else if (wv == 1) { offX2 = ((lane >> 3) & 3) * KP * 128 + (lane & 7) * 16; dX2 = lds_base + A_BYTES + W_BYTES + AS_BYTES; iX2v = 128; }
+    const unsigned in_la = lds_base + (wm * 4) * F6_CHUNK + lane * 16;
+    const unsigned in_lw = lds_base + A_BYTES + (wn * 2) * F6_CHUNK + lane * 16;
+    const unsigned in_lsa = lds_base + A_BYTES + W_BYTES + (wm * 4) * 128 + (lane & 31) * 2;
+    const unsigned in_lsw = lds_base + A_BYTES + W_BYTES + AS_BYTES + (wn * 2) * 128 + (lane & 31) * 2;
+    const int split_bm = p.split_row == 0x7fffffff ? 0x7fffffff : p.split_row / BM;
+    auto stream_ptrs = [&](int bm, int bn, int kp0, unsigned long long &a, unsigned long long &x1, unsigned long long &x2) {
+        a = (unsigned long long)(p.act + ((size_t)(bm * (BM / 32) + wv) * KP + kp0) * F6_CHUNK);
+        const uint8_t *wgt = bm >= split_bm ? p.wgt2 : p.wgt;
+        const void *wscales = bm >= split_bm ? p.wscales2 : p.wscales;
+        x1 = (unsigned long long)(wgt + ((size_t)(bn * 4 + wv) * KP + kp0) * F6_CHUNK);
+        if (wv == 0) x2 = (unsigned long long)((const uint8_t *)p.ascales + ((size_t)(bm * (BM / 32)) * KP + kp0) * 128);
+        else if (wv == 1) x2 = (unsigned long long)((const uint8_t *)wscales + ((size_t)(bn * 4) * KP + kp0) * 128);
+        else x2 = x1;
+    };
+    constexpr long long SLAB_BYTES = (long long)BM * BN * 4;
+    const bool ws_ok = p.workspace != nullptr && p.workspace_bytes >= SK_HEADER_BYTES + 2LL * G * SLAB_BYTES;
+    GemmSchedule sched;
+    sched.init(NT, KP, G, ws_ok ? p.sk_gs : 0, pos);
+    const bool sk = sched.gs > 0;
+    const int F = sched.F;
+    typedef GemmSegment Seg;
+    SVDQ_PROBE_BEGIN();
+
+    // lane offsets of the loop call's epilogue operand loads (a[120 + 16 mi + 8 u + 4 j + e] = lora_act_in[mw0 + 32 mi + lr][16 u + 8 h + 4 j + e],
+    // a[184 + 4 (2 ni + u) ..] = lora_up[nw0 + 32 ni + lr][16 u + 8 h ..], a200 = bias[nw0 + 32 h + lr]) and of the epilogue's stores
+    const unsigned e_off = ((lane & 31) * (unsigned)p.ldo + (lane >> 5) * 8) * 2u, e_lr = lane & 31, e_h = lane >> 5;
+    const unsigned ep_vla = ((lane & 31) * 32 + (lane >> 5) * 8) * 4u, ep_vlu = ((lane & 31) * 32 + (lane >> 5) * 8) * 2u, ep_vbi = ((lane >> 5) * 32 + (lane & 31)) * 2u;
+    unsigned ring = 0, npre = 0, landed = 0;
+    unsigned long long pA = 0, pX1 = 0, pX2 = 0;
+    int bm = 0, bn = 0;
+    Seg cur{0, 0, 0, 0}, nxt{0, 0, 0, 0};
+    bool have = sched.next(cur);
+    if (have) { tile_coords(cur.tile, bm, bn); stream_ptrs(bm, bn, cur.kp0, pA, pX1, pX2); }
+    while (have) {
+        const int kp0 = cur.kp0, kp1 = cur.kp1;
+        const int m0 = bm * BM, n0 = bn * BN;
+        const bool have_next = sched.next(nxt);
+        int nbm = 0, nbn = 0;
+        unsigned ncnt = 0;
+        unsigned long long nA = 0, nX1 = 0, nX2 = 0;
+        if (have_next) { tile_coords(nxt.tile, nbm, nbn); stream_ptrs(nbm, nbn, nxt.kp0, nA, nX1, nX2); ncnt = nxt.kp1 - nxt.kp0; }
+        {
+            const unsigned kp_s = kp1 - kp0;
+            auto srd = [](unsigned long long ptr) {
+                v4i r;
+                r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ptr);
+                r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ptr >> 32));
+                r[2] = -1;
+                r[3] = 0x00020000;
+                return r;
+            };
+            v4i rA = srd(pA), rX1 = srd(pX1), rX2 = srd(pX2);
+            // the tile's epilogue operands (bias, this wave's 128 rows of lora_act_in, its 64 rows of lora_up; rank 32) are requested at the top of the loop call into
+            // AGPRs a[120:200] and land under the loop (tools/gen_gemm_loop3.py, option "ep"): flags bit 0 = low-rank operands, bit 1 = bias; only the call that
+            // ends a tile (kp1 == KP) asks for them
+            const bool ep_tile = kp1 == KP;
+            const unsigned ep_n = kp_s; // K-steps of DMA this call issues behind the operand loads
+            const unsigned ep_flags = ep_tile ? ((p.R == 32 ? 1u : 0u) | (p.bias != nullptr ? 2u : 0u)) : 0u;
+            const unsigned mw0 = (unsigned)m0 + (unsigned)(wv >> 1) * 128u, nw0 = (unsigned)n0 + (unsigned)(wv & 1) * 64u;
+            const unsigned long long ep_la = (unsigned long long)((const char *)p.lora_act_in + (size_t)mw0 * 128u);
+            const unsigned long long ep_lu = (unsigned long long)((const char *)(bm >= split_bm ? p.lora_up2 : p.lora_up) + (size_t)nw0 * 64u);
+            const unsigned long long ep_bi = (unsigned long long)((const char *)(bm >= split_bm ? p.bias2 : p.bias) + (size_t)nw0 * 2u);
+            // the epilogue (generated assembly too: GenEpi3): acc + bias (an MFMA: bias[n] in one k-slot against 1.0), one MFMA per 16 ranks in ascending rank
+            // order, the single rounding to 16 bits (fp16 clamps to +-65504: EpilogueDefault, gemm_base.cuh:667-698), 16-byte stores -- the 8-wave kernel's
+            // operations in its order.  lane owns rows m = mw0 + 32 mi + lr and columns n = nw0 + 32 ni + 8 c + 4 h + e  (r = 4 c + e)
+            const unsigned sc0 = __builtin_bit_cast(unsigned, p.lora_scales[0]), sc1 = __builtin_bit_cast(unsigned, p.lora_scales[1]);
+            const int rows_left = p.M - (int)mw0;
+            const unsigned row_tile_bytes = 64u * (unsigned)p.ldo;
+            const unsigned long long obase = (unsigned long long)((const char *)p.out + ((size_t)mw0 * p.ldo + nw0) * 2);
+#define SVDQ_LOOP3_IO                                                                                                                                    \
+      "+{s[72:75]}"(rA), "+{s[76:79]}"(rX1), "+{s[80:83]}"(rX2)
+#define SVDQ_LOOP3_IN                                                                                                                                    \
+      "{v192}"(in_la), "{v193}"(in_lw), "{v194}"(in_lsa), "{v195}"(in_lsw), "{v200}"(offA), "{v201}"(offA2), "{v202}"(offX1), "{v203}"(offX2),              \
+      "{s46}"(kp_s), "{s47}"(dA), "{s48}"(dX1), "{s49}"(dX2), "{s50}"(iX2v), "{s58}"(ring), "{s59}"(npre), "{s60}"(ncnt),                                   \
+      "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed),                                                                               \
+      "{s51}"(ep_flags), "{s54}"(ep_n), "{s[88:89]}"(ep_la), "{s[90:91]}"(ep_lu), "{s[92:93]}"(ep_bi), "{v206}"(ep_vla), "{v207}"(ep_vlu), "{v208}"(ep_vbi)
+#define SVDQ_EPI3_IN                                                                                                                                     \
+      "{v209}"(e_off), "{v210}"(e_lr), "{v211}"(e_h), "{s94}"(ep_flags), "{s95}"(sc0), "{s96}"(sc1), "{s97}"(rows_left), "{s98}"(row_tile_bytes),          \
+      "{s[100:101]}"(obase)
+#define SVDQ_LOOP3_CLOB "memory", "scc", "m0", "s52", "v212", "v213", "v214", "s53", "s55", "s56", "s57", "s61", "s84", "s85", "s86", "s87", SVDQ_WT_CLOB_V, SVDQ_WT_CLOB_A
+#define SVDQ_EPI3_CLOB "vcc", "s99", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223"
+            SVDQ_PROBE_WT_MID_DECL
+            SVDQ_PROBE_STAMP(0);
+            if (!(sk && (kp0 > 0 || kp1 < KP))) {
+                // a whole tile: loop + epilogue as ONE asm statement -- the accumulators (v[0:127]) and the epilogue operands (a[120:200]) never become compiler
+                // values (as outputs of one statement and inputs of the next, this clang moved all 128 accumulators through AGPRs around the schedule code)
+                if constexpr (DT == SVDQ_BF16) {
+                    asm volatile(
+#include SVDQ_LOOP3_INC_BF16
+                        SVDQ_PROBE_WT_MID_ASM
+#include SVDQ_EPI3_INC_BF16
+                        : SVDQ_PROBE_WT_MID_OUT SVDQ_LOOP3_IO : SVDQ_LOOP3_IN, SVDQ_EPI3_IN : SVDQ_LOOP3_CLOB, SVDQ_EPI3_CLOB, SVDQ_WT_CLOB_ACC, SVDQ_WT_CLOB_EP);
+                } else {
+                    asm volatile(
+#include SVDQ_LOOP3_INC_FP16
+                        SVDQ_PROBE_WT_MID_ASM
+#include SVDQ_EPI3_INC_FP16
+                        : SVDQ_PROBE_WT_MID_OUT SVDQ_LOOP3_IO : SVDQ_LOOP3_IN, SVDQ_EPI3_IN : SVDQ_LOOP3_CLOB, SVDQ_EPI3_CLOB, SVDQ_WT_CLOB_ACC, SVDQ_WT_CLOB_EP);
+                }
+                landed = min(3u, ncnt); // the epilogue waited for vmcnt(0) before its first store: the next tile's prefetch has landed, the next loop call need not drain the stores
+                SVDQ_PROBE_WT_MID_STAMP();
+            } else {
+                // ---- a stream-K segment: the loop alone, then publish or collect partial tiles (the 8-wave kernel's protocol; a lane's 32 quads of accumulators as
+                // 32 coalesced 1 KiB wave stores), the owner runs the epilogue ----
+                v16f acc[2][4]; // [n tile][m tile]
+                v16i ep_a[4], ep_u; // the loop call's epilogue operands (AGPRs)
+                unsigned ep_b;
+#define SVDQ_LOOP3_ACC_OUT                                                                                                                               \
+      "={v[0:15]}"(acc[0][0]), "={v[16:31]}"(acc[0][1]), "={v[32:47]}"(acc[0][2]), "={v[48:63]}"(acc[0][3]),                                              \
+      "={v[64:79]}"(acc[1][0]), "={v[80:95]}"(acc[1][1]), "={v[96:111]}"(acc[1][2]), "={v[112:127]}"(acc[1][3]),                                          \
+      "={a[120:135]}"(ep_a[0]), "={a[136:151]}"(ep_a[1]), "={a[152:167]}"(ep_a[2]), "={a[168:183]}"(ep_a[3]), "={a[184:199]}"(ep_u), "={a200}"(ep_b)
+                if constexpr (DT == SVDQ_BF16) {
+                    asm volatile(
+#include SVDQ_LOOP3_INC_BF16
+                        : SVDQ_LOOP3_ACC_OUT, SVDQ_LOOP3_IO : SVDQ_LOOP3_IN : SVDQ_LOOP3_CLOB);
+                } else {
+                    asm volatile(
+#include SVDQ_LOOP3_INC_FP16
+                        : SVDQ_LOOP3_ACC_OUT, SVDQ_LOOP3_IO : SVDQ_LOOP3_IN : SVDQ_LOOP3_CLOB);
+                }
+                landed = 0;
+                typedef __attribute__((address_space(1))) int gint;
+                typedef __attribute__((address_space(1))) float gfloat;
+                typedef __attribute__((address_space(1))) v4f gv4f;
+                gint *flags = (gint *)reinterpret_cast<int *>(p.workspace);
+                gfloat *slabs = (gfloat *)reinterpret_cast<float *>(p.workspace + SK_HEADER_BYTES);
+                const int trel = cur.tile - F * G;
+                if (kp1 < KP) {
+                    gfloat *slab = slabs + (size_t)sched.slot(cur) * (BM * BN);
+#pragma unroll
+                    for (int j = 0; j < 32; j++) {
+                        v4f v = {acc[j >> 4][(j >> 2) & 3][(j & 3) * 4 + 0], acc[j >> 4][(j >> 2) & 3][(j & 3) * 4 + 1],
+                                 acc[j >> 4][(j >> 2) & 3][(j & 3) * 4 + 2], acc[j >> 4][(j >> 2) & 3][(j & 3) * 4 + 3]};
+                        *(gv4f *)(slab + ((size_t)(j * NW + wave) * 64 + lane) * 4) = v;
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_fetch_add(flags + trel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {
+                    const int first = sched.first_contributor(cur);
+                    const int needed = pos - first;
+                    if (tid == 0) {
+                        int spins = 0;
+                        while (__hip_atomic_load(flags + trel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < needed && ++spins < SK_SPIN_LIMIT)
+                            __builtin_amdgcn_s_sleep(8);
+                        if (spins >= SK_SPIN_LIMIT) {
+                            __hip_atomic_store(flags + SK_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (p.status) __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        __hip_atomic_store(flags + trel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    for (int q = first; q < pos; q++) {
+                        const gfloat *slab = slabs + (size_t)sched.contributor_slot(cur, q) * (BM * BN);
+#pragma unroll
+                        for (int jb = 0; jb < 32; jb += 8) {
+                            v4f t[8];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) t[j] = __builtin_nontemporal_load((const gv4f *)(slab + ((size_t)((jb + j) * NW + wave) * 64 + lane) * 4));
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+#pragma unroll
+                                for (int e = 0; e < 4; e++) acc[(jb + j) >> 4][((jb + j) >> 2) & 3][((jb + j) & 3) * 4 + e] += t[j][e];
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+#define SVDQ_EPI3_ACC_IO                                                                                                                                 \
+      "+{v[0:15]}"(acc[0][0]), "+{v[16:31]}"(acc[0][1]), "+{v[32:47]}"(acc[0][2]), "+{v[48:63]}"(acc[0][3]),                                              \
+      "+{v[64:79]}"(acc[1][0]), "+{v[80:95]}"(acc[1][1]), "+{v[96:111]}"(acc[1][2]), "+{v[112:127]}"(acc[1][3])
+#define SVDQ_EPI3_EP_IN                                                                                                                                  \
+      "{a[120:135]}"(ep_a[0]), "{a[136:151]}"(ep_a[1]), "{a[152:167]}"(ep_a[2]), "{a[168:183]}"(ep_a[3]), "{a[184:199]}"(ep_u), "{a200}"(ep_b)
+                    if constexpr (DT == SVDQ_BF16) {
+                        asm volatile(
+#include SVDQ_EPI3_INC_BF16
+                            : SVDQ_EPI3_ACC_IO : SVDQ_EPI3_EP_IN, SVDQ_EPI3_IN : "memory", "scc", "s84", "s85", "s70", "s71", "v215", SVDQ_EPI3_CLOB, SVDQ_WT_CLOB_T);
+                    } else {
+                        asm volatile(
+#include SVDQ_EPI3_INC_FP16
+                            : SVDQ_EPI3_ACC_IO : SVDQ_EPI3_EP_IN, SVDQ_EPI3_IN : "memory", "scc", "s84", "s85", "s70", "s71", "v215", SVDQ_EPI3_CLOB, SVDQ_WT_CLOB_T);
+                    }
+                    landed = min(3u, ncnt);
+                }
+            }
+            ring = (ring + (kp_s % NSTAGE) * STAGE_BYTES) % (NSTAGE * STAGE_BYTES);
+            npre = min(3u, ncnt); // every body of this loop leaves three K-steps of the operand stream ahead of the one it computed
+            pA = nA; pX1 = nX1; pX2 = nX2;
+            SVDQ_PROBE_STAMP(5);
+            SVDQ_PROBE_NEXT_SEGMENT();
+        }
+        have = have_next;
+        cur = nxt;
+        bm = nbm;
+        bn = nbn;
+    }
+    SVDQ_PROBE_END();
+}
+#undef SVDQ_WT_CLOB_V
+#undef SVDQ_WT_CLOB_A
+#undef SVDQ_WT_CLOB_T
+#undef SVDQ_WT_CLOB_ACC
+#undef SVDQ_WT_CLOB_EP
+#undef SVDQ_LOOP3_IO
+#undef SVDQ_LOOP3_IN
+#undef SVDQ_EPI3_IN
+#undef SVDQ_LOOP3_CLOB
+#undef SVDQ_EPI3_CLOB
+#undef SVDQ_LOOP3_ACC_OUT
+#undef SVDQ_EPI3_ACC_IO
+#undef SVDQ_EPI3_EP_IN
+
 // What the last svdq_gemm_w4a4 call of this thread launched (svdq_gemm_last_plan): tile rows (256 | 128), kernel variant, grid, stream-K groups, row-run length,
 // whether the low-rank operands were packed.  Filled by the dispatch code itself -- tests read it to assert that no rank, shape or format fell back to a slower
 // kernel than the one documented for it (include/svdq_amd.h).
-enum { PLAN_PLAIN = 0, PLAN_CARRY = 1, PLAN_ALL_RANK = 2, PLAN_HYBRID_CARRY = 3, PLAN_SOLO_CARRY = 4, PLAN_SPLIT_DOWN = 5 };
+enum { PLAN_PLAIN = 0, PLAN_CARRY = 1, PLAN_ALL_RANK = 2, PLAN_HYBRID_CARRY = 3, PLAN_SOLO_CARRY = 4, PLAN_SPLIT_DOWN = 5, PLAN_WAVE_TILE_128 = 6 };
 static thread_local int32_t g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static void record_plan(int tile_rows, int variant, int grid, const GemmParams &p) {
     g_last_plan[0] = tile_rows; g_last_plan[1] = variant; g_last_plan[2] = grid; g_last_plan[3] = p.sk_gs; g_last_plan[4] = p.rowrun;
@@ -1424,7 +1719,7 @@ static int persistent_grid(int tiles, int sk_gs, int slots) {
 // the 256 x 128 schedule cannot use the chip evenly: whole rounds that leave >= 10 % of the CUs out (1296 tiles = 6 rounds
 // on 216 of 256 CUs), provided the queue has >= 2 tiles per workgroup to balance with.  Long K stays on geometry 1 (stream-K).
 static int pick_geometry(const svdq_gemm_args *a, bool with_ws) {
-    if (a->geometry != 0) return a->geometry;
+    if (a->geometry != 0 && a->geometry != 8) return a->geometry; // (8: the 128 x 64 wave tile where it serves the launch, this rule otherwise)
     if (!with_ws) return 1;
     // rank 48 .. 160: both geometries have all-rank kernels (256 x 128: lora_up of a tile staged in LDS + packed lora_act_in; 128 x 128: both operands packed), so
     // the choice below is the rank-32 one -- except for a grouped launch from rank 96, whose second lora_up only the 256 x 128 kernel serves without the plain
@@ -1547,6 +1842,19 @@ static void launch_one(GemmParams &p, bool with_ws, hipStream_t st) {
     if (p.lora_fixed) launch_one_laq<DT, FUSE, NW, true>(p, with_ws, st);
     else launch_one_laq<DT, FUSE, NW, false>(p, with_ws, st);
 }
+// geometry 8: the 128 x 64 wave tile kernel (FUSE_NONE, rank <= 32, fp32 low-rank accumulators); schedule and stream-K split as the 256 x 128 geometry's
+template <int DT>
+static void launch_wt128(GemmParams &p, bool with_ws, hipStream_t st) {
+    const int tiles = (p.M_pad / 256) * (p.N / BN), slots = device_cus();
+    p.sk_gs = with_ws ? streamk_groups_for(tiles, p.K / 128, slots) : 0;
+    p.dynamic = 0; p.stagger = 0; p.rowrun = 0;
+    const int g = persistent_grid(tiles, p.sk_gs, slots);
+    dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(256);
+    record_plan(256, PLAN_WAVE_TILE_128, (int)grid.x, p);
+    hipLaunchKernelGGL((gemm_w4a4_wt128_kernel<DT>), grid, block, 0, st, p);
+}
+static bool wt128_serves(const svdq_gemm_args *a) { return a->fuse == SVDQ_FUSE_NONE && a->lora_act_format == SVDQ_LORA_ACT_F32 && (a->R == 32 || a->R == 0); }
+
 template <int DT, int NW>
 static void launch_fuse(GemmParams &p, int fuse, bool with_ws, hipStream_t st) {
     switch (fuse) {
@@ -1679,7 +1987,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         set_error("svdq_gemm_w4a4: variant and reserved must be 0 (timing experiments live in tools/ablate, not in this library)");
         return SVDQ_E_INVALID;
     }
-    if (a->geometry < 0 || a->geometry > 7) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto) .. 7"); return SVDQ_E_INVALID; }
+    if (a->geometry < 0 || a->geometry > 8) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto) .. 8"); return SVDQ_E_INVALID; }
     if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_gemm_w4a4: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
@@ -1818,7 +2126,12 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     p.stagger = geo == 4 || geo == 5;
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(SVDQ_PROF_GEMM_VARIANT(a->fuse), 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
-    if (geo == 1) {
+    // the plain epilogue at rank <= 32 (out-projection, fc2): the 128 x 64 wave tile, one wave per SIMD -- wherever the rule above picked 256 x 128 tiles
+    // (an explicit geometry 1 keeps the 8-wave kernel: tests, same-box A/B)
+    if (wt128_serves(a) && (a->geometry == 8 || (a->geometry == 0 && geo == 1))) {
+        if (a->dtype == SVDQ_BF16) launch_wt128<SVDQ_BF16>(p, with_ws, st);
+        else launch_wt128<SVDQ_FP16>(p, with_ws, st);
+    } else if (geo == 1) {
         if (a->dtype == SVDQ_BF16) launch_fuse<SVDQ_BF16, 8>(p, a->fuse, with_ws, st);
         else launch_fuse<SVDQ_FP16, 8>(p, a->fuse, with_ws, st);
     } else {

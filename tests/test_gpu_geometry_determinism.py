@@ -174,3 +174,67 @@ def test_deterministic_model_forward_is_bit_reproducible():
         fast = model(*args)
     rel = float((fast.float() - outs[0].float()).norm() / outs[0].float().norm())
     assert rel < 0.05, f"deterministic vs fp32-atomics forward differ by {rel:.3e} (W4A4 code-flip level expected: <= 2e-2)"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,K,N,R,bias,split", [(300, 384, 256, 32, True, 0), (512, 128, 128, 0, False, 0), (1000, 640, 384, 16, True, 0), (4608, 3072, 3072, 32, True, 0),
+                                                (1536, 3072, 3072, 32, True, 512), (4608, 1152, 3072, 48, True, 0)],
+                         ids=["small", "one-k-step-no-lora", "rank16-odd-M-falls-back", "out-projection", "grouped", "rank48-falls-back"])
+def test_wave_tile_128_kernel_is_bit_identical_to_the_8_wave_kernel(dtype, M, K, N, R, bias, split):
+    """round 6: the 128 x 64-per-wave / one-wave-per-SIMD kernel (geometry 8; the library's own choice for the plain epilogue at rank <= 32 on 256 x 128 tiles)
+    computes every output with the operations of the 8-wave kernel in the same order: launches that are not split along K agree BIT FOR BIT (bias, low-rank
+    up projection at rank 0 / 32, M tails, one K-step, a grouped launch with two weight sets), and the plan says which kernel ran."""
+    from nunchaku_amd._C import ops
+    from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
+
+    L = O.make_svdq_layer(K, N, max(R, 16), seed=11, dtype=dtype, cheap=True)   # (R = 0: a rank-16 layer launched without its low-rank branch)
+    Lb = O.make_svdq_layer(K, N, max(R, 16), seed=12, dtype=dtype, cheap=True)
+    mod, modb = make_module(L, dtype), make_module(Lb, dtype)
+    for m_ in (mod, modb):
+        m_._ensure_layout()
+    x = t16(O.make_activations(M, K, seed=13, dtype=dtype), dtype)
+    qx, asc, la = mod.quantize(x)
+
+    def run():
+        out = torch.empty(M, N, dtype=TORCH_DT[dtype], device="cuda")
+        second = dict(wgt=modb.qweight, wscales=modb.wscales, bias=modb.bias if bias else None, lora_up=modb.proj_up if R else None) if split else None
+        svdq_gemm_w4a4_cuda(act=qx, wgt=mod.qweight, out=out, ascales=asc, wscales=mod.wscales, lora_act_in=la if R else None, lora_up=mod.proj_up if R else None,
+                            bias=mod.bias if bias else None, second=second, split_rows=split)
+        return out, ops.gemm_last_plan()
+
+    ref, plan1 = _with_geometry(1, run)
+    got, plan8 = _with_geometry(8, run)
+    auto, plan0 = _with_geometry(0, run)
+    assert plan1["variant"] != "wave_tile_128"
+    assert plan8["variant"] == ("wave_tile_128" if R in (0, 32) else plan1["variant"]), plan8   # (its generated epilogue takes rank 32 or none)
+    if R in (0, 32) and plan1["streamk_groups"] == 0:
+        assert plan0["variant"] == "wave_tile_128", plan0   # the library's own choice wherever it would have taken 256 x 128 tiles
+    assert plan8["streamk_groups"] == plan1["streamk_groups"] == 0
+    assert torch.equal(got, ref), f"geometry 8 vs 1: {(got != ref).float().mean():.2e} of the elements differ"
+    assert torch.equal(auto, ref)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_wave_tile_128_kernel_with_k_split_matches_oracle(dtype):
+    """K = 12288 (fc2), M = 1024 and 4608: the 128 x 64 wave tile kernel under the stream-K split (its own publish / collect lane map): within 1 ulp of the oracle
+    and of the 8-wave kernel, repeatable, no owner timed out."""
+    from nunchaku_amd._C import ops
+
+    K, N = 12288, 3072
+    L = O.make_random_svdq_layer(K, N, 32, seed=5, dtype=dtype)
+    mod = make_module(L, dtype, act_unsigned=False)
+    for M in (1024, 4608):
+        x = O.make_activations(M, K, seed=6, dtype=dtype)
+        xt = t16(x, dtype)
+        rows = np.array(sorted(set([0, 1, 127, 128, 255, 256, 511, 512, M - 1]) | set(np.random.default_rng(0).integers(0, M, 40).tolist())))
+        ref = O.svdq_linear(x[rows], L, dtype, "fp32")["out"]
+        qx, asc, la = mod.quantize(xt)
+        outs, plans = {}, {}
+        for g in (1, 8):
+            outs[g] = _with_geometry(g, lambda: mod.forward_quant(qx, asc, la))
+            plans[g] = ops.gemm_last_plan()
+            assert_close_16(f32(outs[g])[rows], ref, dtype, f"geometry {g} M={M}", max_bad_frac=2e-3, ulps=1.0)
+        assert plans[8]["variant"] == "wave_tile_128" and plans[8]["streamk_groups"] > 0 and plans[8]["streamk_groups"] == plans[1]["streamk_groups"], plans
+        assert_close_16(f32(outs[8]), f32(outs[1]), dtype, "geometry 8 vs 1", ulps=1.0)
+        assert torch.equal(outs[8], _with_geometry(8, lambda: mod.forward_quant(qx, asc, la))), "two launches of the split schedule differ"
+        ops.gemm_workspace_status()

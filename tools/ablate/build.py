@@ -27,18 +27,29 @@ SOURCES = ["repack.hip", "quantize.hip", "gemm_w4a4.hip", "attention.hip", "gemv
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-DSVDQ_PROBE", f"-I{HERE}"]
 
 
-def build(opts: str = ""):
+def build(opts: str = "", opts3: str = ""):
+    """opts: option string of gen_gemm_loop2.py (the 64 x 64 wave tile loops); opts3: extra options of gen_gemm_loop3.py (the 128 x 64 wave tile kernel's loop and
+    epilogue are ALWAYS regenerated for the probe library with "stamp": phase stamps inside the one-statement loop + epilogue)"""
+    import gen_gemm_loop3 as G3
     flags = list(FLAGS)
     suffix = ""
+    os.makedirs(GEN, exist_ok=True)
+    o3 = G3.PRODUCT_OPTS + "+stamp" + ("+" + opts3 if opts3 else "")
+    s3 = "_" + o3.replace("+", "_")
+    for dt, mf in (("bf16", "v_mfma_f32_32x32x16_bf16"), ("fp16", "v_mfma_f32_32x32x16_f16")):
+        G3.emit(os.path.join(GEN, f"gemm_loop3_{dt}{s3}.inc"), mf, o3)
+        G3.emit_epilogue(os.path.join(GEN, f"gemm_epi3_{dt}{s3}.inc"), dt, o3)
+        flags += [f'-DSVDQ_LOOP3_INC_{dt.upper()}="gemm_loop3_{dt}{s3}.inc"', f'-DSVDQ_EPI3_INC_{dt.upper()}="gemm_epi3_{dt}{s3}.inc"']
+    flags.append(f"-I{GEN}")
+    if opts3:
+        suffix = "_wt_" + opts3.replace("+", "_")
     if opts:
-        os.makedirs(GEN, exist_ok=True)
-        suffix = "_" + opts.replace("+", "_")
+        suffix += "_" + opts.replace("+", "_")
         for nw, tag in ((8, "8"), (4, "4")):
             for dt, mf in (("BF16", "v_mfma_f32_32x32x16_bf16"), ("FP16", "v_mfma_f32_32x32x16_f16")):
                 name = f"gemm_loop2_w{nw}_{dt.lower()}{suffix}.inc"
                 G2.emit(os.path.join(GEN, name), mf, opts, nw=nw)
                 flags.append(f'-DSVDQ_LOOP_INC_{tag}_{dt}="{name}"')
-        flags.append(f"-I{GEN}")
     lib = os.path.join(HERE, f"libsvdq_amd_probe{suffix}.so")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     subprocess.run([hipcc, *flags, "-o", lib, *SOURCES], cwd=CSRC, check=True)
@@ -55,4 +66,4 @@ def build(opts: str = ""):
 
 
 if __name__ == "__main__":
-    print(*build(sys.argv[1] if len(sys.argv) > 1 else ""), sep="\n")
+    print(*build(sys.argv[1] if len(sys.argv) > 1 else "", sys.argv[2] if len(sys.argv) > 2 else ""), sep="\n")
