@@ -50,8 +50,8 @@ FLUX_STEP_GOP = 59.5e3 + 0.83e3
 # COMMITTED measurement of the same command and says so ("traffic_source"); null when the profile file is absent.
 # Both files carry "csrc_sha16": the hash of the kernel sources they were measured on (kernel_sources_sha16 below, stamped by
 # tools/gpu/r4_profile_bench.sh); a line printed from a tree whose kernels changed since says "stale": true next to the number.
-TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r5_bench_gemm_hbm_counters.json", "r4_bench_gemm_hbm_counters.json")]
-MFMA_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r5_bench_gemm_mfma_util.json", "r4_bench_gemm_mfma_util.json")]
+TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r6_bench_gemm_hbm_counters.json", "r5_bench_gemm_hbm_counters.json", "r4_bench_gemm_hbm_counters.json")]
+MFMA_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r6_bench_gemm_mfma_util.json", "r5_bench_gemm_mfma_util.json", "r4_bench_gemm_mfma_util.json")]
 # per-variant share of a tile spent behind the main loop (shader-cycle stamps of the probe build, tools/gpu/r5_gemm_trace.sh + tools/epilogue_share.py): committed, stamped
 EPILOGUE_SHARE_PROFILE = os.path.join(ROOT, "profiles", "r5_gemm_epilogue_share.json")
 
@@ -251,6 +251,8 @@ def main():
                          "tiles / one workgroup per CU, 2 = 128x128 tiles / two per CU out of phase, 3 = 2 without the phase offset; "
                          "6 / 7 = GELU_QUANT launches with a next-layer rank beyond 32 on the solo-carry kernel / with the split low-rank "
                          "down projection (A/B of what 0 picks from rank 96), everything else as 0")
+    ap.add_argument("--no-fragment-cache", action="store_true",
+                    help="A/B (rank 48 .. 160): the launches pack their weight-side low-rank operands themselves, as ABI 20 did (default: one cached fragment image per parameter, ABI 21)")
     ap.add_argument("--no-attention-split", action="store_true",
                     help="A/B: keep the low-rank down projection of the attention epilogue's quantiser inside the epilogue at every rank (rank 48 .. 160 "
                          "runs it as a contraction kernel behind the attention kernel by default)")
@@ -284,6 +286,7 @@ def main():
     _Ops.gemm_geometry = args.geometry
     _Ops.attention_geometry = args.attention_geometry
     _Ops.attention_split_lowrank = not args.no_attention_split
+    _Ops.cache_packed_lowrank = not args.no_fragment_cache
     mode.set_deterministic(args.deterministic)
     rank, local_rank, world = replica.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

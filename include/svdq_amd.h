@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 20
+#define SVDQ_ABI_VERSION 21
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -221,9 +221,24 @@ typedef struct svdq_gemm_args {
      * inside the attention kernel would add a second one). */
     float q_scale;
     int32_t reserved2;        /* must be 0 */
+    /* ABI 21, optional (NULL = the launch packs them itself, as ABI 19 / 20 did on every launch): the weight-side operands of the rank 48 .. 160 kernels as MFMA
+     * fragments, packed ONCE per parameter with svdq_pack_lora_down / svdq_pack_lora_up (nunchaku_amd/_C.py caches them per storage and version, so a set_lora
+     * re-packs).  next_lora_down_packed(2): used by a launch whose next-layer low-rank down projection runs split (plan variant 5); lora_up_packed: by the
+     * kernels that read lora_up as fragments (128 x 128 tiles at rank 48 .. 160, the solo-carry kernel).  Must hold the image of the very tensor passed in
+     * next_lora_down(2) / lora_up. */
+    const void *next_lora_down_packed, *next_lora_down_packed2;
+    const void *lora_up_packed;
 } svdq_gemm_args;
 
 int svdq_gemm_w4a4(const svdq_gemm_args *args, void *stream);
+
+/* ABI 21: the fragment images above.  ld = [R2][N] rank-major (svdq_repack_lowrank(down=1) order), R2 in 48 .. 160, N % 256 == 0 -> out, svdq_pack_lora_down_bytes(N, R2)
+ * bytes ([N / 16 units][ceil(R2 / 32) rank blocks][64 lanes][8] 16-bit, ranks >= R2 zero); lu = [N][R] natural -> out, svdq_pack_lora_up_bytes(N, R) bytes
+ * ([N / 32][R / 16][64 lanes][8]).  Pure permutations (a weight changes only under a set_lora): pack once, pass with every launch. */
+int64_t svdq_pack_lora_down_bytes(int32_t N, int32_t R2);
+int svdq_pack_lora_down(const void *ld, void *out, int32_t N, int32_t R2, int32_t dtype, void *stream);
+int64_t svdq_pack_lora_up_bytes(int32_t N, int32_t R);
+int svdq_pack_lora_up(const void *lu, void *out, int32_t N, int32_t R, int32_t dtype, void *stream);
 /* size of the GEMM workspace for the current device: 1023 arrival counters + 1 error word + 2 fp32 tiles of 256 x 128 per CU (the stream-K tail), and
  * -- ABI 19 -- a 24 MB tail in which a launch of rank 48 .. 160 keeps its low-rank operands as packed 16-bit MFMA fragments (written by a small pack
  * kernel the call enqueues in front of the GEMM; valid, like the rest, for launches ordered on ONE stream).  Without a workspace (or with one of the
@@ -329,6 +344,9 @@ typedef struct svdq_attention_args {
      * rounding, ~2.5x the error of geometry 1 against an fp32 reference.  Hence automatic = geometry 2 (on the plain grid) iff
      * q_prescaled, L % 256 == 0 and no mask; an explicit geometry uses the persistent schedule when a workspace is given. */
     int32_t geometry;
+    /* ABI 21, optional: qlora_down(2) as the fragment image of svdq_pack_lora_down (N = H * 128) for a launch whose fused quantiser runs its low-rank down
+     * projection split (rank 48 .. 160 with the workspace of svdq_attention_workspace_bytes_for()); NULL = packed by the launch */
+    const void *qlora_down_packed, *qlora_down_packed2;
 } svdq_attention_args;
 
 int svdq_attention(const svdq_attention_args *args, void *stream);

@@ -284,6 +284,28 @@ def _param(t: torch.Tensor | None, kind: str):
     return _cached_conversion(t, kind, lambda src: layout.repack_lowrank(src, down=(kind == "down")))
 
 
+def _packed_fragments(t: torch.Tensor | None, down: bool, N: int, R: int):
+    """ABI 21: the MFMA-fragment image of a low-rank factor in the kernel layout (``down``: rank-major ``[R][N]`` -> svdq_pack_lora_down; else ``[N][R]`` ->
+    svdq_pack_lora_up), packed ONCE per storage and version (a ``set_lora`` writes a new tensor or bumps the version: re-packed) -- the rank 48 .. 160 kernels
+    otherwise re-pack the weight on every launch (190 pack launches per rank-128 FLUX step).  None where the library has no such image."""
+    if t is None or not _Ops.cache_packed_lowrank or R % 16 or t.dtype not in _DT:
+        return None
+    if down and not (48 <= R <= 160 and N % 256 == 0):
+        return None
+    if not down and not (48 <= R <= 160 and N % 32 == 0):
+        return None
+    lib = _lib.load()
+
+    def pack(src):
+        nbytes = int(lib.svdq_pack_lora_down_bytes(N, R) if down else lib.svdq_pack_lora_up_bytes(N, R))
+        out = torch.empty(nbytes, dtype=torch.uint8, device=src.device)
+        fn = lib.svdq_pack_lora_down if down else lib.svdq_pack_lora_up
+        _lib.check(fn(src.data_ptr(), out.data_ptr(), N, R, _DT[src.dtype], _stream()), "pack_lora_down" if down else "pack_lora_up")
+        return out
+
+    return _cached_conversion(t, f"frag_{'down' if down else 'up'}", pack)
+
+
 def _weight(wgt: torch.Tensor, K: int) -> torch.Tensor:
     """qweight: [N, 3K/4] FP6 image (kernel layout) or the checkpoint's [N, K/2] int8 (converted once, cached per storage)."""
     if wgt.shape[-1] * 4 == K * 3:
@@ -312,6 +334,8 @@ class _Ops:
             _lib.check(_lib.load().svdq_gemm_workspace_status(ws.buf.data_ptr(), _stream()), "gemm_workspace_status")
             if ws.status is not None:
                 ws.status.zero_()
+
+    cache_packed_lowrank = True   # ABI 21: keep the fragment images of rank 48 .. 160 low-rank factors per parameter (False: the launches pack them, as ABI 20 did)
 
     PLAN_VARIANTS = ("plain", "carry", "all_rank", "hybrid_carry", "solo_carry", "split_down", "wave_tile_128")
 
@@ -473,6 +497,8 @@ class _Ops:
             R = lora_up.shape[-1]
             lora_up = _param(lora_up, "up")
             a.lora_up, a.lora_act_in = _ptr(lora_up), _ptr(lora_act_in)
+            keep_frag = [_packed_fragments(lora_up, False, N, R) if second is None else None]
+            a.lora_up_packed = _ptr(keep_frag[0])
         keep = None
         if lora_scales is not None and R:
             keep = (C.c_float * (R // 16))(*[float(s) for s in list(lora_scales)[: R // 16]])
@@ -498,6 +524,8 @@ class _Ops:
                 a.R2 = lora_down.shape[-1]
                 lora_down = _param(lora_down, "down")
                 a.next_lora_down, a.lora_act_out = _ptr(lora_down), _ptr(lora_act_out)
+                frag_down = _packed_fragments(lora_down, True, N, a.R2)
+                a.next_lora_down_packed = _ptr(frag_down)
                 if lora_act_out.dtype not in (torch.float32, torch.int64) or (fmt_in is not None and lora_act_out.dtype != fmt_in):
                     raise ValueError("gemm_w4a4: lora_act_in and lora_act_out must share one format (float32, or int64 fixed point)")
                 fmt_in = lora_act_out.dtype
@@ -541,6 +569,10 @@ class _Ops:
             a.lora_up2 = g("lora_up") if R else None
             a.next_smooth2, a.norm_q2, a.norm_k2 = g("smooth_factor"), g("norm_q"), g("norm_k")
             a.next_lora_down2 = g("lora_down") if a.R2 else None
+            frag_down2 = _packed_fragments(conv.get("lora_down"), True, N, a.R2) if a.R2 else None
+            a.next_lora_down_packed2 = _ptr(frag_down2)
+            if a.next_lora_down_packed2 is None:
+                a.next_lora_down_packed = None  # (both sets or none)
             a.split_rows = int(split_rows)
             keep2 = (second, conv)  # keeps the tensors alive until the launch has been issued
         if fmt_in is not None:
@@ -743,6 +775,10 @@ class _Ops:
                 a.qlora_act_format = _lib.LORA_ACT_Q32
             a.qsmooth, a.qlora_down, a.qR = _ptr(quant["smooth"]), _ptr(quant.get("lora_down")), int(quant.get("R", 0))
             a.qsmooth2, a.qlora_down2 = _ptr(quant.get("smooth2")), _ptr(quant.get("lora_down2"))
+            fq = _packed_fragments(quant.get("lora_down"), True, Kq, a.qR)
+            fq2 = _packed_fragments(quant.get("lora_down2"), True, Kq, a.qR)
+            if fq is not None and (quant.get("lora_down2") is None or fq2 is not None):
+                a.qlora_down_packed, a.qlora_down_packed2 = _ptr(fq), _ptr(fq2)
             a.qsplit_rows = int(quant.get("split_rows", 0))
         a.vt_hs, a.ldvt = vt.stride(0), vt.stride(1)
         a.L, a.H, a.head_dim, a.dtype = L, H, D, _DT[q.dtype]

@@ -12,7 +12,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 20
+ABI_VERSION = 21
 LORA_ACT_F32, LORA_ACT_Q32 = 0, 1
 
 
@@ -56,6 +56,7 @@ class GemmArgs(C.Structure):
         ("next_smooth2", C.c_void_p), ("next_lora_down2", C.c_void_p), ("norm_q2", C.c_void_p), ("norm_k2", C.c_void_p),
         ("split_rows", C.c_int32), ("lora_act_format", C.c_int32), ("status", C.c_void_p),
         ("q_scale", C.c_float), ("reserved2", C.c_int32),
+        ("next_lora_down_packed", C.c_void_p), ("next_lora_down_packed2", C.c_void_p), ("lora_up_packed", C.c_void_p),
     ]
 
 
@@ -71,6 +72,7 @@ class AttentionArgs(C.Structure):
         ("qsplit_rows", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("qlora_act_format", C.c_int32), ("q_prescaled", C.c_int32), ("status", C.c_void_p),
         ("kv_len0", C.c_int32), ("kv_start1", C.c_int32), ("kv_end1", C.c_int32), ("geometry", C.c_int32),
+        ("qlora_down_packed", C.c_void_p), ("qlora_down_packed2", C.c_void_p),
     ]
 
 
@@ -112,6 +114,10 @@ EXPORTS = {
     "svdq_unrepack_lowrank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_unpack_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_unpack_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "svdq_pack_lora_down_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "svdq_pack_lora_down": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "svdq_pack_lora_up_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "svdq_pack_lora_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "svdq_prof_enable": (C.c_int, [C.c_int32]),
     "svdq_prof_reset": (C.c_int, []),
     "svdq_prof_select": (C.c_int, [C.c_uint32]),

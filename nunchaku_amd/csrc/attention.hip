@@ -1226,8 +1226,8 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     };
     if (p.qa16) { // pack the down projection(s), the attention kernel (its epilogue stores the 16-bit fragments), the contraction into qlora_act
         const int split_row = a->qsmooth2 ? a->qsplit_rows : 0x7fffffff;
-        if (a->dtype == SVDQ_FP16) launch_lowrank_down_split<SVDQ_FP16>(p.qa16, a->qlora_down, a->qlora_down2, split_row, a->L, a->H * ATT_D, a->qR, (float *)a->qlora_act, split_pack, attention_cus(), st, launch);
-        else launch_lowrank_down_split<SVDQ_BF16>(p.qa16, a->qlora_down, a->qlora_down2, split_row, a->L, a->H * ATT_D, a->qR, (float *)a->qlora_act, split_pack, attention_cus(), st, launch);
+        if (a->dtype == SVDQ_FP16) launch_lowrank_down_split<SVDQ_FP16>(p.qa16, a->qlora_down, a->qlora_down2, split_row, a->L, a->H * ATT_D, a->qR, (float *)a->qlora_act, split_pack, attention_cus(), st, launch, a->qlora_down_packed, a->qlora_down_packed2);
+        else launch_lowrank_down_split<SVDQ_BF16>(p.qa16, a->qlora_down, a->qlora_down2, split_row, a->L, a->H * ATT_D, a->qR, (float *)a->qlora_act, split_pack, attention_cus(), st, launch, a->qlora_down_packed, a->qlora_down_packed2);
     } else launch();
     prof_end(prof, st);
     return hip_check(hipGetLastError(), "svdq_attention launch");

@@ -151,6 +151,8 @@ struct GemmParams {
     float q_scale;           // RMSNORM_ROPE: factor of the Q third, applied before its rounding to 16-bit (svdq_gemm_args.q_scale; 1 = off)
     int stage_lora;          // NW = 8: rank 32, fp32 lora_act_in, 16-byte aligned operands: the loop stages lora_act_in / lora_up of a tile in LDS
     const void *lu_packed;   // solo-carry kernel (128 x 128 tiles, no LDS to stage lora_up in): lora_up as MFMA operand fragments as well (pack_lora_up_kernel)
+    const void *ld_pre, *ld2_pre; // ABI 21: the caller's own fragment images of next_lora_down(2) (svdq_pack_lora_down) or NULL
+    bool lu_pre;             // lu_packed is the caller's image (svdq_pack_lora_up): no pack launch
     const void *la_packed;   // all-rank kernels: lora_act_in as 16-bit MFMA operand fragments (pack_lora_act_kernel, in the workspace tail), scales applied
     int stage_lu_all;        // NW = 8, no carry: 32 < rank <= 160, fp32 lora_act_in, 16-byte aligned: the tile's lora_up (all ranks) is staged in LDS, lora_act_in comes
                              // through registers in batches of 64 ranks (every load of a batch in flight at once); value = ceil(65536 / (R / 8 + 1)), the divider of the gather
@@ -1766,8 +1768,9 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
                 const int units = p.R / 16;
                 hipLaunchKernelGGL((pack_lora_act_kernel<DT>), dim3(p.M_pad / 32, (units + 3) / 4), dim3(256), 0, st, (const float *)p.lora_act_in,
                                    (typename Half<DT>::V8 *)p.la_packed, p.R, units, sc);
-                hipLaunchKernelGGL((pack_lora_up_kernel<DT>), dim3(p.N / 32, (units + 3) / 4), dim3(256), 0, st, (const typename Half<DT>::T *)p.lora_up,
-                                   (typename Half<DT>::V8 *)p.lu_packed, p.R, units);
+                if (!p.lu_pre)
+                    hipLaunchKernelGGL((pack_lora_up_kernel<DT>), dim3(p.N / 32, (units + 3) / 4), dim3(256), 0, st, (const typename Half<DT>::T *)p.lora_up,
+                                       (typename Half<DT>::V8 *)p.lu_packed, p.R, units);
             }
             record_plan(G_::BM, PLAN_SOLO_CARRY, (int)grid.x, p);
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true>), grid, block, 0, st, p);
@@ -1781,8 +1784,9 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
             const int units = p.R / 16;
             hipLaunchKernelGGL((pack_lora_act_kernel<DT>), dim3(p.M_pad / 32, (units + 3) / 4), dim3(256), 0, st, (const float *)p.lora_act_in,
                                (typename Half<DT>::V8 *)p.la_packed, p.R, units, sc);
-            hipLaunchKernelGGL((pack_lora_up_kernel<DT>), dim3(p.N / 32, (units + 3) / 4), dim3(256), 0, st, (const typename Half<DT>::T *)p.lora_up,
-                               (typename Half<DT>::V8 *)p.lu_packed, p.R, units);
+            if (!p.lu_pre)
+                hipLaunchKernelGGL((pack_lora_up_kernel<DT>), dim3(p.N / 32, (units + 3) / 4), dim3(256), 0, st, (const typename Half<DT>::T *)p.lora_up,
+                                   (typename Half<DT>::V8 *)p.lu_packed, p.R, units);
             dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
             record_plan(G_::BM, PLAN_ALL_RANK, (int)grid.x, p);
             hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true>), grid, block, 0, st, p);
@@ -1825,7 +1829,8 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
                     record_plan(G_::BM, PLAN_SPLIT_DOWN, (int)grid.x, p);
                     launch_lowrank_down_split<DT>(p.act16_packed, p.next_lora_down, p.next_lora_down2, p.split_row, p.M_pad, p.N, p.split_R2, (float *)p.lora_act_out,
                                                   p.workspace + workspace_slab_bytes() + LA_PACK_BYTES, device_cus(), st,
-                                                  [&]() { hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true, false, true>), grid, block, 0, st, p); });
+                                                  [&]() { hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, false, true, false, true>), grid, block, 0, st, p); },
+                                                  p.ld_pre, p.ld2_pre);
                     return;
                 }
             }
@@ -1957,6 +1962,30 @@ extern "C" int svdq_gemm_schedule_ex(int32_t M_pad, int32_t N, int32_t K, int32_
 }
 extern "C" int svdq_gemm_schedule(int32_t M_pad, int32_t N, int32_t K, int32_t cus, int32_t with_workspace, int32_t *out, int32_t cap) {
     return svdq_gemm_schedule_ex(M_pad, N, K, cus, with_workspace, 1, out, cap);
+}
+
+extern "C" int64_t svdq_pack_lora_down_bytes(int32_t N, int32_t R2) { return lowrank_split_pack_bytes(N, R2, false); }
+extern "C" int svdq_pack_lora_down(const void *ld, void *out, int32_t N, int32_t R2, int32_t dtype, void *stream) {
+    if (!ld || !out || !lowrank_split_shape_ok(N, R2) || R2 % 16 || (dtype != SVDQ_BF16 && dtype != SVDQ_FP16)) {
+        set_error("svdq_pack_lora_down: needs ld, out, N %% 256 == 0, R2 a multiple of 16 in 48 .. 160 (N=%d R2=%d)", N, R2);
+        return SVDQ_E_INVALID;
+    }
+    if (dtype == SVDQ_BF16) launch_pack_lora_down<SVDQ_BF16>(ld, out, N, R2, (hipStream_t)stream);
+    else launch_pack_lora_down<SVDQ_FP16>(ld, out, N, R2, (hipStream_t)stream);
+    return hip_check(hipGetLastError(), "svdq_pack_lora_down launch");
+}
+extern "C" int64_t svdq_pack_lora_up_bytes(int32_t N, int32_t R) { return (int64_t)N * R * 2; }
+extern "C" int svdq_pack_lora_up(const void *lu, void *out, int32_t N, int32_t R, int32_t dtype, void *stream) {
+    if (!lu || !out || N % 32 || R % 16 || R <= 0 || (dtype != SVDQ_BF16 && dtype != SVDQ_FP16)) {
+        set_error("svdq_pack_lora_up: needs lu, out, N %% 32 == 0, R a positive multiple of 16 (N=%d R=%d)", N, R);
+        return SVDQ_E_INVALID;
+    }
+    const int units = R / 16;
+    if (dtype == SVDQ_BF16)
+        hipLaunchKernelGGL((pack_lora_up_kernel<SVDQ_BF16>), dim3(N / 32, (units + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)lu, (bf16x8 *)out, R, units);
+    else
+        hipLaunchKernelGGL((pack_lora_up_kernel<SVDQ_FP16>), dim3(N / 32, (units + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)lu, (f16x8 *)out, R, units);
+    return hip_check(hipGetLastError(), "svdq_pack_lora_up launch");
 }
 
 extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
@@ -2124,6 +2153,10 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     if (!p.solo_carry && geo != 1 && p.la_packed && !a->wgt2 && (long long)a->N * a->R * 2 <= LU_PACK_BYTES) p.lu_packed = p.workspace + workspace_slab_bytes() + LA_PACK_BYTES;
     p.dynamic = geo == 2 || geo == 4;
     p.stagger = geo == 4 || geo == 5;
+    // ABI 21: the caller's own fragment images replace the workspace copies (and their per-launch pack kernels)
+    p.ld_pre = a->next_lora_down_packed; p.ld2_pre = a->next_lora_down_packed2;
+    p.lu_pre = p.lu_packed != nullptr && a->lora_up_packed != nullptr;
+    if (p.lu_pre) p.lu_packed = a->lora_up_packed;
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(SVDQ_PROF_GEMM_VARIANT(a->fuse), 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
     // the plain epilogue at rank <= 32 (out-projection, fc2): the 128 x 64 wave tile, one wave per SIMD -- wherever the rule above picked 256 x 128 tiles

@@ -154,14 +154,19 @@ static inline bool lowrank_split_shape_ok(int N, int R2) { return R2 > 32 && (R2
 // out[M_pad][R2] += act16 . ld.  ld / ld2: rank-major [R2][N] 16-bit; rows >= split_row use ld2 (0x7fffffff: one set).  cus: compute units the grid is sized for.
 template <int DT, typename Producer>
 static void launch_lowrank_down_split(const void *act16, const void *ld, const void *ld2, int split_row, int M_pad, int N, int R2, float *out, void *ldp_scratch,
-                                      int cus, hipStream_t st, Producer producer) {
+                                      int cus, hipStream_t st, Producer producer, const void *ldp_pre = nullptr, const void *ldp2_pre = nullptr) {
     using V8 = typename Half<DT>::V8;
     using T = typename Half<DT>::T;
     const int nb = (R2 + 31) / 32, units_n = N / 16, rgs = M_pad / 64;
-    V8 *ldp = (V8 *)ldp_scratch, *ldp2 = ldp + (size_t)units_n * nb * 64;
+    const V8 *ldp = (const V8 *)ldp_scratch, *ldp2 = ldp + (size_t)units_n * nb * 64;
     const dim3 pg((units_n * nb + 3) / 4), pb(256);
-    hipLaunchKernelGGL((pack_lora_down_kernel<DT>), pg, pb, 0, st, (const T *)ld, ldp, N, R2, nb);
-    if (ld2 && split_row < M_pad) hipLaunchKernelGGL((pack_lora_down_kernel<DT>), pg, pb, 0, st, (const T *)ld2, ldp2, N, R2, nb);
+    // (ABI 21: a caller that keeps the images -- svdq_pack_lora_down, once per parameter -- passes them and the per-launch pack is skipped)
+    if (ldp_pre) ldp = (const V8 *)ldp_pre;
+    else hipLaunchKernelGGL((pack_lora_down_kernel<DT>), pg, pb, 0, st, (const T *)ld, (V8 *)ldp_scratch, N, R2, nb);
+    if (ld2 && split_row < M_pad) {
+        if (ldp2_pre) ldp2 = (const V8 *)ldp2_pre;
+        else hipLaunchKernelGGL((pack_lora_down_kernel<DT>), pg, pb, 0, st, (const T *)ld2, (V8 *)ldp_scratch + (size_t)units_n * nb * 64, N, R2, nb);
+    }
     producer();
     // K split over workgroups: the largest divisor of N / 256 (a slice is then a multiple of the 16 units the four waves take in two steps) that
     // keeps the grid within two workgroups per CU -- one round, every slice streaming at once
@@ -176,6 +181,13 @@ static void launch_lowrank_down_split(const void *act16, const void *ld, const v
     case 4: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 4>), sg, sb, 0, st, a16, ldp, ldp2, out, split_row, units_n, R2, ks); break;
     default: hipLaunchKernelGGL((lowrank_down_split_kernel<DT, 5>), sg, sb, 0, st, a16, ldp, ldp2, out, split_row, units_n, R2, ks); break;
     }
+}
+
+// svdq_pack_lora_down (ABI 21): the image above for one weight set
+template <int DT>
+static void launch_pack_lora_down(const void *ld, void *out, int N, int R2, hipStream_t st) {
+    const int nb = (R2 + 31) / 32, units_n = N / 16;
+    hipLaunchKernelGGL((pack_lora_down_kernel<DT>), dim3((units_n * nb + 3) / 4), dim3(256), 0, st, (const typename Half<DT>::T *)ld, (typename Half<DT>::V8 *)out, N, R2, nb);
 }
 
 } // namespace svdq

@@ -309,6 +309,57 @@ def _gelu_quant_next_low_rank_down(r2, r1):
     assert np.abs(lh.cpu().numpy()[:M] - la_ref).max() <= 2e-3 * np.abs(la_ref).max() + 1e-4
 
 
+def test_cached_fragment_images_of_low_rank_factors_follow_the_parameter():
+    """ABI 21: the rank 48 .. 160 kernels take the weight-side low-rank operands as MFMA fragments; `_C` packs them once per parameter (storage, version) instead of on
+    every launch.  The cached images give the results of the per-launch pack bit for bit (codes, scales; lora_act up to the order of its atomics), one image per
+    parameter is kept, and a write to the parameter (a set_lora) re-packs: the next launch follows the new weights."""
+    from nunchaku_amd import layout
+    from nunchaku_amd import _C
+    from nunchaku_amd._C import _Ops, ops
+    from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
+
+    dtype, M, C, Hd, r1, r2 = "bf16", 300, 256, 1024, 128, 128
+    fc1 = O.make_svdq_layer(C, Hd, r1, seed=31, dtype=dtype, cheap=True)
+    fc2 = O.make_svdq_layer(Hd, C, r2, seed=32, dtype=dtype, cheap=True)
+    x = O.make_activations(M, C, seed=33, dtype=dtype)
+    m1, m2 = make_module(fc1, dtype), make_module(fc2, dtype, act_unsigned=True)
+    m2._ensure_layout()
+    qx, asc, la = m1.quantize(t16(x, dtype))
+    M_pad = qx.shape[0]
+
+    def run():
+        qh = torch.empty(layout.act_image_shape(M_pad, Hd), dtype=torch.uint8, device="cuda")
+        sh = torch.empty(Hd // 64, M_pad, dtype=TORCH_DT[dtype], device="cuda")
+        lh = torch.empty((M_pad, r2), dtype=torch.float32, device="cuda")
+        svdq_gemm_w4a4_cuda(act=qx, wgt=m1.qweight, qout=qh, ascales=asc, wscales=m1.wscales, oscales=sh, lora_act_in=la, lora_up=m1.proj_up,
+                            lora_down=m2.proj_down, lora_act_out=lh, bias=m1.bias, smooth_factor=m2.smooth_factor)
+        return qh, sh, lh, ops.gemm_last_plan()
+
+    _Ops.gemm_geometry = 7  # the split low-rank down projection at this small size
+    try:
+        _Ops.cache_packed_lowrank = False
+        q0, s0, l0, plan0 = run()
+        _Ops.cache_packed_lowrank = True
+        q1, s1, l1, plan1 = run()
+        assert plan0["variant"] == plan1["variant"] == "split_down", (plan0, plan1)
+        assert torch.equal(q0, q1) and torch.equal(s0, s1)
+        assert float((l0 - l1).abs().max()) <= 1e-5 * float(l0.abs().max()) + 1e-6
+        per = _C._converted.get(m2.proj_down)
+        assert per is not None and sum(1 for k in per if k[0] == "frag_down") == 1, "one fragment image per parameter"
+        img = [v for k, v in per.items() if k[0] == "frag_down"][0][1]
+        run()
+        assert [v for k, v in _C._converted.get(m2.proj_down).items() if k[0] == "frag_down"][0][1] is img, "the image is reused, not re-packed"
+        # a write to the parameter: the image follows (version-checked)
+        with torch.no_grad():
+            m2.proj_down.mul_(2.0)
+        q2, s2, l2, _ = run()
+        assert torch.equal(q2, q1) and torch.equal(s2, s1)
+        assert float((l2 - 2.0 * l1).abs().max()) <= 1e-5 * float(l2.abs().max()) + 1e-6, "lora_act must follow the rewritten down projection"
+    finally:
+        _Ops.gemm_geometry = 0
+        _Ops.cache_packed_lowrank = True
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_fused_gelu_mlp(dtype):
     from nunchaku_amd import layout
