@@ -193,8 +193,9 @@ typedef struct svdq_gemm_args {
      * 48 .. 128 at two or more tiles per CU; 6 asks for it at any size -- tests), every other launch as with 0; 7 (ABI 20) = GELU_QUANT launches with a
      * next-layer low-rank branch of rank 48 .. 160 run it SPLIT (256 x 128 tiles whose epilogue stores the 16-bit GELU output as MFMA fragments into the
      * workspace, a second kernel contracts them with next_lora_down; needs a workspace of svdq_gemm_workspace_bytes_for() bytes and R in 48 .. 160; what
-     * geometry 0 picks for those ranks from a full round of tiles; 7 asks for it at any size), every other launch as with 0.  Results are bit-identical
-     * across geometries for launches without a stream-K split (the split points, hence the fp32 summation order of a split tile, differ); lora_act_out
+     * geometry 0 picks for those ranks from a full round of tiles; 7 asks for it at any size), every other launch as with 0;
+     * 8 (ABI 21) = the plain epilogue at rank 0 / 32 (fp32 low-rank accumulators) runs the 128 x 64-per-wave kernel (plan variant 6), every other launch as with 0.
+     * Results are bit-identical across geometries for launches without a stream-K split (the split points, hence the fp32 summation order of a split tile, differ); lora_act_out
      * differs by fp32 summation order between all of them (atomics). */
     int32_t geometry;
     /* Grouped launch (optional): rows [split_rows, M_pad) use a SECOND weight set of the same shape, rank and
@@ -255,13 +256,15 @@ int64_t svdq_gemm_workspace_bytes_for(const svdq_gemm_args *args);
  * 2 all-rank (rank 48 .. 160: packed lora_act_in; 256-row tiles: lora_up staged in LDS, 128-row tiles: lora_up packed too), 3 hybrid carry (GELU_QUANT, next rank
  * 48 .. 80 -- or any next rank > 32 the solo kernel does not take; behind variant 5), 4 solo carry (GELU_QUANT, next rank >= 96: 128 x 128 tiles, one workgroup per CU; behind variant 5),
  * 5 split low-rank down (ABI 20: GELU_QUANT, next rank 48 .. 160 with a workspace of svdq_gemm_workspace_bytes_for() bytes: all-rank kernel on 256-row tiles
- * + lowrank_down_split_kernel). */
+ * + lowrank_down_split_kernel), 6 wave tile 128 (ABI 21: the plain epilogue at rank 0 / 32 on 256 x 128 tiles with FOUR waves of 128 x 64 each, one per SIMD --
+ * generated loop AND epilogue, bit-identical to variant 0; geometry 8 asks for it, geometry 0 picks it wherever it would have launched 256-row tiles). */
 #define SVDQ_PLAN_PLAIN 0
 #define SVDQ_PLAN_CARRY 1
 #define SVDQ_PLAN_ALL_RANK 2
 #define SVDQ_PLAN_HYBRID_CARRY 3
 #define SVDQ_PLAN_SOLO_CARRY 4
 #define SVDQ_PLAN_SPLIT_DOWN 5
+#define SVDQ_PLAN_WAVE_TILE_128 6
 int svdq_gemm_last_plan(int32_t *out8);
 /* Synchronises `stream`, then returns SVDQ_E_HIP (and clears the flag) if a launch that used `workspace` timed out
  * waiting for partial tiles -- see svdq_gemm_args.workspace; SVDQ_OK otherwise.  Test / debugging aid. */

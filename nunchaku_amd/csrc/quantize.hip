@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
             typedef __attribute__((address_space(3))) void lds_void;
 #pragma unroll
             for (int i = 0; i < 8; i++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void *)(W + QV2_PARAM_BYTES + i * 1024), 16, ldo[i & 3], (i >> 2) * 16 * K * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void *)(W + QV2_PARAM_BYTES + i * 1024), 16, ldo[i & 3] + (i >> 2) * 16 * K * 2, 0, 0, 0); // (rank offset in the range-checked VGPR offset: rank 16 reads its upper half as zero)
         }
         const int ch = kp * 128 + 2 * lane;
         unsigned sm2 = 0, ms2 = 0, mh2 = 0;
@@ -508,8 +508,10 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
                             typedef __attribute__((address_space(3))) void lds_void;
 #pragma unroll
                             for (int i = 0; i < 8; i++)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rl1, (lds_void *)(W + QV2_PARAM_BYTES + QV2_SLAB_BYTES + i * 1024), 16, ldo_keep[i & 3],
-                                                                         ((i >> 2) * 16 + 32) * K * 2, 0, 0);
+                                // (the rank offset rides in the VGPR offset, which the descriptor's range check covers: ranks >= R read as zero.  ADVICE r5:
+                                //  an SGPR offset is outside that check)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rl1, (lds_void *)(W + QV2_PARAM_BYTES + QV2_SLAB_BYTES + i * 1024), 16,
+                                                                         ldo_keep[i & 3] + ((i >> 2) * 16 + 32) * K * 2, 0, 0, 0);
                         }
                     }
                     const u32x2 b0 = *(const lds_u2 *)(W + QV2_PARAM_BYTES + r * 256 + ((piece ^ (r & 15)) << 4) + 8 * h);
@@ -579,8 +581,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void quantize_kernel_v2(QuantPa
                     if (rank0 + 32 < p.R) {
 #pragma unroll
                         for (int i = 0; i < 8; i++) // (ranks >= R lie beyond the descriptor's range and read as zero)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void *)(W + QV2_PARAM_BYTES + (buf ^ 1) * QV2_SLAB_BYTES + i * 1024), 16, ldo_keep[i & 3],
-                                                                     ((i >> 2) * 16 + rank0 + 32) * K * 2, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_void *)(W + QV2_PARAM_BYTES + (buf ^ 1) * QV2_SLAB_BYTES + i * 1024), 16,
+                                                                     ldo_keep[i & 3] + ((i >> 2) * 16 + rank0 + 32) * K * 2, 0, 0, 0);
                         asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // this slab has landed (in-order retirement); the next one may still fly
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -82,6 +82,28 @@ def test_quantize_codes_and_scales(dtype, M, K, R):
     assert np.all(np.abs(la2.cpu().numpy() - la_ref) <= bound)
 
 
+@pytest.mark.parametrize("case", ["bf16_256_512_32_101", "fp16_256_512_32_102", "bf16_300_384_128_103", "fp16_77_1024_16_104"])
+def test_quantiser_matches_its_recorded_gpu_answers(case):
+    """since the quantiser divides the way the reference does (x * rcp(smooth), not the IEEE quotient) the oracle bounds its codes by an envelope
+    instead of pinning them; tests/golden/gpu_quantize_kat.npz (tools/make_gpu_golden.py, recorded on an MI355X) pins codes and scales of the product kernel
+    BIT FOR BIT against its own earlier build on the same seeded inputs -- a low-rate off-by-one regression cannot hide inside the envelope's flip budget."""
+    import os
+    from nunchaku_amd import layout
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpu_quantize_kat.npz")
+    rec = np.load(path)
+    dtype, M, K, R, seed = case.split("_")
+    M, K, R, seed = int(M), int(K), int(R), int(seed)
+    L = O.make_svdq_layer(K, 128, R, seed=seed, dtype=dtype, cheap=True)
+    x = O.make_activations(M, K, seed=seed, dtype=dtype)
+    mod = make_module(L, dtype)
+    qx, asc, _ = mod.quantize(t16(x, dtype))
+    codes = layout.unpack_act(qx, K).cpu().numpy().astype(np.int8)
+    scales = layout.unpack_scales(asc, qx.shape[0]).view(torch.int16).cpu().numpy()
+    assert np.array_equal(codes, rec[case + "_codes"]), f"{(codes != rec[case + '_codes']).sum()} codes differ from the recorded GPU answer"
+    assert np.array_equal(scales, rec[case + "_scales"]), f"{(scales != rec[case + '_scales']).sum()} scales differ from the recorded GPU answer"
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,K,R", [(256, 256, 32), (77, 384, 16), (513, 1024, 48)])
 def test_quantize_fuse_glu(dtype, M, K, R):
