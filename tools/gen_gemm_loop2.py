@@ -148,6 +148,12 @@ class Gen:
 
     def s_mfma(self, dst_buf, buf, t):
         ni, mi = t >> 1, t & 1
+        if "k16" not in self.opts:
+            # round 6: the scale tile S = 2 ws as needs two non-zero k-slots; the legacy K = 8 form of the 16-bit MFMA (k-slots 0 and 4: the first two registers of
+            # each tuple) computes the same bits in the same 8 passes (tools/ablate/mfma_k8_probe: 32.6 cycles either way) and reads half the operand registers:
+            # -3.5 % loop cycles, -2.5 ... -3.2 % launch time on the wave-tile probe, bit-exact (profiles/r6_gemm_wave_tile_probe.txt section 5).  "k16": the old form.
+            op = "v_mfma_f32_32x32x8bf16_1k" if self.smfma.endswith("bf16") else "v_mfma_f32_32x32x8f16"
+            return f"{op} {vr(SBUF[dst_buf], 16)}, {vr(SCL[buf] + 4 * ni, 2)}, {vr(SCL[buf] + 8 + 4 * mi, 2)}, 0"
         return f"{self.smfma} {vr(SBUF[dst_buf], 16)}, {vr(SCL[buf] + 4 * ni, 4)}, {vr(SCL[buf] + 8 + 4 * mi, 4)}, 0"
 
     def fma(self, t, pb, lo, hi):

@@ -115,6 +115,12 @@ class Gen3:
 
     def s_mfma(self, dst_buf, buf, t):
         ni, mi = t >> 2, t & 3
+        if "k16" not in self.opts:
+            # the legacy K = 8 form on the first two registers of each tuple (k-slots 0 and 4 hold the scale: the same S = 2 ws as, bit for bit).  Same 8 passes on
+            # gfx950 (tools/ablate/mfma_k8_probe: 32.6 cycles either way), half the operand registers read: 130 -> 126 / 114 -> 110 cycles per tile-group on the
+            # probe (profiles/r6_gemm_wave_tile_probe.txt section 5).  "k16": the K = 16 form of rounds 1-5
+            op = "v_mfma_f32_32x32x8bf16_1k" if self.smfma.endswith("bf16") else "v_mfma_f32_32x32x8f16"
+            return f"{op} {vr(SBUF[dst_buf], 16)}, {ar(SCL[buf] + 4 * ni, 2)}, {ar(SCL[buf] + 8 + 4 * mi, 2)}, 0"
         return f"{self.smfma} {vr(SBUF[dst_buf], 16)}, {ar(SCL[buf] + 4 * ni, 4)}, {ar(SCL[buf] + 8 + 4 * mi, 4)}, 0"
 
     def fma(self, t, pb, lo, hi):
