@@ -453,12 +453,14 @@ int svdq_gemv_awq_batched(const svdq_gemv_awq_args *args, int32_t count, void *s
 
 /* ------------------------------------------------------------------------------------------
  * Load-time re-layout of reference checkpoint tensors (NVIDIA fragment order -> CDNA4 order).
- * src and dst must not alias.  All but svdq_repack_qweight are pure permutations of equal size.
+ * src and dst must not alias.  All but svdq_repack_qweight (4 -> 6 bits per code) and svdq_repack_wscales (x 32) are pure permutations of equal size.
  * ------------------------------------------------------------------------------------------ */
 /* qweight [N, K/2] int8 (packer.py:187-239) -> FP6 image, N*K*3/4 bytes, consumed by svdq_gemm_w4a4 */
 int svdq_repack_qweight(const void *src, void *dst, int32_t N, int32_t K, void *stream);
-/* wscales [K/64, N] 16-bit (packer.py:241-301) -> scale image [N/32][K/128][2][32]; G must be even */
-int svdq_repack_wscales(const void *src, void *dst, int32_t G, int32_t N, void *stream);
+/* wscales [K/64, N] 16-bit (packer.py:241-301) -> scale image [N/32][K/128][2][32]; G must be even.  ABI 21: takes the dtype, and the image holds 32 x the
+ * scale: the GEMM's product MFMA runs without MX block scales (P = dot / 64), the scale tile is S = 2 ws' as, and ws' = 32 ws makes P S the fp32 product of
+ * the ABI 20 kernels bit for bit.  Exact for bf16; an fp16 scale above 2047 overflows to inf (weights beyond 14 000) -- svdq_unrepack_wscales divides again. */
+int svdq_repack_wscales(const void *src, void *dst, int32_t G, int32_t N, int32_t dtype, void *stream);
 /* bias / smooth_factor [N] 16-bit (same intra-128 permutation, gemm_base.cuh:713) -> natural */
 int svdq_repack_vec(const void *src, void *dst, int32_t N, void *stream);
 /* proj_up [N, R] (down=0) -> natural [n][r];  proj_down [K, R] (down=1) -> [r][k] (rank-major)
@@ -469,7 +471,7 @@ int svdq_repack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_
  * what the host-offload manager keeps in pinned memory (4-bit nibbles: 2/3 of the FP6 image's bytes on the PCIe link).
  * Exact inverses of svdq_repack_*: repack(unrepack(x)) == x and unrepack(repack(c)) == c bit for bit. */
 int svdq_unrepack_qweight(const void *src, void *dst, int32_t N, int32_t K, void *stream); /* FP6 image -> [N, K/2] int8 */
-int svdq_unrepack_wscales(const void *src, void *dst, int32_t G, int32_t N, void *stream);
+int svdq_unrepack_wscales(const void *src, void *dst, int32_t G, int32_t N, int32_t dtype, void *stream);
 int svdq_unrepack_vec(const void *src, void *dst, int32_t N, void *stream);
 int svdq_unrepack_lowrank(const void *src, void *dst, int32_t C, int32_t R, int32_t down, void *stream);
 

@@ -106,14 +106,22 @@ __host__ __device__ __forceinline__ int scale_pos128(int c) {
 
 // reference [g][n]-packed -> natural [g][n] (SIMG == 0; bias / smooth vectors with G == 1) or the
 // S image [N/32][G/2][2][32] the GEMM stages per K-step (SIMG == 1)
+// The weight-side S image holds 32 x the scale (round 6, ABI 21): the GEMM's product MFMA runs WITHOUT MX block scales (one instruction instead of the
+// v_mfma_ld_scale + MFMA pair; P = dot / 64 since both code images hold value / 8), the scale tile is S = 2 ws' as, so ws' = 32 ws makes P S = dot ws as -- the
+// same fp32 product bit for bit (a power of two moves between the factors).  Exact for every bf16 scale; an fp16 scale above 2047 overflows (weights beyond
+// 14 000: nunchaku_amd/layout.py refuses them at load).
+__device__ __forceinline__ uint16_t wscale_times(uint16_t v, int dt, float f) {
+    if (dt == SVDQ_BF16) return __builtin_bit_cast(uint16_t, (__bf16)(__builtin_bit_cast(float, (uint32_t)v << 16) * f));
+    return __builtin_bit_cast(uint16_t, (_Float16)((float)__builtin_bit_cast(_Float16, v) * f));
+}
 template <int SIMG>
-__global__ void repack_wscales_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int G, int N) {
+__global__ void repack_wscales_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int G, int N, int dt) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)G * N) return;
     int g = i / N, n = i % N;
     int nt = n >> 7;
     const uint16_t v = src[((size_t)nt * G + g) * 128 + scale_pos128(n & 127)];
-    if (SIMG) dst[simg_index(n, g, G / 2)] = v;
+    if (SIMG) dst[simg_index(n, g, G / 2)] = wscale_times(v, dt, 32.0f);
     else dst[i] = v;
 }
 
@@ -175,12 +183,12 @@ __global__ void unrepack_qweight_kernel(const uint8_t *__restrict__ img, uint32_
 
 // natural [g][n] (SIMG == 0) or the S image (SIMG == 1) -> the reference's [g][n]-packed order
 template <int SIMG>
-__global__ void unrepack_wscales_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int G, int N) {
+__global__ void unrepack_wscales_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int G, int N, int dt) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)G * N) return;
     int g = i / N, n = i % N;
     int nt = n >> 7;
-    dst[((size_t)nt * G + g) * 128 + scale_pos128(n & 127)] = SIMG ? src[simg_index(n, g, G / 2)] : src[i];
+    dst[((size_t)nt * G + g) * 128 + scale_pos128(n & 127)] = SIMG ? wscale_times(src[simg_index(n, g, G / 2)], dt, 0.03125f) : src[i];
 }
 
 __global__ void unrepack_lowrank_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int C, int R, int down) {
@@ -236,14 +244,15 @@ int svdq_repack_qweight(const void *src, void *dst, int32_t N, int32_t K, void *
     return hip_check(hipGetLastError(), "svdq_repack_qweight launch");
 }
 
-int svdq_repack_wscales(const void *src, void *dst, int32_t G, int32_t N, void *stream) {
+int svdq_repack_wscales(const void *src, void *dst, int32_t G, int32_t N, int32_t dtype, void *stream) {
     if (!src || !dst || src == dst) { set_error("svdq_repack_wscales: null or aliasing pointers"); return SVDQ_E_INVALID; }
+    if (dtype != SVDQ_BF16 && dtype != SVDQ_FP16) { set_error("svdq_repack_wscales: dtype must be SVDQ_BF16 or SVDQ_FP16"); return SVDQ_E_INVALID; }
     if (G <= 0 || G % 2 || N <= 0 || N % 128) {
         set_error("svdq_repack_wscales: G=%d must be a positive even number and N=%d a positive multiple of 128", G, N);
         return SVDQ_E_INVALID;
     }
     hipLaunchKernelGGL(repack_wscales_kernel<1>, dim3(nblk((size_t)G * N, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t *)src, (uint16_t *)dst, G, N);
+                       (const uint16_t *)src, (uint16_t *)dst, G, N, dtype);
     return hip_check(hipGetLastError(), "svdq_repack_wscales launch");
 }
 
@@ -251,7 +260,7 @@ int svdq_repack_vec(const void *src, void *dst, int32_t N, void *stream) {
     if (!src || !dst || src == dst) { set_error("svdq_repack_vec: null or aliasing pointers"); return SVDQ_E_INVALID; }
     if (N <= 0 || N % 128) { set_error("svdq_repack_vec: N=%d must be a positive multiple of 128", N); return SVDQ_E_INVALID; }
     hipLaunchKernelGGL(repack_wscales_kernel<0>, dim3(nblk((size_t)N, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t *)src, (uint16_t *)dst, 1, N);
+                       (const uint16_t *)src, (uint16_t *)dst, 1, N, 0);
     return hip_check(hipGetLastError(), "svdq_repack_vec launch");
 }
 
@@ -278,14 +287,15 @@ int svdq_unrepack_qweight(const void *src, void *dst, int32_t N, int32_t K, void
     return hip_check(hipGetLastError(), "svdq_unrepack_qweight launch");
 }
 
-int svdq_unrepack_wscales(const void *src, void *dst, int32_t G, int32_t N, void *stream) {
+int svdq_unrepack_wscales(const void *src, void *dst, int32_t G, int32_t N, int32_t dtype, void *stream) {
     if (!src || !dst || src == dst) { set_error("svdq_unrepack_wscales: null or aliasing pointers"); return SVDQ_E_INVALID; }
+    if (dtype != SVDQ_BF16 && dtype != SVDQ_FP16) { set_error("svdq_unrepack_wscales: dtype must be SVDQ_BF16 or SVDQ_FP16"); return SVDQ_E_INVALID; }
     if (G <= 0 || G % 2 || N <= 0 || N % 128) {
         set_error("svdq_unrepack_wscales: G=%d must be a positive even number and N=%d a positive multiple of 128", G, N);
         return SVDQ_E_INVALID;
     }
     hipLaunchKernelGGL(unrepack_wscales_kernel<1>, dim3(nblk((size_t)G * N, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t *)src, (uint16_t *)dst, G, N);
+                       (const uint16_t *)src, (uint16_t *)dst, G, N, dtype);
     return hip_check(hipGetLastError(), "svdq_unrepack_wscales launch");
 }
 
@@ -293,7 +303,7 @@ int svdq_unrepack_vec(const void *src, void *dst, int32_t N, void *stream) {
     if (!src || !dst || src == dst) { set_error("svdq_unrepack_vec: null or aliasing pointers"); return SVDQ_E_INVALID; }
     if (N <= 0 || N % 128) { set_error("svdq_unrepack_vec: N=%d must be a positive multiple of 128", N); return SVDQ_E_INVALID; }
     hipLaunchKernelGGL(unrepack_wscales_kernel<0>, dim3(nblk((size_t)N, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t *)src, (uint16_t *)dst, 1, N);
+                       (const uint16_t *)src, (uint16_t *)dst, 1, N, 0);
     return hip_check(hipGetLastError(), "svdq_unrepack_vec launch");
 }
 

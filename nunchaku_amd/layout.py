@@ -23,6 +23,14 @@ def _run(fn_name, src: torch.Tensor, *dims) -> torch.Tensor:
     return dst
 
 
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _lib.SVDQ_BF16
+    if t.dtype == torch.float16:
+        return _lib.SVDQ_FP16
+    raise ValueError(f"nunchaku_amd.layout: weight scales must be bfloat16 or float16, not {t.dtype}")
+
+
 def act_image_shape(rows: int, K: int) -> tuple[int, int]:
     """Shape (uint8) of the FP6 operand image of a [rows, K] matrix of 4-bit codes (6 bits per code)."""
     if K % 128 or rows % 32:
@@ -46,7 +54,10 @@ def repack_qweight(qweight: torch.Tensor) -> torch.Tensor:
 def repack_wscales(wscales: torch.Tensor) -> torch.Tensor:
     """[K/64, N] 16-bit reference order -> scale image [N/32][K/128][2][32] (same storage shape)."""
     G, N = wscales.shape
-    return _run("svdq_repack_wscales", wscales, G, N)
+    # ABI 21: the image holds 32 x the scale (the GEMM's product MFMA runs without MX block scales: csrc/repack.hip).  Exact in bf16; fp16 tops out at 2047
+    if wscales.dtype == torch.float16 and wscales.numel() and float(wscales.abs().max()) > 2047.0:
+        raise ValueError("repack_wscales: an fp16 weight scale above 2047 cannot be held in the kernel's scale image (32 x scale); use bfloat16")
+    return _run("svdq_repack_wscales", wscales, G, N, _dt(wscales))
 
 
 def repack_vec(v: torch.Tensor) -> torch.Tensor:
@@ -76,7 +87,7 @@ def unrepack_qweight(img: torch.Tensor) -> torch.Tensor:
 
 def unrepack_wscales(simg: torch.Tensor) -> torch.Tensor:
     G, N = simg.shape
-    return _run("svdq_unrepack_wscales", simg, G, N)
+    return _run("svdq_unrepack_wscales", simg, G, N, _dt(simg))
 
 
 def unrepack_vec(v: torch.Tensor) -> torch.Tensor:

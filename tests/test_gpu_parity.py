@@ -43,8 +43,15 @@ def test_repack_kernels_match_reference_packer(golden_dir):
     assert np.array_equal(codes.cpu().numpy(), q)
 
     d = np.load(f"{golden_dir}/wscales_6x256.npz")
-    got = layout.repack_wscales(torch.from_numpy(d["packed"]).to(torch.bfloat16).cuda())
-    assert np.array_equal(f32(layout.unpack_scales(got, rows=256)), d["logical"])
+    src = torch.from_numpy(d["packed"]).to(torch.bfloat16).cuda()
+    got = layout.repack_wscales(src)
+    # (ABI 21: the weight-side scale image holds 32 x the scale -- the product MFMA runs without MX block scales; exact, and unrepack divides again)
+    assert np.array_equal(f32(layout.unpack_scales(got, rows=256)), 32.0 * d["logical"])
+    assert torch.equal(layout.unrepack_wscales(got), src)
+    h = torch.from_numpy(d["packed"]).to(torch.float16).cuda()
+    assert torch.equal(layout.unrepack_wscales(layout.repack_wscales(h)), h)
+    with pytest.raises(ValueError):
+        layout.repack_wscales(torch.full_like(h, 4096.0))   # 32 x 4096 is not an fp16 number
 
     d = np.load(f"{golden_dir}/vec_256.npz")
     got = layout.repack_vec(torch.from_numpy(d["packed"]).to(torch.bfloat16).cuda())

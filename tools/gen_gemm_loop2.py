@@ -143,6 +143,10 @@ class Gen:
         ni, mi = t >> 1, t & 1
         w = FRAG[buf] + 6 * ni
         a = FRAG[buf] + 12 + 6 * mi
+        if "mx" not in self.opts:
+            # round 6: no MX block scales -- ONE instruction instead of the v_mfma_ld_scale + MFMA pair, two VGPR reads fewer; P = dot / 64 and the weight-side scale
+            # image carries the factor 32 (svdq_repack_wscales): the same fp32 product P S bit for bit (tools/gen_gemm_loop3.py: p_mfma)
+            return f"v_mfma_f32_32x32x64_f8f6f4 {vr(PBUF[dst_buf], 16)}, {vr(w, 6)}, {vr(a, 6)}, 0 cbsz:2 blgp:2"
         return (f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(PBUF[dst_buf], 16)}, {vr(w, 6)}, {vr(a, 6)}, 0, "
                 f"{vr(MXA)}, {vr(MXB)} op_sel_hi:[0,0,0] cbsz:2 blgp:2")
 

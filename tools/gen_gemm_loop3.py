@@ -110,6 +110,12 @@ class Gen3:
         ni, mi = t >> 2, t & 3
         w = FRAG[buf] + 6 * ni
         a = FRAG[buf] + 12 + 6 * mi
+        if "mx" not in self.opts:
+            # round 6: the product MFMA WITHOUT MX block scales: P = dot / 64 (both code images hold value / 8); the factor 32 the block exponents used to supply lives
+            # in the weight-side scale image (svdq_repack_wscales: 32 x ws), so P S is the same fp32 product bit for bit.  The scaled form is a PAIR of instructions
+            # (v_mfma_ld_scale_b32 + the MFMA, 16 bytes) reading two more VGPRs: 126.0 -> 121.9 / 110.0 -> 105.9 cycles per tile-group on the probe
+            # (profiles/r6_gemm_wave_tile_probe.txt section 6).  "mx": the scaled pair of rounds 1-5 (needs the ABI 20 scale image: probes only)
+            return f"v_mfma_f32_32x32x64_f8f6f4 {vr(PBUF[dst_buf], 16)}, {ar(w, 6)}, {ar(a, 6)}, 0 cbsz:2 blgp:2"
         return (f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(PBUF[dst_buf], 16)}, {ar(w, 6)}, {ar(a, 6)}, 0, "
                 f"{vr(MXA)}, {vr(MXB)} op_sel_hi:[0,0,0] cbsz:2 blgp:2")
 

@@ -101,7 +101,7 @@ def gemm_stats(funcs):
         if split:  # the all-rank GELU_QUANT kernel that stores 16-bit fragments for the split low-rank down projection: carry = 4
             carry = 4
         ops = [ln.split()[0] for ln in ins]
-        loop = [i for i, o in enumerate(ops) if o.startswith("v_mfma_scale")]
+        loop = [i for i, o in enumerate(ops) if o.startswith(("v_mfma_scale", "v_mfma_f32_32x32x64_f8f6f4"))]  # the FP6 product MFMA (rounds 1-5: the MX-scaled pair)
         post = ops[loop[-1] + 1:]
         cls = collections.Counter(classify(o) for o in post)
         hist = collections.Counter(post)
