@@ -413,6 +413,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
     typedef __attribute__((address_space(3))) float lds_float;
     lds_float *carry = (lds_float *)((lds_void *)lds) + CARRY_OFF / 4; // [slab][row / 4][32 ranks][row % 4]
     bool carry_dirty = false; // block-uniform
+    // (round 6, tried: the wave's 64 rows of lora_act_in kept as 16-bit MFMA fragments -- 16 VGPRs -- across the ~20 column tiles a row-run spends in one row
+    //  block, instead of 8 row-per-lane loads + 32 conversions per tile: the GELU_QUANT epilogue has no 16 registers to give, 436 B of scratch per lane.  Dropped.)
     if constexpr (CARRY) {
         typedef __attribute__((address_space(3))) v4f lds_v4f;
         const v4f z4 = {0.f, 0.f, 0.f, 0.f};
@@ -480,8 +482,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                   "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157",  \
                   "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171",  \
                   "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185",  \
-                  "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199",  \
-                  "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v217", "v218", "v219", "v220"
+                  "v186", "v187", "v188", "v189", "v190", "v191", "v217", "v218", "v219", "v220"
+            // (round 6: v192 .. v209 left the loop's register plan -- two-register scale tuples, no MX exponents: tools/gen_gemm_loop2.py -- and are the compiler's
+            //  across the loop)
             // buffer resources of the three operand streams (raw buffers, no range check: the loop never issues a
             // DMA beyond the last K-step of the workgroup's last segment)
             auto srd = [](unsigned long long ptr) {

@@ -20,7 +20,8 @@ cycles on top (compute alone 86, whole loop 129 cycles per tile-group).  v1 spen
 
 Register plan (the C++ side pins its asm operands to the same registers, gemm_w4a4.hip):
   v[0:63] acc   v[64:79] P0  v[80:95] S0  v[96:111] P1  v[112:127] S1   v[128:151] / v[152:175] fragment buffers 0 / 1
-  v[176:191] / v[192:207] scale tuples 0 / 1    v208 v209 MX exponents
+  v[176:183] / v[184:191] scale tuples 0 / 1 (round 6: two registers each -- the K = 8 scale-tile MFMA; v192 .. v209 are free for the caller since the
+  product MFMA lost its MX exponents: the GELU_QUANT carry kernel keeps a row block's low-rank activations there across a run of column tiles)
   v210..v213 in: per-lane LDS offsets of A frags, W frags, as, ws (stage-relative)   v214..v216 in: per-lane DMA offsets
   v217..v220: the same four LDS offsets + 2*STAGE (stages 2, 3: ds offsets are 16-bit)
   s46 K-steps of this segment   s47 s48 s49 LDS destinations of the A / X1 / X2 planes (stage-relative)
@@ -58,7 +59,8 @@ ACC = 0
 PBUF = [64, 96]
 SBUF = [80, 112]
 FRAG = [128, 152]
-SCL = [176, 192]
+SCL = [176, 184]
+TS = 2                # registers per scale tuple (k-slots 0 .. 3: the K = 8 form)
 MXA, MXB = 208, 209
 IN_L = [210, 211, 212, 213]   # A, W, SA, SW (stages 0, 1)
 HI_L = [217, 218, 219, 220]   # + 2 * STAGE (stages 2, 3)
@@ -136,7 +138,7 @@ class Gen:
         for kind, roff in ((3, 0), (2, 8)):
             base, imm = self.lds(kind, stage)
             for i in range(2):
-                out.append(f"ds_read_u16 {vr(SCL[buf] + roff + 4 * i)}, {vr(base)} offset:{imm + i * 128 + grp * 64}")
+                out.append(f"ds_read_u16 {vr(SCL[buf] + (roff // 4 + i) * TS)}, {vr(base)} offset:{imm + i * 128 + grp * 64}")
         return out
 
     def p_mfma(self, dst_buf, buf, t):
@@ -152,13 +154,11 @@ class Gen:
 
     def s_mfma(self, dst_buf, buf, t):
         ni, mi = t >> 1, t & 1
-        if "k16" not in self.opts:
-            # round 6: the scale tile S = 2 ws as needs two non-zero k-slots; the legacy K = 8 form of the 16-bit MFMA (k-slots 0 and 4: the first two registers of
-            # each tuple) computes the same bits in the same 8 passes (tools/ablate/mfma_k8_probe: 32.6 cycles either way) and reads half the operand registers:
-            # -3.5 % loop cycles, -2.5 ... -3.2 % launch time on the wave-tile probe, bit-exact (profiles/r6_gemm_wave_tile_probe.txt section 5).  "k16": the old form.
-            op = "v_mfma_f32_32x32x8bf16_1k" if self.smfma.endswith("bf16") else "v_mfma_f32_32x32x8f16"
-            return f"{op} {vr(SBUF[dst_buf], 16)}, {vr(SCL[buf] + 4 * ni, 2)}, {vr(SCL[buf] + 8 + 4 * mi, 2)}, 0"
-        return f"{self.smfma} {vr(SBUF[dst_buf], 16)}, {vr(SCL[buf] + 4 * ni, 4)}, {vr(SCL[buf] + 8 + 4 * mi, 4)}, 0"
+        # round 6: the scale tile S = 2 ws as needs two non-zero k-slots; the legacy K = 8 form of the 16-bit MFMA (k-slots 0 and 4: the two registers of a tuple)
+        # computes the same bits in the same 8 passes (tools/ablate/mfma_k8_probe: 32.6 cycles either way) and reads half the operand registers:
+        # -3.5 % loop cycles, -2.5 ... -3.2 % launch time on the wave-tile probe, bit-exact (profiles/r6_gemm_wave_tile_probe.txt section 5)
+        op = "v_mfma_f32_32x32x8bf16_1k" if self.smfma.endswith("bf16") else "v_mfma_f32_32x32x8f16"
+        return f"{op} {vr(SBUF[dst_buf], 16)}, {vr(SCL[buf] + ni * TS, 2)}, {vr(SCL[buf] + (2 + mi) * TS, 2)}, 0"
 
     def fma(self, t, pb, lo, hi):
         """acc += P * S for registers lo .. hi-1 of tile t.  "pkf": packed fp32 FMAs (v_pk_fma_f32: two accumulators per
@@ -361,10 +361,8 @@ class Gen:
             e(f"v_mov_b32 {vr(ACC + r)}, 0")
         for b in range(2):
             for tpl in range(4):
-                for k in range(1, 4):
-                    e(f"v_mov_b32 {vr(SCL[b] + 4 * tpl + k)}, 0")
-        e(f"v_mov_b32 {vr(MXA)}, 0x82828282")
-        e(f"v_mov_b32 {vr(MXB)}, 0x81818181")
+                for k in range(1, TS):
+                    e(f"v_mov_b32 {vr(SCL[b] + TS * tpl + k)}, 0")
         for k in range(4):
             e(f"v_add_u32 {vr(HI_L[k])}, {2 * self.geo.stage}, {vr(IN_L[k])}")
         e(f"s_mov_b32 {sr(S_STEP)}, 0")
