@@ -53,7 +53,7 @@ FLUX_STEP_GOP = 59.5e3 + 0.83e3
 TRAFFIC_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r6_bench_gemm_hbm_counters.json", "r5_bench_gemm_hbm_counters.json", "r4_bench_gemm_hbm_counters.json")]
 MFMA_PROFILES = [os.path.join(ROOT, "profiles", n) for n in ("r6_bench_gemm_mfma_util.json", "r5_bench_gemm_mfma_util.json", "r4_bench_gemm_mfma_util.json")]
 # per-variant share of a tile spent behind the main loop (shader-cycle stamps of the probe build, tools/gpu/r5_gemm_trace.sh + tools/epilogue_share.py): committed, stamped
-EPILOGUE_SHARE_PROFILE = os.path.join(ROOT, "profiles", "r5_gemm_epilogue_share.json")
+EPILOGUE_SHARE_PROFILE = os.path.join(ROOT, "profiles", "r6_gemm_epilogue_share.json")
 
 
 def kernel_sources_sha16():

@@ -308,6 +308,10 @@ class Gen3:
             if q in (7, 15):
                 e("s_waitcnt lgkmcnt(0)")
             e(self.p_mfma(pb ^ 1, nbuf, nt))
+            if "pad" in self.opts and q in (2, 6, 10, 14):   # timing probe: what four more scalar issue slots per K-step cost
+                e("s_nop 0")
+            if "padv" in self.opts and q in (2, 6, 10, 14):  # ... four more VALU instructions
+                e(f"v_mov_b32 {vr(215)}, {vr(215)}")
             if q == 8 and even:
                 e("s_waitcnt vmcnt(0)")
                 e("s_nop 0" if "nobar" in self.opts else "s_barrier")
