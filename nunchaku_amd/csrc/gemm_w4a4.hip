@@ -2162,9 +2162,12 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
     if (p.lu_pre) p.lu_packed = a->lora_up_packed;
     hipStream_t st = (hipStream_t)stream;
     const int prof = prof_begin(SVDQ_PROF_GEMM_VARIANT(a->fuse), 2.0 * a->M_pad * (double)a->N * a->K + 2.0 * a->M_pad * (double)a->N * a->R, st);
-    // the plain epilogue at rank <= 32 (out-projection, fc2): the 128 x 64 wave tile, one wave per SIMD -- wherever the rule above picked 256 x 128 tiles
+    // the plain epilogue at rank 0 / 32 with a long K (fc2): the 128 x 64 wave tile, one wave per SIMD -- where the rule above picked 256 x 128 tiles
     // (an explicit geometry 1 keeps the 8-wave kernel: tests, same-box A/B)
-    if (wt128_serves(a) && (a->geometry == 8 || (a->geometry == 0 && geo == 1))) {
+    // (end of round 6: since the scale tile runs on the K = 8 MFMA form and the product MFMA lost its MX scales, the 8-wave loop gained more than the wave-tile
+    //  loop -- at K = 3072 the 8-wave kernel is the faster one again (51.8-53.1 us against 53.4-53.9), at K = 12288 the wave-tile kernel stays ahead (164.7-167.5
+    //  against 169.1-172.4): the library's own choice takes it from K = 8192; profiles/r6_gemm_wave_tile_probe.txt section 8)
+    if (wt128_serves(a) && (a->geometry == 8 || (a->geometry == 0 && geo == 1 && a->K >= 8192))) {
         if (a->dtype == SVDQ_BF16) launch_wt128<SVDQ_BF16>(p, with_ws, st);
         else launch_wt128<SVDQ_FP16>(p, with_ws, st);
     } else if (geo == 1) {
