@@ -555,7 +555,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                   "{s51}"(stg_flags), "{s54}"(stg_lds), "{s[88:89]}"(stg_la_u), "{s[90:91]}"(stg_lu_u), "{s[92:93]}"(stg_b_u),                  \
                   "{s58}"(ring),                                                                                                   \
                   "{s59}"(npre), "{s60}"(ncnt), "{s[62:63]}"(nA), "{s[64:65]}"(nX1), "{s[66:67]}"(nX2), "{s68}"(landed)            \
-                : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", "s84", "s85", "s86", "s87", SVDQ_LOOP_CLOBBER_V
+                : "memory", "scc", "m0", "s53", "s55", "s56", "s57", "s61", "s69", "s84", "s85", "s86", "s87", SVDQ_LOOP_CLOBBER_V
             if constexpr (NW == 8 && DT == SVDQ_BF16) {
                 asm volatile(
 #include SVDQ_LOOP_INC_8_BF16

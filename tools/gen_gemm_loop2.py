@@ -72,6 +72,7 @@ S_NA, S_NX1, S_NX2 = 62, 64, 66
 SRD_A, SRD_X1, SRD_X2 = 72, 76, 80
 S_KOFF, S_KOFF2, S_DSTEP, S_STG = 84, 85, 86, 87
 S_PHASE = 52  # in ("dph" builds): 1 for waves 4..7
+S_NODMA = 69  # option "sp": this K-step issues no DMA
 # staging of the epilogue operands (nw = 8): in: s51 flags (bit 0: low-rank operands, bit 1: bias, bit 2: of the low-rank operands only lora_up; bits 8..10: wave), s54 LDS address of the
 # staging region, s[88:89] this wave's 4 KiB of lora_act_in, s[90:91] its 1 KiB of lora_up, s[92:93] the tile's 256 bytes of bias
 S_STGF, S_STGB, S_SLA, S_SLU, S_SB = 51, 54, 88, 90, 92
@@ -314,15 +315,31 @@ class Gen:
                     # two of the ring's three bodies -- what a rendezvous every 2-3 K-steps (a deeper ring, a K-step of 256 channels) could save at most
                     "s_nop 0" if ("nobar" in self.opts or ("bar1of3" in self.opts and j != 0) or ("bar2of3" in self.opts and j == 2)) else "s_barrier",
                 ]
-                if phase == 0:
+                spread = {}
+                if phase == 0 and "burst" not in self.opts:
+                    # round 6: the K-step's DMAs one unit per tile-group slot behind the barrier instead of one burst (what the wave-tile loop needs; here the
+                    # second wave of the SIMD fills most of an acceptance stall): -4 % workgroup cycles, -1 ... -2 % launch time at the power limit, identical
+                    # outputs (tools/gpu/r6_sp2.sh, profiles/r6_gemm_wave_tile_probe.txt section 9).  "burst": the round 2-5 form
+                    d = self.dma_issue(j * self.geo.stage)
+                    ia = [i for i, ln in enumerate(d) if ln.startswith("s_add_u32 m0")]
+                    units = [d[ia[0]:ia[0] + 3], d[ia[0] + 3:ia[0] + 4], d[ia[0] + 4:ia[1]], d[ia[1]:ia[2]], d[ia[2]:]]
+                    misc = [f"s_mov_b32 {sr(S_NODMA)}, 0"] + misc
+                    misc += [f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}", f"s_cbranch_scc1 {Lsw}", f"{Lbsw}:"] + units[0] + units[1]
+                    spread = {5: units[2], 6: units[3], 7: units[4]}
+                    ool += [f"{Lsw}:"] + self.switch_segment() + [f"s_branch {Lbsw}"]
+                    self._spread = spread
+                elif phase == 0:
                     misc += [f"s_cmp_eq_u32 {sr(S_STEP)}, {sr(S_KP4)}", f"s_cbranch_scc1 {Lsw}", f"{Lbsw}:"] + self.dma_issue(j * self.geo.stage)
                     ool += [f"{Lsw}:"] + self.switch_segment() + [f"s_branch {Lbsw}"]
                 misc += [f"{Lback}:"] + reads_n0[0:4]
-                ool += [f"{Ltail}:", "s_waitcnt vmcnt(0)", "s_barrier", f"s_branch {Lback}"]
+                ool += [f"{Ltail}:"] + ([f"s_mov_b32 {sr(S_NODMA)}, 1"] if "burst" not in self.opts else []) + ["s_waitcnt vmcnt(0)", "s_barrier", f"s_branch {Lback}"]
             elif q in (5, 6):
                 misc = reads_n0[4 * (q - 4):4 * (q - 4) + 4]
             elif q == 7:
                 misc = [f"s_add_u32 {sr(S_STEP)}, {sr(S_STEP)}, 1"]
+            if phase == 0 and "burst" not in self.opts and q in (5, 6, 7):
+                Lnd = self.new_label("nd")
+                misc = list(misc) + [f"s_cmp_eq_u32 {sr(S_NODMA)}, 0", f"s_cbranch_scc0 {Lnd}"] + self._spread[q] + [f"{Lnd}:"]
             for ln in misc:
                 e(ln)
             for ln in self.fma(t, pb, 0, 8):
