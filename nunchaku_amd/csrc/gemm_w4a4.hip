@@ -1218,27 +1218,29 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                             // carry layout [row / 4][rank][row % 4] fp32: a lane's registers 4 g .. 4 g + 3 (rows 8 g + 4 h + 0..3 of its row tile, rank lr)
                             // are 16 contiguous bytes -- plain 16-byte reads and writes, no LDS atomics (ds_add_f32 runs at ~1 lane per clock:
                             // measured 21 k cycles per tile for these 32 instructions per wave, profiles/r4_gemm_rowrun.txt).  The two column waves
-                            // of a row block add to the same words: wave column 0 first, a barrier, then wave column 1.
+                            // of a row block add to the same words, in two turns separated by a barrier.
                             typedef __attribute__((address_space(3))) v4f lds_v4f;
                             lds_v4f *c4 = (lds_v4f *)carry + (unsigned)(t2 >> 5) * (BM * 8u) + ((unsigned)(wm * 16) + h_e) * 32u + lr_e; // + (mi * 8 + 2 g) * 32
                             carry_dirty = true;
+                            // (round 6: both column waves work in both turns -- wave column 0 adds its row tile 0 while wave column 1 adds its row tile 1, a
+                            //  barrier, then the other way round: different words per turn, half the serial LDS time of "column 0 first, then column 1")
+                            auto add_row_tile = [&](int mi, const v16f &dd) {
+                                v4f old[4];
+#pragma unroll
+                                for (int g = 0; g < 4; g++) old[g] = c4[(mi * 8 + 2 * g) * 32];
+#pragma unroll
+                                for (int g = 0; g < 4; g++) {
+                                    v4f v = old[g];
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) v[e] += dd[4 * g + e];
+                                    c4[(mi * 8 + 2 * g) * 32] = v;
+                                }
+                            };
 #pragma unroll
                             for (int turn = 0; turn < 2; turn++) {
-                                if (wn == turn && live) {
-                                    v4f old[2][4];
-#pragma unroll
-                                    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                                        for (int g = 0; g < 4; g++) old[mi][g] = c4[(mi * 8 + 2 * g) * 32];
-#pragma unroll
-                                    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                                        for (int g = 0; g < 4; g++) {
-                                            v4f v = old[mi][g];
-#pragma unroll
-                                            for (int e = 0; e < 4; e++) v[e] += d[mi][4 * g + e];
-                                            c4[(mi * 8 + 2 * g) * 32] = v;
-                                        }
+                                if (live) {
+                                    if ((wn ^ turn) == 0) add_row_tile(0, d[0]); // (wn: wave-uniform -- a scalar branch, no dynamic register indexing)
+                                    else add_row_tile(1, d[1]);
                                 }
                                 if (turn == 0) __syncthreads();
                             }
