@@ -153,6 +153,33 @@ def _small_model(layers=4):
                                                out_channels=16, joint_attention_dim=128, device="cuda").init_synthetic_(seed=5).eval()
 
 
+def test_qwen_model_offload_auto_keeps_every_block_that_fits():
+    """num_blocks_on_gpu="auto" (round 6): the reference's default of one resident block is sized for a 16-24 GB card; on a 288 GB part every block that fits in
+    three quarters of the free memory stays resident -- for this small model all of them: nothing is offloaded, nothing crosses the link, the forward is the resident one
+    bit for bit (deterministic mode), and an explicit count still offloads."""
+    from nunchaku_amd import mode
+    from nunchaku_amd.models.offload import CPUOffloadManager
+
+    g = torch.Generator(device="cuda").manual_seed(9)
+    lat = torch.randn(1, 256, 64, device="cuda", generator=g).bfloat16()
+    enc = torch.randn(1, 256, 128, device="cuda", generator=g).bfloat16()
+    t = torch.tensor([0.6], device="cuda")
+    with torch.no_grad(), mode.deterministic_mode():
+        model = _small_model(4)
+        ref = model(lat, enc, None, t, [(1, 16, 16)]).sample.clone()
+        fit = CPUOffloadManager.blocks_that_fit(list(model.transformer_blocks), "cuda", num_slots=2)
+        assert fit == 4, fit
+        model.set_offload(True, num_blocks_on_gpu="auto", num_slots=2)
+        mgr = model.offload_manager
+        assert mgr.num_blocks_on_gpu == 4 and mgr.n_offloaded == 0 and not mgr._images
+        assert torch.equal(model(lat, enc, None, t, [(1, 16, 16)]).sample, ref)
+        assert torch.equal(model(lat, enc, None, t, [(1, 16, 16)]).sample, ref)
+        model.set_offload(False)
+        assert torch.equal(model(lat, enc, None, t, [(1, 16, 16)]).sample, ref)
+    with pytest.raises(ValueError):
+        CPUOffloadManager(list(model.transformer_blocks), num_blocks_on_gpu="all")
+
+
 @pytest.mark.parametrize("late,num_slots", [(False, 2), (True, 2), (False, 3)], ids=["nibbles", "after-first-forward", "three-slots"])
 def test_qwen_model_offload_equals_resident(late, num_slots):
     """set_offload(True): blocks live in pinned host memory (their tensors are views of one flat image each), a ring of device
