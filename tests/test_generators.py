@@ -268,3 +268,119 @@ def test_gemm_loop_lds_dma_discipline():
         assert sum(1 for ln in block if ln == "s_add_u32 m0, m0, 1024") == 3
         assert f"s_add_u32 m0, m0, {G2.STG_LU}" in block and f"s_add_u32 m0, s{G2.S_STGB}, {G2.STG_BIAS}" in block
         assert g.geo.nstage == 3 and g.geo.stage * 3 + 2 * 256 * 4 + 16 + G2.STG_BIAS + 256 <= 160 * 1024  # the kernel's LDS map (Geo<8>)
+
+
+def test_wave_tile_loop_and_epilogue_in_tree_match_their_generator(tmp_path):
+    """round 6: the 128 x 64 wave tile kernel's loop (tools/gen_gemm_loop3.py, product options) and its generated epilogue"""
+    import gen_gemm_loop3 as G3
+
+    for dt, mfma in (("bf16", "v_mfma_f32_32x32x16_bf16"), ("fp16", "v_mfma_f32_32x32x16_f16")):
+        out = tmp_path / f"gemm_loop3_{dt}.inc"
+        G3.emit(str(out), mfma, G3.PRODUCT_OPTS)
+        assert out.read_text() == open(os.path.join(CSRC, out.name)).read(), f"{out.name} is stale: run python tools/gen_gemm_loop3.py"
+        out = tmp_path / f"gemm_epi3_{dt}.inc"
+        G3.emit_epilogue(str(out), dt)
+        assert out.read_text() == open(os.path.join(CSRC, out.name)).read(), f"{out.name} is stale: run python tools/gen_gemm_loop3.py"
+
+
+def _reg_range(tok):
+    """'v[12:15]' / 'a7' / 's[62:63]' -> (file, first, last)"""
+    m = re.match(r"^([vas])\[(\d+):(\d+)\]$", tok) or re.match(r"^([vas])(\d+)$", tok)
+    if not m:
+        return None
+    g = m.groups()
+    return (g[0], int(g[1]), int(g[2] if len(g) == 3 else g[1]))
+
+
+def test_wave_tile_loop_register_plan_and_dma_discipline():
+    """Static walk over the generated wave-tile loop: every body of the ring issues exactly 16 + 16 MFMAs, 256 v_fmac (each accumulator register once per group),
+    36 LDS reads and the K-step's 10 LDS-DMA instructions; an LDS-DMA never issues right behind its M0 write; the registers the text names stay inside the plan the
+    C++ side pins and clobbers (acc v[0:127], P / S v[128:191], inputs v[192:208] + the operand-load temporaries v[212:214], fragments / tuples a[0:119], the
+    epilogue operands a[120:200]); the product MFMA is the unscaled form and the scale tile the K = 8 form (round 6)."""
+    import gen_gemm_loop3 as G3
+
+    g = G3.Gen3("v_mfma_f32_32x32x16_bf16", G3.PRODUCT_OPTS)
+    lines = [ln for ln in g.build() if not ln.startswith(";")]
+    assert not any("v_mfma_scale" in ln or "32x32x16_bf16" in ln for ln in lines)
+    since_m0 = None
+    for ln in lines:
+        op = ln.split()[0]
+        if op.endswith(":"):
+            continue
+        if op.startswith("buffer_load") and ln.rstrip().endswith(" lds"):
+            assert since_m0 is not None and since_m0 >= 1, f"LDS-DMA right behind its M0 write: {ln}"
+        if op.startswith("s_") and re.search(r"\bm0\b", ln.split(",")[0]):
+            since_m0 = 0
+        elif since_m0 is not None:
+            since_m0 += 1
+        for tok in re.findall(r"[vas]\[\d+:\d+\]|\b[va]\d+\b", ln):
+            r = _reg_range(tok)
+            if r is None:
+                continue
+            f, lo, hi = r
+            if f == "v":
+                assert hi <= 208 or 212 <= lo <= 214, f"VGPR outside the plan: {ln}"
+            elif f == "a":
+                assert hi <= 200, f"AGPR outside the plan: {ln}"
+    bodies = [i for i, ln in enumerate(lines) if re.match(r"\.Lsvdq3_bin\d_\d+_%=:", ln)]
+    assert len(bodies) == 4
+    top = next(i for i, ln in enumerate(lines) if re.match(r"\.Lsvdq3_top_\d+_%=:", ln))
+    end = next(i for i, ln in enumerate(lines) if ln.startswith("s_branch .Lsvdq3_top_"))
+    assert top < bodies[0] and bodies[-1] < end
+    for b, e in zip(bodies, bodies[1:] + [end]):
+        body = [ln for ln in lines[b:e] if not ln.endswith(":")]
+        ops = [ln.split()[0] for ln in body]
+        assert ops.count("v_mfma_f32_32x32x64_f8f6f4") == 16 and ops.count("v_mfma_f32_32x32x8bf16_1k") == 16
+        fm = [ln for ln in body if ln.startswith("v_fmac_f32")]
+        assert len(fm) == 256
+        dst = [int(re.match(r"v_fmac_f32 v(\d+),", ln).group(1)) for ln in fm]
+        assert sorted(dst[:128]) == list(range(128)) and sorted(dst[128:]) == list(range(128)), "every accumulator once per group"
+        assert sum(1 for o in ops if o.startswith("ds_read")) == 36
+        assert sum(1 for ln in body if ln.startswith("buffer_load") and ln.endswith(" lds")) == 10
+    # even bodies carry the wait + barrier, odd ones none (ring of four, option b2)
+    for k, (b, e) in enumerate(zip(bodies, bodies[1:] + [end])):
+        assert ("s_barrier" in lines[b:e]) == (k % 2 == 0)
+
+
+def test_wave_tile_epilogue_walk():
+    """The generated plain epilogue: 8 bias MFMAs + 16 low-rank MFMAs on every accumulator tile, v_permlane32_swap never within two instructions of a write of its
+    operands, 16 stores of 16 bytes per wave with the offsets of the 8-wave kernel's store, fp16 clamps before its conversions, and no register outside
+    acc v[0:127] / temporaries v[128:191] / inputs v[209:211] / a[120:200]."""
+    import gen_gemm_loop3 as G3
+
+    for dt in ("bf16", "fp16"):
+        lines = [ln for ln in G3.GenEpi3(dt).build() if not ln.startswith(";")]
+        mf = [ln for ln in lines if ln.startswith("v_mfma")]
+        assert len(mf) == 8 + 16
+        tiles = [int(re.match(r"\S+ v\[(\d+):", ln).group(1)) // 16 for ln in mf]
+        assert sorted(tiles[:8]) == list(range(8)) and sorted(tiles[8:16]) == list(range(8)) and sorted(tiles[16:]) == list(range(8))
+        stores = [ln for ln in lines if ln.startswith("global_store_dwordx4")]
+        assert len(stores) == 16
+        offs = sorted(int(m.group(1)) if (m := re.search(r"offset:(\d+)", ln)) else 0 for ln in stores)
+        assert offs == sorted([0, 32, 64, 96] * 4)
+        written = {}   # register -> index of the last VALU instruction that wrote it
+        idx = 0
+        for ln in lines:
+            if ln.endswith(":"):
+                continue
+            op = ln.split()[0]
+            toks = re.findall(r"[va]\[\d+:\d+\]|\b[va]\d+\b", ln)
+            for tok in toks:
+                f, lo, hi = _reg_range(tok)
+                assert (f == "v" and (hi <= 191 or 209 <= lo <= 211)) or (f == "a" and 120 <= lo and hi <= 200), ln
+            if op == "s_nop":
+                idx += int(ln.split()[1]) + 1
+                continue
+            if op == "v_permlane32_swap_b32":
+                for tok in toks:
+                    f, lo, hi = _reg_range(tok)
+                    for r in range(lo, hi + 1):
+                        assert idx - written.get(r, -100) > 2, f"{dt}: {ln} reads v{r} too soon after its write"
+            if op.startswith("v_") and toks and not op.startswith("v_cmp"):
+                f, lo, hi = _reg_range(toks[0])
+                if f == "v":
+                    for r in range(lo, hi + 1):
+                        written[r] = idx
+            idx += 1
+        if dt == "fp16":
+            assert sum(1 for ln in lines if ln.startswith("v_med3_f32")) == 128
