@@ -107,3 +107,31 @@ def test_split_low_rank_down_kernels_fit_two_workgroups_per_cu(built_lib):
     for name, r in res.items():
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
         assert r["vgpr_count"] <= 256 and r["group_segment_fixed_size"] <= 40960, (name, r)
+
+
+def test_wave_tile_kernel_resources(built_lib):
+    """round 6: gemm_w4a4_wt128_kernel<DT> -- loop and plain epilogue generated, one asm statement per whole tile: no scratch (the first build, with a C++ epilogue
+    on 128 live accumulators, had 644 B per lane and 1300 AGPR moves per tile), the whole 512-register file of one wave per SIMD, the ring of four stages in LDS;
+    the C++ left around the two generated blocks (schedule, stream-K publish / collect) stays under 1500 VALU instructions"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("isa_stats", os.path.join(ROOT, "tools", "isa_stats.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from nunchaku_amd import _lib
+
+    res = mod.kernel_resources(_lib.lib_path(), "gemm_w4a4_wt128_kernel")
+    assert len(res) == 2, sorted(res)
+    for name, r in res.items():
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
+        assert r["group_segment_fixed_size"] == 4 * 38912, (name, r)
+        assert 256 < r["vgpr_count"] <= 512, (name, r)
+    funcs = mod.disassemble(_lib.lib_path())
+    for name, ins in funcs.items():
+        if "gemm_w4a4_wt128_kernel" not in name:
+            continue
+        ops = [ln.split()[0] for ln in ins]
+        assert not any(o.startswith("scratch_") for o in ops), name
+        assert sum(1 for o in ops if o.startswith("v_accvgpr")) < 900, name   # (the stream-K segment path still moves accumulators around its C++)
+        # two copies of the loop (whole tile / stream-K segment) and two of the epilogue: 4 x 16 + 4 x 16 MFMAs per body x 4 bodies x 2 + entries
+        assert sum(1 for o in ops if o.startswith("v_mfma_f32_32x32x64_f8f6f4")) == 2 * (4 * 16 + 4)
