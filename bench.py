@@ -256,8 +256,9 @@ def main():
     ap.add_argument("--no-attention-split", action="store_true",
                     help="A/B: keep the low-rank down projection of the attention epilogue's quantiser inside the epilogue at every rank (rank 48 .. 160 "
                          "runs it as a contraction kernel behind the attention kernel by default)")
-    ap.add_argument("--deterministic", action="store_true",
-                    help="fixed-point low-rank accumulation (nunchaku_amd.mode): bit-reproducible steps")
+    ap.add_argument("--deterministic", nargs="?", const="strict", default=False, choices=["strict", "runs"],
+                    help="fixed-point low-rank accumulation (nunchaku_amd.mode): bit-reproducible steps; 'strict' (default of the flag): independent of the "
+                         "launch configuration; 'runs': a GELU_QUANT workgroup sums its run of column tiles in fp32 in a fixed order first (ABI 22)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured HIP graph (no per-launch events: the roofline object is then "
                          "measured on one extra eager step after the timed region)")

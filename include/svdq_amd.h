@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SVDQ_ABI_VERSION 21
+#define SVDQ_ABI_VERSION 22
 
 /* model dtype of the 16-bit tensors */
 enum { SVDQ_BF16 = 0, SVDQ_FP16 = 1 };
@@ -71,8 +71,16 @@ enum {
  *   SVDQ_LORA_ACT_Q32: natural [m][r] int64 holding value * 2^32 (Q31.32 fixed point), M_pad*R*8 bytes; partial sums are
  *                      combined with 64-bit INTEGER atomics, which are associative: the result is bit-reproducible from
  *                      run to run ("deterministic mode").  Producer and consumer must agree; the buffer must be zeroed
- *                      (all-zero bytes are 0.0 in both formats). */
-enum { SVDQ_LORA_ACT_F32 = 0, SVDQ_LORA_ACT_Q32 = 1 };
+ *                      (all-zero bytes are 0.0 in both formats).  The sums do not depend on the launch configuration
+ *                      either (tile geometry, grid, stream-K): "strict".
+ *   SVDQ_LORA_ACT_Q32_RUNS (ABI 22): the same buffers and the same integer atomics BETWEEN workgroups, but a GELU_QUANT
+ *                      launch on 256 x 128 tiles may first sum the column tiles one workgroup walks in a row (a "row run",
+ *                      svdq_gemm_last_plan variant 1) in fp32 in LDS, in a fixed order, and convert the run's sum once: no
+ *                      atomics inside a tile.  Bit-reproducible from run to run and between replicas for a given (shape,
+ *                      geometry, device) -- what the deterministic mode is used for -- at about half the cost of the strict
+ *                      form; NOT equal to the sums of another geometry or grid.  svdq_quantize_w4a4_act_fuse_lora and
+ *                      svdq_attention treat it as SVDQ_LORA_ACT_Q32 (their partial sums have no such run). */
+enum { SVDQ_LORA_ACT_F32 = 0, SVDQ_LORA_ACT_Q32 = 1, SVDQ_LORA_ACT_Q32_RUNS = 2 };
 
 /* ------------------------------------------------------------------------------------------
  * svdq_quantize_w4a4_act_fuse_lora

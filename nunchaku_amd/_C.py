@@ -19,6 +19,7 @@ import weakref
 import torch
 
 from . import _lib
+from . import mode as _mode
 
 _DT = {torch.bfloat16: _lib.SVDQ_BF16, torch.float16: _lib.SVDQ_FP16}
 
@@ -578,7 +579,7 @@ class _Ops:
         if fmt_in is not None:
             if fmt_in not in (torch.float32, torch.int64):
                 raise ValueError("gemm_w4a4: lora_act_in must be float32 (or int64: the deterministic fixed-point format)")
-            a.lora_act_format = _lib.LORA_ACT_Q32 if fmt_in == torch.int64 else _lib.LORA_ACT_F32
+            a.lora_act_format = _lib.LORA_ACT_F32 if fmt_in != torch.int64 else _lib.LORA_ACT_Q32_RUNS if _mode.gemm_lora_act_format_runs() else _lib.LORA_ACT_Q32
         a.q_scale = float(q_scale)  # extension: the Q third times q_scale before its rounding (for attention(q_prescaled=True))
         if out_vt is not None and a.fuse != _lib.FUSE_RMSNORM_ROPE:
             raise ValueError("gemm_w4a4: out_vt needs the RMSNorm+RoPE epilogue (rotary_emb, norm_q, norm_k)")

@@ -12,8 +12,8 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "li
 
 SVDQ_BF16, SVDQ_FP16 = 0, 1
 FUSE_NONE, FUSE_SILU, FUSE_GELU_QUANT, FUSE_RMSNORM_ROPE = 0, 1, 2, 3
-ABI_VERSION = 21
-LORA_ACT_F32, LORA_ACT_Q32 = 0, 1
+ABI_VERSION = 22
+LORA_ACT_F32, LORA_ACT_Q32, LORA_ACT_Q32_RUNS = 0, 1, 2
 
 
 class QuantizeArgs(C.Structure):

@@ -1149,7 +1149,7 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
             return SVDQ_E_INVALID;
         }
     }
-    if (a->qlora_act_format != SVDQ_LORA_ACT_F32 && a->qlora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_attention: unknown qlora_act_format %d", a->qlora_act_format); return SVDQ_E_INVALID; }
+    if (a->qlora_act_format != SVDQ_LORA_ACT_F32 && a->qlora_act_format != SVDQ_LORA_ACT_Q32 && a->qlora_act_format != SVDQ_LORA_ACT_Q32_RUNS) { set_error("svdq_attention: unknown qlora_act_format %d", a->qlora_act_format); return SVDQ_E_INVALID; }
     if (a->kv_len0 < 0 || a->kv_len0 > a->L || (a->kv_len0 == 0 && (a->kv_start1 || a->kv_end1)) ||
         (a->kv_len0 > 0 && (a->kv_start1 < a->kv_len0 || a->kv_end1 < a->kv_start1 || a->kv_end1 > a->L) && (a->kv_start1 || a->kv_end1))) {
         set_error("svdq_attention: key mask needs 0 < kv_len0 <= kv_start1 <= kv_end1 <= L=%d (kv_len0 = 0: no mask; kv_start1 = kv_end1 = 0: one range)", a->L);
@@ -1174,7 +1174,7 @@ extern "C" int svdq_attention(const svdq_attention_args *a, void *stream) {
     p.L = a->L; p.H = a->H; p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;
     p.scale_log2e = a->q_prescaled ? 1.0f : a->scale * 1.4426950408889634f; // (prescaled: Q carries scale * log2(e), svdq_gemm_args.q_scale)
     p.qact = (uint8_t *)a->qact; p.qscales = (uint16_t *)a->qscales; p.qlora_act = a->qlora_act;
-    p.qlora_q32 = a->qlora_act_format == SVDQ_LORA_ACT_Q32;
+    p.qlora_q32 = a->qlora_act_format != SVDQ_LORA_ACT_F32;
     p.status = a->status;
     p.kv_len0 = a->kv_len0; p.kv_start1 = a->kv_start1; p.kv_end1 = a->kv_end1;
     p.qsmooth = (const uint16_t *)a->qsmooth; p.qlora_down = (const uint16_t *)a->qlora_down;

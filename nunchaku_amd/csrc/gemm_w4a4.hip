@@ -236,7 +236,8 @@ template <int DT, int FUSE, int NW, bool LAQ /* lora_act_in / lora_act_out are Q
                                 behind it (lowrank_down_split_kernel): the epilogue stores its 16-bit GELU output as MFMA fragments instead of contracting it per tile */>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams p) {
     static_assert(!SPLIT || (RALL && NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT), "SPLIT: the all-rank GELU_QUANT kernel on 256 x 128 tiles");
-    static_assert(!CARRY || (FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ), "the low-rank-down carry: GELU_QUANT with fp32 low-rank accumulators");
+    static_assert(!CARRY || FUSE == SVDQ_FUSE_GELU_QUANT, "the low-rank-down carry: GELU_QUANT");
+    static_assert(!(CARRY && LAQ) || (NW == 8 && !HYB), "the fp32 carry under fixed-point accumulators (SVDQ_LORA_ACT_Q32_RUNS): 256 x 128 tiles, next-layer rank <= 32");
     static_assert(!RALL || (!LAQ && !CARRY), "the all-rank kernels: fp32 low-rank accumulators, no carry");
     // (RALL on 128 x 128 tiles: no LDS to stage lora_up in -- both low-rank operands come as packed MFMA fragments from the workspace tail, like the solo-carry kernel's)
     static_assert(!HYB || (CARRY && NW == 8), "HYB: a carry kernel on 256 x 128 tiles");
@@ -1200,7 +1201,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                         if (SVDQ_PROBE_OFF(1)) {
                             asm volatile("" :: "v"(d[mi]));
                         } else if (to_carry) {
-                            // into the workgroup's carry: below, both row tiles at once (the two column waves of a row block take turns)
+                            // into the workgroup's carry: below, both row tiles at once (the two column waves of a row block take turns).  (LAQ, i.e.
+                            // SVDQ_LORA_ACT_Q32_RUNS: the same fp32 carry -- tiles in the run's order, the column waves in turn order: a fixed order --
+                            // converted to Q31.32 when the run is flushed)
                         } else if (live && LAQ) {
                             // deterministic mode: Q31.32 fixed point, 64-bit INTEGER atomics -- the sum does not depend on the order
                             long long *dst = (long long *)p.lora_act_out + at;
@@ -1346,8 +1349,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                     const v4f v = src[j * (64 * NW)];
                     src[j * (64 * NW)] = z4;
                     if (live) {
+                        if constexpr (LAQ) {
+                            long long *dq = (long long *)p.lora_act_out + (dst - (float *)p.lora_act_out);
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                __hip_atomic_fetch_add(dq + (size_t)(j * (64 * NW / 32) * 4 + e) * p.R2, float_to_q32(v[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
 #pragma unroll
                         for (int e = 0; e < 4; e++) unsafeAtomicAdd(dst + (size_t)(j * (64 * NW / 32) * 4 + e) * p.R2, v[e]);
+                        }
                     }
                 }
             }
@@ -1798,6 +1808,18 @@ static void launch_one_laq(GemmParams &p, bool with_ws, hipStream_t st) {
             return;
         }
     }
+    if constexpr (NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT && LAQ) {
+        // SVDQ_LORA_ACT_Q32_RUNS (ABI 22): the row-run schedule with its fp32 carry, the run's sum converted to fixed point at the flush -- no atomics in a tile
+        if (p.lora_fixed == SVDQ_LORA_ACT_Q32_RUNS && p.R2 > 0 && p.R2 <= 32 && rowrun_applies(p.M_pad, p.N, p.R2, p.sk_gs, slots)) {
+            const int TM = p.M_pad / G_::BM, TN = p.N / BN;
+            p.rowrun = GemmSchedule::run_length(TM, TN, slots);
+            g = (TM * ((TN + p.rowrun - 1) / p.rowrun) + 7) / 8 * 8;
+            dim3 grid(SVDQ_PROBE_GRID(g, tiles, slots)), block(G_::THREADS);
+            record_plan(G_::BM, PLAN_CARRY, (int)grid.x, p);
+            hipLaunchKernelGGL((gemm_w4a4_kernel<DT, FUSE, NW, LAQ, true>), grid, block, 0, st, p);
+            return;
+        }
+    }
     constexpr bool CAN_CARRY = NW == 8 && FUSE == SVDQ_FUSE_GELU_QUANT && !LAQ;
     if constexpr (CAN_CARRY) {
         if (p.R2 > 32 && rowrun_applies(p.M_pad, p.N, p.R2, p.sk_gs, slots)) { // beyond rank 32 (and not the solo-carry kernel's case): the hybrid carry
@@ -2022,7 +2044,7 @@ extern "C" int svdq_gemm_w4a4(const svdq_gemm_args *a, void *stream) {
         return SVDQ_E_INVALID;
     }
     if (a->geometry < 0 || a->geometry > 8) { set_error("svdq_gemm_w4a4: geometry must be 0 (auto) .. 8"); return SVDQ_E_INVALID; }
-    if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_gemm_w4a4: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
+    if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32 && a->lora_act_format != SVDQ_LORA_ACT_Q32_RUNS) { set_error("svdq_gemm_w4a4: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
     switch (a->fuse) {
     case SVDQ_FUSE_NONE:
     case SVDQ_FUSE_SILU:

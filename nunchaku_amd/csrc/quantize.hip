@@ -639,7 +639,7 @@ static int launch_quantize(const svdq_quantize_args *a, hipStream_t st) {
     while ((long)tiles * ((KP + cpw - 1) / cpw) > 8192) cpw *= 2;
     if (cpw > KP) cpw = ((KP + 3) / 4) * 4;
     const int slices = (KP + cpw - 1) / cpw;
-    const int q32 = a->lora_act_format == SVDQ_LORA_ACT_Q32;
+    const int q32 = a->lora_act_format == SVDQ_LORA_ACT_Q32 || a->lora_act_format == SVDQ_LORA_ACT_Q32_RUNS;
     const int atomics = (slices > 1 ? 1 : 0) | (q32 ? 2 : 0); // lora_act_add mode
     if (a->R > 0 && (atomics & 1) && !a->lora_act_zeroed) {
         // the reference zeroes the buffer inside the op as well (launch_impl.cuh:487)
@@ -686,8 +686,8 @@ extern "C" int svdq_quantize_w4a4_act_fuse_lora(const svdq_quantize_args *a, voi
     if (!a) { set_error("svdq_quantize: args is NULL"); return SVDQ_E_INVALID; }
     if (a->fp4) { set_error("svdq_quantize: fp4 (NVFP4) is not supported on gfx950"); return SVDQ_E_UNSUPPORTED; }
     if (a->fuse_glu && (a->ln_stats || a->x2)) { set_error("svdq_quantize: fuse_glu does not combine with the LayerNorm front end or a grouped launch"); return SVDQ_E_INVALID; }
-    if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32) { set_error("svdq_quantize: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
-    if (a->lora_act_format == SVDQ_LORA_ACT_Q32 && ((uintptr_t)a->lora_act & 7)) { set_error("svdq_quantize: a Q31.32 lora_act must be 8-byte aligned"); return SVDQ_E_INVALID; }
+    if (a->lora_act_format != SVDQ_LORA_ACT_F32 && a->lora_act_format != SVDQ_LORA_ACT_Q32 && a->lora_act_format != SVDQ_LORA_ACT_Q32_RUNS) { set_error("svdq_quantize: unknown lora_act_format %d", a->lora_act_format); return SVDQ_E_INVALID; }
+    if (a->lora_act_format != SVDQ_LORA_ACT_F32 && ((uintptr_t)a->lora_act & 7)) { set_error("svdq_quantize: a Q31.32 lora_act must be 8-byte aligned"); return SVDQ_E_INVALID; }
     if (!a->x || !a->act || !a->ascales) { set_error("svdq_quantize: x, act and ascales are required"); return SVDQ_E_INVALID; }
     if (a->M <= 0 || a->M_pad < a->M || a->M_pad % 256) {
         set_error("svdq_quantize: need 0 < M=%d <= M_pad=%d and M_pad %% 256 == 0", a->M, a->M_pad);

@@ -15,18 +15,39 @@ import contextlib
 
 import torch
 
-deterministic = False
+deterministic = False  # False | True ("strict") | "runs"
 
 
-def set_deterministic(flag: bool = True) -> None:
+def _level(flag):
+    """``False`` | ``True`` / ``"strict"`` | ``"runs"``.
+
+    strict: the fixed-point sums do not depend on the launch configuration either (tile geometry, grid, stream-K) -- every partial sum is an integer atomic.
+    runs (``SVDQ_LORA_ACT_Q32_RUNS``, ABI 22): a GELU_QUANT launch sums the column tiles one workgroup walks in a row in fp32, in a fixed order, and adds the
+    run's sum as fixed point: bit-reproducible from run to run and between replicas for a given shape and device -- what the mode is used for -- at about half
+    the step-time cost of strict; not equal to the sums of another launch geometry."""
+    if flag in (False, None, 0):
+        return False
+    if flag == "runs":
+        return "runs"
+    if flag in (True, 1, "strict"):
+        return True
+    raise ValueError(f"deterministic level {flag!r}: False, True / 'strict' or 'runs'")
+
+
+def set_deterministic(flag=True) -> None:
     global deterministic
-    deterministic = bool(flag)
+    deterministic = _level(flag)
+
+
+def gemm_lora_act_format_runs() -> bool:
+    """the GEMM wrapper passes SVDQ_LORA_ACT_Q32_RUNS for int64 low-rank buffers"""
+    return deterministic == "runs"
 
 
 @contextlib.contextmanager
-def deterministic_mode(flag: bool = True):
+def deterministic_mode(flag=True):
     global deterministic
-    old, deterministic = deterministic, bool(flag)
+    old, deterministic = deterministic, _level(flag)
     try:
         yield
     finally:

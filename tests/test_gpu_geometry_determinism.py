@@ -146,6 +146,52 @@ def test_deterministic_quantiser_and_fused_mlp():
     assert float((d > 0).float().mean()) < 0.2
 
 
+def test_deterministic_runs_level_row_run_carry():
+    """ABI 22, ``mode.deterministic_mode("runs")`` (SVDQ_LORA_ACT_Q32_RUNS): at the FLUX fc1 shape the GELU_QUANT launch takes the row-run schedule with its
+    fp32 carry (plan variant "carry": no atomics inside a tile), the run's sum enters the int64 accumulators once -- launches are bit-equal to each other, the
+    sums agree with the strict level's to fp32 accuracy; a launch too small for row runs takes the strict path and is bit-equal to it."""
+    from nunchaku_amd import mode
+    from nunchaku_amd.ops.gemm import svdq_gemm_w4a4_cuda
+    from nunchaku_amd.mode import alloc_lora_act
+    from nunchaku_amd._C import ops
+
+    dtype, K, N = "bf16", 3072, 12288
+    L1 = O.make_random_svdq_layer(K, N, 32, seed=17, dtype=dtype)
+    L2 = O.make_random_svdq_layer(N, K, 32, seed=18, dtype=dtype)
+    fc1, fc2 = make_module(L1, dtype), make_module(L2, dtype, act_unsigned=True)
+
+    def fc1_launch(x, M):
+        qx, asc, la = fc1.quantize(x.view(M, K))
+        M_pad = (M + 255) // 256 * 256
+        qh = torch.empty(M_pad, N * 3 // 4, dtype=torch.uint8, device="cuda")
+        sh = torch.empty(N // 64, M_pad, dtype=x.dtype, device="cuda")
+        lh, zeroed = alloc_lora_act(M_pad, 32, "cuda")
+        fc1._ensure_layout(); fc2._ensure_layout()
+        svdq_gemm_w4a4_cuda(act=qx, wgt=fc1.qweight, qout=qh, ascales=asc, wscales=fc1.wscales, oscales=sh, lora_act_in=la, lora_up=fc1.proj_up,
+                            lora_down=fc2.proj_down, lora_act_out=lh, bias=fc1.bias, smooth_factor=fc2.smooth_factor, lora_act_zeroed=zeroed)
+        return qh, sh, lh, ops.gemm_last_plan()
+
+    for M, carried in ((4608, True), (1024, False)):
+        x = t16(O.make_activations(M, K, seed=19, dtype=dtype), dtype)
+        with mode.deterministic_mode("strict"):
+            q0, s0, l0, plan0 = fc1_launch(x, M)
+            assert l0.dtype == torch.int64 and plan0["variant"] == "plain", plan0
+        with mode.deterministic_mode("runs"):
+            got = [fc1_launch(x, M) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert got[0][3]["variant"] == ("carry" if carried else "plain"), got[0][3]
+        assert (got[0][3]["rowrun"] > 0) == carried, got[0][3]
+        for q, s_, l, _ in got[1:]:
+            assert torch.equal(l, got[0][2]) and torch.equal(q, got[0][0]) and torch.equal(s_, got[0][1]), "runs level: two launches differ"
+        assert torch.equal(got[0][0], q0) and torch.equal(got[0][1], s0), "codes and scales do not depend on the accumulator format"
+        if carried:  # fp32 sums of a run of <= 24 tiles against the exact integer sum of the same partials
+            a, b = mode.lora_act_to_float(got[0][2]), mode.lora_act_to_float(l0)
+            assert torch.allclose(a, b, rtol=0, atol=8e-6 * float(b.abs().max()) + 1e-7)
+            assert not torch.equal(got[0][2], l0), "expected the carried sums to differ from the strict ones in the last bits (else the carry did not run)"
+        else:
+            assert torch.equal(got[0][2], l0), "no row runs: the runs level IS the strict path"
+
+
 def test_deterministic_model_forward_is_bit_reproducible():
     """A FLUX-shaped step (fused norms, grouped launches, attention-side quantiser, stream-K GEMMs, persistent attention):
     bit-equal outputs over repeated forwards in deterministic mode."""

@@ -70,7 +70,7 @@ int main(int argc, char **argv) {
     std::string lib = "nunchaku_amd/csrc/libsvdq_amd.so";
     int R2opt = 32;
     int M = 4096, K = 12288, N = 3072, R = 32, fuse = 0, iters = 20, warm = 1500, dtype = SVDQ_BF16, reserved = 0, use_ws = 1, split = 0;
-    bool zero = false, do_trace = false, q32 = false, no_bias = false;
+    bool zero = false, do_trace = false, q32 = false, q32_runs = false, no_bias = false;
     double sustain = 0;
     std::vector<int> variants = {1}; // svdq_gemm_args.geometry values
     for (int i = 1; i < argc; i++) {
@@ -90,6 +90,7 @@ int main(int argc, char **argv) {
         else if (a == "--split") split = atoi(argv[++i]);
         else if (a == "--sustain") sustain = atof(argv[++i]);
         else if (a == "--q32") q32 = true;
+        else if (a == "--q32runs") { q32 = true; q32_runs = true; }
         else if (a == "--no-bias") no_bias = true;
         else if (a == "--geoms") { variants.clear(); char *s = argv[++i]; for (char *t = strtok(s, ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -112,7 +113,7 @@ int main(int argc, char **argv) {
     a.ascales = dev_half((size_t)G * M_pad, dtype, 0.05f, 0.4f, zero);
     a.wscales = dev_half((size_t)G * N, dtype, 0.002f, 0.01f, zero);
     a.bias = no_bias ? nullptr : dev_half(N, dtype, -0.1f, 0.1f, zero);
-    if (R > 0) { a.lora_act_in = dev_f32((size_t)M_pad * R * (q32 ? 2 : 1), -1.f, 1.f, zero || q32); a.lora_act_format = q32 ? SVDQ_LORA_ACT_Q32 : SVDQ_LORA_ACT_F32; a.lora_up = dev_half((size_t)N * R, dtype, -0.05f, 0.05f, zero); }
+    if (R > 0) { a.lora_act_in = dev_f32((size_t)M_pad * R * (q32 ? 2 : 1), -1.f, 1.f, zero || q32); a.lora_act_format = q32_runs ? SVDQ_LORA_ACT_Q32_RUNS : q32 ? SVDQ_LORA_ACT_Q32 : SVDQ_LORA_ACT_F32; a.lora_up = dev_half((size_t)N * R, dtype, -0.05f, 0.05f, zero); }
     a.M = M; a.M_pad = M_pad; a.N = N; a.K = K; a.R = R; a.ldo = N; a.dtype = dtype; a.fuse = fuse; a.reserved = reserved;
     a.act_unsigned = act_unsigned;
     void *out; CK(hipMalloc(&out, (size_t)M_pad * N * 2)); a.out = out;
