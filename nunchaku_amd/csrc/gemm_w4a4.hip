@@ -52,6 +52,14 @@
 #define SVDQ_PROBE_WT_MID_DECL
 #define SVDQ_PROBE_WT_MID_STAMP()
 #endif
+// compile-time timing variants of the RMSNORM_ROPE epilogue (probe builds only: tools/ablate/build.py with SVDQ_PROBE_DEFS; profiles/r6_qkv_epilogue_levers.txt):
+// SVDQ_PROBE_ROT 1 = the rotary table read as lane-contiguous 16-byte loads, 2 = no rotary table loads; SVDQ_PROBE_VROW 1 = V tiles row-major into `out`
+#ifndef SVDQ_PROBE_ROT
+#define SVDQ_PROBE_ROT 0
+#endif
+#ifndef SVDQ_PROBE_VROW
+#define SVDQ_PROBE_VROW 0
+#endif
 
 // generated main loops (tools/gen_gemm_loop2.py); the probe build substitutes option variants
 #ifndef SVDQ_LOOP_INC_8_BF16
@@ -988,16 +996,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
                     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
-                            if (SVDQ_PROBE_OFF(16)) continue; // (probe build only, timing: no rotary table loads at all)
-                            if (SVDQ_PROBE_OFF(8)) {          // (probe build only, timing: the same bytes as eight lane-contiguous 16-byte loads per row tile -- a table in lane order)
+                            if constexpr (SVDQ_PROBE_ROT == 1) { // (timing variant: the same bytes as eight lane-contiguous 16-byte loads per row tile -- a table in lane order)
                                 const v4f t4 = *reinterpret_cast<const v4f *>(p.rotary_emb + (size_t)(m0 + wm * 64 + mi * 32) * 128 + wn * 2048 + lane * 32 + (ni * 4 + c) * 4);
                                 rot[mi][ni][c][0] = make_float2(t4[0], t4[1]);
                                 rot[mi][ni][c][1] = make_float2(t4[2], t4[3]);
-                                continue;
-                            }
+                            } else if constexpr (SVDQ_PROBE_ROT == 0) {
                             const float *rp = rrow + (wn * 8 + ni * 4 + c) * 128;
                             rot[mi][ni][c][0] = *reinterpret_cast<const float2 *>(rp);
                             rot[mi][ni][c][1] = *reinterpret_cast<const float2 *>(rp + 4);
+                            }
                         }
                 }
                 __syncthreads(); // the previous tile's readers of the epilogue scratch are done
@@ -1267,7 +1274,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_w4a4_kernel(const GemmParams 
         // One v_permlane32_swap per dword turns two 8-byte pieces per lane into one 16-byte piece, so a
         // wave store writes 32 contiguous bytes per row with dwordx4 stores (8 instead of 32 per wave).
         bool vt_tile = false;
-        if constexpr (FUSE == SVDQ_FUSE_RMSNORM_ROPE) vt_tile = p.out_vt != nullptr && n0 >= 2 * (p.N / 3) && !SVDQ_PROBE_OFF(32); // block-uniform  (probe bit 32, timing: V row-major into `out`)
+        if constexpr (FUSE == SVDQ_FUSE_RMSNORM_ROPE) vt_tile = p.out_vt != nullptr && n0 >= 2 * (p.N / 3) && !SVDQ_PROBE_VROW; // block-uniform
         if (vt_tile) {
             // V^T for svdq_attention: element (m, n) -> out_vt[(n - 2N/3) * ldvt + m].  A lane owns one row m, so
             // a register is 32 consecutive m of one channel across the half-wave: neighbouring lanes trade halves

@@ -50,6 +50,10 @@ def build(opts: str = "", opts3: str = ""):
                 name = f"gemm_loop2_w{nw}_{dt.lower()}{suffix}.inc"
                 G2.emit(os.path.join(GEN, name), mf, opts, nw=nw)
                 flags.append(f'-DSVDQ_LOOP_INC_{tag}_{dt}="{name}"')
+    # SVDQ_PROBE_DEFS="-DSVDQ_PROBE_ROT=1 ..." SVDQ_PROBE_TAG=rot1: compile-time timing variants of an epilogue (gemm_w4a4.hip "compile-time timing variants")
+    if os.environ.get("SVDQ_PROBE_DEFS"):
+        flags += os.environ["SVDQ_PROBE_DEFS"].split()
+        suffix += "_" + os.environ.get("SVDQ_PROBE_TAG", "defs")
     lib = os.path.join(HERE, f"libsvdq_amd_probe{suffix}.so")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     subprocess.run([hipcc, *flags, "-o", lib, *SOURCES], cwd=CSRC, check=True)

@@ -27,6 +27,7 @@ run dev1024_lora16 --steps 12 --warmup 2 --prof-steps 5 --lora 16
 run qwen1664x928 --steps 8 --warmup 2 --prof-steps 4 --config qwen1024 --resolution 1664 928 --txt-tokens 37
 run qwen1664x928_r128 --steps 8 --warmup 2 --prof-steps 4 --config qwen1024 --resolution 1664 928 --txt-tokens 37 --rank 128
 run dev1024_det --steps 12 --warmup 2 --prof-steps 5 --deterministic
+run dev1024_det_runs --steps 12 --warmup 2 --prof-steps 5 --deterministic runs
 run schnell512 --config schnell512
 run dev1360x768 --steps 12 --warmup 2 --prof-steps 5 --resolution 1360 768
 run qwen1024 --steps 8 --warmup 2 --prof-steps 4 --config qwen1024
