@@ -199,3 +199,36 @@ def test_workspace_cache_is_bounded_by_bytes(built_lib, monkeypatch):
     stream[0] = 10
     grown = _C._workspace(dev, min_bytes=300 << 20)
     assert grown is not small and list(_C._workspaces) == [(0, 10, "gemm")]
+
+
+def test_deterministic_levels_of_the_mode():
+    """nunchaku_amd.mode: False | True / "strict" | "runs" (ABI 22); the level decides the int64 allocation (both) and which fixed-point format the GEMM wrapper names;
+    the header's enumerators and the binding's constants agree."""
+    import os
+    import re
+
+    import pytest
+
+    from nunchaku_amd import _lib, mode
+
+    assert mode.deterministic is False and mode.lora_act_words() == 1 and not mode.gemm_lora_act_format_runs()
+    with mode.deterministic_mode():
+        assert mode.deterministic is True and mode.lora_act_words() == 2 and not mode.gemm_lora_act_format_runs()
+        t, zeroed = mode.alloc_lora_act(4, 32, "cpu")
+        assert t.dtype == torch.int64 and t.shape == (4, 32) and not zeroed
+        with mode.deterministic_mode("runs"):
+            assert mode.deterministic == "runs" and mode.lora_act_words() == 2 and mode.gemm_lora_act_format_runs()
+            assert mode.alloc_lora_act(4, 32, "cpu")[0].dtype == torch.int64
+            with mode.deterministic_mode(False):
+                assert mode.alloc_lora_act(4, 32, "cpu")[0].dtype == torch.float32
+        assert mode.deterministic is True
+    assert mode.deterministic is False
+    mode.set_deterministic("strict")
+    assert mode.deterministic is True
+    mode.set_deterministic(False)
+    with pytest.raises(ValueError):
+        mode.set_deterministic("fast")
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "svdq_amd.h")).read()
+    m = re.search(r"enum \{ SVDQ_LORA_ACT_F32 = (\d+), SVDQ_LORA_ACT_Q32 = (\d+), SVDQ_LORA_ACT_Q32_RUNS = (\d+) \}", hdr)
+    assert m and tuple(int(x) for x in m.groups()) == (_lib.LORA_ACT_F32, _lib.LORA_ACT_Q32, _lib.LORA_ACT_Q32_RUNS)
+    assert int(re.search(r"#define SVDQ_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
