@@ -192,6 +192,34 @@ def test_deterministic_runs_level_row_run_carry():
             assert torch.equal(got[0][2], l0), "no row runs: the runs level IS the strict path"
 
 
+def test_deterministic_runs_level_grouped_mlp_of_a_joint_block():
+    """The launch a FLUX joint block really issues -- text (512 rows) and image (4096 rows) MLPs grouped into one GELU_QUANT launch and one fc2 launch -- at the
+    level "runs": the 16-bit outputs of repeated calls are bit-equal (the row runs of a grouped launch are a function of the shapes alone), and they agree with
+    the strict level's up to the 4-bit code flips a last-bit difference of the low-rank sums can cause."""
+    from nunchaku_amd import mode
+    from nunchaku_amd.ops.fused import fused_gelu_mlp_pair
+
+    dtype, K, N, Ma, Mb = "bf16", 3072, 12288, 512, 4096
+    mods = []
+    for i in range(2):
+        L1 = O.make_random_svdq_layer(K, N, 32, seed=31 + 2 * i, dtype=dtype)
+        L2 = O.make_random_svdq_layer(N, K, 32, seed=32 + 2 * i, dtype=dtype)
+        mods.append((make_module(L1, dtype), make_module(L2, dtype, act_unsigned=True)))
+    xa = t16(O.make_activations(Ma, K, seed=41, dtype=dtype), dtype).view(1, Ma, K)
+    xb = t16(O.make_activations(Mb, K, seed=42, dtype=dtype), dtype).view(1, Mb, K)
+    call = lambda: fused_gelu_mlp_pair(xa, mods[0][0], mods[0][1], xb, mods[1][0], mods[1][1])
+    with mode.deterministic_mode("strict"):
+        ya0, yb0 = (t.clone() for t in call())
+    with mode.deterministic_mode("runs"):
+        outs = [tuple(t.clone() for t in call()) for _ in range(3)]
+    torch.cuda.synchronize()
+    for ya, yb in outs[1:]:
+        assert torch.equal(ya, outs[0][0]) and torch.equal(yb, outs[0][1]), "runs level: two grouped MLP calls differ"
+    for got, ref in ((outs[0][0], ya0), (outs[0][1], yb0)):
+        d = (got.float() - ref.float()).abs()
+        assert float(d.max()) <= 0.05 * float(ref.float().abs().max()) and float((d > 0).float().mean()) < 0.05
+
+
 def test_deterministic_model_forward_is_bit_reproducible():
     """A FLUX-shaped step (fused norms, grouped launches, attention-side quantiser, stream-K GEMMs, persistent attention):
     bit-equal outputs over repeated forwards in deterministic mode."""
