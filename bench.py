@@ -464,7 +464,7 @@ def main():
             # aggregate steps/s (value) and the slowest / fastest replica's own rate over its K steps
             "per_replica": {"min_steps_per_s": args.steps / own_max, "max_steps_per_s": args.steps / own_min},
             "vs_baseline": None,
-            "dtype": "int4 codes as FP6 (e2m3) operands of the MX-scaled MFMA (exact), fp32 accumulate, bf16 I/O",
+            "dtype": "int4 codes as FP6 (e2m3) operands of the f8f6f4 MFMA (exact products; per-group scales applied in fp32), fp32 accumulate, bf16 I/O",
             "data": "synthetic",
             "config": {
                 "workload": workload,
