@@ -1,6 +1,8 @@
 """What the attention kernel's fused output quantiser costs at the FLUX.1 shape (1 x 24 heads x 4608 tokens x 128, Q prescaled: the 4 x 64 kernel on the plain grid):
 16-bit output only / fused quantiser at rank 32 (codes + scales + low-rank down with atomics over the 24 heads) / fused quantiser at rank 0 (no low-rank part)."""
 import math, os, sys, torch
+import nunchaku_amd._lib as _L
+_L._LIB_PATH = os.environ.get("SVDQ_LIB", _L._LIB_PATH)  # same-box A/B against another build of the library (tools only)
 from oracle import svdq_oracle as O
 from tests.helpers import make_module
 from nunchaku_amd.ops.attention import attention_packed, attention_packed_quantized, q_prescale
